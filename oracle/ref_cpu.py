@@ -1,0 +1,602 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU restatement of SUG's encoder + alignment path.
+
+Functional torch (CPU, fp32, device-agnostic) restatement of the reference
+algorithm, written against a flat ``{state_dict key: tensor}`` parameter
+dictionary instead of ``nn.Module`` classes.  Every function cites the
+reference file:line it follows (paths relative to the reference checkout).
+
+Pinned by ``tests/golden/*.npz``: outputs of the reference itself, produced in
+the build container by ``tests/golden/make_goldens.py`` (which imports the
+reference, runs it, and also asserts this restatement reproduces it).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
+``cpu_baseline`` leg may import this file; ``sug_amd`` never does.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+SIGMAS = (0.01, 0.1, 1, 10, 100)          # model/mmd.py:23
+MIN_VAR_EST = 1e-8                        # model/mmd.py:22
+
+
+# --------------------------------------------------------------------------
+# point-set operators, [B,C,N] layout  (model/point_utils.py, model/model_utils.py)
+# --------------------------------------------------------------------------
+def knn_idx(x, k):
+    """model/model_utils.py:178-185. x [B,C,N] -> idx [B,N,k] int64 (k largest of -d^2)."""
+    inner = -2 * torch.matmul(x.transpose(2, 1), x)
+    sq = (x ** 2).sum(dim=1, keepdim=True)
+    neg_d = -sq - inner - sq.transpose(2, 1)
+    return neg_d.topk(k=k, dim=-1)[1]
+
+
+def knn_neg_dist(x):
+    """The [B,N,N] score matrix ranked by knn_idx (model/model_utils.py:179-181)."""
+    inner = -2 * torch.matmul(x.transpose(2, 1), x)
+    sq = (x ** 2).sum(dim=1, keepdim=True)
+    return -sq - inner - sq.transpose(2, 1)
+
+
+def graph_feature(x, k=20, idx=None):
+    """model/model_utils.py:188-210. x [B,C,N(,1)] -> [B,2C,N,k] = cat(x_j - x_i, x_i)."""
+    B, N = x.size(0), x.size(2)
+    x = x.reshape(B, -1, N)
+    if idx is None:
+        idx = knn_idx(x, k)
+    C = x.size(1)
+    rows = x.transpose(2, 1).reshape(B * N, C)
+    flat = (idx + torch.arange(B, device=x.device).view(-1, 1, 1) * N).reshape(-1)
+    nbr = rows[flat].view(B, N, k, C)
+    ctr = rows.view(B, N, 1, C).expand(B, N, k, C)
+    return torch.cat((nbr - ctr, ctr), dim=3).permute(0, 3, 1, 2)
+
+
+def sqdist_cf(src, dst):
+    """model/point_utils.py:112-131. src [B,C,N], dst [B,C,M] -> [B,N,M] (expanded form)."""
+    B, _, N = src.shape
+    M = dst.shape[2]
+    d = -2 * torch.matmul(src.permute(0, 2, 1), dst)
+    d = d + (src ** 2).sum(1).view(B, N, 1)
+    d = d + (dst ** 2).sum(1).view(B, 1, M)
+    return d
+
+
+def fps_cf(xyz, npoint, start=None):
+    """model/point_utils.py:5-26. xyz [B,3,N] -> [B,npoint] int64.
+
+    ``start`` None draws ``torch.randint(0, N, (B,))`` from the CPU default
+    generator exactly like the reference (:17)."""
+    B, _, N = xyz.shape
+    if start is None:
+        start = torch.randint(0, N, (B,), dtype=torch.long)
+    far = start.to(xyz.device)
+    out = torch.zeros(B, npoint, dtype=torch.long, device=xyz.device)
+    mind = torch.full((B, N), 1e10, device=xyz.device)
+    ar = torch.arange(B, device=xyz.device)
+    for i in range(npoint):
+        out[:, i] = far
+        c = xyz[ar, :, far].view(B, 3, 1)
+        d = ((xyz - c) ** 2).sum(1)
+        mind = torch.where(d < mind, d, mind)
+        far = mind.max(-1)[1]
+    return out
+
+
+def gather_cf(points, idx):
+    """model/point_utils.py:60-83. points [B,C,N](,1), idx [B,S] or [B,S,K] -> [B,C,S(,K)]."""
+    if points.dim() == 4:
+        points = points.squeeze(-1)
+    B = points.shape[0]
+    rows = points.permute(0, 2, 1)
+    bi = torch.arange(B, device=points.device).view([B] + [1] * (idx.dim() - 1)).expand_as(idx)
+    g = rows[bi, idx, :]
+    return g.permute(0, 2, 1) if g.dim() == 3 else g.permute(0, 3, 1, 2)
+
+
+def ball_query_cf(radius, nsample, xyz, new_xyz):
+    """model/point_utils.py:86-109. xyz [B,3,N], new_xyz [B,3,S] -> [B,S,nsample] int64.
+
+    radius given: first ``nsample`` indices in ascending index order with
+    d^2 <= r^2 (the mask is ``>``, :102), short rows padded with the first hit;
+    radius None: ``nsample`` nearest by a full sort of the distances (:108)."""
+    B, _, N = xyz.shape
+    S = new_xyz.shape[2]
+    d = sqdist_cf(new_xyz, xyz)
+    if radius is None:
+        return torch.sort(d, dim=-1)[1][:, :, :nsample]
+    g = torch.arange(N, device=xyz.device).view(1, 1, N).repeat(B, S, 1)
+    g[d > radius ** 2] = N
+    g = g.sort(dim=-1)[0][:, :, :nsample]
+    first = g[:, :, 0:1].expand(B, S, nsample)
+    return torch.where(g == N, first, g)
+
+
+def upsample_inter(xyz1, xyz2, points1, points2, k):
+    """model/point_utils.py:134-165. inverse-distance k-NN interpolation, cat with points1."""
+    if points1 is not None and points1.dim() == 4:
+        points1 = points1.squeeze(-1)
+    if points2.dim() == 4:
+        points2 = points2.squeeze(-1)
+    B, _, N = xyz1.shape
+    d, idx = sqdist_cf(xyz1, xyz2).sort(dim=-1)
+    d, idx = d[:, :, :k], idx[:, :, :k]
+    d = torch.where(d < 1e-10, torch.full_like(d, 1e-10), d)
+    w = 1.0 / d
+    w = w / w.sum(dim=-1).view(B, N, 1)
+    interp = (gather_cf(points2, idx) * w.view(B, 1, N, k)).sum(dim=3)
+    if points1 is None:
+        return interp
+    return torch.cat([points1, interp], dim=1)
+
+
+# --------------------------------------------------------------------------
+# point-set operators, [B,N,C] layout  (model/pointnet2_utils.py)
+# --------------------------------------------------------------------------
+def sqdist_cl(src, dst):
+    """model/pointnet2_utils.py:19-38. src [B,N,C], dst [B,M,C] -> [B,N,M]."""
+    B, N, _ = src.shape
+    M = dst.shape[1]
+    d = -2 * torch.matmul(src, dst.permute(0, 2, 1))
+    d = d + (src ** 2).sum(-1).view(B, N, 1)
+    d = d + (dst ** 2).sum(-1).view(B, 1, M)
+    return d
+
+
+def gather_cl(points, idx):
+    """model/pointnet2_utils.py:41-57. points [B,N,C], idx [B,S(,K)] -> [B,S(,K),C]."""
+    B = points.shape[0]
+    bi = torch.arange(B, device=points.device).view([B] + [1] * (idx.dim() - 1)).expand_as(idx)
+    return points[bi, idx, :]
+
+
+def fps_cl(xyz, npoint, start=None):
+    """model/pointnet2_utils.py:60-81. xyz [B,N,3] -> [B,npoint] int64 (random start :72)."""
+    return fps_cf(xyz.permute(0, 2, 1), npoint, start)
+
+
+def ball_query_cl(radius, nsample, xyz, new_xyz):
+    """model/pointnet2_utils.py:84-104. xyz [B,N,3], new_xyz [B,S,3] -> [B,S,nsample]."""
+    B, N, _ = xyz.shape
+    S = new_xyz.shape[1]
+    d = sqdist_cl(new_xyz, xyz)
+    g = torch.arange(N, device=xyz.device).view(1, 1, N).repeat(B, S, 1)
+    g[d > radius ** 2] = N
+    g = g.sort(dim=-1)[0][:, :, :nsample]
+    first = g[:, :, 0:1].expand(B, S, nsample)
+    return torch.where(g == N, first, g)
+
+
+def sample_and_group(npoint, radius, nsample, xyz, points, start=None):
+    """model/pointnet2_utils.py:107-135. -> new_xyz [B,S,3], new_points [B,S,ns,3+D]."""
+    B, N, C = xyz.shape
+    fidx = fps_cl(xyz, npoint, start)
+    new_xyz = gather_cl(xyz, fidx)
+    idx = ball_query_cl(radius, nsample, xyz, new_xyz)
+    g_xyz = gather_cl(xyz, idx) - new_xyz.view(B, npoint, 1, C)
+    if points is None:
+        return new_xyz, g_xyz
+    return new_xyz, torch.cat([g_xyz, gather_cl(points, idx)], dim=-1)
+
+
+def sample_and_group_all(xyz, points):
+    """model/pointnet2_utils.py:138-155."""
+    B, N, C = xyz.shape
+    new_xyz = torch.zeros(B, 1, C, device=xyz.device)
+    g = xyz.view(B, 1, N, C)
+    if points is not None:
+        g = torch.cat([g, points.view(B, 1, N, -1)], dim=-1)
+    return new_xyz, g
+
+
+# --------------------------------------------------------------------------
+# layers (model/model_utils.py, model/Model.py) on a flat parameter dict
+# --------------------------------------------------------------------------
+def _bn(p, pre, x, training):
+    rm, rv = p.get(pre + 'running_mean'), p.get(pre + 'running_var')
+    return F.batch_norm(x, rm, rv, p[pre + 'weight'], p[pre + 'bias'], training, 0.1, 1e-5)
+
+
+def conv_bn_act(p, pre, x, act='relu', training=True):
+    """conv_2d, model/model_utils.py:8-32: 1x1 Conv2d -> BatchNorm2d -> act.
+    'leakyrelu' is nn.LeakyReLU() i.e. slope 0.01 (:27)."""
+    y = F.conv2d(x, p[pre + 'conv.0.weight'], p.get(pre + 'conv.0.bias'))
+    y = _bn(p, pre + 'conv.1.', y, training)
+    if act == 'relu':
+        return F.relu(y)
+    if act == 'tanh':
+        return torch.tanh(y)
+    if act == 'leakyrelu':
+        return F.leaky_relu(y, 0.01)
+    raise ValueError(act)
+
+
+def fc_ln_act(p, pre, x, act='leakyrelu'):
+    """fc_layer(bn=True), model/model_utils.py:35-57: Linear -> LayerNorm -> act (slope 0.2)."""
+    y = F.linear(x, p[pre + 'fc.0.weight'], p.get(pre + 'fc.0.bias'))
+    y = F.layer_norm(y, (y.shape[-1],), p[pre + 'fc.1.weight'], p[pre + 'fc.1.bias'])
+    return F.relu(y) if act == 'relu' else F.leaky_relu(y, 0.2)
+
+
+def transform_net(p, pre, x, K, training=True):
+    """model/model_utils.py:60-89 (DGCNN_Flag=False path)."""
+    y = conv_bn_act(p, pre + 'conv2d1.', x, 'relu', training)
+    y = conv_bn_act(p, pre + 'conv2d2.', y, 'relu', training)
+    y = conv_bn_act(p, pre + 'conv2d3.', y, 'relu', training)
+    y = y.max(dim=2)[0].reshape(y.size(0), -1)
+    y = fc_ln_act(p, pre + 'fc1.', y)
+    y = fc_ln_act(p, pre + 'fc2.', y)
+    y = F.linear(y, p[pre + 'fc3.weight'], p[pre + 'fc3.bias'])
+    y = y + torch.eye(K, device=y.device).view(1, K * K)
+    return y.view(-1, K, K)
+
+
+def adapt_layer_off(p, pre, fea, loc, training=True, start=None, num_node=64):
+    """model/model_utils.py:92-128. fea [B,64,N,1], loc [B,3,N] ->
+    (out [B,128,N,1], node_fea [B,64,64,1], node_offset [B,3,64])."""
+    fidx = fps_cf(loc, num_node, start)
+    f_loc = gather_cf(loc, fidx)
+    f_fea = gather_cf(fea, fidx)
+    gidx = ball_query_cf(0.3, 64, loc, f_loc)
+    g_fea = gather_cf(fea, gidx) - f_fea.unsqueeze(3)
+    sem = torch.tanh(F.conv2d(g_fea, p[pre + 'pred_offset.0.weight']))
+    g_loc = gather_cf(loc, gidx) - f_loc.unsqueeze(3)
+    off = (sem * g_loc).mean(dim=-1)
+    n_loc = f_loc + off
+    gidx2 = ball_query_cf(None, 64, loc, n_loc)
+    res = conv_bn_act(p, pre + 'residual.', fea, 'relu', training)
+    node_fea = gather_cf(res, gidx2).max(dim=-1, keepdim=True)[0]
+    out = upsample_inter(loc, n_loc, fea, node_fea, k=3).unsqueeze(3)
+    return out, node_fea, off
+
+
+def dgcnn_g(p, pre, x, training=True, start=None, k=20, knn_override=None):
+    """DGCNN.forward, model/Model.py:73-121. x [B,3,1024,1] -> (feat [B,1024], node_fea [B,64,64,1]).
+    ``knn_override`` (list of 4 idx tensors) teacher-forces the neighbour lists."""
+    loc = x.squeeze(-1)
+    B = x.size(0)
+    ko = knn_override or [None] * 4
+    x1 = conv_bn_act(p, pre + 'conv1.', graph_feature(x, k, ko[0]), 'leakyrelu', training).max(dim=-1)[0]
+    x2 = conv_bn_act(p, pre + 'conv2.', graph_feature(x1, k, ko[1]), 'leakyrelu', training).max(dim=-1)[0]
+    x_, node_fea, _ = adapt_layer_off(p, pre + 'node_fea_adapt.', x2.view(B, 64, -1, 1), loc, training, start)
+    x2 = F.conv1d(x_.squeeze(-1), p[pre + 'conv1d.weight'], p[pre + 'conv1d.bias'])
+    x3 = conv_bn_act(p, pre + 'conv3.', graph_feature(x2, k, ko[2]), 'leakyrelu', training).max(dim=-1)[0]
+    x4 = conv_bn_act(p, pre + 'conv4.', graph_feature(x3, k, ko[3]), 'leakyrelu', training).max(dim=-1)[0]
+    x5 = F.conv1d(torch.cat((x1, x2, x3, x4), dim=1), p[pre + 'conv5.weight'])
+    x5 = F.leaky_relu(_bn(p, pre + 'bn5.', x5, training), 0.2)
+    feat = torch.cat((x5.max(dim=-1)[0], x5.mean(dim=-1)), 1)
+    return feat, node_fea, (x1, x2, x3, x4)
+
+
+def pointnet_g(p, pre, x, training=True, start=None):
+    """Pointnet_g.forward, model/Model.py:248-283. x [B,3,N,1] -> (feat [B,1024], node_fea, node_off)."""
+    loc = x.squeeze(-1)
+    t1 = transform_net(p, pre + 'trans_net1.', x, 3, training)
+    y = torch.bmm(x.squeeze(-1).transpose(2, 1), t1).transpose(2, 1).unsqueeze(3)
+    y = conv_bn_act(p, pre + 'conv1.', y, 'relu', training)
+    y = conv_bn_act(p, pre + 'conv2.', y, 'relu', training)
+    t2 = transform_net(p, pre + 'trans_net2.', y, 64, training)
+    y = torch.bmm(y.squeeze(-1).transpose(2, 1), t2).transpose(2, 1).unsqueeze(3)
+    y, node_fea, node_off = adapt_layer_off(p, pre + 'conv3.', y, loc, training, start)
+    y = conv_bn_act(p, pre + 'conv4.', y, 'relu', training)
+    y = conv_bn_act(p, pre + 'conv5.', y, 'relu', training)
+    y = y.max(dim=2)[0].squeeze(-1)
+    y = _bn(p, pre + 'bn1.', y, training)
+    return y, node_fea, node_off
+
+
+def set_abstraction(p, pre, xyz, points, npoint, radius, nsample, n_mlp=3, group_all=False,
+                    adapt=False, training=True, start=None):
+    """PointNetSetAbstraction.forward, model/pointnet2_utils.py:174-207.
+    xyz [B,3,N], points [B,D,N] or None -> new_xyz [B,3,S], new_points [B,D',S](, node_fea)."""
+    xyz = xyz.permute(0, 2, 1)
+    if points is not None:
+        points = points.permute(0, 2, 1)
+    if group_all:
+        new_xyz, g = sample_and_group_all(xyz, points)
+    else:
+        new_xyz, g = sample_and_group(npoint, radius, nsample, xyz, points, start)
+    g = g.permute(0, 3, 2, 1)
+    node = None
+    for i in range(n_mlp):
+        g = F.conv2d(g, p[pre + 'mlp_convs.%d.weight' % i], p[pre + 'mlp_convs.%d.bias' % i])
+        g = F.relu(_bn(p, pre + 'mlp_bns.%d.' % i, g, training))
+        if adapt and i == 1:
+            node = g
+    out = g.max(dim=2)[0]
+    new_xyz = new_xyz.permute(0, 2, 1)
+    if adapt:
+        return new_xyz, out, node.max(dim=2)[0]
+    return new_xyz, out
+
+
+def pointnet2_g(p, pre, x, training=True, starts=(None, None)):
+    """Pointnet2_g.forward, model/Model.py:138-161. x [B,3,N,1] -> (feat [B,1024], node_fea [B,64,64,1])."""
+    xyz = x.squeeze(-1)
+    B = xyz.shape[0]
+    l1_xyz, l1_pts, node = set_abstraction(p, pre + 'sa1.', xyz, None, 512, 0.2, 32, adapt=True,
+                                           training=training, start=starts[0])
+    l2_xyz, l2_pts = set_abstraction(p, pre + 'sa2.', l1_xyz, l1_pts, 128, 0.4, 64,
+                                     training=training, start=starts[1])
+    _, l3_pts = set_abstraction(p, pre + 'sa3.', l2_xyz, l2_pts, None, None, None, group_all=True,
+                                training=training)
+    node = F.max_pool1d(node, 3, stride=8).view(B, 64, 64, 1)
+    return l3_pts.view(B, 1024), node, None
+
+
+def pointnet_c(p, pre, x, dgcnn, adapt=False, drop_p=0.0, training=True):
+    """Pointnet_c.forward, model/Model.py:436-449 (PTran_flag False). Dropout2d on a 2-D
+    input acts element-wise; parity runs use drop_p=0."""
+    act = 'leakyrelu' if dgcnn else 'relu'
+    y = fc_ln_act(p, pre + 'mlp1.', x, act)
+    y = F.dropout(y, drop_p, training)
+    y = fc_ln_act(p, pre + 'mlp2.', y, act)
+    mid = y
+    y = F.dropout(y, drop_p, training)
+    y = F.linear(y, p[pre + 'mlp3.weight'], p[pre + 'mlp3.bias'])
+    return (y, mid) if adapt else y
+
+
+def calayer(p, pre, x, training=True):
+    """CALayer.forward, model/Model.py:28-34. x [B,4096,1,1] -> [B,4096]."""
+    y = F.relu(F.conv2d(x, p[pre + 'conv_du.0.weight'], p[pre + 'conv_du.0.bias']))
+    y = torch.sigmoid(F.conv2d(y, p[pre + 'conv_du.2.weight'], p[pre + 'conv_du.2.bias']))
+    y = (x * y + x).view(x.shape[0], -1)
+    return _bn(p, pre + 'bn.', y, training)
+
+
+def net_mda(p, model_name, x, training=True, starts=None, drop_p=0.0, mid_feat=False,
+            node_adaptation_s=False, node_adaptation_t=False, semantic_adaption=False,
+            knn_override=None):
+    """Net_MDA.forward, model/Model.py:485-520 (adaptation/GradReverse is the identity, :37-50)."""
+    if model_name == 'Pointnet':
+        feat, node, _ = pointnet_g(p, 'g.', x, training, None if starts is None else starts[0])
+    elif model_name == 'DGCNN':
+        feat, node, _ = dgcnn_g(p, 'g.', x, training, None if starts is None else starts[0],
+                                knn_override=knn_override)
+    elif model_name == 'Pointnet2':
+        feat, node, _ = pointnet2_g(p, 'g.', x, training, starts or (None, None))
+    else:
+        raise NotImplementedError(model_name)
+    B = node.size(0)
+    if mid_feat:
+        return feat, node
+    if node_adaptation_s or node_adaptation_t:
+        pre = 'attention_s.' if node_adaptation_s else 'attention_t.'
+        return calayer(p, pre, node.contiguous().view(B, -1, 1, 1), training)
+    dg = model_name == 'DGCNN'
+    if not semantic_adaption:
+        return (pointnet_c(p, 'c1.', feat, dg, False, drop_p, training),
+                pointnet_c(p, 'c2.', feat, dg, False, drop_p, training))
+    y1, s1 = pointnet_c(p, 'c1.', feat, dg, True, drop_p, training)
+    y2, s2 = pointnet_c(p, 'c2.', feat, dg, True, drop_p, training)
+    return y1, y2, s1, s2
+
+
+def pointnet_cls(p, x, training=True, drop_p=0.0):
+    """Pointnet_cls.forward, model/model_pointnet.py:22-55 (config 1, train_source.py)."""
+    t1 = transform_net(p, 'trans_net1.', x, 3, training)
+    y = torch.bmm(x.squeeze(-1).transpose(2, 1), t1).transpose(2, 1).unsqueeze(3)
+    y = conv_bn_act(p, 'conv1.', y, 'relu', training)
+    y = conv_bn_act(p, 'conv2.', y, 'relu', training)
+    t2 = transform_net(p, 'trans_net2.', y, 64, training)
+    y = torch.bmm(y.squeeze(-1).transpose(2, 1), t2).transpose(2, 1).unsqueeze(3)
+    y = conv_bn_act(p, 'conv3.', y, 'relu', training)
+    y = conv_bn_act(p, 'conv4.', y, 'relu', training)
+    y = conv_bn_act(p, 'conv5.', y, 'relu', training)
+    y = y.max(dim=2)[0].reshape(y.size(0), -1)
+    y = F.dropout(fc_ln_act(p, 'mlp1.', y), drop_p, training)
+    y = F.dropout(fc_ln_act(p, 'mlp2.', y), drop_p, training)
+    return F.linear(y, p['mlp3.weight'], p['mlp3.bias'])
+
+
+# --------------------------------------------------------------------------
+# MMD alignment loss (model/mmd.py)
+# --------------------------------------------------------------------------
+def one_hot(labels, num_class=10):
+    """create_one_hot_labels, utils/common_utils.py:161-164."""
+    oh = torch.zeros(labels.shape[0], num_class, device=labels.device)
+    oh[torch.arange(labels.shape[0], device=labels.device), labels] = 1
+    return oh
+
+
+def most_overlapped(a, b, num_class=10):
+    """get_most_overlapped_element, utils/common_utils.py:167-194."""
+    sa, ia = torch.sort(a)
+    sb, ib = torch.sort(b)
+    pa = pb = 0
+    sel_a, sel_b = [], []
+    for c in range(num_class):
+        na, nb = int((sa == c).sum()), int((sb == c).sum())
+        n = min(na, nb)
+        sel_a += [pa + i for i in range(n)]
+        sel_b += [pb + i for i in range(n)]
+        pa += na
+        pb += nb
+    return [int(ia[i]) for i in sel_a], [int(ib[i]) for i in sel_b]
+
+
+def mix_rbf_kernel(X, Y, sigmas=SIGMAS):
+    """_mix_rbf_kernel, model/mmd.py:239-254."""
+    m = X.size(0)
+    Z = torch.cat((X, Y), 0)
+    G = torch.mm(Z, Z.t())
+    dg = torch.diag(G).unsqueeze(1)
+    e = dg.expand_as(G) - 2 * G + dg.expand_as(G).t()
+    K = 0.0
+    for s in sigmas:
+        K = K + torch.exp(-(1.0 / (2 * s ** 2)) * e)
+    return K[:m, :m], K[:m, m:], K[m:, m:]
+
+
+def mmd2_biased(K_XX, K_XY, K_YY, w=None):
+    """_mmd2(const_diagonal=False, biased=True), model/mmd.py:274-312."""
+    m = K_XX.size(0)
+    dX, dY = torch.diag(K_XX), torch.diag(K_YY)
+    sxx = (K_XX.sum(dim=1) - dX).sum()
+    syy = (K_YY.sum(dim=1) - dY).sum()
+    col = K_XY.sum(dim=0)
+    if w is not None:
+        col = w.reshape(-1).to(col.device) * col
+    return (sxx + dX.sum()) / (m * m) + (syy + dY.sum()) / (m * m) - 2.0 * col.sum() / (m * m)
+
+
+def mix_rbf_mmd2(X, Y, sigmas=SIGMAS, sample_weights=None):
+    """mix_rbf_mmd2, model/mmd.py:257-260."""
+    return mmd2_biased(*mix_rbf_kernel(X, Y, sigmas), w=sample_weights)
+
+
+def distance2weights(d, method):
+    """distance2weights, model/mmd.py:178-202 ('mean2one' truncates 1/mean to an int, :200)."""
+    if method == 'mean2one':
+        scale = (1 / d.mean()).type(torch.int)
+        return (d * scale).reshape(-1)
+    if method == 'none':
+        return d.clone().reshape(-1)
+    if method == 'naive_inverse':
+        w = 1 / (d + MIN_VAR_EST)
+        return (w / w.sum()).reshape(-1)
+    if method == 'exp_inverse':
+        w = torch.exp(-d)
+        return (w / w.sum()).reshape(-1)
+    raise ValueError(method)
+
+
+def _kl_div(x, y):
+    """scipy.special.kl_div for strictly positive inputs: x log(x/y) - x + y."""
+    return x * torch.log(x / y) - x + y
+
+
+def prob_weights_soft(pred_s, pred_t, label_s, label_t, label_weight, weighting='mean2one'):
+    """prob_weights_soft, model/mmd.py:134-148 (+ normalized :151-153,
+    kl_divergence_distance dataset_splitter.py:244-245)."""
+    def aug(pred, lab):
+        v = torch.cat((torch.softmax(pred.detach(), dim=1).view(-1, 10), one_hot(lab) * label_weight), dim=1)
+        v = v + MIN_VAR_EST
+        return v / v.sum()
+    a, b = aug(pred_s, label_s), aug(pred_t, label_t)
+    d = (_kl_div(a, b) * 0.5 + _kl_div(b, a) * 0.5).sum(1)
+    return distance2weights(d, weighting).reshape(1, -1)
+
+
+def chamfer_weights(pc_s, pc_t, weighting='mean2one'):
+    """geometric_weights, model/mmd.py:107-131 + cd_distance :169-175.  PARITY UNPINNED:
+    ChamferDistance is third-party (github.com/otaheri/chamfer_distance, unpinned, absent);
+    restated from the call-site contract dist1[b,i] = min_j |p1_i - p2_j|^2 (and symmetric)."""
+    if pc_s.shape[1] == 3:
+        a, b = pc_s.squeeze(-1).transpose(1, 2), pc_t.squeeze(-1).transpose(1, 2)
+    else:
+        a, b = pc_s, pc_t
+    d = ((a[:, :, None, :] - b[:, None, :, :]) ** 2).sum(-1)
+    dist = d.min(dim=2)[0].mean(dim=1) + d.min(dim=1)[0].mean(dim=1)
+    return distance2weights(dist, weighting).reshape(1, -1)
+
+
+def soft_mmd(label_s, feat_s, label_t, feat_t, label_scale, sample_weights=None):
+    """soft_mmd, model/mmd.py:56-66."""
+    X = torch.cat((feat_s, one_hot(label_s) * label_scale), dim=1)
+    Y = torch.cat((feat_t, one_hot(label_t) * label_scale), dim=1)
+    return mix_rbf_mmd2(X, Y, SIGMAS, sample_weights)
+
+
+def mmd_cal(label_s, feat_s, label_t, feat_t, args, data_s=None, data_t=None):
+    """mmd_cal, model/mmd.py:25-41 (the second cal_sample_weights call wins, :30-31)."""
+    w = None
+    if data_s is not None and (args.get('GEO_WEIGHTS') or args.get('SEM_WEIGHTS')):
+        if args.get('GEO_WEIGHTS'):
+            w = chamfer_weights(data_s, data_t, args['GEO_WEIGHTS'])
+        else:
+            w = prob_weights_soft(data_s, data_t, label_s, label_t, args['LABEL_WEIGHT'], args['SEM_WEIGHTS'])
+    name = args['NAME']
+    if name == 'SOFT_MMD':
+        return soft_mmd(label_s, feat_s, label_t, feat_t, float(args['LABEL_SCALE']), w)
+    if name == 'HARD_MMD':
+        same = torch.eq(label_s, label_t)
+        return mix_rbf_mmd2(feat_s[same], feat_t[same])
+    if name == 'MAX_HARD_MMD':
+        ia, ib = most_overlapped(label_s.cpu(), label_t.cpu())
+        return mix_rbf_mmd2(feat_s[ia], feat_t[ib])
+    if name == 'OFF':
+        return mix_rbf_mmd2(feat_s, feat_t)
+    raise RuntimeError('Not Supported MMD Method')
+
+
+# --------------------------------------------------------------------------
+# one SUG training step (train_dg_single_gpu.py:246-335), functional
+# --------------------------------------------------------------------------
+GEO_CFG = {'NAME': 'SOFT_MMD', 'LABEL_SCALE': 50, 'GEO_SCALE': 1}
+SEM_CFG = {'NAME': 'SOFT_MMD', 'LABEL_SCALE': 5, 'SEM_WEIGHTS': 'mean2one', 'LABEL_WEIGHT': 0.5, 'SEM_SCALE': 1}
+
+
+def sug_losses(p, model_name, data, label, data_t, label_t, geo_cfg=GEO_CFG, sem_cfg=SEM_CFG,
+               drop_p=0.0, starts=None, mmd_weight=1.0, cls_weight=1.0, src_loss_weight=1.0):
+    """Loss of one step with TARGET_LOSS 0, ADV_WEIGHT 0, past PURE_CLS_EPOCH
+    (train_dg_single_gpu.py:260-324). ``starts`` = 4 FPS start specs in call order
+    (sem-s, sem-t, node-s, node-t) or None to draw like the reference."""
+    st = starts or [None] * 4
+    ps1, ps2, fs1, fs2 = net_mda(p, model_name, data, True, st[0], drop_p, semantic_adaption=True)
+    pt1, pt2, ft1, ft2 = net_mda(p, model_name, data_t, True, st[1], drop_p, semantic_adaption=True)
+    loss_s = 0.5 * F.cross_entropy(ps1, label) + 0.5 * F.cross_entropy(ps2, label)
+    loss_cls = cls_weight * src_loss_weight * loss_s
+    node_s = net_mda(p, model_name, data, True, st[2], drop_p, node_adaptation_s=True)
+    node_t = net_mda(p, model_name, data_t, True, st[3], drop_p, node_adaptation_t=True)
+    loss_geo = mmd_weight * geo_cfg['GEO_SCALE'] * mmd_cal(label, node_s, label_t, node_t, geo_cfg, data, data_t)
+    l1 = sem_cfg['SEM_SCALE'] * mmd_cal(label, fs1, label_t, ft1, sem_cfg, ps1, pt1)
+    l2 = sem_cfg['SEM_SCALE'] * mmd_cal(label, fs2, label_t, ft2, sem_cfg, ps2, pt2)
+    loss_sem = mmd_weight * (0.5 * l1 + 0.5 * l2)
+    return loss_cls, loss_geo, loss_sem
+
+
+def synth_clouds(B, N, gen):
+    """Synthetic input of SURVEY 8d: U(-1,1)^3 then normal_pc (data/data_utils.py:5-15) -> [B,3,N,1]."""
+    pc = torch.rand(B, N, 3, generator=gen) * 2 - 1
+    pc = pc - pc.mean(dim=1, keepdim=True)
+    pc = pc / pc.pow(2).sum(-1).sqrt().max(dim=1)[0].view(B, 1, 1)
+    return pc.permute(0, 2, 1).unsqueeze(-1).contiguous()
+
+
+def is_buffer(key):
+    return key.endswith(('running_mean', 'running_var', 'num_batches_tracked'))
+
+
+def as_params(state, device=None):
+    """Clone a state dict into leaf tensors: parameters require grad, BN buffers do not."""
+    out = {}
+    for k, v in state.items():
+        t = v.detach().clone()
+        if device is not None:
+            t = t.to(device)
+        out[k] = t.requires_grad_(not is_buffer(k) and t.dtype.is_floating_point)
+    return out
+
+
+def fill_params(shapes, seed=0):
+    """Deterministic, RNG-stream-independent parameter fill shared by the golden
+    generator (applied to the reference modules) and the tests (applied to the
+    build's modules): value depends only on (key, shape, seed)."""
+    import zlib
+    out = {}
+    for k, shp in shapes.items():
+        g = torch.Generator().manual_seed((zlib.crc32(k.encode()) + seed) % (2 ** 31))
+        n = 1
+        for s in shp:
+            n *= s
+        if k.endswith('running_var'):
+            t = torch.rand(n, generator=g) * 0.5 + 0.75
+        elif k.endswith('running_mean'):
+            t = torch.randn(n, generator=g) * 0.1
+        elif k.endswith('num_batches_tracked'):
+            t = torch.zeros(n, dtype=torch.long)
+        elif len(shp) == 1 and k.endswith('weight'):        # BN / LN gains (both signs exercised)
+            t = 1.0 + 0.2 * torch.randn(n, generator=g)
+            t[::7] = -t[::7]
+        elif len(shp) == 1:
+            t = 0.1 * torch.randn(n, generator=g)
+        else:
+            fan_in = 1
+            for s in shp[1:]:
+                fan_in *= s
+            t = torch.randn(n, generator=g) * (1.0 / math.sqrt(fan_in))
+        out[k] = t.view(shp) if len(shp) else t.view(())
+    return out
