@@ -1,0 +1,184 @@
+/*
+ * sug_amd.h -- C ABI of libsug_amd.so: MI355X (gfx950) kernels for SUG's
+ * point-cloud encoder + MMD alignment hot path.
+ *
+ * Conventions (mirroring the reference's only native interface, the pybind
+ * module of model/pointnet2/src/pointnet2_api.cpp:10-24):
+ *   - the caller owns every buffer (device pointers), pre-allocates all outputs
+ *     and scratch; kernels write in place and retain nothing;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*),
+ *     re-entrant, holds no global state, never synchronises, never allocates;
+ *   - return 0 on success or a negative SUG_ERR_* code (never exit());
+ *     sug_last_error() returns a thread-local message for the last failure;
+ *   - feature tensors are point-major rows ("channel-last"): element (b,n,c) of
+ *     a [B,N,C] tensor lives at base[(b*N+n)*ld + c]; `ld` (row stride, in
+ *     elements, >= C) lets a caller write/read a column slice of a wider
+ *     buffer.  xyz tensors are dense [B,N,3].  Indices are int32.
+ *   - all arithmetic is IEEE fp32 with a fixed operation order (stated per
+ *     function) so that index results are bit-reproducible against the CPU
+ *     reference path; nothing is compiled with fast-math or fp contraction.
+ */
+#ifndef SUG_AMD_H
+#define SUG_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SUG_OK 0
+#define SUG_ERR_ARG (-1)          /* bad argument / unsupported size        */
+#define SUG_ERR_LAUNCH (-2)       /* hipLaunch failed                       */
+
+const char* sug_last_error(void);
+/* ABI version of the loaded library (bumped when a signature changes). */
+int sug_abi_version(void);
+
+/* ---- kNN graph ----------------------------------------------------------
+ * replaces knn(), model/model_utils.py:178-185 (the [B,N,N] matrix + topk).
+ * score(i,j) = (-|x_j|^2 - (-2 * <x_i,x_j>)) - |x_i|^2, <.,.> an ascending-c
+ * fma chain, |.|^2 a sequential sum of separately rounded squares; the k
+ * largest scores per i, descending, ties -> lowest j first.  Requires
+ * N >= k, 1 <= k <= 32. x: [B,N,C] rows (ld = ldx). idx: [B,N,k]. */
+int sug_knn(const float* x, int64_t ldx, int B, int N, int C, int k,
+            int32_t* idx, void* stream);
+
+/* Reverse neighbour lists of a kNN graph (needed by the EdgeConv backward):
+ * for every destination point m the entries e = n*k + j with idx[b,n,j] == m,
+ * ascending in e.  rev_off: [B,N+1] (exclusive prefix, per cloud), rev_ent:
+ * [B,N*k].  No reference counterpart (autograd's index_put_ does this
+ * implicitly, model/model_utils.py:204). */
+int sug_knn_reverse(const int32_t* idx, int B, int N, int k,
+                    int32_t* rev_off, int32_t* rev_ent, void* stream);
+
+/* ---- farthest point sampling -------------------------------------------
+ * replaces farthest_point_sample(), model/point_utils.py:5-26,
+ * model/pointnet2_utils.py:60-81, model/PTran_utils.py:53-73, and
+ * furthest_point_sampling_wrapper (model/pointnet2/src/sampling.cpp:38-39).
+ * d = ((dx*dx + dy*dy) + dz*dz); running min; arg-max ties -> lowest index.
+ * start[b] is the first centroid (the caller draws it the way the reference
+ * does: torch.randint on the CPU generator).  xyz [B,N,3], out [B,npoint].
+ * N <= 8192. */
+int sug_fps(const float* xyz, const int32_t* start, int B, int N, int npoint,
+            int32_t* out, void* stream);
+
+/* ---- ball query -----------------------------------------------------------
+ * replaces query_ball_point(radius != None), model/point_utils.py:99-106,
+ * model/pointnet2_utils.py:97-103 and ball_query_wrapper_fast
+ * (model/pointnet2/src/ball_query.cpp:14-15) with the *torch path's* rule:
+ * d = ((-2*<q,p>) + |q|^2) + |p|^2; keep !(d > r2); first nsample hits in
+ * ascending index order, short rows padded with the first hit, rows with no
+ * hit filled with N.  xyz [B,N,3], query [B,S,3], out [B,S,nsample]. */
+int sug_ball_query(const float* xyz, const float* query, int B, int N, int S,
+                   float r2, int nsample, int32_t* out, void* stream);
+
+/* ---- k nearest candidates of a few queries (full-sort semantics) ---------
+ * replaces query_ball_point(radius=None), model/point_utils.py:107-108
+ * (sort of the [B,S,N] distances, first k): ascending d (same formula as the
+ * ball query), ties -> lowest index.  k <= 64, N <= 4096.
+ * dist_out may be NULL; else [B,S,k]. */
+int sug_knn_query(const float* xyz, const float* query, int B, int N, int S,
+                  int k, int32_t* idx_out, float* dist_out, void* stream);
+
+/* ---- 3 nearest of few candidates for many queries --------------------------
+ * replaces the sort + [:3] of upsample_inter(), model/point_utils.py:153-155
+ * and three_nn_wrapper_fast (model/pointnet2/src/interpolate.cpp:14-15).
+ * query [B,N,3] (the dense cloud), cand [B,S,3] (the nodes), S <= 2048.
+ * idx3/dist3: [B,N,3], ascending d, ties -> lowest index; d is the raw
+ * expanded-form value (the 1e-10 clamp is the caller's). */
+int sug_three_nn(const float* query, const float* cand, int B, int N, int S,
+                 int32_t* idx3, float* dist3, void* stream);
+
+/* ---- row gather / scatter (index_points) ------------------------------------
+ * replaces index_points(), model/point_utils.py:60-83,
+ * model/pointnet2_utils.py:41-57 and gather_points/group_points wrappers
+ * (model/pointnet2/src/pointnet2_api.cpp:13-18).
+ * out[b,s,:] = feat[b, idx[b,s], :]; idx [B,S] (S may be npoint*nsample).
+ * Out-of-range indices (the reference's zero-hit value N) read as 0. */
+int sug_gather_rows(const float* feat, int64_t ldf, const int32_t* idx,
+                    int B, int N, int S, int C, float* out, int64_t ldo, void* stream);
+/* dfeat[b, idx[b,s], :] += g[b,s,:]  (dfeat must be zero-initialised by the caller) */
+int sug_scatter_add_rows(const float* g, int64_t ldg, const int32_t* idx,
+                         int B, int N, int S, int C, float* dfeat, int64_t ldf, void* stream);
+
+/* out[b,s,c] = max_j feat[b, idx[b,s,j], c], arg[b,s,c] = the winning point index
+ * (replaces index_points + torch.max(dim=-1), model/model_utils.py:122-123). */
+int sug_group_max(const float* feat, int64_t ldf, const int32_t* idx, int B, int N, int S,
+                  int ns, int C, float* out, int32_t* arg, void* stream);
+int sug_group_max_bwd(const float* g, const int32_t* arg, int B, int N, int S, int C,
+                      float* dfeat, int64_t ldf, void* stream);
+
+/* ---- EdgeConv: neighbour gather + BN statistics + max over k -----------------
+ * replaces get_graph_feature + conv_2d + max(dim=-1),
+ * model/model_utils.py:188-210, :8-32 and model/Model.py:88-109, using
+ * W.[x_j - x_i ; x_i] = W1.x_j + (W2-W1).x_i: the caller provides
+ * PQ[b,n,:] = [P | Q] = x[b,n,:] . [W1 ; W2-W1]^T (one dense GEMM, [B*N, 2*Co],
+ * row stride ldpq) and this kernel forms y[b,n,j,c] = P[b,idx[b,n,j],c] + Q[b,n,c]
+ * on the fly, never materialising the k-expanded tensor.
+ * Outputs: z[b,n,c]   = max_j y (gamma[c] >= 0) or min_j y (gamma[c] < 0) -- the
+ *                       element BN+LeakyReLU (monotone per channel) maps to the max;
+ *          arg[b,n,c] = the winning j (uint8);
+ *          s1[b,n,c]  = sum_j y (may be NULL; needed for the backward);
+ *          stats[0:Co] += sum y, stats[Co:2Co] += sum y^2 (fp64, caller zeroes).
+ * Co % 4 == 0, Co <= 1024, k <= 255. */
+int sug_edgeconv_fwd(const float* pq, int64_t ldpq, const int32_t* idx, const float* gamma,
+                     int B, int N, int k, int Co, float* z, uint8_t* arg, float* s1,
+                     double* stats, void* stream);
+
+/* Train-mode BatchNorm bookkeeping for a channel-last tensor: from fp64 sums of
+ * `count` values per channel produce mean/rstd and the folded affine
+ * scale = gamma*rstd, shift = beta - mean*scale; update running_mean/var the
+ * way nn.BatchNorm2d does (momentum, unbiased running variance).
+ * coef: [4,C] = scale, shift, mean, rstd.  running_* may be NULL. */
+int sug_bn_finalize(const double* stats, const float* gamma, const float* beta, int C,
+                    double count, float eps, float momentum, float* running_mean,
+                    float* running_var, float* coef, void* stream);
+
+/* out[r,c] = act(scale[c]*z[r,c] + shift[c]), act = LeakyReLU(slope) (slope 0: ReLU,
+ * slope 1: identity).  rows = B*N.  */
+int sug_affine_act(const float* z, int64_t ldz, const float* coef, int64_t rows, int C,
+                   float slope, float* out, int64_t ldo, void* stream);
+
+/* Column sums for BN over rows of a channel-last tensor: stats[0:C] += sum,
+ * stats[C:2C] += sum of squares (fp64, caller zeroes).  Used for per-point
+ * conv_2d layers (model/model_utils.py:8-32 on [B,C,N,1]). */
+int sug_col_stats(const float* y, int64_t ldy, int64_t rows, int C, double* stats, void* stream);
+
+/* EdgeConv backward, step 1: G = gout * act'(scale*z+shift);
+ * a[b,n,c] = scale[c]*G;  red[0:Co] += sum G, red[Co:2Co] += sum G*(z-mean)*rstd (fp64). */
+int sug_edgeconv_bwd_reduce(const float* gout, int64_t ldg, const float* z, const float* coef,
+                            int64_t rows, int Co, float slope, float* a, double* red, void* stream);
+/* EdgeConv backward, step 2: dPQ [B*N, 2*Co] (row stride lddpq) from a, arg, s1, PQ,
+ * the reverse lists and the reduced sums (exact train-mode BN gradient):
+ *  dQ[n,c] = a[n,c] - (scale/M)*(k*dbeta + rstd*dgamma*(s1[n,c] - k*mean))
+ *  dP[m,c] = sum_{(n,j) in rev(m)} (a[n,c]*[arg[n,c]==j] - (scale/M)*rstd*dgamma*Q[n,c])
+ *            - (scale/M)*cnt[m]*(dbeta + rstd*dgamma*(P[m,c]-mean)),   M = B*N*k. */
+int sug_edgeconv_bwd_scatter(const float* a, const uint8_t* arg, const float* s1,
+                             const float* pq, int64_t ldpq, const int32_t* rev_off,
+                             const int32_t* rev_ent, const float* coef, const double* red,
+                             int B, int N, int k, int Co, float* dpq, int64_t lddpq, void* stream);
+
+/* ---- Gaussian multi-kernel MMD --------------------------------------------------
+ * replaces _mix_rbf_kernel + _mmd2(biased=True), model/mmd.py:239-254, :274-312.
+ * Z = [X;Y] : [2m, D] rows (ld = ldz).  e_ij = n_i - 2<z_i,z_j> + n_j with n the
+ * Gram diagonal; K = sum_s exp(-e/(2 sigma_s^2)); w (NULL or [m]) multiplies the
+ * column sums of K_XY.  sums[0..2] += S_XX, S_YY, S_wXY (fp64, caller zeroes);
+ * mmd2 = (S_XX + S_YY - 2 S_wXY)/m^2 is formed by the caller.
+ * wt (NULL or [2m,2m]) receives c'_ij * dK_ij/de_ij for the backward
+ * (dZ = 2*(diag(rowsum(wt)) - wt) . Z).  neg_gamma: device array [nsigma] holding
+ * -1/(2 sigma_s^2) rounded to fp32 (the way torch rounds the python scalar,
+ * model/mmd.py:251-252); nsigma <= 8. */
+int sug_mmd_rbf(const float* z, int64_t ldz, int m, int D, const float* w,
+                const float* neg_gamma, int nsigma, double* sums, float* wt, void* stream);
+
+/* Chamfer distance per cloud pair (SDA geometric weights; geometric_weights(),
+ * model/mmd.py:107-131 -- third-party op in the reference, parity unpinned):
+ * out[b] = mean_i min_j |a_i-b_j|^2 + mean_j min_i |a_i-b_j|^2, direct-form distance.
+ * a [B,N,3], b [B,M,3], out [B] (caller zeroes). */
+int sug_chamfer(const float* a, const float* b, int B, int N, int M, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SUG_AMD_H */

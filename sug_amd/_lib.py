@@ -1,0 +1,66 @@
+"""ctypes binding of libsug_amd.so (the C ABI declared in include/sug_amd.h).
+
+There is no CPU or eager fallback: if the library is missing or a tensor is not on
+a HIP device, the calling op raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libsug_amd.so')
+
+_vp, _i32, _i64, _f32, _f64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double
+
+# symbol -> argtypes, in the order of include/sug_amd.h (restype int unless noted)
+SIGNATURES = {
+    'sug_knn': [_vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp],
+    'sug_knn_reverse': [_vp, _i32, _i32, _i32, _vp, _vp, _vp],
+    'sug_fps': [_vp, _vp, _i32, _i32, _i32, _vp, _vp],
+    'sug_ball_query': [_vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp, _vp],
+    'sug_knn_query': [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
+    'sug_three_nn': [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
+    'sug_gather_rows': [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp],
+    'sug_scatter_add_rows': [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp],
+    'sug_group_max': [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
+    'sug_group_max_bwd': [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp],
+    'sug_edgeconv_fwd': [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
+    'sug_bn_finalize': [_vp, _vp, _vp, _i32, _f64, _f32, _f32, _vp, _vp, _vp, _vp],
+    'sug_affine_act': [_vp, _i64, _vp, _i64, _i32, _f32, _vp, _i64, _vp],
+    'sug_col_stats': [_vp, _i64, _i64, _i32, _vp, _vp],
+    'sug_edgeconv_bwd_reduce': [_vp, _i64, _vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp],
+    'sug_edgeconv_bwd_scatter': [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32,
+                                 _vp, _i64, _vp],
+    'sug_mmd_rbf': [_vp, _i64, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp],
+    'sug_chamfer': [_vp, _vp, _i32, _i32, _i32, _vp, _vp],
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                'sug_amd: %s not found -- build it with `make -C sug_amd/csrc` or '
+                '`python -c "import __graft_entry__ as g; g.build()"`; there is no fallback path'
+                % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = ctypes.c_int
+        L.sug_last_error.restype = ctypes.c_char_p
+        L.sug_last_error.argtypes = []
+        L.sug_abi_version.restype = ctypes.c_int
+        L.sug_abi_version.argtypes = []
+        if L.sug_abi_version() != 1:
+            raise RuntimeError('sug_amd: ABI version mismatch, rebuild libsug_amd.so')
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError('%s failed (%d): %s' % (what, rc, lib().sug_last_error().decode()))

@@ -1,0 +1,54 @@
+// Shared helpers for the libsug_amd.so kernels (gfx950 only, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+#include "../../include/sug_amd.h"
+
+void sug_set_error(const char* fmt, ...);
+
+#define SUG_REQUIRE(cond, ...)                \
+  do {                                        \
+    if (!(cond)) {                            \
+      sug_set_error(__VA_ARGS__);             \
+      return SUG_ERR_ARG;                     \
+    }                                         \
+  } while (0)
+
+#define SUG_LAUNCH_CHECK(name)                                              \
+  do {                                                                      \
+    hipError_t e_ = hipGetLastError();                                      \
+    if (e_ != hipSuccess) {                                                 \
+      sug_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); \
+      return SUG_ERR_LAUNCH;                                                \
+    }                                                                       \
+  } while (0)
+
+#define WAVE 64
+
+static inline int sug_divup(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// |p|^2 as the CPU reference's torch.sum(x**2) over 3 channels: separately rounded
+// squares, summed left to right (verified bitwise against the reference).
+__device__ __forceinline__ float sq3(float x, float y, float z) {
+  return __fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z));
+}
+// <a,b> as the reference's K=3 sgemm: ascending fma chain.
+__device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
+  return fmaf(az, bz, fmaf(ay, by, __fmul_rn(ax, bx)));
+}
+// square_distance(src=q, dst=p), model/point_utils.py:128-130: ((-2*dot) + |q|^2) + |p|^2
+__device__ __forceinline__ float sqdist_expanded(float dot, float nq, float np) {
+  return __fadd_rn(__fadd_rn(__fmul_rn(-2.0f, dot), nq), np);
+}
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}

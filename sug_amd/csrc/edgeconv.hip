@@ -1,0 +1,380 @@
+// EdgeConv gather-reduce (forward + backward) and train-mode BatchNorm helpers for
+// channel-last tensors.  Reference: get_graph_feature + conv_2d + max over k,
+// model/model_utils.py:188-210, :8-32, model/Model.py:88-109.
+//
+// y[b,n,j,c] = P[b,idx[b,n,j],c] + Q[b,n,c] with [P|Q] = x.[W1 ; W2-W1]^T is never
+// stored: the forward keeps only the per-point extreme z (max or min by sign(gamma),
+// BN+LeakyReLU being monotone per channel), its arg, sum_j y and the fp64 BN sums.
+//
+// Data movement per cloud and layer (fp32): read PQ once for Q (4*N*Co) + k gathered
+// P rows per point (L2 hits; 4*N*k*Co), write z (4), arg (1), s1 (4) per element.
+// Lanes run along channels (float4 per lane) so every gathered row is one
+// contiguous 16*LPP-byte read.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+template <int NCH>
+__global__ __launch_bounds__(256) void edgeconv_fwd_kernel(
+    const float* __restrict__ pq, int64_t ldpq, const int32_t* __restrict__ idx,
+    const float* __restrict__ gamma, int64_t BN, int N, int k, int Co, int LPP,
+    float* __restrict__ z, uint8_t* __restrict__ arg, float* __restrict__ s1,
+    double* __restrict__ stats) {
+  extern __shared__ float s_red[];  // 2*Co
+  for (int i = threadIdx.x; i < 2 * Co; i += 256) s_red[i] = 0.f;
+  __syncthreads();
+  const int nchunk = Co >> 2;
+  const int ppb = 256 / LPP;
+  const int slot = threadIdx.x / LPP, ch0 = threadIdx.x % LPP;
+  float4 a1[NCH], a2[NCH], gs[NCH];
+#pragma unroll
+  for (int u = 0; u < NCH; ++u) {
+    a1[u] = make_float4(0, 0, 0, 0);
+    a2[u] = make_float4(0, 0, 0, 0);
+    const int ch = ch0 + u * LPP;
+    gs[u] = ch < nchunk ? ld4(gamma + ch * 4) : make_float4(1, 1, 1, 1);
+  }
+  for (int64_t p = (int64_t)blockIdx.x * ppb + slot; p < BN; p += (int64_t)gridDim.x * ppb) {
+    const int64_t b = p / N;
+    const int32_t* ir = idx + p * k;
+    const float* base = pq + b * N * ldpq;
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) {
+      const int ch = ch0 + u * LPP;
+      if (ch >= nchunk) continue;
+      const float4 q = ld4(pq + p * ldpq + Co + ch * 4);
+      float bx = 0, by = 0, bz = 0, bw = 0;
+      int jx = 0, jy = 0, jz = 0, jw = 0;
+      float sx = 0, sy = 0, sz = 0, sw = 0, qx = 0, qy = 0, qz = 0, qw = 0;
+      const bool px = gs[u].x >= 0.f, py = gs[u].y >= 0.f, pz = gs[u].z >= 0.f, pw = gs[u].w >= 0.f;
+#pragma unroll 4
+      for (int j = 0; j < k; ++j) {
+        int nb = ir[j];
+        nb = nb < 0 ? 0 : (nb >= N ? N - 1 : nb);
+        const float4 pv = ld4(base + (int64_t)nb * ldpq + ch * 4);
+        const float yx = __fadd_rn(pv.x, q.x), yy = __fadd_rn(pv.y, q.y);
+        const float yz = __fadd_rn(pv.z, q.z), yw = __fadd_rn(pv.w, q.w);
+        sx += yx; sy += yy; sz += yz; sw += yw;
+        qx = fmaf(yx, yx, qx); qy = fmaf(yy, yy, qy); qz = fmaf(yz, yz, qz); qw = fmaf(yw, yw, qw);
+        if (j == 0 || (px ? yx > bx : yx < bx)) { bx = yx; jx = j; }
+        if (j == 0 || (py ? yy > by : yy < by)) { by = yy; jy = j; }
+        if (j == 0 || (pz ? yz > bz : yz < bz)) { bz = yz; jz = j; }
+        if (j == 0 || (pw ? yw > bw : yw < bw)) { bw = yw; jw = j; }
+      }
+      const int64_t o = p * Co + ch * 4;
+      st4(z + o, make_float4(bx, by, bz, bw));
+      *reinterpret_cast<uint32_t*>(arg + o) =
+          (uint32_t)jx | ((uint32_t)jy << 8) | ((uint32_t)jz << 16) | ((uint32_t)jw << 24);
+      if (s1) st4(s1 + o, make_float4(sx, sy, sz, sw));
+      a1[u].x += sx; a1[u].y += sy; a1[u].z += sz; a1[u].w += sw;
+      a2[u].x += qx; a2[u].y += qy; a2[u].z += qz; a2[u].w += qw;
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < NCH; ++u) {
+    const int ch = ch0 + u * LPP;
+    if (ch >= nchunk) continue;
+    atomicAdd(&s_red[ch * 4 + 0], a1[u].x);
+    atomicAdd(&s_red[ch * 4 + 1], a1[u].y);
+    atomicAdd(&s_red[ch * 4 + 2], a1[u].z);
+    atomicAdd(&s_red[ch * 4 + 3], a1[u].w);
+    atomicAdd(&s_red[Co + ch * 4 + 0], a2[u].x);
+    atomicAdd(&s_red[Co + ch * 4 + 1], a2[u].y);
+    atomicAdd(&s_red[Co + ch * 4 + 2], a2[u].z);
+    atomicAdd(&s_red[Co + ch * 4 + 3], a2[u].w);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * Co; i += 256) atomicAdd(&stats[i], (double)s_red[i]);
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ stats,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, int C,
+                                                          double count, float eps, float momentum,
+                                                          float* __restrict__ rmean,
+                                                          float* __restrict__ rvar,
+                                                          float* __restrict__ coef) {
+  for (int c = blockIdx.x * 256 + threadIdx.x; c < C; c += gridDim.x * 256) {
+    const double mean = stats[c] / count;
+    double var = stats[C + c] / count - mean * mean;
+    if (var < 0) var = 0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float scale = gamma[c] * rstd;
+    coef[c] = scale;
+    coef[C + c] = beta[c] - (float)mean * scale;
+    coef[2 * C + c] = (float)mean;
+    coef[3 * C + c] = rstd;
+    if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+    if (rvar) {
+      const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+      rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ z, int64_t ldz,
+                                                         const float* __restrict__ coef, int64_t rows,
+                                                         int C, float slope, float* __restrict__ out,
+                                                         int64_t ldo) {
+  const int64_t total = rows * C;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int c = (int)(e % C);
+    const int64_t r = e / C;
+    const float u = fmaf(coef[c], z[r * ldz + c], coef[C + c]);
+    out[r * ldo + c] = u > 0.f ? u : u * slope;
+  }
+}
+
+__global__ __launch_bounds__(256) void affine_act_vec4_kernel(const float* __restrict__ z, int64_t ldz,
+                                                              const float* __restrict__ coef,
+                                                              int64_t rows, int C, float slope,
+                                                              float* __restrict__ out, int64_t ldo) {
+  const int C4 = C >> 2;
+  const int64_t total = rows * C4;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int c = (int)(e % C4) * 4;
+    const int64_t r = e / C4;
+    const float4 zv = ld4(z + r * ldz + c), sc = ld4(coef + c), sh = ld4(coef + C + c);
+    float4 u;
+    u.x = fmaf(sc.x, zv.x, sh.x); u.y = fmaf(sc.y, zv.y, sh.y);
+    u.z = fmaf(sc.z, zv.z, sh.z); u.w = fmaf(sc.w, zv.w, sh.w);
+    u.x = u.x > 0.f ? u.x : u.x * slope; u.y = u.y > 0.f ? u.y : u.y * slope;
+    u.z = u.z > 0.f ? u.z : u.z * slope; u.w = u.w > 0.f ? u.w : u.w * slope;
+    st4(out + r * ldo + c, u);
+  }
+}
+
+// Column sums (+ squares) of a [rows, C] channel-last tensor.  MODE 0: plain BN stats.
+// MODE 1: EdgeConv backward reduce (also writes a = scale*G).
+template <int MODE>
+__global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict__ y, int64_t ldy,
+                                                         const float* __restrict__ z,
+                                                         const float* __restrict__ coef, int64_t rows,
+                                                         int C, float slope, float* __restrict__ a,
+                                                         double* __restrict__ red, int CW,
+                                                         int rows_per_block) {
+  extern __shared__ float s_red[];  // 2*C
+  for (int i = threadIdx.x; i < 2 * C; i += 256) s_red[i] = 0.f;
+  __syncthreads();
+  const int RY = 256 / CW;
+  const int cx = threadIdx.x % CW, ry = threadIdx.x / CW;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  int64_t r1 = r0 + rows_per_block;
+  if (r1 > rows) r1 = rows;
+  for (int c = cx; c < C; c += CW) {
+    float s = 0.f, q = 0.f;
+    float scale = 0.f, shift = 0.f, mean = 0.f, rstd = 0.f;
+    if (MODE == 1) {
+      scale = coef[c]; shift = coef[C + c]; mean = coef[2 * C + c]; rstd = coef[3 * C + c];
+    }
+    for (int64_t r = r0 + ry; r < r1; r += RY) {
+      if (MODE == 0) {
+        const float v = y[r * ldy + c];
+        s += v;
+        q = fmaf(v, v, q);
+      } else {
+        const float zv = z[r * C + c];
+        const float u = fmaf(scale, zv, shift);
+        const float g = y[r * ldy + c] * (u > 0.f ? 1.f : slope);
+        a[r * C + c] = scale * g;
+        s += g;
+        q = fmaf(g, (zv - mean) * rstd, q);
+      }
+    }
+    atomicAdd(&s_red[c], s);
+    atomicAdd(&s_red[C + c], q);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(&red[i], (double)s_red[i]);
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void edgeconv_bwd_scatter_kernel(
+    const float* __restrict__ a, const uint8_t* __restrict__ arg, const float* __restrict__ s1,
+    const float* __restrict__ pq, int64_t ldpq, const int32_t* __restrict__ rev_off,
+    const int32_t* __restrict__ rev_ent, const float* __restrict__ coef,
+    const double* __restrict__ red, int64_t BN, int N, int k, int Co, int LPP, float invM,
+    float* __restrict__ dpq, int64_t lddpq) {
+  const int nchunk = Co >> 2;
+  const int ppb = 256 / LPP;
+  const int slot = threadIdx.x / LPP, ch0 = threadIdx.x % LPP;
+  const float kf = (float)k;
+  for (int64_t p = (int64_t)blockIdx.x * ppb + slot; p < BN; p += (int64_t)gridDim.x * ppb) {
+    const int64_t b = p / N;
+    const int m = (int)(p - b * N);
+    const int32_t* offp = rev_off + b * (N + 1) + m;
+    const int off = offp[0], cnt = offp[1] - offp[0];
+    const int32_t* ent = rev_ent + b * (int64_t)N * k + off;
+    const int64_t rowb = b * N;
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) {
+      const int ch = ch0 + u * LPP;
+      if (ch >= nchunk) continue;
+      const int c = ch * 4;
+      const float4 sc = ld4(coef + c), mean = ld4(coef + 2 * Co + c), rstd = ld4(coef + 3 * Co + c);
+      const float dbx = (float)red[c + 0], dby = (float)red[c + 1], dbz = (float)red[c + 2], dbw = (float)red[c + 3];
+      const float dgx = (float)red[Co + c + 0], dgy = (float)red[Co + c + 1];
+      const float dgz = (float)red[Co + c + 2], dgw = (float)red[Co + c + 3];
+      // f = scale/M, h = f*rstd*dgamma
+      const float fx = sc.x * invM, fy = sc.y * invM, fz = sc.z * invM, fw = sc.w * invM;
+      const float hx = fx * rstd.x * dgx, hy = fy * rstd.y * dgy, hz = fz * rstd.z * dgz, hw = fw * rstd.w * dgw;
+      float ax = 0, ay = 0, az = 0, aw = 0;
+      for (int t = 0; t < cnt; ++t) {
+        const int e = ent[t];
+        const int n = e / k, j = e - n * k;
+        const int64_t o = (rowb + n) * Co + c;
+        const float4 av = ld4(a + o);
+        const uint32_t aj = *reinterpret_cast<const uint32_t*>(arg + o);
+        const float4 qv = ld4(pq + (rowb + n) * ldpq + Co + c);
+        ax += ((int)(aj & 255u) == j ? av.x : 0.f) - hx * qv.x;
+        ay += ((int)((aj >> 8) & 255u) == j ? av.y : 0.f) - hy * qv.y;
+        az += ((int)((aj >> 16) & 255u) == j ? av.z : 0.f) - hz * qv.z;
+        aw += ((int)(aj >> 24) == j ? av.w : 0.f) - hw * qv.w;
+      }
+      const float4 pm = ld4(pq + p * ldpq + c);
+      const float cf = (float)cnt;
+      float4 dP, dQ;
+      dP.x = ax - cf * (fx * dbx + hx * (pm.x - mean.x));
+      dP.y = ay - cf * (fy * dby + hy * (pm.y - mean.y));
+      dP.z = az - cf * (fz * dbz + hz * (pm.z - mean.z));
+      dP.w = aw - cf * (fw * dbw + hw * (pm.w - mean.w));
+      const float4 ap = ld4(a + p * Co + c), sp = ld4(s1 + p * Co + c);
+      dQ.x = ap.x - (kf * fx * dbx + hx * (sp.x - kf * mean.x));
+      dQ.y = ap.y - (kf * fy * dby + hy * (sp.y - kf * mean.y));
+      dQ.z = ap.z - (kf * fz * dbz + hz * (sp.z - kf * mean.z));
+      dQ.w = ap.w - (kf * fw * dbw + hw * (sp.w - kf * mean.w));
+      st4(dpq + p * lddpq + c, dP);
+      st4(dpq + p * lddpq + Co + c, dQ);
+    }
+  }
+}
+
+inline int lanes_per_point(int Co) {
+  int lpp = 1;
+  while (lpp < (Co >> 2) && lpp < 64) lpp <<= 1;
+  return lpp;
+}
+
+inline int col_width(int C) {
+  int cw = 1;
+  while (cw < C && cw < 256) cw <<= 1;
+  return cw;
+}
+
+}  // namespace
+
+extern "C" int sug_edgeconv_fwd(const float* pq, int64_t ldpq, const int32_t* idx, const float* gamma,
+                                int B, int N, int k, int Co, float* z, uint8_t* arg, float* s1,
+                                double* stats, void* stream) {
+  SUG_REQUIRE(pq && idx && gamma && z && arg && stats, "sug_edgeconv_fwd: null pointer");
+  SUG_REQUIRE(B > 0 && N > 0 && k > 0 && k <= 255, "sug_edgeconv_fwd: bad shape B=%d N=%d k=%d", B, N, k);
+  SUG_REQUIRE(Co > 0 && Co % 4 == 0 && Co <= 1024, "sug_edgeconv_fwd: Co=%d must be a multiple of 4, <= 1024", Co);
+  SUG_REQUIRE(ldpq >= 2 * Co && ldpq % 4 == 0, "sug_edgeconv_fwd: ldpq=%lld", (long long)ldpq);
+  SUG_REQUIRE(((uintptr_t)pq % 16) == 0 && ((uintptr_t)z % 16) == 0 && ((uintptr_t)gamma % 16) == 0 &&
+                  (!s1 || ((uintptr_t)s1 % 16) == 0) && ((uintptr_t)arg % 4) == 0,
+              "sug_edgeconv_fwd: pointers must be 16-byte aligned");
+  const int lpp = lanes_per_point(Co);
+  const int nch = sug_divup(Co >> 2, lpp);
+  const int64_t BN = (int64_t)B * N;
+  const int ppb = 256 / lpp;
+  int grid = sug_divup(BN, ppb);
+  if (grid > 4096) grid = 4096;
+  const size_t sh = (size_t)2 * Co * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  if (nch == 1)
+    hipLaunchKernelGGL((edgeconv_fwd_kernel<1>), dim3(grid), dim3(256), sh, st, pq, ldpq, idx, gamma, BN, N, k, Co, lpp, z, arg, s1, stats);
+  else if (nch == 2)
+    hipLaunchKernelGGL((edgeconv_fwd_kernel<2>), dim3(grid), dim3(256), sh, st, pq, ldpq, idx, gamma, BN, N, k, Co, lpp, z, arg, s1, stats);
+  else
+    hipLaunchKernelGGL((edgeconv_fwd_kernel<4>), dim3(grid), dim3(256), sh, st, pq, ldpq, idx, gamma, BN, N, k, Co, lpp, z, arg, s1, stats);
+  SUG_LAUNCH_CHECK("sug_edgeconv_fwd");
+  return SUG_OK;
+}
+
+extern "C" int sug_bn_finalize(const double* stats, const float* gamma, const float* beta, int C,
+                               double count, float eps, float momentum, float* running_mean,
+                               float* running_var, float* coef, void* stream) {
+  SUG_REQUIRE(stats && gamma && beta && coef, "sug_bn_finalize: null pointer");
+  SUG_REQUIRE(C > 0 && count > 0, "sug_bn_finalize: bad shape");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(sug_divup(C, 256)), dim3(256), 0, (hipStream_t)stream,
+                     stats, gamma, beta, C, count, eps, momentum, running_mean, running_var, coef);
+  SUG_LAUNCH_CHECK("sug_bn_finalize");
+  return SUG_OK;
+}
+
+extern "C" int sug_affine_act(const float* z, int64_t ldz, const float* coef, int64_t rows, int C,
+                              float slope, float* out, int64_t ldo, void* stream) {
+  SUG_REQUIRE(z && coef && out, "sug_affine_act: null pointer");
+  SUG_REQUIRE(rows > 0 && C > 0 && ldz >= C && ldo >= C, "sug_affine_act: bad shape");
+  hipStream_t st = (hipStream_t)stream;
+  const bool vec = (C % 4 == 0) && (ldz % 4 == 0) && (ldo % 4 == 0) && ((uintptr_t)z % 16 == 0) &&
+                   ((uintptr_t)out % 16 == 0) && ((uintptr_t)coef % 16 == 0);
+  const int64_t total = vec ? rows * (C / 4) : rows * C;
+  int64_t g = (total + 255) / 256;
+  if (g > 4096) g = 4096;
+  if (vec)
+    hipLaunchKernelGGL(affine_act_vec4_kernel, dim3((int)g), dim3(256), 0, st, z, ldz, coef, rows, C, slope, out, ldo);
+  else
+    hipLaunchKernelGGL(affine_act_kernel, dim3((int)g), dim3(256), 0, st, z, ldz, coef, rows, C, slope, out, ldo);
+  SUG_LAUNCH_CHECK("sug_affine_act");
+  return SUG_OK;
+}
+
+extern "C" int sug_col_stats(const float* y, int64_t ldy, int64_t rows, int C, double* stats,
+                             void* stream) {
+  SUG_REQUIRE(y && stats, "sug_col_stats: null pointer");
+  SUG_REQUIRE(rows > 0 && C > 0 && C <= 8192 && ldy >= C, "sug_col_stats: bad shape");
+  const int cw = col_width(C);
+  const int rpb = 64 * (256 / cw) > 256 ? 64 * (256 / cw) : 256;
+  hipLaunchKernelGGL((col_reduce_kernel<0>), dim3(sug_divup(rows, rpb)), dim3(256),
+                     (size_t)2 * C * sizeof(float), (hipStream_t)stream, y, ldy, nullptr, nullptr, rows,
+                     C, 0.f, nullptr, stats, cw, rpb);
+  SUG_LAUNCH_CHECK("sug_col_stats");
+  return SUG_OK;
+}
+
+extern "C" int sug_edgeconv_bwd_reduce(const float* gout, int64_t ldg, const float* z, const float* coef,
+                                       int64_t rows, int Co, float slope, float* a, double* red,
+                                       void* stream) {
+  SUG_REQUIRE(gout && z && coef && a && red, "sug_edgeconv_bwd_reduce: null pointer");
+  SUG_REQUIRE(rows > 0 && Co > 0 && Co <= 8192 && ldg >= Co, "sug_edgeconv_bwd_reduce: bad shape");
+  const int cw = col_width(Co);
+  const int rpb = 64 * (256 / cw) > 256 ? 64 * (256 / cw) : 256;
+  hipLaunchKernelGGL((col_reduce_kernel<1>), dim3(sug_divup(rows, rpb)), dim3(256),
+                     (size_t)2 * Co * sizeof(float), (hipStream_t)stream, gout, ldg, z, coef, rows, Co,
+                     slope, a, red, cw, rpb);
+  SUG_LAUNCH_CHECK("sug_edgeconv_bwd_reduce");
+  return SUG_OK;
+}
+
+extern "C" int sug_edgeconv_bwd_scatter(const float* a, const uint8_t* arg, const float* s1,
+                                        const float* pq, int64_t ldpq, const int32_t* rev_off,
+                                        const int32_t* rev_ent, const float* coef, const double* red,
+                                        int B, int N, int k, int Co, float* dpq, int64_t lddpq,
+                                        void* stream) {
+  SUG_REQUIRE(a && arg && s1 && pq && rev_off && rev_ent && coef && red && dpq,
+              "sug_edgeconv_bwd_scatter: null pointer");
+  SUG_REQUIRE(B > 0 && N > 0 && k > 0 && k <= 255, "sug_edgeconv_bwd_scatter: bad shape");
+  SUG_REQUIRE(Co > 0 && Co % 4 == 0 && Co <= 1024, "sug_edgeconv_bwd_scatter: Co=%d", Co);
+  SUG_REQUIRE(ldpq >= 2 * Co && ldpq % 4 == 0 && lddpq >= 2 * Co && lddpq % 4 == 0,
+              "sug_edgeconv_bwd_scatter: bad row strides");
+  const int lpp = lanes_per_point(Co);
+  const int nch = sug_divup(Co >> 2, lpp);
+  const int64_t BN = (int64_t)B * N;
+  const int ppb = 256 / lpp;
+  int grid = sug_divup(BN, ppb);
+  if (grid > 4096) grid = 4096;
+  const float invM = (float)(1.0 / ((double)BN * k));
+  hipStream_t st = (hipStream_t)stream;
+  if (nch == 1)
+    hipLaunchKernelGGL((edgeconv_bwd_scatter_kernel<1>), dim3(grid), dim3(256), 0, st, a, arg, s1, pq, ldpq, rev_off, rev_ent, coef, red, BN, N, k, Co, lpp, invM, dpq, lddpq);
+  else if (nch == 2)
+    hipLaunchKernelGGL((edgeconv_bwd_scatter_kernel<2>), dim3(grid), dim3(256), 0, st, a, arg, s1, pq, ldpq, rev_off, rev_ent, coef, red, BN, N, k, Co, lpp, invM, dpq, lddpq);
+  else
+    hipLaunchKernelGGL((edgeconv_bwd_scatter_kernel<4>), dim3(grid), dim3(256), 0, st, a, arg, s1, pq, ldpq, rev_off, rev_ent, coef, red, BN, N, k, Co, lpp, invM, dpq, lddpq);
+  SUG_LAUNCH_CHECK("sug_edgeconv_bwd_scatter");
+  return SUG_OK;
+}

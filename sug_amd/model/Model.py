@@ -1,0 +1,219 @@
+"""Encoders, heads and the Net_MDA wrapper (mirror of the reference's model/Model.py).
+
+The forward API (`Net_MDA.forward` flags and return tuples, model/Model.py:485-520), the
+sub-module names (`g`, `c1`, `c2`, `attention_s`, `attention_t`) and every parameter name
+match the reference, so `train_dg_single_gpu.py`-style drivers and reference checkpoints
+work unchanged.  Inside, the encoders run on point-major rows [B,N,C] and call the HIP
+kernels (sug_amd.ops); inputs and outputs keep the reference layout ([B,3,N,1] in,
+[B,1024] / [B,64,64,1] out).  KPConv / PointNet++-MSG are out of scope.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from .model_utils import conv_2d, fc_layer, transform_net, adapt_layer_off, _bn_rows
+from .pointnet2_utils import PointNetSetAbstraction
+
+K = 20      # model/Model.py:52
+
+
+class CALayer(nn.Module):
+    """Channel attention on the flattened node features (model/Model.py:16-34)."""
+
+    def __init__(self, channel, reduction=8):
+        super(CALayer, self).__init__()
+        self.conv_du = nn.Sequential(
+            nn.Conv2d(channel, channel // reduction, 1, padding=0, bias=True),
+            nn.ReLU(inplace=False),
+            nn.Conv2d(channel // reduction, channel, 1, padding=0, bias=True),
+            nn.Sigmoid())
+        self.bn = nn.BatchNorm1d(4096)
+
+    def forward(self, x):
+        """x [B,4096,1,1] (or [B,4096]) -> [B,4096]; the two 1x1 convs on a 1x1 map are GEMMs."""
+        v = x.reshape(x.shape[0], -1)
+        c0, c2 = self.conv_du[0], self.conv_du[2]
+        y = F.relu(F.linear(v, c0.weight.view(c0.weight.shape[0], -1), c0.bias))
+        y = torch.sigmoid(F.linear(y, c2.weight.view(c2.weight.shape[0], -1), c2.bias))
+        return self.bn(v * y + v)
+
+
+class GradReverse(torch.autograd.Function):
+    """model/Model.py:37-50: the reference calls `.forward` directly, so it is the identity in
+    both directions; kept for API parity."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def grad_reverse(x, lambd=1.0):
+    return x.view_as(x)
+
+
+class DGCNN(nn.Module):
+    """EdgeConv encoder with the SA-node module (model/Model.py:54-121)."""
+
+    def __init__(self):
+        super(DGCNN, self).__init__()
+        self.k = K
+        self.input_transform_net = transform_net(6, 3)      # unused by forward, as in the reference
+        self.conv1 = conv_2d(6, 64, kernel=1, bias=False, activation='leakyrelu')
+        self.conv2 = conv_2d(64 * 2, 64, kernel=1, bias=False, activation='leakyrelu')
+        self.conv3 = conv_2d(64 * 2, 128, kernel=1, bias=False, activation='leakyrelu')
+        self.conv4 = conv_2d(128 * 2, 256, kernel=1, bias=False, activation='leakyrelu')
+        self.bn5 = nn.BatchNorm1d(512)
+        self.conv5 = nn.Conv1d(64 + 64 + 128 + 256, 512, kernel_size=1, bias=False)
+        self.node_fea_adapt = adapt_layer_off()
+        self.conv1d = nn.Conv1d(128, 64, 1)
+        self.dim_redu = nn.MaxPool1d(3, stride=16)
+
+    def forward(self, x, node=False, knn_idx=None):
+        """x [B,3,N,1] -> (feat [B,1024], node_fea [B,64,64,1](, None)).
+        `knn_idx` (4 tensors [B,N,k]) overrides the neighbour graphs (tests: teacher forcing)."""
+        B, N = x.size(0), x.size(2)
+        loc = x.squeeze(-1).transpose(1, 2).contiguous()              # [B,N,3] rows
+        gi = knn_idx or [None] * 4
+        nb = lambda f, i: gi[i] if gi[i] is not None else ops.knn(f, self.k)
+        x1 = self.conv1.edge_rows(loc, nb(loc, 0))                    # [B,N,64]
+        x2 = self.conv2.edge_rows(x1, nb(x1, 1))                      # [B,N,64]
+        x_, node_fea, _ = self.node_fea_adapt.rows(x2, loc)           # [B,N,128], [B,64,64]
+        x2 = F.linear(x_, self.conv1d.weight.squeeze(-1), self.conv1d.bias)
+        x3 = self.conv3.edge_rows(x2, nb(x2, 2))                      # [B,N,128]
+        x4 = self.conv4.edge_rows(x3, nb(x3, 3))                      # [B,N,256]
+        x5 = F.linear(torch.cat((x1, x2, x3, x4), dim=2), self.conv5.weight.squeeze(-1))
+        x5 = F.leaky_relu(_bn_rows(self.bn5, x5), negative_slope=0.2)
+        feat = torch.cat((x5.max(dim=1)[0], x5.mean(dim=1)), 1)
+        node_fea = node_fea.transpose(1, 2).unsqueeze(-1)             # [B,64(ch),64(node),1]
+        if node:
+            return feat, node_fea, None
+        return feat, node_fea
+
+
+class Pointnet2_g(nn.Module):
+    """PointNet++ encoder (model/Model.py:123-161)."""
+
+    def __init__(self, normal_channel=False):
+        super(Pointnet2_g, self).__init__()
+        in_channel = 6 if normal_channel else 3
+        self.normal_channel = normal_channel
+        self.num_class = 10
+        self.sa1 = PointNetSetAbstraction(512, 0.2, 32, in_channel, [64, 64, 128], False)
+        self.sa2 = PointNetSetAbstraction(128, 0.4, 64, 128 + 3, [128, 128, 256], False)
+        self.sa3 = PointNetSetAbstraction(None, None, None, 256 + 3, [256, 512, 1024], True)
+        self.channel_redu = nn.Conv2d(512, 64, 1)
+        self.dim_redu = nn.MaxPool1d(3, stride=8)
+
+    def forward(self, xyz, node=False):
+        rows = xyz.squeeze(-1).transpose(1, 2).contiguous()           # [B,N,3(+3)]
+        B = rows.shape[0]
+        norm = rows[:, :, 3:].contiguous() if self.normal_channel else None
+        loc = rows[:, :, :3].contiguous()
+        l1_xyz, l1_pts, node_fea = self.sa1.rows(loc, norm, adapt=True)     # [B,512,3], [B,512,128], [B,512,64]
+        l2_xyz, l2_pts = self.sa2.rows(l1_xyz, l1_pts)
+        _, l3_pts = self.sa3.rows(l2_xyz, l2_pts)
+        feat = l3_pts.reshape(B, 1024)
+        node_fea = self.dim_redu(node_fea.transpose(1, 2)).reshape(B, 64, 64, 1)
+        if node:
+            return feat, node_fea, None
+        return feat, node_fea
+
+
+class Pointnet_g(nn.Module):
+    """PointNet encoder with the SA-node module (model/Model.py:235-283)."""
+
+    def __init__(self):
+        super(Pointnet_g, self).__init__()
+        self.trans_net1 = transform_net(3, 3)
+        self.trans_net2 = transform_net(64, 64)
+        self.conv1 = conv_2d(3, 64, 1)
+        self.conv2 = conv_2d(64, 64, 1)
+        self.conv3 = adapt_layer_off()
+        self.conv4 = conv_2d(128, 128, 1)
+        self.conv5 = conv_2d(128, 1024, 1)
+        self.bn1 = nn.BatchNorm1d(1024)
+
+    def forward(self, x, node=False):
+        loc = x.squeeze(-1).transpose(1, 2).contiguous()              # [B,N,3]
+        y = torch.bmm(loc, self.trans_net1.rows(loc))
+        y = self.conv2.rows(self.conv1.rows(y))
+        y = torch.bmm(y, self.trans_net2.rows(y))
+        y, node_fea, node_off = self.conv3.rows(y, loc)
+        y = self.conv5.rows(self.conv4.rows(y))
+        y = self.bn1(torch.max(y, dim=1)[0])
+        node_fea = node_fea.transpose(1, 2).unsqueeze(-1)
+        node_off = node_off.transpose(1, 2)
+        if node:
+            return y, node_fea, node_off
+        return y, node_fea
+
+
+class Pointnet_c(nn.Module):
+    """Classifier head (model/Model.py:412-449)."""
+
+    def __init__(self, num_class=10, dgcnn_flag=False, PTran_flag=False):
+        super(Pointnet_c, self).__init__()
+        activate, bias = ('leakyrelu', True) if dgcnn_flag else ('relu', False)
+        self.mlp1 = fc_layer(1024, 512, bn=True, activation=activate, bias=bias)
+        self.dropout1 = nn.Dropout2d(p=0.4)
+        self.mlp2 = fc_layer(512, 256, bn=True, activation=activate, bias=True)
+        self.dropout2 = nn.Dropout2d(p=0.4)
+        self.mlp3 = nn.Linear(256, num_class)
+        self.PTran = PTran_flag
+
+    def forward(self, x, adapt=False):
+        if not self.PTran:
+            x = self.dropout1(self.mlp1(x))
+        x = self.mlp2(x)
+        mid_feature = x
+        x = self.mlp3(self.dropout2(x))
+        if adapt:
+            return x, mid_feature
+        return x
+
+
+class Net_MDA(nn.Module):
+    """model/Model.py:452-520.  model_name in {'Pointnet', 'Pointnet2', 'DGCNN'}."""
+
+    def __init__(self, model_name='Pointnet'):
+        super(Net_MDA, self).__init__()
+        self.dgcnn_flag = False
+        self.PTran_flag = False
+        if model_name == 'Pointnet':
+            self.g = Pointnet_g()
+        elif model_name == 'Pointnet2':
+            self.g = Pointnet2_g()
+        elif model_name == 'DGCNN':
+            self.g = DGCNN()
+            self.dgcnn_flag = True
+        else:
+            raise NotImplementedError("Unsupported model name")
+        self.attention_s = CALayer(64 * 64)
+        self.attention_t = CALayer(64 * 64)
+        self.c1 = Pointnet_c(dgcnn_flag=self.dgcnn_flag, PTran_flag=self.PTran_flag)
+        self.c2 = Pointnet_c(dgcnn_flag=self.dgcnn_flag, PTran_flag=self.PTran_flag)
+
+    def forward(self, x, constant=1, adaptation=False, node_vis=False, mid_feat=False, node_adaptation_s=False,
+                node_adaptation_t=False, semantic_adaption=False):
+        x, feat_ori, node_idx = self.g(x, node=True)
+        batch_size = feat_ori.size(0)
+        if node_vis:
+            return node_idx
+        if mid_feat:
+            return x, feat_ori
+        if node_adaptation_s:
+            return self.attention_s(feat_ori.contiguous().view(batch_size, -1))
+        elif node_adaptation_t:
+            return self.attention_t(feat_ori.contiguous().view(batch_size, -1))
+        if adaptation:
+            x = grad_reverse(x, constant)
+        if not semantic_adaption:
+            return self.c1(x, adapt=False), self.c2(x, adapt=False)
+        y1, sem_feature1 = self.c1(x, adapt=True)
+        y2, sem_feature2 = self.c2(x, adapt=True)
+        return y1, y2, sem_feature1, sem_feature2

@@ -1,0 +1,127 @@
+"""Gaussian multi-kernel MMD alignment loss with SDA sample weights (mirror of the
+reference's model/mmd.py: same function names, arguments and `args` dict keys).
+
+The (2m x 2m) kernel-matrix reduction runs in one HIP kernel (sug_mmd_rbf); the SDA
+weights are computed on the device (the reference round-trips them through the CPU,
+model/mmd.py:138-142, :295)."""
+from copy import deepcopy
+
+import torch
+
+from .. import ops
+from ..utils.common_utils import create_one_hot_labels, get_most_overlapped_element
+
+min_var_est = 1e-8
+sigma_list = [0.01, 0.1, 1, 10, 100]
+
+
+def mmd_cal(label_s, feat_s, label_t, feat_t, args: dict, data_s=None, data_t=None, KPC=False):
+    """model/mmd.py:25-41."""
+    sample_weights = None
+    sample_weights_flag = args.get("GEO_WEIGHTS", None) or args.get("SEM_WEIGHTS", None)
+    if data_s is not None and sample_weights_flag:
+        sample_weights = cal_sample_weights(data_s, data_t, args, label_s=label_s, label_t=label_t)
+    if args["NAME"] == "SOFT_MMD":
+        return soft_mmd(label_s, feat_s, label_t, feat_t, float(args["LABEL_SCALE"]), sample_weights=sample_weights)
+    elif args["NAME"] == "HARD_MMD":
+        return hard_mmd(label_s, feat_s, label_t, feat_t)
+    elif args["NAME"] == "MAX_HARD_MMD":
+        return max_hard_mmd(label_s, feat_s, label_t, feat_t)
+    elif args["NAME"] == "OFF":
+        return mix_rbf_mmd2(feat_s, feat_t, sigma_list)
+    raise RuntimeError("Not Supported MMD Method")
+
+
+def cal_sample_weights(data_s, data_t, args, label_s=None, label_t=None, KPC=False):
+    """model/mmd.py:44-53."""
+    if args.get("GEO_WEIGHTS", None):
+        return geometric_weights(data_s, data_t, weighting=args["GEO_WEIGHTS"], KPC=KPC)
+    elif args.get("SEM_WEIGHTS", None):
+        return prob_weights_soft(data_s, data_t, label_s, label_t, args["LABEL_WEIGHT"], args["SEM_WEIGHTS"])
+    raise RuntimeError("Not suppprted weighting opperation")
+
+
+def soft_mmd(label_s, feat_s, label_t, feat_t, label_weight, sample_weights=None):
+    """model/mmd.py:56-66: MMD on [features | one-hot(label) * label_weight]."""
+    m = feat_s.shape[0]
+    onehot = torch.cat((create_one_hot_labels(label_s), create_one_hot_labels(label_t)), 0) * label_weight
+    Z = torch.cat((torch.cat((feat_s, feat_t), 0), onehot), dim=1)          # [2m, D+10]
+    return ops.mix_rbf_mmd2_rows(Z, m, sample_weights, sigma_list)
+
+
+def hard_mmd(label_s, feat_s, label_t, feat_t):
+    """model/mmd.py:69-77."""
+    same = torch.eq(label_s, label_t)
+    return mix_rbf_mmd2(feat_s[same], feat_t[same], sigma_list)
+
+
+def max_hard_mmd(label_s, feat_s, label_t, feat_t):
+    """model/mmd.py:96-104."""
+    ind_s, ind_t = get_most_overlapped_element(label_s.cpu(), label_t.cpu())
+    assert len(ind_s) == len(ind_t), "The feature shape mis-matched"
+    return mix_rbf_mmd2(feat_s[ind_s], feat_t[ind_t], sigma_list)
+
+
+def geometric_weights(pc_s, pc_t, metric="chamfer_distance", weighting="none", KPC=False):
+    """model/mmd.py:107-131: Chamfer distance between paired clouds -> weights [1,m].
+    The reference calls a third-party ChamferDistance op; sug_chamfer follows its call-site
+    contract (parity unpinned, see oracle/ref_cpu.py:chamfer_weights)."""
+    assert pc_s.shape[0] == pc_t.shape[0]
+    if metric != "chamfer_distance":
+        raise RuntimeError("Currently Only Support CD distance")
+    if pc_s.shape[1] == 3:
+        a = pc_s.reshape(pc_s.shape[0], 3, -1).transpose(1, 2)
+        b = pc_t.reshape(pc_t.shape[0], 3, -1).transpose(1, 2)
+    else:
+        a, b = pc_s, pc_t
+    distance = ops.chamfer(a, b)
+    return distance2weights(distances=distance, method=weighting).reshape(1, -1)
+
+
+def normalized(vec):
+    """model/mmd.py:151-153 (global-sum normalisation)."""
+    vec = vec + min_var_est
+    return vec / torch.sum(vec)
+
+
+def _kl_div(x, y):
+    # scipy.special.kl_div for positive inputs (dataset_splitter.py:244-245 uses it both ways)
+    return x * torch.log(x / y) - x + y
+
+
+def prob_weights_soft(pred_s, pred_t, label_s, label_t, label_weight, weighting="mean2one"):
+    """model/mmd.py:134-148, on the device."""
+    assert label_weight < 1, "For Entropy, Label weight should be less than one"
+    a = torch.cat((torch.softmax(pred_s.detach(), dim=1).view(-1, 10),
+                   create_one_hot_labels(label_s) * label_weight), dim=1)
+    b = torch.cat((torch.softmax(pred_t.detach(), dim=1).view(-1, 10),
+                   create_one_hot_labels(label_t) * label_weight), dim=1)
+    a, b = normalized(a), normalized(b)
+    distance = (_kl_div(a, b) * 0.5 + _kl_div(b, a) * 0.5).sum(1)
+    return distance2weights(distances=distance, method=weighting).reshape(1, -1)
+
+
+def distance2weights(distances, method="naive_inverse"):
+    """model/mmd.py:178-202 for tensor inputs ('mean2one' truncates 1/mean to an integer, :200)."""
+    if method == "naive_inverse":
+        w = 1 / (distances + min_var_est)
+        weights = w / w.sum()
+    elif method == "exp_inverse":
+        w = torch.exp(-distances)
+        weights = w / w.sum()
+    elif method == "none":
+        weights = deepcopy(distances)
+    elif method == "mean2one":
+        scale_ = (1 / distances.mean()).type(torch.int)
+        weights = distances * scale_
+    else:
+        raise RuntimeError("Not supported weighting method %s" % method)
+    return weights.reshape(-1, 1).squeeze()
+
+
+def mix_rbf_mmd2(X, Y, sigma_list, biased=True, sample_weights=None):
+    """model/mmd.py:257-260 (biased estimator; the only one the reference's callers use)."""
+    assert X.size(0) == Y.size(0)
+    if not biased:
+        raise NotImplementedError("only the biased estimator is on the hot path")
+    return ops.mix_rbf_mmd2_rows(torch.cat((X, Y), 0), X.size(0), sample_weights, sigma_list)

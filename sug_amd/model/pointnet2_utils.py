@@ -1,0 +1,102 @@
+"""Point-set operators in the [B,N,C] layout and the PointNet++ set-abstraction module
+(mirror of the reference's model/pointnet2_utils.py:19-207), over the HIP kernels."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from .model_utils import _bn_rows
+
+
+def square_distance(src, dst):
+    """model/pointnet2_utils.py:19-38 ([B,N,C] x [B,M,C] -> [B,N,M]); API parity only."""
+    B, N, _ = src.shape
+    M = dst.shape[1]
+    d = -2 * torch.matmul(src, dst.permute(0, 2, 1))
+    d = d + torch.sum(src ** 2, -1).view(B, N, 1)
+    d = d + torch.sum(dst ** 2, -1).view(B, 1, M)
+    return d
+
+
+def index_points(points, idx):
+    """model/pointnet2_utils.py:41-57. points [B,N,C], idx [B,S(,K)] -> [B,S(,K),C]."""
+    return ops.gather_rows(points, idx)
+
+
+def farthest_point_sample(xyz, npoint):
+    """model/pointnet2_utils.py:60-81. xyz [B,N,3] -> [B,npoint] int64 (CPU-generator start, :72)."""
+    B, N, _ = xyz.shape
+    start = torch.randint(0, N, (B,), dtype=torch.long)
+    return ops.fps(xyz, npoint, start).long()
+
+
+def query_ball_point(radius, nsample, xyz, new_xyz):
+    """model/pointnet2_utils.py:84-104. xyz [B,N,3], new_xyz [B,S,3] -> [B,S,nsample] int64."""
+    return ops.ball_query(xyz, new_xyz, radius, nsample).long()
+
+
+def sample_and_group(npoint, radius, nsample, xyz, points, returnfps=False):
+    """model/pointnet2_utils.py:107-135 -> new_xyz [B,S,3], new_points [B,S,nsample,3+D]."""
+    B, N, C = xyz.shape
+    start = torch.randint(0, N, (B,), dtype=torch.long)
+    fps_idx = ops.fps(xyz, npoint, start)
+    new_xyz = ops.gather_rows(xyz, fps_idx)
+    idx = ops.ball_query(xyz, new_xyz, radius, nsample)
+    grouped_xyz = ops.gather_rows(xyz, idx)
+    new_points = grouped_xyz - new_xyz.view(B, npoint, 1, C)
+    if points is not None:
+        new_points = torch.cat([new_points, ops.gather_rows(points, idx)], dim=-1)
+    if returnfps:
+        return new_xyz, new_points, grouped_xyz, fps_idx.long()
+    return new_xyz, new_points
+
+
+def sample_and_group_all(xyz, points):
+    """model/pointnet2_utils.py:138-155."""
+    B, N, C = xyz.shape
+    new_xyz = torch.zeros(B, 1, C, device=xyz.device)
+    grouped = xyz.view(B, 1, N, C)
+    if points is not None:
+        grouped = torch.cat([grouped, points.view(B, 1, N, -1)], dim=-1)
+    return new_xyz, grouped
+
+
+class PointNetSetAbstraction(nn.Module):
+    """model/pointnet2_utils.py:158-207: FPS -> ball query -> group -> 1x1 conv/BN/ReLU stack ->
+    max over the group.  Parameters are named as in the reference (mlp_convs.i, mlp_bns.i)."""
+
+    def __init__(self, npoint, radius, nsample, in_channel, mlp, group_all, adapt=False):
+        super(PointNetSetAbstraction, self).__init__()
+        self.npoint, self.radius, self.nsample = npoint, radius, nsample
+        self.mlp_convs = nn.ModuleList()
+        self.mlp_bns = nn.ModuleList()
+        self.adapt = adapt
+        last = in_channel
+        for out_channel in mlp:
+            self.mlp_convs.append(nn.Conv2d(last, out_channel, 1))
+            self.mlp_bns.append(nn.BatchNorm2d(out_channel))
+            last = out_channel
+        self.group_all = group_all
+
+    def rows(self, xyz, points, adapt=False):
+        """xyz [B,N,3], points [B,N,D] or None -> new_xyz [B,S,3], feats [B,S,D'](, node [B,S,D1])."""
+        if self.group_all:
+            new_xyz, g = sample_and_group_all(xyz, points)
+        else:
+            new_xyz, g = sample_and_group(self.npoint, self.radius, self.nsample, xyz, points)
+        node = None
+        for i, conv in enumerate(self.mlp_convs):                      # g: [B,S,ns,C] rows
+            w = conv.weight.view(conv.weight.shape[0], -1)
+            g = F.relu(_bn_rows(self.mlp_bns[i], F.linear(g, w, conv.bias)))
+            if adapt and i == 1:
+                node = g
+        out = torch.max(g, dim=2)[0]
+        if adapt:
+            return new_xyz, out, torch.max(node, dim=2)[0]
+        return new_xyz, out
+
+    def forward(self, xyz, points, adapt=False):
+        """Reference layout: xyz [B,3,N], points [B,D,N] -> new_xyz [B,3,S], new_points [B,D',S]."""
+        r = self.rows(xyz.permute(0, 2, 1).contiguous(),
+                      None if points is None else points.permute(0, 2, 1).contiguous(), adapt)
+        return tuple(t.permute(0, 2, 1) for t in r)

@@ -1,0 +1,340 @@
+"""Torch-facing wrappers over the C ABI (include/sug_amd.h).
+
+Tensors are plumbing here: device memory + the current HIP stream.  Every op
+requires fp32/int32 tensors on a HIP device and raises otherwise -- there is no
+CPU path.  Feature tensors are point-major rows [B,N,C].
+"""
+import ctypes
+
+import torch
+
+from ._lib import lib, check
+
+SIGMA_LIST = (0.01, 0.1, 1, 10, 100)       # model/mmd.py:23
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _st():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError('sug_amd ops run on a HIP device only (got a %s tensor); '
+                               'there is no CPU fallback' % t.device)
+
+
+def _rows3(t):
+    """[B,N,C] fp32 rows with unit channel stride -> (B, N, C, ld); copies if the layout
+    is not expressible as a single row stride."""
+    assert t.dim() == 3 and t.dtype == torch.float32
+    B, N, C = t.shape
+    if t.stride(2) != 1 or t.stride(0) != N * t.stride(1) or t.stride(1) < C:
+        t = t.contiguous()
+    return t, B, N, C, t.stride(1)
+
+
+def _i32(t):
+    return t if t.dtype == torch.int32 else t.to(torch.int32)
+
+
+# ----------------------------------------------------------------------------- index ops
+def knn(x, k):
+    """x [B,N,C] rows -> idx [B,N,k] int32 (sug_knn)."""
+    _need_gpu(x)
+    x, B, N, C, ld = _rows3(x.detach())
+    idx = torch.empty(B, N, k, dtype=torch.int32, device=x.device)
+    check(lib().sug_knn(_p(x), ld, B, N, C, k, _p(idx), _st()), 'sug_knn')
+    return idx
+
+
+def knn_reverse(idx):
+    """idx [B,N,k] int32 -> (rev_off [B,N+1], rev_ent [B,N*k])."""
+    _need_gpu(idx)
+    idx = _i32(idx).contiguous()
+    B, N, k = idx.shape
+    off = torch.empty(B, N + 1, dtype=torch.int32, device=idx.device)
+    ent = torch.empty(B, N * k, dtype=torch.int32, device=idx.device)
+    check(lib().sug_knn_reverse(_p(idx), B, N, k, _p(off), _p(ent), _st()), 'sug_knn_reverse')
+    return off, ent
+
+
+def fps(xyz, npoint, start):
+    """xyz [B,N,3], start [B] (any int dtype/device) -> [B,npoint] int32."""
+    _need_gpu(xyz)
+    xyz = xyz.detach().contiguous()
+    B, N, _ = xyz.shape
+    start = start.to(device=xyz.device, dtype=torch.int32, non_blocking=True)
+    out = torch.empty(B, npoint, dtype=torch.int32, device=xyz.device)
+    check(lib().sug_fps(_p(xyz), _p(start), B, N, npoint, _p(out), _st()), 'sug_fps')
+    return out
+
+
+def ball_query(xyz, query, radius, nsample):
+    """xyz [B,N,3], query [B,S,3] -> [B,S,nsample] int32; r^2 rounded to fp32 the way torch
+    rounds the python scalar in `sqrdists > radius ** 2` (model/point_utils.py:102)."""
+    _need_gpu(xyz, query)
+    xyz, query = xyz.detach().contiguous(), query.detach().contiguous()
+    B, N, _ = xyz.shape
+    S = query.shape[1]
+    r2 = float(torch.tensor(radius ** 2, dtype=torch.float32))
+    out = torch.empty(B, S, nsample, dtype=torch.int32, device=xyz.device)
+    check(lib().sug_ball_query(_p(xyz), _p(query), B, N, S, r2, nsample, _p(out), _st()), 'sug_ball_query')
+    return out
+
+
+def knn_query(xyz, query, k, want_dist=False):
+    """k nearest of xyz [B,N,3] for each query [B,S,3] (sort semantics) -> idx [B,S,k]."""
+    _need_gpu(xyz, query)
+    xyz, query = xyz.detach().contiguous(), query.detach().contiguous()
+    B, N, _ = xyz.shape
+    S = query.shape[1]
+    idx = torch.empty(B, S, k, dtype=torch.int32, device=xyz.device)
+    dist = torch.empty(B, S, k, dtype=torch.float32, device=xyz.device) if want_dist else None
+    check(lib().sug_knn_query(_p(xyz), _p(query), B, N, S, k, _p(idx), _p(dist), _st()), 'sug_knn_query')
+    return (idx, dist) if want_dist else idx
+
+
+def three_nn_raw(query, cand):
+    _need_gpu(query, cand)
+    query, cand = query.detach().contiguous(), cand.detach().contiguous()
+    B, N, _ = query.shape
+    S = cand.shape[1]
+    idx = torch.empty(B, N, 3, dtype=torch.int32, device=query.device)
+    dist = torch.empty(B, N, 3, dtype=torch.float32, device=query.device)
+    check(lib().sug_three_nn(_p(query), _p(cand), B, N, S, _p(idx), _p(dist), _st()), 'sug_three_nn')
+    return idx, dist
+
+
+class _ThreeNN(torch.autograd.Function):
+    """dist3 is differentiable w.r.t. the candidate (node) positions:
+    d/dc |q-c|^2 = 2(c-q); the query cloud is an input and gets no gradient."""
+
+    @staticmethod
+    def forward(ctx, query, cand):
+        idx, dist = three_nn_raw(query, cand)
+        ctx.save_for_backward(query, cand, idx)
+        ctx.mark_non_differentiable(idx)
+        return idx, dist
+
+    @staticmethod
+    def backward(ctx, _gidx, gdist):
+        query, cand, idx = ctx.saved_tensors
+        B, N, _ = query.shape
+        S = cand.shape[1]
+        li = idx.long().view(B, N * 3)
+        sel = torch.gather(cand, 1, li.unsqueeze(-1).expand(B, N * 3, 3)).view(B, N, 3, 3)
+        g = (2.0 * gdist).unsqueeze(-1) * (sel - query.unsqueeze(2))          # [B,N,3,3]
+        gc = torch.zeros(B, S, 3, device=cand.device, dtype=cand.dtype)
+        gc.scatter_add_(1, li.unsqueeze(-1).expand(B, N * 3, 3), g.view(B, N * 3, 3))
+        return None, gc
+
+
+def three_nn(query, cand):
+    """-> (idx3 [B,N,3] int32, dist3 [B,N,3]); dist3 carries gradient to `cand`."""
+    return _ThreeNN.apply(query, cand)
+
+
+# ----------------------------------------------------------------------------- gathers
+class _GatherRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, idx):
+        _need_gpu(feat, idx)
+        feat_c, B, N, C, ld = _rows3(feat)
+        idx2 = _i32(idx).reshape(B, -1).contiguous()
+        S = idx2.shape[1]
+        out = torch.empty(B, S, C, dtype=torch.float32, device=feat.device)
+        check(lib().sug_gather_rows(_p(feat_c), ld, _p(idx2), B, N, S, C, _p(out), C, _st()), 'sug_gather_rows')
+        ctx.save_for_backward(idx2)
+        ctx.shape = (B, N, C)
+        return out.view(*idx.shape, C)
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx2,) = ctx.saved_tensors
+        B, N, C = ctx.shape
+        S = idx2.shape[1]
+        g = g.reshape(B, S, C).contiguous()
+        d = torch.zeros(B, N, C, dtype=torch.float32, device=g.device)
+        check(lib().sug_scatter_add_rows(_p(g), C, _p(idx2), B, N, S, C, _p(d), C, _st()), 'sug_scatter_add_rows')
+        return d, None
+
+
+def gather_rows(feat, idx):
+    """feat [B,N,C], idx [B,S] or [B,S,K] -> [B,S(,K),C]  (index_points)."""
+    return _GatherRows.apply(feat, idx)
+
+
+class _GroupMax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, idx):
+        _need_gpu(feat, idx)
+        feat_c, B, N, C, ld = _rows3(feat)
+        idx = _i32(idx).contiguous()
+        S, ns = idx.shape[1], idx.shape[2]
+        out = torch.empty(B, S, C, dtype=torch.float32, device=feat.device)
+        arg = torch.empty(B, S, C, dtype=torch.int32, device=feat.device)
+        check(lib().sug_group_max(_p(feat_c), ld, _p(idx), B, N, S, ns, C, _p(out), _p(arg), _st()), 'sug_group_max')
+        ctx.save_for_backward(arg)
+        ctx.shape = (B, N, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (arg,) = ctx.saved_tensors
+        B, N, C = ctx.shape
+        S = arg.shape[1]
+        g = g.contiguous()
+        d = torch.zeros(B, N, C, dtype=torch.float32, device=g.device)
+        check(lib().sug_group_max_bwd(_p(g), _p(arg), B, N, S, C, _p(d), C, _st()), 'sug_group_max_bwd')
+        return d, None
+
+
+def group_max(feat, idx):
+    """max_j feat[b, idx[b,s,j], :] -> [B,S,C]."""
+    return _GroupMax.apply(feat, idx)
+
+
+# ----------------------------------------------------------------------------- BN helpers
+def bn_coef(stats, gamma, beta, count, eps, momentum, running_mean, running_var):
+    C = gamma.numel()
+    coef = torch.empty(4, C, dtype=torch.float32, device=gamma.device)
+    check(lib().sug_bn_finalize(_p(stats), _p(gamma), _p(beta), C, float(count), eps, momentum,
+                                _p(running_mean), _p(running_var), _p(coef), _st()), 'sug_bn_finalize')
+    return coef
+
+
+def eval_coef(gamma, beta, running_mean, running_var, eps):
+    rstd = torch.rsqrt(running_var + eps)
+    scale = gamma * rstd
+    return torch.stack([scale, beta - running_mean * scale, running_mean, rstd]).contiguous()
+
+
+def affine_act(z, coef, slope, out=None):
+    """out[...,c] = leaky(scale[c]*z + shift[c]); z [..., C] rows."""
+    _need_gpu(z)
+    C = z.shape[-1]
+    z2 = z.reshape(-1, C)
+    if z2.stride(1) != 1:
+        z2 = z2.contiguous()
+    rows = z2.shape[0]
+    if out is None:
+        out = torch.empty(rows, C, dtype=torch.float32, device=z.device)
+    o2 = out.view(-1, C) if out.is_contiguous() else out
+    check(lib().sug_affine_act(_p(z2), z2.stride(0), _p(coef), rows, C, float(slope), _p(o2), o2.stride(0), _st()),
+          'sug_affine_act')
+    return out.view(*z.shape)
+
+
+# ----------------------------------------------------------------------------- EdgeConv
+class _EdgeConv(torch.autograd.Function):
+    """BN(train or eval) + LeakyReLU + max over k of y = P[idx] + Q, see include/sug_amd.h."""
+
+    @staticmethod
+    def forward(ctx, pq, idx, gamma, beta, running_mean, running_var, training, slope, eps, momentum):
+        _need_gpu(pq, idx, gamma)
+        pq, B, N, C2, ld = _rows3(pq)
+        Co = C2 // 2
+        idx = _i32(idx).contiguous()
+        k = idx.shape[2]
+        dev = pq.device
+        gamma_c, beta_c = gamma.detach().contiguous(), beta.detach().contiguous()
+        need_bwd = any(ctx.needs_input_grad[i] for i in (0, 2, 3))
+        z = torch.empty(B, N, Co, dtype=torch.float32, device=dev)
+        arg = torch.empty(B, N, Co, dtype=torch.uint8, device=dev)
+        s1 = torch.empty(B, N, Co, dtype=torch.float32, device=dev) if need_bwd else None
+        stats = torch.zeros(2 * Co, dtype=torch.float64, device=dev)
+        check(lib().sug_edgeconv_fwd(_p(pq), ld, _p(idx), _p(gamma_c), B, N, k, Co, _p(z), _p(arg), _p(s1),
+                                     _p(stats), _st()), 'sug_edgeconv_fwd')
+        if training:
+            coef = bn_coef(stats, gamma_c, beta_c, B * N * k, eps, momentum, running_mean, running_var)
+        else:
+            coef = eval_coef(gamma_c, beta_c, running_mean, running_var, eps)
+        out = affine_act(z, coef, slope)
+        if need_bwd:
+            ctx.save_for_backward(pq, idx, z, arg, s1, coef)
+            ctx.meta = (B, N, k, Co, ld, float(slope), bool(training))
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        pq, idx, z, arg, s1, coef = ctx.saved_tensors
+        B, N, k, Co, ld, slope, training = ctx.meta
+        dev = gout.device
+        gout = gout.contiguous()
+        a = torch.empty(B, N, Co, dtype=torch.float32, device=dev)
+        red = torch.zeros(2 * Co, dtype=torch.float64, device=dev)
+        check(lib().sug_edgeconv_bwd_reduce(_p(gout), Co, _p(z), _p(coef), B * N, Co, slope, _p(a), _p(red), _st()),
+              'sug_edgeconv_bwd_reduce')
+        off, ent = knn_reverse(idx)
+        dpq = torch.empty(B, N, 2 * Co, dtype=torch.float32, device=dev)
+        red_used = red if training else torch.zeros_like(red)       # eval mode: statistics are constants
+        check(lib().sug_edgeconv_bwd_scatter(_p(a), _p(arg), _p(s1), _p(pq), ld, _p(off), _p(ent), _p(coef),
+                                             _p(red_used), B, N, k, Co, _p(dpq), 2 * Co, _st()),
+              'sug_edgeconv_bwd_scatter')
+        dbeta = red[:Co].float()
+        dgamma = red[Co:].float()
+        return dpq, None, dgamma, dbeta, None, None, None, None, None, None
+
+
+def edgeconv_bn_act_max(pq, idx, gamma, beta, running_mean, running_var, training, slope, eps=1e-5, momentum=0.1):
+    """pq [B,N,2*Co] = x.[W1;W2-W1]^T, idx [B,N,k] -> [B,N,Co]."""
+    return _EdgeConv.apply(pq, idx, gamma, beta, running_mean, running_var, training, slope, eps, momentum)
+
+
+# ----------------------------------------------------------------------------- MMD
+_neg_gamma_cache = {}
+
+
+def _neg_gammas(sigmas, device):
+    key = (tuple(float(s) for s in sigmas), str(device))
+    if key not in _neg_gamma_cache:
+        vals = [-(1.0 / (2 * s ** 2)) for s in sigmas]             # python doubles, model/mmd.py:251
+        _neg_gamma_cache[key] = torch.tensor(vals, dtype=torch.float32, device=device)
+    return _neg_gamma_cache[key]
+
+
+class _MixRbfMMD2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, Z, m, w, sigmas):
+        _need_gpu(Z)
+        Zc = Z if (Z.stride(1) == 1 and Z.stride(0) >= Z.shape[1]) else Z.contiguous()
+        D = Zc.shape[1]
+        dev = Z.device
+        ng = _neg_gammas(sigmas, dev)
+        sums = torch.zeros(3, dtype=torch.float64, device=dev)
+        need = ctx.needs_input_grad[0]
+        wt = torch.empty(2 * m, 2 * m, dtype=torch.float32, device=dev) if need else None
+        wc = w.detach().reshape(-1).to(device=dev, dtype=torch.float32).contiguous() if w is not None else None
+        check(lib().sug_mmd_rbf(_p(Zc), Zc.stride(0), m, D, _p(wc), _p(ng), len(sigmas), _p(sums), _p(wt), _st()),
+              'sug_mmd_rbf')
+        if need:
+            ctx.save_for_backward(Zc, wt)
+        mm = float(m) * float(m)
+        return ((sums[0] + sums[1] - 2.0 * sums[2]) / mm).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        Z, wt = ctx.saved_tensors
+        dZ = 2.0 * (wt.sum(dim=1, keepdim=True) * Z - wt @ Z)
+        return g * dZ, None, None, None
+
+
+def mix_rbf_mmd2_rows(Z, m, sample_weights=None, sigmas=SIGMA_LIST):
+    """Z = cat(X, Y) [2m, D] -> biased MMD^2 (0-d tensor)."""
+    return _MixRbfMMD2.apply(Z, m, sample_weights, tuple(sigmas))
+
+
+def chamfer(a, b):
+    """a [B,N,3], b [B,M,3] -> [B]: mean_i min_j d + mean_j min_i d."""
+    _need_gpu(a, b)
+    a, b = a.detach().contiguous(), b.detach().contiguous()
+    B, N, _ = a.shape
+    M = b.shape[1]
+    out = torch.zeros(B, dtype=torch.float32, device=a.device)
+    check(lib().sug_chamfer(_p(a), _p(b), B, N, M, _p(out), _st()), 'sug_chamfer')
+    return out

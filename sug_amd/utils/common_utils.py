@@ -1,0 +1,30 @@
+"""The two helpers of utils/common_utils.py that model/mmd.py calls."""
+import torch
+
+
+def create_one_hot_labels(original_labels, num_class=10):
+    """utils/common_utils.py:161-164, built on the labels' own device (the reference builds
+    it on the CPU and copies it over, model/mmd.py:61-62)."""
+    n = original_labels.shape[0]
+    one_hot = torch.zeros(n, num_class, device=original_labels.device)
+    one_hot.scatter_(1, original_labels.view(-1, 1).long(), 1.0)
+    return one_hot
+
+
+def get_most_overlapped_element(vec_a, vec_b, num_class=10):
+    """utils/common_utils.py:167-194: per class, pair up min(count_a, count_b) members in
+    sorted-label order; returns the two index lists."""
+    vec_a, vec_b = vec_a.cpu(), vec_b.cpu()
+    sorted_a, order_a = torch.sort(vec_a)
+    sorted_b, order_b = torch.sort(vec_b)
+    assert torch.max(sorted_a) < num_class, "The input class is larger than pre-defined"
+    ca = torch.bincount(sorted_a, minlength=num_class).tolist()
+    cb = torch.bincount(sorted_b, minlength=num_class).tolist()
+    pick_a, pick_b, pa, pb = [], [], 0, 0
+    for c in range(num_class):
+        n = min(ca[c], cb[c])
+        pick_a.extend(range(pa, pa + n))
+        pick_b.extend(range(pb, pb + n))
+        pa += ca[c]
+        pb += cb[c]
+    return [int(order_a[i]) for i in pick_a], [int(order_b[i]) for i in pick_b]

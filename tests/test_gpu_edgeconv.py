@@ -1,0 +1,67 @@
+"""GPU parity of the fused EdgeConv layer (GEMM split + gather/BN-stat/max kernel + exact
+BN backward) against the oracle's k-expanded formulation.  fp32 tolerance 1e-4 (north star)."""
+import pytest
+import torch
+
+from oracle import ref_cpu as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _layer(C, Co, seed):
+    from sug_amd.model.model_utils import conv_2d
+    m = conv_2d(2 * C, Co, 1, activation='leakyrelu', bias=False)
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    sd = O.fill_params(shapes, seed)
+    m.load_state_dict(sd)
+    return m, sd
+
+
+@pytest.mark.parametrize('C,Co,N,k,train', [(3, 64, 256, 20, True), (64, 64, 256, 20, True),
+                                            (64, 128, 200, 20, True), (128, 256, 128, 20, True),
+                                            (64, 128, 256, 16, False), (8, 12, 100, 5, True)])
+def test_edgeconv_forward_backward(C, Co, N, k, train):
+    B = 3
+    g = torch.Generator().manual_seed(C + Co + N)
+    x = torch.randn(B, C, N, generator=g)
+    idx = torch.randint(0, N, (B, N, k), generator=g)
+    probe = torch.randn(B, Co, N, generator=g)
+    m, sd = _layer(C, Co, 5)
+    m = m.cuda().train(train)
+
+    # oracle (k-expanded: get_graph_feature -> conv -> BN -> LeakyReLU -> max)
+    p = O.as_params({'c.' + kk: v for kk, v in sd.items()})
+    xo = x.clone().requires_grad_(True)
+    yo = O.conv_bn_act(p, 'c.', O.graph_feature(xo, k, idx), 'leakyrelu', train).max(dim=-1)[0]
+    (yo * probe).sum().backward()
+
+    xg = x.transpose(1, 2).contiguous().cuda().requires_grad_(True)
+    yg = m.edge_rows(xg, idx.to(torch.int32).cuda())
+    (yg * probe.transpose(1, 2).cuda()).sum().backward()
+
+    torch.testing.assert_close(yg.detach().cpu().transpose(1, 2), yo.detach(), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(xg.grad.cpu().transpose(1, 2), xo.grad, rtol=2e-4, atol=2e-4)
+    gw = m.conv[0].weight.grad.cpu()
+    torch.testing.assert_close(gw, p['c.conv.0.weight'].grad, rtol=2e-4, atol=2e-4 * float(p['c.conv.0.weight'].grad.abs().max()))
+    torch.testing.assert_close(m.conv[1].weight.grad.cpu(), p['c.conv.1.weight'].grad, rtol=2e-4, atol=2e-3)
+    torch.testing.assert_close(m.conv[1].bias.grad.cpu(), p['c.conv.1.bias'].grad, rtol=2e-4, atol=2e-3)
+    if train:   # running statistics follow nn.BatchNorm2d (momentum 0.1, unbiased running var)
+        torch.testing.assert_close(m.conv[1].running_mean.cpu(), p['c.conv.1.running_mean'], rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(m.conv[1].running_var.cpu(), p['c.conv.1.running_var'], rtol=1e-5, atol=1e-6)
+
+
+def test_edgeconv_is_deterministic():
+    B, C, Co, N, k = 2, 64, 128, 512, 20
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, N, C, generator=g).cuda()
+    idx = torch.randint(0, N, (B, N, k), generator=g, dtype=torch.int32).cuda()
+    m, _ = _layer(C, Co, 6)
+    m = m.cuda().train()
+    outs = []
+    for _ in range(2):
+        xi = x.clone().requires_grad_(True)
+        y = m.edge_rows(xi, idx)
+        y.square().sum().backward()
+        outs.append((y.detach().clone(), xi.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1])

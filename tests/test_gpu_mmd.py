@@ -1,0 +1,65 @@
+"""GPU parity of the MMD kernel and the mmd.py mirror against goldens from the reference."""
+import pytest
+import torch
+
+from oracle import ref_cpu as O
+
+pytestmark = pytest.mark.gpu
+TOL = dict(rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize('tag,lsc', [('sem', 5.0), ('geo', 50.0), ('sem32', 5.0)])
+def test_mmd_values_and_grads(mmd_golden, tag, lsc):
+    from sug_amd.model import mmd
+    G = mmd_golden
+    X = G[tag + '_X'].cuda().requires_grad_(True)
+    Y = G[tag + '_Y'].cuda().requires_grad_(True)
+    ls, lt, w = G[tag + '_ls'].cuda(), G[tag + '_lt'].cuda(), G[tag + '_w'].cuda()
+    torch.testing.assert_close(mmd.mix_rbf_mmd2(X, Y, mmd.sigma_list).cpu(), G[tag + '_plain'], **TOL)
+    torch.testing.assert_close(mmd.mix_rbf_mmd2(X, Y, mmd.sigma_list, sample_weights=w).cpu(), G[tag + '_weighted'], **TOL)
+    v = mmd.soft_mmd(ls, X, lt, Y, lsc, sample_weights=w)
+    torch.testing.assert_close(v.detach().cpu(), G[tag + '_soft'], **TOL)
+    v.backward()
+    s = float(G[tag + '_soft_gx'].abs().max())
+    torch.testing.assert_close(X.grad.cpu(), G[tag + '_soft_gx'], rtol=1e-3, atol=1e-4 * s)
+    torch.testing.assert_close(Y.grad.cpu(), G[tag + '_soft_gy'], rtol=1e-3, atol=1e-4 * s)
+    torch.testing.assert_close(mmd.hard_mmd(ls, X, ls.clone(), Y).cpu(), G[tag + '_hard'], **TOL)
+    torch.testing.assert_close(mmd.max_hard_mmd(ls, X, lt, Y).cpu(), G[tag + '_maxhard'], **TOL)
+
+
+@pytest.mark.parametrize('tag', ['sem', 'sem32'])
+def test_sda_weights_and_mmd_cal(mmd_golden, tag):
+    from sug_amd.model import mmd
+    G = mmd_golden
+    ps, pt = G[tag + '_ps'].cuda(), G[tag + '_pt'].cuda()
+    ls, lt = G[tag + '_ls'].cuda(), G[tag + '_lt'].cuda()
+    for meth in ('mean2one', 'none'):
+        w = mmd.prob_weights_soft(ps, pt, ls, lt, 0.5, meth)
+        torch.testing.assert_close(w.cpu(), G[tag + '_pw_' + meth], rtol=1e-4, atol=1e-7)
+    cfg = {'NAME': 'SOFT_MMD', 'LABEL_SCALE': 5, 'SEM_WEIGHTS': 'none', 'LABEL_WEIGHT': 0.5}
+    v = mmd.mmd_cal(ls, G[tag + '_X'].cuda(), lt, G[tag + '_Y'].cuda(), cfg, data_s=ps, data_t=pt)
+    torch.testing.assert_close(v.cpu(), G[tag + '_cal_none'], **TOL)
+    with pytest.raises(RuntimeError):
+        mmd.mmd_cal(ls, ps, lt, pt, {'NAME': 'nope'})
+
+
+@pytest.mark.parametrize('m,D', [(256, 4106), (5, 7), (33, 266)])
+def test_mmd_vs_oracle_sizes(m, D):
+    """Full-size (global batch 256) and ragged sizes against the oracle, with gradients."""
+    from sug_amd import ops
+    g = torch.Generator().manual_seed(m + D)
+    X = torch.randn(m, D, generator=g) * (0.05 if D > 1000 else 1.0)
+    Y = torch.randn(m, D, generator=g) * (0.05 if D > 1000 else 1.0) + 0.02
+    w = torch.rand(m, generator=g) + 0.5
+    Xo, Yo = X.clone().requires_grad_(True), Y.clone().requires_grad_(True)
+    vo = O.mix_rbf_mmd2(Xo, Yo, sample_weights=w)
+    vo.backward()
+    Z = torch.cat((X, Y), 0).cuda().requires_grad_(True)
+    v = ops.mix_rbf_mmd2_rows(Z, m, w.cuda())
+    v.backward()
+    torch.testing.assert_close(v.detach().cpu(), vo.detach(), rtol=1e-4, atol=1e-5)
+    go = torch.cat((Xo.grad, Yo.grad), 0)
+    torch.testing.assert_close(Z.grad.cpu(), go, rtol=1e-3, atol=1e-4 * float(go.abs().max()))
+    # MMD of a sample with itself is exactly 0 in the biased estimator (size-independent property)
+    Zs = torch.cat((X, X), 0).cuda()
+    assert abs(float(ops.mix_rbf_mmd2_rows(Zs, m))) < 1e-6

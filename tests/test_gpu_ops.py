@@ -1,0 +1,241 @@
+"""GPU parity of the index / gather kernels (through the C ABI) against the golden
+fixtures produced by the reference and against the CPU oracle on fresh seeded inputs.
+
+Bar: indices bit-exact.  Where the CPU reference itself has exact score ties (padded
+clouds, duplicates) its topk/sort order is arbitrary; there the test demands that the
+HIP choice carries the *same score* position by position ("ties").
+"""
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import ref_cpu as O
+
+pytestmark = pytest.mark.gpu
+
+
+def rows(x):            # [B,C,N] -> [B,N,C] on the GPU
+    return x.transpose(1, 2).contiguous().cuda()
+
+
+def assert_same_or_tied(idx_hip, idx_ref, score, ulps=0):
+    """idx_* [B,N,k]; score [B,N,M] = the oracle's ranking matrix.  Exact match, or the
+    scores at the two choices agree to `ulps` units in the last place at every slot."""
+    idx_hip, idx_ref = idx_hip.cpu().long(), idx_ref.cpu().long()
+    if torch.equal(idx_hip, idx_ref):
+        return 1.0
+    sh = torch.gather(score, 2, idx_hip)
+    sr = torch.gather(score, 2, idx_ref)
+    tol = ulps * torch.finfo(torch.float32).eps * score.abs().max()
+    bad = (sh - sr).abs() > tol
+    assert not bad.any(), '%d slots differ beyond ties (max score gap %g)' % (int(bad.sum()), float((sh - sr).abs().max()))
+    return float((idx_hip == idx_ref).float().mean())
+
+
+def test_knn_xyz_grid_exact(ops_golden):
+    from sug_amd import ops
+    x = ops_golden['knn_grid_x']
+    idx = ops.knn(rows(x), 20)
+    assert torch.equal(idx.cpu().long(), ops_golden['knn_grid_idx'])
+
+
+def test_knn_xyz_random_exact(ops_golden):
+    from sug_amd import ops
+    x = ops_golden['knn_rand_x']
+    idx = ops.knn(rows(x), 20)
+    frac = assert_same_or_tied(idx, ops_golden['knn_rand_idx'], O.knn_neg_dist(x), ulps=0)
+    assert frac == 1.0, 'xyz kNN must be bit-exact on tie-free clouds (got %.6f)' % frac
+
+
+def test_knn_padded_cloud_ties(ops_golden):
+    from sug_amd import ops
+    x = ops_golden['knn_pad_x']
+    idx = ops.knn(rows(x), 20)
+    assert_same_or_tied(idx, ops_golden['knn_pad_idx'], O.knn_neg_dist(x), ulps=0)
+    # the HIP rule among exact ties is "lowest index first": deterministic
+    idx2 = ops.knn(rows(x), 20)
+    assert torch.equal(idx, idx2)
+
+
+def test_knn_feature_space_grid_exact(ops_golden):
+    from sug_amd import ops
+    x = ops_golden['knn_feat_x']
+    idx = ops.knn(rows(x), 20)
+    assert torch.equal(idx.cpu().long(), ops_golden['knn_feat_idx'])
+
+
+@pytest.mark.parametrize('C,k,N', [(64, 20, 1024), (128, 20, 1024), (3, 16, 2048), (3, 20, 1000), (5, 7, 300), (64, 32, 256)])
+def test_knn_random_features_vs_oracle(C, k, N):
+    from sug_amd import ops
+    g = torch.Generator().manual_seed(C * 1000 + k)
+    x = torch.randn(2, C, N, generator=g)
+    idx = ops.knn(rows(x), k)
+    ref = O.knn_idx(x, k)
+    # fp32 dot products of length C: CPU sgemm and the kernel's fma chain may round differently
+    frac = assert_same_or_tied(idx, ref, O.knn_neg_dist(x), ulps=8 if C > 3 else 0)
+    assert frac > 0.999
+
+
+def test_knn_column_slice_input():
+    """ld > C: neighbours of a 64-column slice of a wider row buffer."""
+    from sug_amd import ops
+    g = torch.Generator().manual_seed(3)
+    buf = torch.randn(2, 512, 192, generator=g).cuda()
+    a = ops.knn(buf[:, :, 64:128], 20)
+    b = ops.knn(buf[:, :, 64:128].contiguous(), 20)
+    assert torch.equal(a, b)
+
+
+def test_knn_reverse_lists():
+    from sug_amd import ops
+    g = torch.Generator().manual_seed(4)
+    idx = torch.randint(0, 300, (3, 300, 20), generator=g, dtype=torch.int32).cuda()
+    off, ent = ops.knn_reverse(idx)
+    off, ent, idxc = off.cpu(), ent.cpu(), idx.cpu()
+    for b in range(3):
+        flat = idxc[b].reshape(-1)
+        assert off[b, -1] == flat.numel()
+        for m in (0, 1, 17, 299):
+            lst = ent[b, off[b, m]:off[b, m + 1]]
+            want = torch.nonzero(flat == m).reshape(-1).to(torch.int32)
+            assert torch.equal(lst, want)
+
+
+def test_fps_golden(ops_golden):
+    from sug_amd import ops
+    out = ops.fps(rows(ops_golden['fps_cf_xyz']), 64, ops_golden['fps_cf_start'])
+    assert torch.equal(out.cpu().long(), ops_golden['fps_cf_idx'])
+    out = ops.fps(ops_golden['fps_cl_xyz'].cuda(), 512, ops_golden['fps_cl_start'])
+    assert torch.equal(out.cpu().long(), ops_golden['fps_cl_idx'])
+    out = ops.fps(rows(ops_golden['fps_dup_xyz']), 32, ops_golden['fps_dup_start'])
+    assert torch.equal(out.cpu().long(), ops_golden['fps_dup_idx'])
+
+
+def test_fps_draws_start_like_reference(ops_golden):
+    """The mirror function must consume the CPU generator exactly like the reference."""
+    from sug_amd.model import point_utils, pointnet2_utils
+    torch.manual_seed(777)
+    out = point_utils.farthest_point_sample(ops_golden['fps_cf_xyz'].cuda(), 64)
+    assert out.dtype == torch.int64 and torch.equal(out.cpu(), ops_golden['fps_cf_idx'])
+    torch.manual_seed(778)
+    out = pointnet2_utils.farthest_point_sample(ops_golden['fps_cl_xyz'].cuda(), 512)
+    assert torch.equal(out.cpu(), ops_golden['fps_cl_idx'])
+
+
+@pytest.mark.parametrize('N,npoint', [(100, 100), (1024, 1), (4096, 64), (777, 33)])
+def test_fps_vs_oracle_shapes(N, npoint):
+    from sug_amd import ops
+    g = torch.Generator().manual_seed(N + npoint)
+    xyz = O.synth_clouds(3, N, g).squeeze(-1)
+    start = torch.randint(0, N, (3,), generator=g)
+    out = ops.fps(rows(xyz), npoint, start)
+    assert torch.equal(out.cpu().long(), O.fps_cf(xyz, npoint, start))
+
+
+def test_ball_query_golden(ops_golden):
+    from sug_amd import ops
+    xyz, new = ops_golden['fps_cf_xyz'], ops_golden['bq_cf_new']
+    out = ops.ball_query(rows(xyz), rows(new), 0.3, 64)
+    assert torch.equal(out.cpu().long(), ops_golden['bq_cf_r03'])
+    out = ops.ball_query(rows(xyz), rows(new), 0.05, 64)
+    assert torch.equal(out.cpu().long(), ops_golden['bq_cf_small_r'])
+    x1 = ops_golden['fps_cl_xyz'][:1]
+    nx1 = O.gather_cl(x1, ops_golden['fps_cl_idx'][:1])
+    out = ops.ball_query(x1.cuda(), nx1.cuda(), 0.2, 32)
+    assert torch.equal(out.cpu().long(), ops_golden['bq_cl_r02'])
+
+
+def test_ball_query_no_hit_rows_yield_N():
+    from sug_amd import ops
+    xyz = torch.rand(1, 50, 3)
+    q = torch.full((1, 2, 3), 10.0)
+    out = ops.ball_query(xyz.cuda(), q.cuda(), 0.1, 8).cpu().long()
+    ref = O.ball_query_cl(0.1, 8, xyz, q)
+    assert torch.equal(out, ref) and int(out.min()) == 50
+
+
+def test_knn_query_golden(ops_golden):
+    from sug_amd import ops
+    xyz, moved = ops_golden['fps_cf_xyz'], ops_golden['bq_cf_moved']
+    idx, dist = ops.knn_query(rows(xyz), rows(moved), 64, want_dist=True)
+    score = O.sqdist_cf(moved, xyz)
+    assert_same_or_tied(idx, ops_golden['bq_cf_knn'], score, ulps=0)
+    assert torch.equal(dist.cpu(), torch.gather(score, 2, idx.cpu().long()))
+
+
+@pytest.mark.parametrize('N,S,k', [(2048, 5, 16), (300, 7, 64), (64, 3, 64)])
+def test_knn_query_vs_oracle(N, S, k):
+    from sug_amd import ops
+    g = torch.Generator().manual_seed(N + S)
+    xyz = O.synth_clouds(2, N, g).squeeze(-1)
+    q = torch.rand(2, 3, S, generator=g) - 0.5
+    idx = ops.knn_query(rows(xyz), rows(q), k)
+    assert_same_or_tied(idx, O.ball_query_cf(None, k, xyz, q), O.sqdist_cf(q, xyz), ulps=0)
+
+
+def test_three_nn_and_upsample_golden(ops_golden):
+    from sug_amd import ops
+    from sug_amd.model import point_utils
+    xyz, moved = ops_golden['fps_cf_xyz'], ops_golden['bq_cf_moved']
+    idx3, d3 = ops.three_nn_raw(rows(xyz), rows(moved))
+    d, i = O.sqdist_cf(xyz, moved).sort(dim=-1)
+    assert torch.equal(idx3.cpu().long(), i[:, :, :3])
+    assert torch.equal(d3.cpu(), d[:, :, :3])
+    out = point_utils.upsample_inter(xyz.cuda(), moved.cuda(), ops_golden['up_p1'].cuda(), ops_golden['up_p2'].cuda(), 3)
+    torch.testing.assert_close(out.cpu(), ops_golden['up_out'], rtol=1e-5, atol=1e-6)
+
+
+def test_gather_group_and_grads(ops_golden):
+    from sug_amd import ops
+    g = torch.Generator().manual_seed(8)
+    feat = torch.randn(2, 200, 24, generator=g)
+    idx = torch.randint(0, 200, (2, 50, 6), generator=g)
+    f_gpu = feat.cuda().requires_grad_(True)
+    f_cpu = feat.clone().requires_grad_(True)
+    out = ops.gather_rows(f_gpu, idx.cuda())
+    ref = O.gather_cl(f_cpu, idx)
+    assert torch.equal(out.detach().cpu(), ref.detach())
+    w = torch.randn(ref.shape, generator=g)
+    (out * w.cuda()).sum().backward()
+    (ref * w).sum().backward()
+    torch.testing.assert_close(f_gpu.grad.cpu(), f_cpu.grad, rtol=1e-5, atol=1e-5)
+    # grouped max + its gradient
+    f_gpu.grad = None
+    f_cpu.grad = None
+    out = ops.group_max(f_gpu, idx.cuda())
+    ref = O.gather_cl(f_cpu, idx).max(dim=2)[0]
+    assert torch.equal(out.detach().cpu(), ref.detach())
+    w = torch.randn(ref.shape, generator=g)
+    (out * w.cuda()).sum().backward()
+    (ref * w).sum().backward()
+    torch.testing.assert_close(f_gpu.grad.cpu(), f_cpu.grad, rtol=1e-5, atol=1e-5)
+
+
+def test_index_points_and_graph_feature_mirrors(ops_golden):
+    from sug_amd.model import model_utils
+    out = model_utils.get_graph_feature(ops_golden['gf_x'].cuda(), k=4, idx=ops_golden['gf_idx'].cuda())
+    assert torch.equal(out.cpu(), ops_golden['gf_out'])
+    x = ops_golden['knn_grid_x']
+    assert torch.equal(model_utils.knn(x.cuda(), 20).cpu(), ops_golden['knn_grid_idx'])
+
+
+def test_sample_and_group_golden(ops_golden):
+    from sug_amd.model import pointnet2_utils as p2
+    xs = ops_golden['fps_cl_xyz'][:, :512].contiguous()
+    pts = ops_golden['sag_pts']
+    torch.manual_seed(779)
+    nxyz, npts = p2.sample_and_group(128, 0.4, 64, xs.cuda(), pts.cuda())
+    assert torch.equal(nxyz.cpu(), ops_golden['sag_new_xyz'])
+    assert torch.equal(npts[:, :, 0].cpu(), ops_golden['sag_new_points_row0'])
+    torch.testing.assert_close(npts.sum(dim=2).cpu(), ops_golden['sag_new_points_sum'], rtol=1e-5, atol=1e-5)
+
+
+def test_chamfer_vs_oracle():
+    from sug_amd import ops
+    g = torch.Generator().manual_seed(9)
+    a, b = O.synth_clouds(3, 1024, g), O.synth_clouds(3, 1024, g)
+    d = ops.chamfer(a.squeeze(-1).transpose(1, 2).cuda(), b.squeeze(-1).transpose(1, 2).cuda())
+    pa, pb = a.squeeze(-1).transpose(1, 2), b.squeeze(-1).transpose(1, 2)
+    dm = ((pa[:, :, None] - pb[:, None]) ** 2).sum(-1)
+    ref = dm.min(2)[0].mean(1) + dm.min(1)[0].mean(1)
+    torch.testing.assert_close(d.cpu(), ref, rtol=1e-5, atol=1e-7)
