@@ -30,6 +30,11 @@ extern "C" {
 #define SUG_OK 0
 #define SUG_ERR_ARG (-1)          /* bad argument / unsupported size        */
 #define SUG_ERR_LAUNCH (-2)       /* hipLaunch failed                       */
+/* Per-channel sums (BN statistics, BN gradients) are reduced without atomics so that
+ * results are bit-reproducible run to run: kernels write one fp32 partial row per
+ * workgroup into a caller-provided workspace `ws` of SUG_STATS_BLOCKS * 2*C floats,
+ * then an ordered fp64 pass fills the 2*C-double result (no zeroing needed). */
+#define SUG_STATS_BLOCKS 1024
 
 const char* sug_last_error(void);
 /* ABI version of the loaded library (bumped when a signature changes). */
@@ -120,11 +125,12 @@ int sug_group_max_bwd(const float* g, const int32_t* arg, int B, int N, int S, i
  *                       element BN+LeakyReLU (monotone per channel) maps to the max;
  *          arg[b,n,c] = the winning j (uint8);
  *          s1[b,n,c]  = sum_j y (may be NULL; needed for the backward);
- *          stats[0:Co] += sum y, stats[Co:2Co] += sum y^2 (fp64, caller zeroes).
+ *          stats[0:Co] = sum y, stats[Co:2Co] = sum y^2 over all B*N*k values (fp64);
+ *          ws: workspace, SUG_STATS_BLOCKS*2*Co floats.
  * Co % 4 == 0, Co <= 1024, k <= 255. */
 int sug_edgeconv_fwd(const float* pq, int64_t ldpq, const int32_t* idx, const float* gamma,
                      int B, int N, int k, int Co, float* z, uint8_t* arg, float* s1,
-                     double* stats, void* stream);
+                     double* stats, float* ws, void* stream);
 
 /* Train-mode BatchNorm bookkeeping for a channel-last tensor: from fp64 sums of
  * `count` values per channel produce mean/rstd and the folded affine
@@ -140,15 +146,18 @@ int sug_bn_finalize(const double* stats, const float* gamma, const float* beta, 
 int sug_affine_act(const float* z, int64_t ldz, const float* coef, int64_t rows, int C,
                    float slope, float* out, int64_t ldo, void* stream);
 
-/* Column sums for BN over rows of a channel-last tensor: stats[0:C] += sum,
- * stats[C:2C] += sum of squares (fp64, caller zeroes).  Used for per-point
- * conv_2d layers (model/model_utils.py:8-32 on [B,C,N,1]). */
-int sug_col_stats(const float* y, int64_t ldy, int64_t rows, int C, double* stats, void* stream);
+/* Column sums for BN over rows of a channel-last tensor: stats[0:C] = sum,
+ * stats[C:2C] = sum of squares (fp64).  Used for per-point conv_2d layers
+ * (model/model_utils.py:8-32 on [B,C,N,1]).  ws: SUG_STATS_BLOCKS*2*C floats. */
+int sug_col_stats(const float* y, int64_t ldy, int64_t rows, int C, double* stats, float* ws,
+                  void* stream);
 
 /* EdgeConv backward, step 1: G = gout * act'(scale*z+shift);
- * a[b,n,c] = scale[c]*G;  red[0:Co] += sum G, red[Co:2Co] += sum G*(z-mean)*rstd (fp64). */
+ * a[b,n,c] = scale[c]*G;  red[0:Co] = sum G, red[Co:2Co] = sum G*(z-mean)*rstd (fp64).
+ * ws: SUG_STATS_BLOCKS*2*Co floats. */
 int sug_edgeconv_bwd_reduce(const float* gout, int64_t ldg, const float* z, const float* coef,
-                            int64_t rows, int Co, float slope, float* a, double* red, void* stream);
+                            int64_t rows, int Co, float slope, float* a, double* red, float* ws,
+                            void* stream);
 /* EdgeConv backward, step 2: dPQ [B*N, 2*Co] (row stride lddpq) from a, arg, s1, PQ,
  * the reverse lists and the reduced sums (exact train-mode BN gradient):
  *  dQ[n,c] = a[n,c] - (scale/M)*(k*dbeta + rstd*dgamma*(s1[n,c] - k*mean))

@@ -6,6 +6,11 @@ a HIP device, the calling op raises.
 import ctypes
 import os
 
+# torch must be imported before libsug_amd.so is opened: both need libamdhip64.so.7 and the
+# process must end up with ONE HIP runtime (torch's bundled copy), otherwise launches from this
+# library see "no ROCm-capable device".
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libsug_amd.so')
 
@@ -23,16 +28,18 @@ SIGNATURES = {
     'sug_scatter_add_rows': [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp],
     'sug_group_max': [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
     'sug_group_max_bwd': [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp],
-    'sug_edgeconv_fwd': [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
+    'sug_edgeconv_fwd': [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     'sug_bn_finalize': [_vp, _vp, _vp, _i32, _f64, _f32, _f32, _vp, _vp, _vp, _vp],
     'sug_affine_act': [_vp, _i64, _vp, _i64, _i32, _f32, _vp, _i64, _vp],
-    'sug_col_stats': [_vp, _i64, _i64, _i32, _vp, _vp],
-    'sug_edgeconv_bwd_reduce': [_vp, _i64, _vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp],
+    'sug_col_stats': [_vp, _i64, _i64, _i32, _vp, _vp, _vp],
+    'sug_edgeconv_bwd_reduce': [_vp, _i64, _vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp],
     'sug_edgeconv_bwd_scatter': [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32,
                                  _vp, _i64, _vp],
     'sug_mmd_rbf': [_vp, _i64, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp],
     'sug_chamfer': [_vp, _vp, _i32, _i32, _i32, _vp, _vp],
 }
+
+STATS_BLOCKS = 1024        # SUG_STATS_BLOCKS
 
 _lib = None
 

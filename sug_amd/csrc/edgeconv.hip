@@ -22,10 +22,8 @@ __global__ __launch_bounds__(256) void edgeconv_fwd_kernel(
     const float* __restrict__ pq, int64_t ldpq, const int32_t* __restrict__ idx,
     const float* __restrict__ gamma, int64_t BN, int N, int k, int Co, int LPP,
     float* __restrict__ z, uint8_t* __restrict__ arg, float* __restrict__ s1,
-    double* __restrict__ stats) {
-  extern __shared__ float s_red[];  // 2*Co
-  for (int i = threadIdx.x; i < 2 * Co; i += 256) s_red[i] = 0.f;
-  __syncthreads();
+    float* __restrict__ ws) {
+  extern __shared__ __attribute__((aligned(16))) float s_red[];  // [256/LPP][2*Co] per-slot partial sums
   const int nchunk = Co >> 2;
   const int ppb = 256 / LPP;
   const int slot = threadIdx.x / LPP, ch0 = threadIdx.x % LPP;
@@ -73,21 +71,32 @@ __global__ __launch_bounds__(256) void edgeconv_fwd_kernel(
       a2[u].x += qx; a2[u].y += qy; a2[u].z += qz; a2[u].w += qw;
     }
   }
+  // deterministic block reduction: every (slot, chunk) cell is written by exactly one thread,
+  // then summed over slots in a fixed order; blocks are summed in order by reduce_partials.
+  float* mine = s_red + (size_t)slot * 2 * Co;
 #pragma unroll
   for (int u = 0; u < NCH; ++u) {
     const int ch = ch0 + u * LPP;
     if (ch >= nchunk) continue;
-    atomicAdd(&s_red[ch * 4 + 0], a1[u].x);
-    atomicAdd(&s_red[ch * 4 + 1], a1[u].y);
-    atomicAdd(&s_red[ch * 4 + 2], a1[u].z);
-    atomicAdd(&s_red[ch * 4 + 3], a1[u].w);
-    atomicAdd(&s_red[Co + ch * 4 + 0], a2[u].x);
-    atomicAdd(&s_red[Co + ch * 4 + 1], a2[u].y);
-    atomicAdd(&s_red[Co + ch * 4 + 2], a2[u].z);
-    atomicAdd(&s_red[Co + ch * 4 + 3], a2[u].w);
+    st4(mine + ch * 4, a1[u]);
+    st4(mine + Co + ch * 4, a2[u]);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * Co; i += 256) atomicAdd(&stats[i], (double)s_red[i]);
+  for (int i = threadIdx.x; i < 2 * Co; i += 256) {
+    float acc = 0.f;
+    for (int sl = 0; sl < ppb; ++sl) acc += s_red[(size_t)sl * 2 * Co + i];
+    ws[(size_t)blockIdx.x * 2 * Co + i] = acc;
+  }
+}
+
+// out[i] = sum over blocks (ascending) of ws[blk][i], in fp64.
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ ws, int nblk,
+                                                              int W, double* __restrict__ out) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < W; i += gridDim.x * 256) {
+    double acc = 0.0;
+    for (int b = 0; b < nblk; ++b) acc += (double)ws[(size_t)b * W + i];
+    out[i] = acc;
+  }
 }
 
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ stats,
@@ -154,11 +163,9 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict
                                                          const float* __restrict__ z,
                                                          const float* __restrict__ coef, int64_t rows,
                                                          int C, float slope, float* __restrict__ a,
-                                                         double* __restrict__ red, int CW,
+                                                         float* __restrict__ ws, int CW,
                                                          int rows_per_block) {
-  extern __shared__ float s_red[];  // 2*C
-  for (int i = threadIdx.x; i < 2 * C; i += 256) s_red[i] = 0.f;
-  __syncthreads();
+  extern __shared__ float s_red[];  // [256/CW][2*C]
   const int RY = 256 / CW;
   const int cx = threadIdx.x % CW, ry = threadIdx.x / CW;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
@@ -184,11 +191,15 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict
         q = fmaf(g, (zv - mean) * rstd, q);
       }
     }
-    atomicAdd(&s_red[c], s);
-    atomicAdd(&s_red[C + c], q);
+    s_red[(size_t)ry * 2 * C + c] = s;
+    s_red[(size_t)ry * 2 * C + C + c] = q;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(&red[i], (double)s_red[i]);
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    float acc = 0.f;
+    for (int r = 0; r < RY; ++r) acc += s_red[(size_t)r * 2 * C + i];
+    ws[(size_t)blockIdx.x * 2 * C + i] = acc;
+  }
 }
 
 template <int NCH>
@@ -268,8 +279,8 @@ inline int col_width(int C) {
 
 extern "C" int sug_edgeconv_fwd(const float* pq, int64_t ldpq, const int32_t* idx, const float* gamma,
                                 int B, int N, int k, int Co, float* z, uint8_t* arg, float* s1,
-                                double* stats, void* stream) {
-  SUG_REQUIRE(pq && idx && gamma && z && arg && stats, "sug_edgeconv_fwd: null pointer");
+                                double* stats, float* ws, void* stream) {
+  SUG_REQUIRE(pq && idx && gamma && z && arg && stats && ws, "sug_edgeconv_fwd: null pointer");
   SUG_REQUIRE(B > 0 && N > 0 && k > 0 && k <= 255, "sug_edgeconv_fwd: bad shape B=%d N=%d k=%d", B, N, k);
   SUG_REQUIRE(Co > 0 && Co % 4 == 0 && Co <= 1024, "sug_edgeconv_fwd: Co=%d must be a multiple of 4, <= 1024", Co);
   SUG_REQUIRE(ldpq >= 2 * Co && ldpq % 4 == 0, "sug_edgeconv_fwd: ldpq=%lld", (long long)ldpq);
@@ -281,16 +292,18 @@ extern "C" int sug_edgeconv_fwd(const float* pq, int64_t ldpq, const int32_t* id
   const int64_t BN = (int64_t)B * N;
   const int ppb = 256 / lpp;
   int grid = sug_divup(BN, ppb);
-  if (grid > 4096) grid = 4096;
-  const size_t sh = (size_t)2 * Co * sizeof(float);
+  if (grid > SUG_STATS_BLOCKS) grid = SUG_STATS_BLOCKS;
+  const size_t sh = (size_t)ppb * 2 * Co * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   if (nch == 1)
-    hipLaunchKernelGGL((edgeconv_fwd_kernel<1>), dim3(grid), dim3(256), sh, st, pq, ldpq, idx, gamma, BN, N, k, Co, lpp, z, arg, s1, stats);
+    hipLaunchKernelGGL((edgeconv_fwd_kernel<1>), dim3(grid), dim3(256), sh, st, pq, ldpq, idx, gamma, BN, N, k, Co, lpp, z, arg, s1, ws);
   else if (nch == 2)
-    hipLaunchKernelGGL((edgeconv_fwd_kernel<2>), dim3(grid), dim3(256), sh, st, pq, ldpq, idx, gamma, BN, N, k, Co, lpp, z, arg, s1, stats);
+    hipLaunchKernelGGL((edgeconv_fwd_kernel<2>), dim3(grid), dim3(256), sh, st, pq, ldpq, idx, gamma, BN, N, k, Co, lpp, z, arg, s1, ws);
   else
-    hipLaunchKernelGGL((edgeconv_fwd_kernel<4>), dim3(grid), dim3(256), sh, st, pq, ldpq, idx, gamma, BN, N, k, Co, lpp, z, arg, s1, stats);
+    hipLaunchKernelGGL((edgeconv_fwd_kernel<4>), dim3(grid), dim3(256), sh, st, pq, ldpq, idx, gamma, BN, N, k, Co, lpp, z, arg, s1, ws);
   SUG_LAUNCH_CHECK("sug_edgeconv_fwd");
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(sug_divup(2 * Co, 256)), dim3(256), 0, st, ws, grid, 2 * Co, stats);
+  SUG_LAUNCH_CHECK("sug_edgeconv_fwd(reduce)");
   return SUG_OK;
 }
 
@@ -323,30 +336,45 @@ extern "C" int sug_affine_act(const float* z, int64_t ldz, const float* coef, in
   return SUG_OK;
 }
 
+// rows per block such that the grid stays within SUG_STATS_BLOCKS
+static int col_rows_per_block(int64_t rows, int cw) {
+  int64_t rpb = 64 * (256 / cw) > 256 ? 64 * (256 / cw) : 256;
+  while ((rows + rpb - 1) / rpb > SUG_STATS_BLOCKS) rpb *= 2;
+  return (int)rpb;
+}
+
 extern "C" int sug_col_stats(const float* y, int64_t ldy, int64_t rows, int C, double* stats,
-                             void* stream) {
-  SUG_REQUIRE(y && stats, "sug_col_stats: null pointer");
-  SUG_REQUIRE(rows > 0 && C > 0 && C <= 8192 && ldy >= C, "sug_col_stats: bad shape");
+                             float* ws, void* stream) {
+  SUG_REQUIRE(y && stats && ws, "sug_col_stats: null pointer");
+  SUG_REQUIRE(rows > 0 && C > 0 && C <= 4096 && ldy >= C, "sug_col_stats: bad shape");
   const int cw = col_width(C);
-  const int rpb = 64 * (256 / cw) > 256 ? 64 * (256 / cw) : 256;
-  hipLaunchKernelGGL((col_reduce_kernel<0>), dim3(sug_divup(rows, rpb)), dim3(256),
-                     (size_t)2 * C * sizeof(float), (hipStream_t)stream, y, ldy, nullptr, nullptr, rows,
-                     C, 0.f, nullptr, stats, cw, rpb);
+  const int rpb = col_rows_per_block(rows, cw);
+  const int grid = sug_divup(rows, rpb);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL((col_reduce_kernel<0>), dim3(grid), dim3(256),
+                     (size_t)(256 / cw) * 2 * C * sizeof(float), st, y, ldy, nullptr, nullptr, rows,
+                     C, 0.f, nullptr, ws, cw, rpb);
   SUG_LAUNCH_CHECK("sug_col_stats");
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(sug_divup(2 * C, 256)), dim3(256), 0, st, ws, grid, 2 * C, stats);
+  SUG_LAUNCH_CHECK("sug_col_stats(reduce)");
   return SUG_OK;
 }
 
 extern "C" int sug_edgeconv_bwd_reduce(const float* gout, int64_t ldg, const float* z, const float* coef,
                                        int64_t rows, int Co, float slope, float* a, double* red,
-                                       void* stream) {
-  SUG_REQUIRE(gout && z && coef && a && red, "sug_edgeconv_bwd_reduce: null pointer");
-  SUG_REQUIRE(rows > 0 && Co > 0 && Co <= 8192 && ldg >= Co, "sug_edgeconv_bwd_reduce: bad shape");
+                                       float* ws, void* stream) {
+  SUG_REQUIRE(gout && z && coef && a && red && ws, "sug_edgeconv_bwd_reduce: null pointer");
+  SUG_REQUIRE(rows > 0 && Co > 0 && Co <= 4096 && ldg >= Co, "sug_edgeconv_bwd_reduce: bad shape");
   const int cw = col_width(Co);
-  const int rpb = 64 * (256 / cw) > 256 ? 64 * (256 / cw) : 256;
-  hipLaunchKernelGGL((col_reduce_kernel<1>), dim3(sug_divup(rows, rpb)), dim3(256),
-                     (size_t)2 * Co * sizeof(float), (hipStream_t)stream, gout, ldg, z, coef, rows, Co,
-                     slope, a, red, cw, rpb);
+  const int rpb = col_rows_per_block(rows, cw);
+  const int grid = sug_divup(rows, rpb);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL((col_reduce_kernel<1>), dim3(grid), dim3(256),
+                     (size_t)(256 / cw) * 2 * Co * sizeof(float), st, gout, ldg, z, coef, rows, Co,
+                     slope, a, ws, cw, rpb);
   SUG_LAUNCH_CHECK("sug_edgeconv_bwd_reduce");
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(sug_divup(2 * Co, 256)), dim3(256), 0, st, ws, grid, 2 * Co, red);
+  SUG_LAUNCH_CHECK("sug_edgeconv_bwd_reduce(reduce)");
   return SUG_OK;
 }
 

@@ -73,7 +73,9 @@ __global__ __launch_bounds__(256) void mmd_rbf_kernel(const float* __restrict__ 
       const float wi = w ? w[i - m] : 1.0f;
       cf = -2.0f * wi * inv_m2;
     }
-    if (wt) wt[(int64_t)i * M2 + j] = cf * Kp;
+    // e_ii is identically 0: no gradient, and keeping cf*Kp_ii (huge) on the diagonal would
+    // cancel catastrophically in dZ = 2*(diag(rowsum(wt)) - wt).Z
+    if (wt) wt[(int64_t)i * M2 + j] = (i == j) ? 0.f : cf * Kp;
   }
   double dxx = wave_sum_d((double)kxx), dyy = wave_sum_d((double)kyy), dxy = wave_sum_d((double)kxy);
   if ((threadIdx.x & (WAVE - 1)) == 0) {

@@ -8,7 +8,7 @@ import ctypes
 
 import torch
 
-from ._lib import lib, check
+from ._lib import lib, check, STATS_BLOCKS
 
 SIGMA_LIST = (0.01, 0.1, 1, 10, 100)       # model/mmd.py:23
 
@@ -247,9 +247,10 @@ class _EdgeConv(torch.autograd.Function):
         z = torch.empty(B, N, Co, dtype=torch.float32, device=dev)
         arg = torch.empty(B, N, Co, dtype=torch.uint8, device=dev)
         s1 = torch.empty(B, N, Co, dtype=torch.float32, device=dev) if need_bwd else None
-        stats = torch.zeros(2 * Co, dtype=torch.float64, device=dev)
+        stats = torch.empty(2 * Co, dtype=torch.float64, device=dev)
+        ws = torch.empty(STATS_BLOCKS * 2 * Co, dtype=torch.float32, device=dev)
         check(lib().sug_edgeconv_fwd(_p(pq), ld, _p(idx), _p(gamma_c), B, N, k, Co, _p(z), _p(arg), _p(s1),
-                                     _p(stats), _st()), 'sug_edgeconv_fwd')
+                                     _p(stats), _p(ws), _st()), 'sug_edgeconv_fwd')
         if training:
             coef = bn_coef(stats, gamma_c, beta_c, B * N * k, eps, momentum, running_mean, running_var)
         else:
@@ -267,9 +268,10 @@ class _EdgeConv(torch.autograd.Function):
         dev = gout.device
         gout = gout.contiguous()
         a = torch.empty(B, N, Co, dtype=torch.float32, device=dev)
-        red = torch.zeros(2 * Co, dtype=torch.float64, device=dev)
-        check(lib().sug_edgeconv_bwd_reduce(_p(gout), Co, _p(z), _p(coef), B * N, Co, slope, _p(a), _p(red), _st()),
-              'sug_edgeconv_bwd_reduce')
+        red = torch.empty(2 * Co, dtype=torch.float64, device=dev)
+        ws = torch.empty(STATS_BLOCKS * 2 * Co, dtype=torch.float32, device=dev)
+        check(lib().sug_edgeconv_bwd_reduce(_p(gout), Co, _p(z), _p(coef), B * N, Co, slope, _p(a), _p(red),
+                                            _p(ws), _st()), 'sug_edgeconv_bwd_reduce')
         off, ent = knn_reverse(idx)
         dpq = torch.empty(B, N, 2 * Co, dtype=torch.float32, device=dev)
         red_used = red if training else torch.zeros_like(red)       # eval mode: statistics are constants

@@ -57,11 +57,14 @@ def test_knn_padded_cloud_ties(ops_golden):
     assert torch.equal(idx, idx2)
 
 
-def test_knn_feature_space_grid_exact(ops_golden):
+def test_knn_feature_space_golden(ops_golden):
+    """C=64: length-64 fp32 dot products round differently in the CPU sgemm and in the kernel's
+    ascending fma chain, so rank flips are allowed only between scores within a few ulps."""
     from sug_amd import ops
     x = ops_golden['knn_feat_x']
     idx = ops.knn(rows(x), 20)
-    assert torch.equal(idx.cpu().long(), ops_golden['knn_feat_idx'])
+    frac = assert_same_or_tied(idx, ops_golden['knn_feat_idx'], O.knn_neg_dist(x), ulps=8)
+    assert frac > 0.999
 
 
 @pytest.mark.parametrize('C,k,N', [(64, 20, 1024), (128, 20, 1024), (3, 16, 2048), (3, 20, 1000), (5, 7, 300), (64, 32, 256)])

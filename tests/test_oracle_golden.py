@@ -1,0 +1,107 @@
+"""CPU: the oracle (oracle/ref_cpu.py, what travels to the GPU box) reproduces the golden
+vectors produced by the reference, and the host-side mirror has the reference's parameters."""
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import ref_cpu as O
+
+
+def test_ops_oracle_vs_golden(ops_golden):
+    G = ops_golden
+    assert torch.equal(O.knn_idx(G['knn_grid_x'], 20), G['knn_grid_idx'])
+    assert torch.equal(O.knn_idx(G['knn_rand_x'], 20), G['knn_rand_idx'])
+    assert torch.equal(O.graph_feature(G['gf_x'], 4, G['gf_idx']), G['gf_out'])
+    assert torch.equal(O.fps_cf(G['fps_cf_xyz'], 64, G['fps_cf_start']), G['fps_cf_idx'])
+    assert torch.equal(O.fps_cl(G['fps_cl_xyz'], 512, G['fps_cl_start']), G['fps_cl_idx'])
+    assert torch.equal(O.fps_cf(G['fps_dup_xyz'], 32, G['fps_dup_start']), G['fps_dup_idx'])
+    torch.manual_seed(777)                      # the restatement draws the start like the reference
+    assert torch.equal(O.fps_cf(G['fps_cf_xyz'], 64), G['fps_cf_idx'])
+    xyz, new = G['fps_cf_xyz'], G['bq_cf_new']
+    assert torch.equal(O.ball_query_cf(0.3, 64, xyz, new), G['bq_cf_r03'])
+    assert torch.equal(O.ball_query_cf(0.05, 64, xyz, new), G['bq_cf_small_r'])
+    assert torch.equal(O.ball_query_cf(None, 64, xyz, G['bq_cf_moved']), G['bq_cf_knn'])
+    x1 = G['fps_cl_xyz'][:1]
+    assert torch.equal(O.ball_query_cl(0.2, 32, x1, O.gather_cl(x1, G['fps_cl_idx'][:1])), G['bq_cl_r02'])
+    torch.testing.assert_close(O.upsample_inter(xyz, G['bq_cf_moved'], G['up_p1'], G['up_p2'], 3), G['up_out'],
+                               rtol=1e-6, atol=1e-6)
+    assert torch.equal(O.sqdist_cf(new, xyz)[:, :4], G['sqd_cf'])
+    xs = G['fps_cl_xyz'][:, :512].contiguous()
+    nxyz, npts = O.sample_and_group(128, 0.4, 64, xs, G['sag_pts'], G['sag_start'])
+    assert torch.equal(nxyz, G['sag_new_xyz'])
+    assert torch.equal(npts[:, :, 0], G['sag_new_points_row0'])
+
+
+@pytest.mark.parametrize('tag,lsc', [('sem', 5.0), ('geo', 50.0), ('sem32', 5.0)])
+def test_mmd_oracle_vs_golden(mmd_golden, tag, lsc):
+    G = mmd_golden
+    X, Y = G[tag + '_X'].requires_grad_(True), G[tag + '_Y'].requires_grad_(True)
+    ls, lt, w = G[tag + '_ls'], G[tag + '_lt'], G[tag + '_w']
+    tol = dict(rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(O.mix_rbf_mmd2(X, Y), G[tag + '_plain'], **tol)
+    torch.testing.assert_close(O.mix_rbf_mmd2(X, Y, sample_weights=w), G[tag + '_weighted'], **tol)
+    v = O.soft_mmd(ls, X, lt, Y, lsc, w)
+    torch.testing.assert_close(v, G[tag + '_soft'], **tol)
+    gx, gy = torch.autograd.grad(v, (X, Y))
+    # fp32 autograd through the diagonal K_ii (gamma up to 5000) cancels only approximately, so
+    # the reference's own gradient is noise-limited at this level (MMD backward)
+    m = X.shape[0]
+    noise = 5050.5 * (4.0 / (m * m)) * max(float(X.abs().max()), lsc) * 4 * torch.finfo(torch.float32).eps
+    torch.testing.assert_close(gx, G[tag + '_soft_gx'], rtol=1e-3, atol=noise)
+    torch.testing.assert_close(O.mmd_cal(ls, X, ls.clone(), Y, {'NAME': 'HARD_MMD'}), G[tag + '_hard'], **tol)
+    torch.testing.assert_close(O.mmd_cal(ls, X, lt, Y, {'NAME': 'MAX_HARD_MMD'}), G[tag + '_maxhard'], **tol)
+    for meth in ('mean2one', 'none'):
+        torch.testing.assert_close(O.prob_weights_soft(G[tag + '_ps'], G[tag + '_pt'], ls, lt, 0.5, meth),
+                                   G[tag + '_pw_' + meth], rtol=1e-5, atol=1e-8)
+
+
+def test_pointnet_forward_oracle_vs_golden():
+    """One full encoder on CPU (PointNet, B=4): the restatement equals the reference output."""
+    G = load_golden('model_pointnet.npz')
+    from sug_amd.model.Model import Net_MDA
+    shapes = {k: tuple(v.shape) for k, v in Net_MDA('Pointnet').state_dict().items()}
+    p = O.fill_params(shapes, G['seed'])
+    torch.manual_seed(G['seed'] + 1)
+    with torch.no_grad():
+        y1, y2, s1, s2 = O.net_mda(p, 'Pointnet', G['x'], True, semantic_adaption=True)
+    torch.testing.assert_close(y1, G['y1'], rtol=1e-5, atol=2e-5)
+    torch.testing.assert_close(s2, G['s2'], rtol=1e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize('name,fname', [('DGCNN', 'model_dgcnn.npz'), ('Pointnet', 'model_pointnet.npz'),
+                                        ('Pointnet2', 'model_pointnet2.npz')])
+def test_mirror_has_reference_parameters(name, fname):
+    """Same parameter / buffer names as the reference (so its checkpoints load): every name the
+    reference produced a gradient or BN buffer for exists here, and the FPS start draws
+    recorded in the golden are what the CPU generator yields."""
+    from sug_amd.model.Model import Net_MDA
+    G = load_golden(fname)
+    net = Net_MDA(name)
+    names = set(net.state_dict().keys())
+    for k in G['grad_names'] + G['bn_names']:
+        assert k in names, k
+    B, N = G['x'].shape[0], G['x'].shape[2]
+    torch.manual_seed(G['seed'] + 1)
+    first = torch.randint(0, N, (B,))
+    want = G['start0'][0] if name == 'Pointnet2' else G['start0']
+    assert torch.equal(first, want)
+
+
+def test_mirror_refuses_to_run_without_gpu():
+    from sug_amd.model.Model import Net_MDA
+    net = Net_MDA('DGCNN')
+    with pytest.raises(RuntimeError, match='HIP device'):
+        net(torch.zeros(2, 3, 1024, 1), semantic_adaption=True)
+
+
+def test_host_helpers():
+    from sug_amd.utils.common_utils import create_one_hot_labels, get_most_overlapped_element
+    from sug_amd.model import mmd
+    lab = torch.tensor([3, 0, 9, 3])
+    assert torch.equal(create_one_hot_labels(lab), O.one_hot(lab))
+    a, b = torch.tensor([1, 3, 3, 0, 7, 1]), torch.tensor([3, 1, 1, 1, 2, 0])
+    assert get_most_overlapped_element(a, b) == O.most_overlapped(a, b)
+    d = torch.tensor([0.2, 0.3, 0.1])
+    for meth in ('mean2one', 'none', 'naive_inverse', 'exp_inverse'):
+        torch.testing.assert_close(mmd.distance2weights(d, meth), O.distance2weights(d, meth))
+    assert float(mmd.distance2weights(torch.tensor([2.0, 4.0]), 'mean2one').abs().sum()) == 0.0   # int(1/3) == 0
