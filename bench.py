@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Benchmark of the SUG hot path on MI355X: full training steps of the DGCNN-backbone
+Net_MDA with MSA + SDA losses (BASELINE.json configs[1]: N=1024, k=20, batch 32 per domain).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+A step = 2 semantic + 2 node forwards (4 encoder passes over 2B clouds), 3 soft-MMD losses
+with SDA weights, one backward, 3 Adam updates (train_dg_single_gpu.py:246-335).  Inputs are
+synthetic (U(-1,1)^3 -> normal_pc, labels randint(0,10)) and resident in HBM before the
+timed region; weights are random-init.  Prints ONE JSON line on rank 0.
+
+`roofline` describes the dominant hand-written kernel of the step, timed live with events
+on the stream it is launched on; `cpu_baseline` times the CPU oracle (oracle/ref_cpu.py,
+the restatement of the reference's algorithm) on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+FP32_PEAK_TFLOPS = 157.3       # fp32 vector = fp32-input MFMA rate
+
+
+def synth(B, N, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    def clouds():
+        pc = torch.rand(B, N, 3, generator=g) * 2 - 1
+        pc = pc - pc.mean(dim=1, keepdim=True)
+        pc = pc / pc.pow(2).sum(-1).sqrt().max(dim=1)[0].view(B, 1, 1)     # normal_pc, data/data_utils.py:5-15
+        return pc.permute(0, 2, 1).unsqueeze(-1).contiguous()
+    data, data_t = clouds(), clouds()
+    lab, lab_t = torch.randint(0, 10, (B,), generator=g), torch.randint(0, 10, (B,), generator=g)
+    return [t.to(device) for t in (data, lab, data_t, lab_t)]
+
+
+def kernel_model(name, shape):
+    """Algorithmic bytes / FLOPs of one launch (per-kernel table)."""
+    B, N, k = shape['B'], shape['N'], shape['k']
+    if name.startswith('knn'):
+        C = shape['C']
+        return {'bytes': B * (4 * C * N + 4 * N * k), 'flops': B * N * N * (2 * C + 3)}
+    if name.startswith('edgeconv_fwd'):
+        Co = shape['Co']            # read PQ (8Co) + idx (4k); write z (4Co) + arg (Co) + s1 (4Co)
+        return {'bytes': B * N * (8 * Co + 4 * k + 9 * Co), 'flops': B * N * k * Co * 6}
+    if name.startswith('edgeconv_bwd'):
+        Co = shape['Co']            # read a, arg, s1, PQ, rev lists; write dPQ (8Co)
+        return {'bytes': B * N * (4 * Co + Co + 4 * Co + 8 * Co + 8 * Co + 4 * k + 4), 'flops': B * N * k * Co * 4}
+    return {'bytes': 0, 'flops': 0}
+
+
+def cpu_baseline(B, N, steps=1):
+    """The CPU oracle's full SUG step (same algorithm as the reference: materialised [B,N,N]
+    distances + topk, k-expanded EdgeConv tensors, 4 encoder passes, 3 MMDs, backward, 3 Adam)."""
+    from oracle import ref_cpu as O
+    from sug_amd.model.Model import Net_MDA
+    torch.set_num_threads(os.cpu_count() or 1)
+    net = Net_MDA('DGCNN')
+    p = O.as_params(net.state_dict())
+    g = [v for k, v in p.items() if k.startswith('g.') and v.requires_grad]
+    opt = [torch.optim.Adam([v for k, v in p.items() if k.startswith('g.') and v.requires_grad and 'pred_offset' not in k], lr=1e-3, weight_decay=5e-5),
+           torch.optim.Adam([v for k, v in p.items() if k.startswith(('c1.', 'c2.')) and v.requires_grad], lr=1e-3, weight_decay=5e-5),
+           torch.optim.Adam(g + [v for k, v in p.items() if k.startswith('attention') and v.requires_grad], lr=1e-3, weight_decay=5e-5)]
+    data, lab, data_t, lab_t = synth(B, N, 666, 'cpu')
+    sem = dict(O.SEM_CFG)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        lc, lg, ls = O.sug_losses(p, 'DGCNN', data, lab, data_t, lab_t, O.GEO_CFG, sem, drop_p=0.4)
+        (lc + lg + ls).backward()
+        opt[2].step(); opt[0].step(); opt[1].step()
+        for o in opt:
+            o.zero_grad()
+    dt = time.perf_counter() - t0
+    return 2 * B * steps / dt, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=32, help='clouds per domain per GPU')
+    ap.add_argument('--npoints', type=int, default=1024)
+    ap.add_argument('--model', default='DGCNN')
+    ap.add_argument('--cpu-batch', type=int, default=4, help='per-domain batch of the CPU baseline sample')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+    dev = torch.device('cuda', local)
+
+    from sug_amd import ops, _lib
+    from sug_amd.model.Model import Net_MDA
+    from sug_amd.train_step import SUGStep
+    _lib.lib()                                          # fail loudly if the HIP library is missing
+
+    torch.manual_seed(666)                              # train_dg_single_gpu.py:65
+    model = Net_MDA(args.model).to(dev).train()
+    if world > 1:                                       # same initial weights on every rank
+        for t in list(model.parameters()) + list(model.buffers()):
+            dist.broadcast(t.data, 0)
+    trainer = SUGStep(model, lr=1e-3, weight_decay=5e-5)
+    B, N = args.batch, args.npoints
+    data, lab, data_t, lab_t = synth(B, N, 666 + rank, dev)
+    torch.manual_seed(666 + rank)                       # FPS start draws, per rank (train_dg.py:78)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.step(data, lab, data_t, lab_t)
+    sync()
+    ops.PROFILE = {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses = trainer.step(data, lab, data_t, lab_t)
+    sync()
+    dt = time.perf_counter() - t0
+    prof, ops.PROFILE = ops.PROFILE, None
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    loss_vals = [None if l is None else float(l) for l in losses]
+
+    if rank == 0:
+        clouds = world * 2 * B * args.steps
+        value = clouds / dt
+        # ---- per-kernel live timings (events on the launch stream) -> roofline of the dominant one
+        kern = {}
+        for name, recs in prof.items():
+            ms = [a.elapsed_time(b) for a, b, _ in recs]
+            shape = recs[0][2]
+            mdl = kernel_model(name, shape)
+            avg = sum(ms) / len(ms)
+            kern[name] = {'launches': len(ms), 'avg_ms': avg, 'total_ms': sum(ms),
+                          'GBps': mdl['bytes'] / avg / 1e6 if avg > 0 else 0.0,
+                          'TFLOPs': mdl['flops'] / avg / 1e9 if avg > 0 else 0.0, 'bytes': mdl['bytes']}
+        roofline = None
+        if kern:
+            dom = max(kern, key=lambda n: kern[n]['total_ms'])
+            kd = kern[dom]
+            ai = kernel_model(dom, prof[dom][0][2])
+            compute_bound = ai['flops'] / max(ai['bytes'], 1) > FP32_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS
+            if compute_bound:
+                roofline = {'kernel': dom, 'bound': 'mfma', 'achieved': kd['TFLOPs'], 'peak': FP32_PEAK_TFLOPS,
+                            'unit': 'TFLOP/s', 'frac': kd['TFLOPs'] / FP32_PEAK_TFLOPS, 'traffic': None,
+                            'note': 'fp32 kernel; peak = fp32 vector/MFMA rate; HBM GB/s at algorithmic bytes: %.1f' % kd['GBps']}
+            else:
+                roofline = {'kernel': dom, 'bound': 'hbm', 'achieved': kd['GBps'], 'peak': HBM_PEAK_GBS,
+                            'unit': 'GB/s', 'frac': kd['GBps'] / HBM_PEAK_GBS, 'traffic': None}
+            roofline['avg_launch_ms'] = kd['avg_ms']
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cps, secs = cpu_baseline(args.cpu_batch, N)
+            cpu = {'value': cps, 'unit': 'point-clouds/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
+                   'sample': '1 full SUG step, DGCNN N=%d, batch %d per domain (%d clouds), %.1f s'
+                             % (N, args.cpu_batch, 2 * args.cpu_batch, secs)}
+        out = {'metric': 'point-clouds/sec (train step, N=%d)' % N, 'value': value, 'unit': 'point-clouds/sec',
+               'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
+               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+               'data': 'synthetic',
+               'config': {'workload': '%s EdgeConv backbone, N=%d k=20, batch=%d per domain per GPU, MSA+SDA losses on '
+                                      '(2 sem + 2 node forwards, 3 soft-MMD, backward, 3 Adam)' % (args.model, N, B),
+                          'global_batch': world * B, 'parallelism': 'dp%d' % world},
+               'roofline': roofline, 'cpu_baseline': cpu, 'losses': loss_vals,
+               'kernels': {k: {kk: (round(vv, 5) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in kern.items()}}
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -13,6 +13,21 @@ from ._lib import lib, check, STATS_BLOCKS
 SIGMA_LIST = (0.01, 0.1, 1, 10, 100)       # model/mmd.py:23
 
 
+# bench.py sets PROFILE = {} to time selected kernels with events on the launch stream
+PROFILE = None
+
+
+def _timed(name, shape, call):
+    if PROFILE is None:
+        return call()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    r = call()
+    b.record()
+    PROFILE.setdefault(name, []).append((a, b, shape))
+    return r
+
+
 def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
@@ -48,7 +63,8 @@ def knn(x, k):
     _need_gpu(x)
     x, B, N, C, ld = _rows3(x.detach())
     idx = torch.empty(B, N, k, dtype=torch.int32, device=x.device)
-    check(lib().sug_knn(_p(x), ld, B, N, C, k, _p(idx), _st()), 'sug_knn')
+    check(_timed('knn_C%d' % C, {'B': B, 'N': N, 'C': C, 'k': k},
+                 lambda: lib().sug_knn(_p(x), ld, B, N, C, k, _p(idx), _st())), 'sug_knn')
     return idx
 
 
@@ -249,8 +265,9 @@ class _EdgeConv(torch.autograd.Function):
         s1 = torch.empty(B, N, Co, dtype=torch.float32, device=dev) if need_bwd else None
         stats = torch.empty(2 * Co, dtype=torch.float64, device=dev)
         ws = torch.empty(STATS_BLOCKS * 2 * Co, dtype=torch.float32, device=dev)
-        check(lib().sug_edgeconv_fwd(_p(pq), ld, _p(idx), _p(gamma_c), B, N, k, Co, _p(z), _p(arg), _p(s1),
-                                     _p(stats), _p(ws), _st()), 'sug_edgeconv_fwd')
+        check(_timed('edgeconv_fwd_Co%d' % Co, {'B': B, 'N': N, 'k': k, 'Co': Co},
+                     lambda: lib().sug_edgeconv_fwd(_p(pq), ld, _p(idx), _p(gamma_c), B, N, k, Co, _p(z), _p(arg),
+                                                    _p(s1), _p(stats), _p(ws), _st())), 'sug_edgeconv_fwd')
         if training:
             coef = bn_coef(stats, gamma_c, beta_c, B * N * k, eps, momentum, running_mean, running_var)
         else:
@@ -275,9 +292,10 @@ class _EdgeConv(torch.autograd.Function):
         off, ent = knn_reverse(idx)
         dpq = torch.empty(B, N, 2 * Co, dtype=torch.float32, device=dev)
         red_used = red if training else torch.zeros_like(red)       # eval mode: statistics are constants
-        check(lib().sug_edgeconv_bwd_scatter(_p(a), _p(arg), _p(s1), _p(pq), ld, _p(off), _p(ent), _p(coef),
-                                             _p(red_used), B, N, k, Co, _p(dpq), 2 * Co, _st()),
-              'sug_edgeconv_bwd_scatter')
+        check(_timed('edgeconv_bwd_scatter_Co%d' % Co, {'B': B, 'N': N, 'k': k, 'Co': Co},
+                     lambda: lib().sug_edgeconv_bwd_scatter(_p(a), _p(arg), _p(s1), _p(pq), ld, _p(off), _p(ent),
+                                                            _p(coef), _p(red_used), B, N, k, Co, _p(dpq), 2 * Co,
+                                                            _st())), 'sug_edgeconv_bwd_scatter')
         dbeta = red[:Co].float()
         dgamma = red[Co:].float()
         return dpq, None, dgamma, dbeta, None, None, None, None, None, None

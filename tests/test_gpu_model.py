@@ -87,11 +87,15 @@ def test_encoder_parity(name, fname):
         got = sd[k].double().sum().item()
         assert abs(got - v) <= 1e-4 * max(1.0, abs(v)), 'BN buffer %s: %.8g vs %.8g' % (k, got, v)
     torch.manual_seed(seed + 2)
-    close(net(G['x'].cuda(), node_adaptation_s=True), G['node_s'], 2e-4, 'node features')
+    node_s = net(G['x'].cuda(), node_adaptation_s=True)
     torch.manual_seed(seed + 3)
     feat, node = net(G['x'].cuda(), mid_feat=True)
     close(feat, G['mid_feat'], 2e-4, 'mid feat')
     close(node.reshape(node.shape[0], -1), G['mid_node'], 2e-4, 'mid node')
+    # attention output ends in BatchNorm1d over the B samples: with B=2 every channel is
+    # (x1-x2)/sqrt((x1-x2)^2/4+eps), which amplifies input rounding by up to 1/sqrt(eps) ~ 300
+    B = G['x'].shape[0]
+    close(node_s, G['node_s'], 2e-4 if B >= 4 else 2e-3, 'node features')
 
 
 def test_dgcnn_parity_teacher_forced():
