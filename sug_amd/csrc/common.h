@@ -24,6 +24,10 @@ void sug_set_error(const char* fmt, ...);
     }                                                                       \
   } while (0)
 
+// knn_mfma.hip
+int sug_knn_mfma_supported(const float* x, int64_t ldx, int C);
+int sug_knn_mfma(const float* x, int64_t ldx, int B, int N, int C, int k, int32_t* idx, hipStream_t st);
+
 #define WAVE 64
 
 static inline int sug_divup(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -89,13 +89,25 @@ __global__ __launch_bounds__(256) void edgeconv_fwd_kernel(
   }
 }
 
-// out[i] = sum over blocks (ascending) of ws[blk][i], in fp64.
+// out[i] = sum over workgroup rows of ws[row][i], in fp64, in a fixed order: 16 strided
+// partial sums per column (rows p, p+16, ...) combined in ascending p.  grid = ceil(W/16).
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ ws, int nblk,
                                                               int W, double* __restrict__ out) {
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < W; i += gridDim.x * 256) {
-    double acc = 0.0;
-    for (int b = 0; b < nblk; ++b) acc += (double)ws[(size_t)b * W + i];
-    out[i] = acc;
+  __shared__ double s_p[16][17];
+  const int cl = threadIdx.x & 15, p = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  double acc = 0.0;
+  if (c < W) {
+#pragma unroll 8
+    for (int b = p; b < nblk; b += 16) acc += (double)ws[(size_t)b * W + c];
+  }
+  s_p[p][cl] = acc;
+  __syncthreads();
+  if (p == 0 && c < W) {
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += s_p[i][cl];
+    out[c] = t;
   }
 }
 
@@ -302,7 +314,7 @@ extern "C" int sug_edgeconv_fwd(const float* pq, int64_t ldpq, const int32_t* id
   else
     hipLaunchKernelGGL((edgeconv_fwd_kernel<4>), dim3(grid), dim3(256), sh, st, pq, ldpq, idx, gamma, BN, N, k, Co, lpp, z, arg, s1, ws);
   SUG_LAUNCH_CHECK("sug_edgeconv_fwd");
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(sug_divup(2 * Co, 256)), dim3(256), 0, st, ws, grid, 2 * Co, stats);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(sug_divup(2 * Co, 16)), dim3(256), 0, st, ws, grid, 2 * Co, stats);
   SUG_LAUNCH_CHECK("sug_edgeconv_fwd(reduce)");
   return SUG_OK;
 }
@@ -355,7 +367,7 @@ extern "C" int sug_col_stats(const float* y, int64_t ldy, int64_t rows, int C, d
                      (size_t)(256 / cw) * 2 * C * sizeof(float), st, y, ldy, nullptr, nullptr, rows,
                      C, 0.f, nullptr, ws, cw, rpb);
   SUG_LAUNCH_CHECK("sug_col_stats");
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(sug_divup(2 * C, 256)), dim3(256), 0, st, ws, grid, 2 * C, stats);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(sug_divup(2 * C, 16)), dim3(256), 0, st, ws, grid, 2 * C, stats);
   SUG_LAUNCH_CHECK("sug_col_stats(reduce)");
   return SUG_OK;
 }
@@ -373,7 +385,7 @@ extern "C" int sug_edgeconv_bwd_reduce(const float* gout, int64_t ldg, const flo
                      (size_t)(256 / cw) * 2 * Co * sizeof(float), st, gout, ldg, z, coef, rows, Co,
                      slope, a, ws, cw, rpb);
   SUG_LAUNCH_CHECK("sug_edgeconv_bwd_reduce");
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(sug_divup(2 * Co, 256)), dim3(256), 0, st, ws, grid, 2 * Co, red);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(sug_divup(2 * Co, 16)), dim3(256), 0, st, ws, grid, 2 * Co, red);
   SUG_LAUNCH_CHECK("sug_edgeconv_bwd_reduce(reduce)");
   return SUG_OK;
 }
