@@ -25,7 +25,7 @@ void sug_set_error(const char* fmt, ...);
   } while (0)
 
 // knn_mfma.hip
-int sug_knn_mfma_supported(const float* x, int64_t ldx, int C);
+int sug_knn_mfma_supported(const float* x, int64_t ldx, int C, int k);
 int sug_knn_mfma(const float* x, int64_t ldx, int B, int N, int C, int k, int32_t* idx, hipStream_t st);
 
 #define WAVE 64

@@ -15,19 +15,27 @@
 // flight under the MFMA chain).  LDS rows are stored de-interleaved [even feats | odd feats]
 // so one ds_read_b128 feeds the A operand of four consecutive k-steps (lanes 0-31 supply
 // k=2s, lanes 32-63 k=2s+1); row stride C+4 floats keeps the b128 reads conflict-free.
-// Selection: a score passes a (stale) k-th-best threshold test and is appended to a per-lane
-// LDS FIFO; FIFOs are drained into the register lists only when one is nearly full, which
-// cuts the number of wave-wide insertion sweeps ~4x versus inserting slot by slot.
+// Selection (what bounds this kernel): two sweeps -- see knn_mfma_kernel.
 //
 // Algorithmic bytes 4*C*N + 4*N*k per cloud; FLOPs N^2*(2C+3): compute bound.
 #include "common.h"
+#include <type_traits>
+
+#ifdef SUG_KNN_STAMP      // diagnostic build only (tools/bench_knn.py): per-phase cycle stamps of block 0
+__device__ unsigned long long g_knn_stamp[8];
+extern "C" int sug_debug_read_stamps(unsigned long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_knn_stamp), sizeof(g_knn_stamp));
+}
+#define STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_knn_stamp[i] = clock64(); } while (0)
+#else
+#define STAMP(i)
+#endif
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int TJ = 32;   // candidate rows per tile = MFMA M
-constexpr int QC = 32;   // FIFO capacity per lane
 
 template <int K>
 __device__ __forceinline__ void insert_desc(float (&v)[K], int (&id)[K], float s, int j) {
@@ -136,15 +144,65 @@ __device__ __forceinline__ void tile_store(const TileRegs<CP>& t, float* __restr
   }
 }
 
+// S^T tile of one candidate tile against the wave's 32 queries (k-ordered fp32 fma chain).
+template <int CP>
+__device__ __forceinline__ f32x16 score_tile(const float* __restrict__ arow, const float (&bq)[CP / 2]) {
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  if constexpr (CP == 4) {
+    const float2 a2 = *reinterpret_cast<const float2*>(arow);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.x, bq[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.y, bq[1], acc, 0, 0, 0);
+  } else {
+#pragma unroll
+    for (int g = 0; g < CP / 8; ++g) {
+      const float4 a4 = *reinterpret_cast<const float4*>(arow + 4 * g);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, bq[4 * g + 0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, bq[4 * g + 1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, bq[4 * g + 2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, bq[4 * g + 3], acc, 0, 0, 0);
+    }
+  }
+  return acc;
+}
+
+// Sortable 64-bit key of a (score, index) pair: larger key = better neighbour
+// (higher score; among equal scores the lower index).
+__device__ __forceinline__ unsigned long long pack_key(float s, int j) {
+  unsigned int u = __float_as_uint(s);
+  u ^= (u >> 31) ? 0xffffffffu : 0x80000000u;
+  return ((unsigned long long)u << 32) | (unsigned int)(0x7fffffff - j);
+}
+
+// Ring capacity per lane (entries of 8 B): the LDS budget is 160 KB per workgroup.
+template <int CP>
+struct RingCap { static constexpr int value = (CP == 128) ? 48 : 64; };
+
+// One sweep over the candidates, branch-free per candidate:
+//  * the K best SCORES of a lane stay sorted in registers: inserting s into a descending list
+//    is new[t] = med3(old[t-1], old[t], s), one v_med3_f32 per slot, no indices;
+//  * a candidate that beats the current K-th score (i.e. enters the list) is also appended,
+//    with its index, to a per-lane LDS ring by a predicated store (a rejected candidate writes
+//    the dummy slot CAP).  Every member of the final top-K is in the ring; about
+//    K(1+ln(n/K)) ~ 85 entries pass per lane over a cloud, so the ring (CAP ~ 64) is
+//    compacted -- keep score > tau plus the first ties at tau, tau = current K-th score --
+//    only a few times, all waves of the workgroup in the same iteration (a wave compacting
+//    alone would stall the others at the per-tile barrier).
+// The <= K survivors of a lane and of its partner lane (l ^ 32, same query, other half of the
+// candidates) are then ranked by counting: position = number of better keys among the 2K.
+// Same result as a sorted (score desc, index asc) scan of all N candidates.
 template <int CP, int K>
 __global__ __launch_bounds__(256, 1) void knn_mfma_kernel(const float* __restrict__ x, int64_t ldx,
                                                           int N, int k, int32_t* __restrict__ idx) {
   constexpr int RS = CP + 4;
   constexpr int HALF = CP / 2;
+  constexpr int CAP = RingCap<CP>::value;
+  static_assert(CAP >= K + 24, "ring too small");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* s_tile = reinterpret_cast<float*>(smem);                 // [2][TJ][RS]
-  float* s_norm = s_tile + 2 * TJ * RS;                           // [2][TJ]
-  float2* s_q = reinterpret_cast<float2*>(s_norm + 2 * TJ);       // [QC][256] (score, index bits)
+  float* s_tile = reinterpret_cast<float*>(smem);                 // [3][TJ][RS]
+  float* s_norm = s_tile + 3 * TJ * RS;                           // [3][TJ] (+pad)
+  float2* s_ring = reinterpret_cast<float2*>(s_norm + 4 * TJ);    // [CAP+1][256] (score, index bits)
 
   const int b = blockIdx.y;
   const float* xb = x + (int64_t)b * N * ldx;
@@ -152,6 +210,7 @@ __global__ __launch_bounds__(256, 1) void knn_mfma_kernel(const float* __restric
   const int qj = lane & 31, h = lane >> 5;
   const int q0 = blockIdx.x * 128;
 
+  STAMP(0);
   // ---- query operands: stage the wave's 32 query rows through the tile buffers
   float bq[HALF];
   float ni = 0.f;
@@ -171,110 +230,181 @@ __global__ __launch_bounds__(256, 1) void knn_mfma_kernel(const float* __restric
     }
   }
   __syncthreads();
-
-  float v[K];
-  int id[K];
-#pragma unroll
-  for (int t = 0; t < K; ++t) {
-    v[t] = -INFINITY;
-    id[t] = 0x7fffffff;
-  }
-  float vmin = -INFINITY;
-  int cnt = 0;
-  float2* myq = s_q + threadIdx.x;
+  STAMP(1);
 
   const int ntile = (N + TJ - 1) / TJ;
-  TileRegs<CP> tr;
-  tile_load<CP>(tr, xb, ldx, N, 0);
-  tile_store<CP>(tr, s_tile, s_norm, N, 0);
-  __syncthreads();
-
-  for (int t = 0; t < ntile; ++t) {
-    const int buf = t & 1;
-    if (t + 1 < ntile) tile_load<CP>(tr, xb, ldx, N, (t + 1) * TJ);
-
-    // ---- S^T tile: 32 candidates x 32 queries, k-ordered fp32 fma chain on the matrix pipe
-    f32x16 acc;
+  float v[K];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const float* arow = s_tile + buf * TJ * RS + qj * RS + h * HALF;
+  for (int t = 0; t < K; ++t) v[t] = -INFINITY;
+  int cnt = 0;
+  float2* ring = s_ring + threadIdx.x;
+
+  // Exact compaction: keep entries with score > tau and the first (K - #strict) entries equal
+  // to tau, in order (<= K entries remain).
+  auto compact = [&]() {
+    const float tau = v[K - 1];
+    int ns = 0;
+#pragma unroll 8
+    for (int i = 0; i < CAP; ++i) ns += (i < cnt && ring[i * 256].x > tau) ? 1 : 0;
+    int room = K - ns, out = 0;
+#pragma unroll 8
+    for (int i = 0; i < CAP; ++i) {
+      const float2 e = ring[i * 256];
+      const bool live = i < cnt;
+      const bool strict = live && e.x > tau;
+      const bool tie = live && e.x == tau && room > 0 && e.x > -INFINITY;
+      const bool keep = strict || tie;
+      ring[(keep ? out : CAP) * 256] = e;
+      out += keep ? 1 : 0;
+      room -= tie ? 1 : 0;
+    }
+    cnt = out;
+  };
+  // Cheap in-flight compaction: one pass, keep score >= tau (all ties).
+  auto compact_fast = [&]() {
+    const float tau = v[K - 1];
+    int out = 0;
+#pragma unroll 8
+    for (int i = 0; i < CAP; ++i) {
+      const float2 e = ring[i * 256];
+      const bool keep = (i < cnt) && (e.x >= tau) && (e.x > -INFINITY);
+      ring[(keep ? out : CAP) * 256] = e;
+      out += keep ? 1 : 0;
+    }
+    cnt = out;
+  };
+
+#define SUG_SB() __builtin_amdgcn_sched_barrier(0)
+  // One pipeline step: the MFMA chain of the NEXT tile (matrix pipe) is issued in pieces
+  // between the pieces of the CURRENT tile's selection (VALU): per candidate slot c,
+  //   [mfma] score + ring append [mfma] med3 upper half [mfma] med3 lower half [mfma]
+  // with the source order pinned by sched_barrier(0) -- left alone, hipcc emits the whole
+  // dependent MFMA chain first and the in-order wave then cannot overlap anything.
+  constexpr int NM = HALF;                       // k-steps (MFMAs) per tile
+  constexpr int P = (CP == 4) ? 0 : NM / 16;     // MFMAs issued per candidate slot (2 or 4)
+  auto step = [&](const f32x16& acc_cur, f32x16& acc_next, const float* __restrict__ arow,
+                  const float* __restrict__ nrm, int jbase) {
+    float nn[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 n4 = *reinterpret_cast<const float4*>(nrm + 8 * g);
+      nn[4 * g + 0] = n4.x; nn[4 * g + 1] = n4.y; nn[4 * g + 2] = n4.z; nn[4 * g + 3] = n4.w;
+    }
+    float av[(CP == 4) ? 2 : HALF];
     if constexpr (CP == 4) {
       const float2 a2 = *reinterpret_cast<const float2*>(arow);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.x, bq[0], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.y, bq[1], acc, 0, 0, 0);
+      av[0] = a2.x; av[1] = a2.y;
     } else {
 #pragma unroll
       for (int g = 0; g < HALF / 4; ++g) {
         const float4 a4 = *reinterpret_cast<const float4*>(arow + 4 * g);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, bq[4 * g + 0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, bq[4 * g + 1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, bq[4 * g + 2], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, bq[4 * g + 3], acc, 0, 0, 0);
+        av[4 * g + 0] = a4.x; av[4 * g + 1] = a4.y; av[4 * g + 2] = a4.z; av[4 * g + 3] = a4.w;
       }
     }
-
-    // ---- scores + threshold filter -> FIFO (ascending candidate index within the lane)
-    const float* nrm = s_norm + buf * TJ + 4 * h;
-    const int jbase = t * TJ + 4 * h;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const float4 n4 = *reinterpret_cast<const float4*>(nrm + 8 * g);
-      const float nn[4] = {n4.x, n4.y, n4.z, n4.w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        // pairwise_distance = -xx - inner - xx^T, inner = -2*dot (model_utils.py:179-181)
-        const float s = __fsub_rn(__fsub_rn(-nn[e], __fmul_rn(-2.0f, acc[4 * g + e])), ni);
-        if (s > vmin) {
-          myq[cnt * 256] = make_float2(s, __int_as_float(jbase + 8 * g + e));
-          ++cnt;
-        }
-      }
+    for (int r = 0; r < 16; ++r) acc_next[r] = 0.f;
+    if constexpr (CP == 4) {
+      acc_next = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bq[0], acc_next, 0, 0, 0);
+      acc_next = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bq[1], acc_next, 0, 0, 0);
     }
+    SUG_SB();
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      if constexpr (P >= 1) acc_next = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c * P + 0], bq[c * P + 0], acc_next, 0, 0, 0);
+      SUG_SB();
+      // pairwise_distance = -xx - inner - xx^T, inner = -2*dot (model_utils.py:179-181)
+      const float s = __fsub_rn(__fsub_rn(-nn[c], __fmul_rn(-2.0f, acc_cur[c])), ni);
+      const bool enters = s > v[K - 1];
+      ring[(enters ? cnt : CAP) * 256] = make_float2(s, __int_as_float(jbase + 8 * (c >> 2) + (c & 3)));
+      cnt += enters ? 1 : 0;
+      SUG_SB();
+      if constexpr (P >= 2) acc_next = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c * P + 1], bq[c * P + 1], acc_next, 0, 0, 0);
+      SUG_SB();
+#pragma unroll
+      for (int u = K - 1; u >= K / 2; --u) v[u] = __builtin_amdgcn_fmed3f(v[u - 1], v[u], s);
+      // pin the results here: hipcc otherwise sinks half of the chain out of the pipelined block
+#pragma unroll
+      for (int u = K - 1; u >= K / 2; --u) asm volatile("" : "+v"(v[u]));
+      SUG_SB();
+      if constexpr (P >= 3) acc_next = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c * P + 2], bq[c * P + 2], acc_next, 0, 0, 0);
+      SUG_SB();
+#pragma unroll
+      for (int u = K / 2 - 1; u > 0; --u) v[u] = __builtin_amdgcn_fmed3f(v[u - 1], v[u], s);
+      v[0] = fmaxf(v[0], s);
+#pragma unroll
+      for (int u = K / 2 - 1; u >= 0; --u) asm volatile("" : "+v"(v[u]));
+      SUG_SB();
+      if constexpr (P >= 4) acc_next = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c * P + 3], bq[c * P + 3], acc_next, 0, 0, 0);
+      SUG_SB();
+    }
+  };
 
-    if (t + 1 < ntile) tile_store<CP>(tr, s_tile + (buf ^ 1) * TJ * RS, s_norm + (buf ^ 1) * TJ, N, (t + 1) * TJ);
-
-    // ---- drain the FIFOs when one could overflow on the next tile (or at the very end).
-    // The decision is taken block-wide inside the per-tile barrier so that all four waves
-    // drain in the same iteration: drains of different waves at different tiles would each
-    // stall the whole workgroup at the barrier (block time = sum over waves).
-    const int need = __syncthreads_or(cnt > QC - 16);
-    if (need || t + 1 == ntile) {
-      for (int i = 0; __any(i < cnt); ++i) {
-        if (i < cnt) {
-          const float2 e = myq[i * 256];
-          if (e.x > v[K - 1]) insert_desc<K>(v, id, e.x, __float_as_int(e.y));
-        }
+  // Software pipeline over candidate tiles (3 LDS buffers, one barrier per tile):
+  //   iteration t:  MFMA chain of tile t+1 (matrix pipe)  ||  selection of tile t (VALU)
+  //                 registers of tile t+2 -> LDS, global loads of tile t+3 in flight.
+  {
+    TileRegs<CP> tr;
+    auto tbuf = [&](int t) { return s_tile + (t % 3) * TJ * RS; };
+    auto nbuf = [&](int t) { return s_norm + (t % 3) * TJ; };
+    tile_load<CP>(tr, xb, ldx, N, 0);
+    tile_store<CP>(tr, tbuf(0), nbuf(0), N, 0);
+    __syncthreads();
+    if (ntile > 1) tile_load<CP>(tr, xb, ldx, N, TJ);
+    f32x16 acc_cur = score_tile<CP>(tbuf(0) + qj * RS + h * HALF, bq);
+    if (ntile > 1) tile_store<CP>(tr, tbuf(1), nbuf(1), N, TJ);
+    __syncthreads();
+    if (ntile > 2) tile_load<CP>(tr, xb, ldx, N, 2 * TJ);
+    for (int t = 0; t < ntile; ++t) {
+      // (the last iteration's MFMA chain runs on a stale buffer; its result is never used)
+      f32x16 acc_next;
+      step(acc_cur, acc_next, tbuf(t + 1) + qj * RS + h * HALF, nbuf(t) + 4 * h, t * TJ + 4 * h);
+      if (t + 2 < ntile) tile_store<CP>(tr, tbuf(t + 2), nbuf(t + 2), N, (t + 2) * TJ);
+      // block-wide decision inside the per-tile barrier: compact when a ring could overflow
+      const int need = __syncthreads_or(cnt > CAP - 16);
+      if (t + 3 < ntile) tile_load<CP>(tr, xb, ldx, N, (t + 3) * TJ);
+      if (need) {
+        compact_fast();
+        if (__syncthreads_or(cnt > CAP - 16)) compact();      // degenerate clouds: many exact ties
       }
-      cnt = 0;
-      vmin = v[K - 1];
+      acc_cur = acc_next;
     }
   }
+#undef SUG_SB
+  STAMP(2);
+  compact();
+  STAMP(3);
 
-  // ---- merge the two half-lists of a query (lanes l and l^32), tie-aware
-  float pv[K];
-  int pi[K];
+  // ---- this lane's <= K survivors as sortable keys (0 = empty, below every real key)
+  unsigned long long key[K];
 #pragma unroll
-  for (int t = 0; t < K; ++t) {
-    pv[t] = __shfl_xor(v[t], 32);
-    pi[t] = __shfl_xor(id[t], 32);
+  for (int i = 0; i < K; ++i) {
+    const float2 e = ring[i * 256];
+    key[i] = (i < cnt) ? pack_key(e.x, __float_as_int(e.y)) : 0ull;
   }
-#pragma unroll
-  for (int t = 0; t < K; ++t) {
-    if (better(pv[t], pi[t], v[K - 1], id[K - 1])) insert_desc_tie<K>(v, id, pv[t], pi[t]);
-  }
+  STAMP(4);
+  // ---- rank among own + partner keys (all distinct): rank = number of better keys
   const int q = q0 + wv * TJ + qj;
-  if (h == 0 && q < N) {
-    int32_t* o = idx + ((int64_t)b * N + q) * k;
+  int32_t* o = idx + ((int64_t)b * N + (q < N ? q : 0)) * k;
+  unsigned long long pk[K];
 #pragma unroll
-    for (int t = 0; t < K; ++t)
-      if (t < k) o[t] = id[t];
+  for (int u = 0; u < K; ++u) pk[u] = __shfl_xor(key[u], 32);
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    int rank = 0;
+#pragma unroll
+    for (int u = 0; u < K; ++u) {
+      rank += (key[u] > key[i]) ? 1 : 0;
+      rank += (pk[u] > key[i]) ? 1 : 0;
+    }
+    if (key[i] != 0ull && rank < k && q < N) o[rank] = 0x7fffffff - (int)(unsigned int)(key[i] & 0xffffffffull);
   }
+  STAMP(5);
 }
 
 template <int CP, int K>
 int launch(const float* x, int64_t ldx, int B, int N, int k, int32_t* idx, hipStream_t st) {
   constexpr int RS = CP + 4;
-  const size_t sh = (size_t)(2 * TJ * RS + 2 * TJ) * sizeof(float) + (size_t)QC * 256 * sizeof(float2);
+  const size_t sh = (size_t)(3 * TJ * RS + 4 * TJ) * sizeof(float) + (size_t)(RingCap<CP>::value + 1) * 256 * sizeof(float2);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_mfma_kernel<CP, K>),
@@ -297,7 +427,8 @@ int dispatch(const float* x, int64_t ldx, int B, int N, int C, int k, int32_t* i
 }  // namespace
 
 // Returns 1 if the MFMA path handles this shape/alignment (else the caller uses knn.hip).
-int sug_knn_mfma_supported(const float* x, int64_t ldx, int C) {
+int sug_knn_mfma_supported(const float* x, int64_t ldx, int C, int k) {
+  if (k > 20) return 0;                 // LDS ring budget: larger k uses the scalar kernel
   if (C == 3) return 1;
   if (C != 64 && C != 128) return 0;
   return ((uintptr_t)x % 16 == 0) && (ldx % 4 == 0);
@@ -305,6 +436,5 @@ int sug_knn_mfma_supported(const float* x, int64_t ldx, int C) {
 
 int sug_knn_mfma(const float* x, int64_t ldx, int B, int N, int C, int k, int32_t* idx, hipStream_t st) {
   if (k <= 16) return dispatch<16>(x, ldx, B, N, C, k, idx, st);
-  if (k <= 20) return dispatch<20>(x, ldx, B, N, C, k, idx, st);
-  return dispatch<32>(x, ldx, B, N, C, k, idx, st);
+  return dispatch<20>(x, ldx, B, N, C, k, idx, st);
 }
