@@ -105,6 +105,10 @@ def main():
     ap.add_argument('--cpu-batch', type=int, default=16, help='per-domain batch of the CPU baseline sample')
     ap.add_argument('--cpu-steps', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--graph', action='store_true',
+                    help='EXPERIMENTAL: replay the step from a hipGraph (faults on ROCm 7.0/gfx950, see DESIGN.md)')
+    ap.add_argument('--no-share-prefix', action='store_true',
+                    help='recompute the kNN+conv1/conv2 stage in the node passes instead of sharing it (identical results)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -126,7 +130,8 @@ def main():
     if world > 1:                                       # same initial weights on every rank
         for t in list(model.parameters()) + list(model.buffers()):
             dist.broadcast(t.data, 0)
-    trainer = SUGStep(model, lr=1e-3, weight_decay=5e-5)
+    trainer = SUGStep(model, lr=1e-3, weight_decay=5e-5, share_prefix=not args.no_share_prefix,
+                      use_graph=args.graph)
     B, N = args.batch, args.npoints
     data, lab, data_t, lab_t = synth(B, N, 666 + rank, dev)
     torch.manual_seed(666 + rank)                       # FPS start draws, per rank (train_dg.py:78)
@@ -137,10 +142,17 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # Kernel events: in graph mode they are captured as event-record nodes (and read back for
+    # the last replayed step); in eager mode only the kNN kernels are instrumented because every
+    # event pair costs host time in a host-bound step.
+    ops.PROFILE_ONLY = None if trainer.use_graph else {'knn'}
+    for i in range(max(args.warmup, 3 if trainer.use_graph else 1)):
+        if trainer.use_graph and i == 1:
+            ops.PROFILE = {}                            # the capture happens inside this step
         trainer.step(data, lab, data_t, lab_t)
     sync()
-    ops.PROFILE = {}
+    if not trainer.use_graph:
+        ops.PROFILE = {}
     t0 = time.perf_counter()
     for _ in range(args.steps):
         losses = trainer.step(data, lab, data_t, lab_t)
@@ -193,7 +205,9 @@ def main():
                'data': 'synthetic',
                'config': {'workload': '%s EdgeConv backbone, N=%d k=20, batch=%d per domain per GPU, MSA+SDA losses on '
                                       '(2 sem + 2 node forwards, 3 soft-MMD, backward, 3 Adam)' % (args.model, N, B),
-                          'global_batch': world * B, 'parallelism': 'dp%d' % world},
+                          'global_batch': world * B, 'parallelism': 'dp%d' % world,
+                          'launch': 'hipGraph replay of the whole step' if trainer.use_graph else 'eager',
+                          'share_prefix': trainer.share_prefix},
                'roofline': roofline, 'cpu_baseline': cpu, 'losses': loss_vals,
                'kernels': {k: {kk: (round(vv, 5) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in kern.items()}}
         print(json.dumps(out))

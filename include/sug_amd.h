@@ -136,7 +136,7 @@ int sug_edgeconv_fwd(const float* pq, int64_t ldpq, const int32_t* idx, const fl
  * `count` values per channel produce mean/rstd and the folded affine
  * scale = gamma*rstd, shift = beta - mean*scale; update running_mean/var the
  * way nn.BatchNorm2d does (momentum, unbiased running variance).
- * coef: [4,C] = scale, shift, mean, rstd.  running_* may be NULL. */
+ * coef: [5,C] = scale, shift, mean, rstd, unbiased variance.  running_* may be NULL. */
 int sug_bn_finalize(const double* stats, const float* gamma, const float* beta, int C,
                     double count, float eps, float momentum, float* running_mean,
                     float* running_var, float* coef, void* stream);

@@ -128,11 +128,10 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
     coef[C + c] = beta[c] - (float)mean * scale;
     coef[2 * C + c] = (float)mean;
     coef[3 * C + c] = rstd;
+    const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+    coef[4 * C + c] = (float)unb;
     if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
-    if (rvar) {
-      const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
-      rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
-    }
+    if (rvar) rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
   }
 }
 

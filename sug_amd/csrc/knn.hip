@@ -204,20 +204,22 @@ int dispatch_knn_c(const float* x, int64_t ldx, int B, int N, int C, int k, int3
 }
 
 // ---- reverse lists ---------------------------------------------------------
-// One block per cloud.  counts -> exclusive scan -> fill (atomic cursor) -> each
-// destination sorts its own (short) list so float sums downstream are deterministic.
+// One block per cloud, everything in LDS: counts -> exclusive scan -> fill (atomic cursor)
+// -> each destination sorts its own (short) list so float sums downstream are deterministic
+// -> coalesced write-out.  LDS: 2N ints + N*k ints (N=1024, k=20: 88 KB).
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void knn_reverse_kernel(const int32_t* __restrict__ idx, int N,
                                                             int k, int32_t* __restrict__ rev_off,
                                                             int32_t* __restrict__ rev_ent) {
-  extern __shared__ int s_i[];  // cnt[N] | cur[N] | scan scratch[BLOCK]
+  extern __shared__ int s_i[];  // cnt[N] | cur[N] | scan scratch[BLOCK] | ent[N*k]
   int* cnt = s_i;
   int* cur = s_i + N;
   int* scr = s_i + 2 * N;
+  int* ent = s_i + 2 * N + BLOCK;
   const int b = blockIdx.x;
   const int32_t* ib = idx + (int64_t)b * N * k;
   int32_t* off = rev_off + (int64_t)b * (N + 1);
-  int32_t* ent = rev_ent + (int64_t)b * N * k;
+  int32_t* gent = rev_ent + (int64_t)b * N * k;
   for (int i = threadIdx.x; i < N; i += BLOCK) cnt[i] = 0;
   __syncthreads();
   const int total = N * k;
@@ -226,7 +228,6 @@ __global__ __launch_bounds__(BLOCK) void knn_reverse_kernel(const int32_t* __res
     if (m >= 0 && m < N) atomicAdd(&cnt[m], 1);
   }
   __syncthreads();
-  // exclusive scan of cnt over N (N <= BLOCK*PER)
   const int PER = (N + BLOCK - 1) / BLOCK;
   const int lo = threadIdx.x * PER;
   int local = 0;
@@ -246,20 +247,17 @@ __global__ __launch_bounds__(BLOCK) void knn_reverse_kernel(const int32_t* __res
     off[i] = run;
     run += c;
   }
-  if (threadIdx.x == BLOCK - 1) off[N] = scr[BLOCK - 1];
+  const int filled = scr[BLOCK - 1];
+  if (threadIdx.x == BLOCK - 1) off[N] = filled;
   __syncthreads();
   for (int e = threadIdx.x; e < total; e += BLOCK) {
     const int m = ib[e];
-    if (m >= 0 && m < N) {
-      const int p = atomicAdd(&cur[m], 1);
-      ent[p] = e;
-    }
+    if (m >= 0 && m < N) ent[atomicAdd(&cur[m], 1)] = e;
   }
   __syncthreads();
-  __threadfence_block();
   for (int m = threadIdx.x; m < N; m += BLOCK) {
-    const int s = cur[m] - cnt[m], n = cnt[m];
-    for (int i = 1; i < n; ++i) {  // insertion sort, lists average k entries
+    const int n = cnt[m], s = cur[m] - n;
+    for (int i = 1; i < n; ++i) {  // insertion sort in LDS, lists average k entries
       const int key = ent[s + i];
       int j = i - 1;
       while (j >= 0 && ent[s + j] > key) {
@@ -269,6 +267,8 @@ __global__ __launch_bounds__(BLOCK) void knn_reverse_kernel(const int32_t* __res
       ent[s + j + 1] = key;
     }
   }
+  __syncthreads();
+  for (int e = threadIdx.x; e < filled; e += BLOCK) gent[e] = ent[e];
 }
 
 }  // namespace
@@ -292,8 +292,14 @@ extern "C" int sug_knn_reverse(const int32_t* idx, int B, int N, int k, int32_t*
   SUG_REQUIRE(idx && rev_off && rev_ent, "sug_knn_reverse: null pointer");
   SUG_REQUIRE(B > 0 && N > 0 && k > 0, "sug_knn_reverse: bad shape");
   constexpr int BLOCK = 1024;
-  size_t sh = (size_t)(2 * N + BLOCK) * sizeof(int);
-  SUG_REQUIRE(sh <= 64 * 1024, "sug_knn_reverse: N=%d too large", N);
+  size_t sh = (size_t)(2 * N + BLOCK + (size_t)N * k) * sizeof(int);
+  SUG_REQUIRE(sh <= 160 * 1024, "sug_knn_reverse: N*k=%d too large for the LDS-resident build", N * k);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_reverse_kernel<BLOCK>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
   hipLaunchKernelGGL((knn_reverse_kernel<BLOCK>), dim3(B), dim3(BLOCK), sh, (hipStream_t)stream, idx,
                      N, k, rev_off, rev_ent);
   SUG_LAUNCH_CHECK("sug_knn_reverse");

@@ -72,6 +72,36 @@ class DGCNN(nn.Module):
         self.node_fea_adapt = adapt_layer_off()
         self.conv1d = nn.Conv1d(128, 64, 1)
         self.dim_redu = nn.MaxPool1d(3, stride=16)
+        # Opt-in common-subexpression sharing (set by SUGStep): the semantic and the node pass of
+        # one training step run the encoder twice on the same batch with the same weights; the
+        # stage in front of the SA-node module (kNN + conv1, kNN + conv2) is then bit-identical
+        # in both passes (train-mode BN uses batch statistics, no dropout, deterministic
+        # kernels), so the second pass reuses it and only replays the BN running-stat update.
+        # Requires a single backward over both passes (the graph of the prefix is shared).
+        self.share_prefix = False
+        self._prefix_cache = {}
+
+    def clear_prefix_cache(self):
+        self._prefix_cache = {}
+
+    def _prefix(self, x, loc, nb):
+        if not (self.share_prefix and self.training):
+            x1 = self.conv1.edge_rows(loc, nb(loc, 0))
+            return x1, self.conv2.edge_rows(x1, nb(x1, 1))
+        ver = sum(p._version for m in (self.conv1, self.conv2) for p in m.parameters())
+        key = (x.data_ptr(), x._version, tuple(x.shape), torch.is_grad_enabled(), ver)
+        hit = self._prefix_cache.get(key)
+        if hit is not None:
+            x1, x2, st1, st2 = hit
+            self.conv1.replay_bn_update(st1)
+            self.conv2.replay_bn_update(st2)
+            return x1, x2
+        x1, st1 = self.conv1.edge_rows(loc, nb(loc, 0), return_stats=True)
+        x2, st2 = self.conv2.edge_rows(x1, nb(x1, 1), return_stats=True)
+        if len(self._prefix_cache) >= 4:            # a step has two inputs; never grow unbounded
+            self._prefix_cache.clear()
+        self._prefix_cache[key] = (x1, x2, st1, st2)
+        return x1, x2
 
     def forward(self, x, node=False, knn_idx=None):
         """x [B,3,N,1] -> (feat [B,1024], node_fea [B,64,64,1](, None)).
@@ -79,9 +109,10 @@ class DGCNN(nn.Module):
         B, N = x.size(0), x.size(2)
         loc = x.squeeze(-1).transpose(1, 2).contiguous()              # [B,N,3] rows
         gi = knn_idx or [None] * 4
+        if knn_idx is not None:
+            self._prefix_cache = {}
         nb = lambda f, i: gi[i] if gi[i] is not None else ops.knn(f, self.k)
-        x1 = self.conv1.edge_rows(loc, nb(loc, 0))                    # [B,N,64]
-        x2 = self.conv2.edge_rows(x1, nb(x1, 1))                      # [B,N,64]
+        x1, x2 = self._prefix(x, loc, nb)                             # [B,N,64], [B,N,64]
         x_, node_fea, _ = self.node_fea_adapt.rows(x2, loc)           # [B,N,128], [B,64,64]
         x2 = F.linear(x_, self.conv1d.weight.squeeze(-1), self.conv1d.bias)
         x3 = self.conv3.edge_rows(x2, nb(x2, 2))                      # [B,N,128]

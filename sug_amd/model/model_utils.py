@@ -49,7 +49,7 @@ class conv_2d(nn.Module):
     def forward(self, x):
         return self.rows(x.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
 
-    def edge_rows(self, x, idx):
+    def edge_rows(self, x, idx, return_stats=False):
         """Fused EdgeConv layer: max_k act(bn(W.[x_j - x_i ; x_i])) for x [B,N,C] rows and
         idx [B,N,k] (get_graph_feature + conv + max, model_utils.py:188-210, Model.py:88-94).
         W.[x_j-x_i; x_i] = W1.x_j + (W2-W1).x_i, so one [B*N,C]x[C,2Co] GEMM replaces the
@@ -66,9 +66,20 @@ class conv_2d(nn.Module):
         bn = self.conv[1]
         if bn.training and bn.num_batches_tracked is not None:
             bn.num_batches_tracked.add_(1)
-        return ops.edgeconv_bn_act_max(pq.view(B, N, -1), idx, bn.weight, bn.bias, bn.running_mean,
-                                       bn.running_var, bn.training, _ACT_SLOPE[self.activation],
-                                       bn.eps, bn.momentum)
+        out, coef = ops.edgeconv_bn_act_max(pq.view(B, N, -1), idx, bn.weight, bn.bias, bn.running_mean,
+                                            bn.running_var, bn.training, _ACT_SLOPE[self.activation],
+                                            bn.eps, bn.momentum)
+        return (out, coef) if return_stats else out
+
+    def replay_bn_update(self, coef):
+        """Apply the running-statistics update of one more train-mode forward on the same batch
+        (coef from edge_rows(..., return_stats=True)): what nn.BatchNorm2d would do again."""
+        bn = self.conv[1]
+        m = bn.momentum
+        bn.running_mean.mul_(1.0 - m).add_(coef[2] * m)
+        bn.running_var.mul_(1.0 - m).add_(coef[4] * m)
+        if bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
 
 
 class fc_layer(nn.Module):
@@ -140,7 +151,7 @@ class adapt_layer_off(nn.Module):
         """fea [B,N,64], loc [B,N,3] -> (out [B,N,128], node_fea [B,num_node,64], node_off [B,num_node,3])."""
         B, N, _ = loc.shape
         S = self.num_node
-        start = torch.randint(0, N, (B,), dtype=torch.long)           # CPU generator, point_utils.py:17
+        start = ops.draw_start(B, N)           # CPU generator, point_utils.py:17
         fidx = ops.fps(loc, S, start)                                 # [B,S]
         f_loc = ops.gather_rows(loc, fidx)                            # [B,S,3]
         gidx = ops.ball_query(loc, f_loc, 0.3, 64)                    # [B,S,64]

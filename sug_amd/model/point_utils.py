@@ -16,7 +16,7 @@ def farthest_point_sample(xyz, npoint):
     """model/point_utils.py:5-26. xyz [B,3,N] -> [B,npoint] int64.  The first centroid is
     drawn from the CPU default generator, one draw per call, like the reference (:17)."""
     B, _, N = xyz.shape
-    start = torch.randint(0, N, (B,), dtype=torch.long)
+    start = ops.draw_start(B, N)
     return ops.fps(_rows(xyz), npoint, start).long()
 
 

@@ -26,7 +26,7 @@ def index_points(points, idx):
 def farthest_point_sample(xyz, npoint):
     """model/pointnet2_utils.py:60-81. xyz [B,N,3] -> [B,npoint] int64 (CPU-generator start, :72)."""
     B, N, _ = xyz.shape
-    start = torch.randint(0, N, (B,), dtype=torch.long)
+    start = ops.draw_start(B, N)
     return ops.fps(xyz, npoint, start).long()
 
 
@@ -38,7 +38,7 @@ def query_ball_point(radius, nsample, xyz, new_xyz):
 def sample_and_group(npoint, radius, nsample, xyz, points, returnfps=False):
     """model/pointnet2_utils.py:107-135 -> new_xyz [B,S,3], new_points [B,S,nsample,3+D]."""
     B, N, C = xyz.shape
-    start = torch.randint(0, N, (B,), dtype=torch.long)
+    start = ops.draw_start(B, N)
     fps_idx = ops.fps(xyz, npoint, start)
     new_xyz = ops.gather_rows(xyz, fps_idx)
     idx = ops.ball_query(xyz, new_xyz, radius, nsample)

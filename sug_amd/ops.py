@@ -13,14 +13,31 @@ from ._lib import lib, check, STATS_BLOCKS
 SIGMA_LIST = (0.01, 0.1, 1, 10, 100)       # model/mmd.py:23
 
 
-# bench.py sets PROFILE = {} to time selected kernels with events on the launch stream
+# bench.py sets PROFILE = {} to time selected kernels with events on the launch stream.
+# PROFILE_ONLY (a set of name prefixes or None) restricts which kernels get events: every
+# event pair costs host time, and an eager step is host-bound.  While a hipGraph is being
+# captured the events are created `external` so that they become event-record nodes.
 PROFILE = None
+PROFILE_ONLY = None
+
+# FPS start indices: the reference draws torch.randint(0, N, (B,)) from the CPU default
+# generator once per farthest_point_sample call.  A provider (SUGStep's graph mode) may hand
+# out device-resident slices instead, filled from the same draws, so a step can be replayed.
+START_PROVIDER = None
+
+
+def draw_start(B, N):
+    if START_PROVIDER is not None:
+        return START_PROVIDER(B, N)
+    return torch.randint(0, N, (B,), dtype=torch.long)
 
 
 def _timed(name, shape, call):
-    if PROFILE is None:
+    if PROFILE is None or (PROFILE_ONLY is not None and not name.startswith(tuple(PROFILE_ONLY))):
         return call()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ext = torch.cuda.is_current_stream_capturing()
+    a = torch.cuda.Event(enable_timing=True, external=ext)
+    b = torch.cuda.Event(enable_timing=True, external=ext)
     a.record()
     r = call()
     b.record()
@@ -218,7 +235,7 @@ def group_max(feat, idx):
 # ----------------------------------------------------------------------------- BN helpers
 def bn_coef(stats, gamma, beta, count, eps, momentum, running_mean, running_var):
     C = gamma.numel()
-    coef = torch.empty(4, C, dtype=torch.float32, device=gamma.device)
+    coef = torch.empty(5, C, dtype=torch.float32, device=gamma.device)
     check(lib().sug_bn_finalize(_p(stats), _p(gamma), _p(beta), C, float(count), eps, momentum,
                                 _p(running_mean), _p(running_var), _p(coef), _st()), 'sug_bn_finalize')
     return coef
@@ -227,7 +244,7 @@ def bn_coef(stats, gamma, beta, count, eps, momentum, running_mean, running_var)
 def eval_coef(gamma, beta, running_mean, running_var, eps):
     rstd = torch.rsqrt(running_var + eps)
     scale = gamma * rstd
-    return torch.stack([scale, beta - running_mean * scale, running_mean, rstd]).contiguous()
+    return torch.stack([scale, beta - running_mean * scale, running_mean, rstd, running_var]).contiguous()
 
 
 def affine_act(z, coef, slope, out=None):
@@ -276,10 +293,11 @@ class _EdgeConv(torch.autograd.Function):
         if need_bwd:
             ctx.save_for_backward(pq, idx, z, arg, s1, coef)
             ctx.meta = (B, N, k, Co, ld, float(slope), bool(training))
-        return out
+        ctx.mark_non_differentiable(coef)
+        return out, coef
 
     @staticmethod
-    def backward(ctx, gout):
+    def backward(ctx, gout, _gcoef):
         pq, idx, z, arg, s1, coef = ctx.saved_tensors
         B, N, k, Co, ld, slope, training = ctx.meta
         dev = gout.device
@@ -302,7 +320,8 @@ class _EdgeConv(torch.autograd.Function):
 
 
 def edgeconv_bn_act_max(pq, idx, gamma, beta, running_mean, running_var, training, slope, eps=1e-5, momentum=0.1):
-    """pq [B,N,2*Co] = x.[W1;W2-W1]^T, idx [B,N,k] -> [B,N,Co]."""
+    """pq [B,N,2*Co] = x.[W1;W2-W1]^T, idx [B,N,k] -> (out [B,N,Co], coef [5,Co] = scale, shift,
+    batch mean, rstd, unbiased batch variance)."""
     return _EdgeConv.apply(pq, idx, gamma, beta, running_mean, running_var, training, slope, eps, momentum)
 
 

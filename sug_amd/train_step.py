@@ -14,11 +14,14 @@ all-reduce per step; with `global_mmd=True` the MMD is the single-GPU loss of th
 batch (differentiable all-gather of the [m, D+10] features and of logits/labels for the SDA
 weights; backward = reduce-scatter), otherwise reference-style local MMD (train_dg.py).
 """
+import os
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import ops
 from .model import mmd
 
 GEO_MMD = {'NAME': 'SOFT_MMD', 'LABEL_SCALE': 50, 'GEO_SCALE': 1}
@@ -85,10 +88,49 @@ def allreduce_grads_(params, world):
         off += n
 
 
+class _StartFeeder:
+    """FPS start indices for a replayable step: drawn from the CPU default generator in call
+    order with the same (B, N) sequence as an eager step (so the random stream is the
+    reference's), but delivered through one static device buffer."""
+
+    def __init__(self, device):
+        self.device = device
+        self.plan = []          # (B, N) per farthest_point_sample call of one step
+        self.host = self.dev = None
+        self.cursor = 0
+
+    def record(self, B, N):     # provider during the eager planning step
+        self.plan.append((B, N))
+        return torch.randint(0, N, (B,), dtype=torch.long)
+
+    def build(self):
+        total = sum(b for b, _ in self.plan)
+        self.host = torch.empty(total, dtype=torch.int32).pin_memory()
+        self.dev = torch.zeros(total, dtype=torch.int32, device=self.device)
+
+    def refill(self):           # before every replay
+        off = 0
+        for B, N in self.plan:
+            self.host[off:off + B] = torch.randint(0, N, (B,), dtype=torch.long).to(torch.int32)
+            off += B
+        self.dev.copy_(self.host, non_blocking=True)
+
+    def provide(self, B, N):    # provider during capture
+        off = sum(b for b, _ in self.plan[:self.cursor])
+        assert self.plan[self.cursor] == (B, N), 'step structure changed between planning and capture'
+        self.cursor += 1
+        return self.dev[off:off + B]
+
+
 class SUGStep:
     def __init__(self, model, lr=1e-3, weight_decay=5e-5, lr_scaler=1.0, methods=None, criterion=None,
-                 global_mmd=True, fused_adam=None):
+                 global_mmd=True, fused_adam=None, share_prefix=True, use_graph=False):
         self.model = model
+        # one backward over all four forwards of a step -> the encoder may share the stage in
+        # front of the SA-node module between the semantic and node pass of a batch (exact)
+        self.share_prefix = share_prefix and hasattr(model.g, 'share_prefix')
+        if hasattr(model.g, 'share_prefix'):
+            model.g.share_prefix = self.share_prefix
         self.methods = dict(METHODS)
         if methods:
             self.methods.update(methods)
@@ -100,6 +142,20 @@ class SUGStep:
             fused_adam = next(model.parameters()).is_cuda
         if fused_adam:
             kw['fused'] = True
+        # EXPERIMENTAL hipGraph mode (off by default): the whole step (4 forwards, losses, backward,
+        # 3 Adam updates) is captured once and replayed; an eager step of ~1200 launches is
+        # host-bound.  On ROCm 7.0 / gfx950 back-to-back replays of this graph end in a GPU fault
+        # inside a torch scatter kernel (root cause not found): do not enable
+        # outside a debugging session.  Single-GPU only.
+        self.use_graph = bool(use_graph) and self.world == 1 and next(model.parameters()).is_cuda
+        self._graph = None
+        self._tick = torch.zeros(1, device=next(model.parameters()).device) if self.use_graph else None
+        self._feeder = None
+        self._static_in = None
+        self._static_out = None
+        self._graph_epoch = None
+        if self.use_graph:
+            kw['capturable'] = True
         # train_dg_single_gpu.py:191-203
         params = [{'params': v} for k, v in model.g.named_parameters() if 'pred_offset' not in k]
         self.optimizer_g = torch.optim.Adam(params, lr=lr, weight_decay=weight_decay, **kw)
@@ -148,7 +204,55 @@ class SUGStep:
 
     # ------------------------------------------------------------------ step
     def step(self, data, label, data_t, label_t, epoch=0):
-        """Returns (loss_cls, loss_geo_mmd, loss_sem_mmd) as 0-d device tensors (no host sync)."""
+        """Returns (loss_cls, loss_geo_mmd, loss_sem_mmd) as 0-d device tensors (no host sync).
+        In graph mode the returned tensors are static buffers overwritten by the next step."""
+        if self.use_graph:
+            return self._graph_step(data, label, data_t, label_t, epoch)
+        return self._eager_step(data, label, data_t, label_t, epoch)
+
+    def _graph_step(self, data, label, data_t, label_t, epoch):
+        mmd_on = epoch >= self.methods['PURE_CLS_EPOCH']
+        if self._feeder is None:
+            # step 1: eager, recording the (B, N) sequence of FPS start draws
+            self._feeder = _StartFeeder(data.device)
+            ops.START_PROVIDER = self._feeder.record
+            try:
+                out = self._eager_step(data, label, data_t, label_t, epoch)
+            finally:
+                ops.START_PROVIDER = None
+            self._feeder.build()
+            return out
+        if self._graph is None or self._graph_epoch != mmd_on or any(
+                a.shape != b.shape for a, b in zip(self._static_in, (data, label, data_t, label_t))):
+            self._static_in = [t.clone() for t in (data, label, data_t, label_t)]
+            self._graph_epoch = mmd_on
+            for o in (self.optimizer_g, self.optimizer_c, self.optimizer_dis):
+                o.zero_grad(set_to_none=True)
+            self._feeder.cursor = 0
+            self._graph = torch.cuda.CUDAGraph()
+            if os.environ.get('SUG_GRAPH_DUMP'):
+                self._graph.enable_debug_mode()
+            ops.START_PROVIDER = self._feeder.provide
+            try:
+                with torch.cuda.graph(self._graph):
+                    self._static_out = self._eager_step(*self._static_in, epoch)
+            finally:
+                ops.START_PROVIDER = None
+            if os.environ.get('SUG_GRAPH_DUMP'):
+                self._graph.debug_dump(os.environ['SUG_GRAPH_DUMP'])
+        for dst, src in zip(self._static_in, (data, label, data_t, label_t)):
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src, non_blocking=True)
+        self._feeder.refill()
+        # One eager op on ordinary (non-graph-pool) memory between two replays.  Without it,
+        # back-to-back hipGraphLaunch of this graph faults in its second replay on ROCm 7.0 /
+        # gfx950 (a torch scatter reads out-of-range indices; any eager kernel or copy touching
+        # normal-pool memory in between avoids it, a sleep or a device sync does not).
+        self._tick.add_(1)
+        self._graph.replay()
+        return self._static_out
+
+    def _eager_step(self, data, label, data_t, label_t, epoch=0):
         mmd_on = epoch >= self.methods['PURE_CLS_EPOCH']
         loss_cls, loss_geo, loss_sem = self.losses(data, label, data_t, label_t, mmd_on)
         loss = loss_cls
@@ -157,6 +261,8 @@ class SUGStep:
         if loss_sem is not None:
             loss = loss + loss_sem
         loss.backward()
+        if self.share_prefix:
+            self.model.g.clear_prefix_cache()
         if self.world > 1:
             allreduce_grads_(self.model.parameters(), self.world)
         self.optimizer_dis.step()

@@ -82,3 +82,34 @@ def test_two_training_steps_match_reference():
             allow = 2e-3 * v.numel() + 2e-3 * pa
         assert abs(v.sum().item() - ps) <= allow, (k, v.sum().item(), ps, allow)
     print('worst checksum deviation / allowance vs oracle = %.3f' % worst)
+
+
+def test_prefix_sharing_is_exact():
+    """SUGStep(share_prefix=True) (the semantic and node pass of a batch share kNN+conv1/conv2)
+    gives bit-identical losses, gradients and BN buffers to four independent passes."""
+    from sug_amd.model.Model import Net_MDA
+    from sug_amd.train_step import SUGStep
+    G = load_golden('step_dgcnn.npz')
+    seed = G['seed']
+    res = []
+    for share in (False, True):
+        net = Net_MDA('DGCNN')
+        net.load_state_dict(O.fill_params({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed))
+        for m in net.modules():
+            if isinstance(m, torch.nn.Dropout2d):
+                m.p = 0.0
+        net = net.cuda().train()
+        tr = SUGStep(net, share_prefix=share, fused_adam=False)
+        torch.manual_seed(seed)
+        lc, lg, ls = tr.losses(G['data'].cuda(), G['label'].cuda(), G['data_t'].cuda(), G['label_t'].cuda())
+        (lc + lg + ls).backward()
+        res.append(([lc.item(), lg.item(), ls.item()],
+                    {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None},
+                    {k: v.clone() for k, v in net.state_dict().items() if 'running' in k or 'num_batches' in k}))
+    assert res[0][0] == res[1][0]
+    assert res[0][1].keys() == res[1][1].keys()
+    gmax = max(float(g.abs().max()) for g in res[0][1].values())
+    for k in res[0][1]:     # sharing only changes the order in which upstream gradients are summed
+        torch.testing.assert_close(res[1][1][k], res[0][1][k], rtol=1e-4, atol=1e-6 * gmax)
+    for k in res[0][2]:
+        assert torch.equal(res[0][2][k], res[1][2][k]), k
