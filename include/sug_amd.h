@@ -168,6 +168,26 @@ int sug_edgeconv_bwd_scatter(const float* a, const uint8_t* arg, const float* s1
                              const int32_t* rev_ent, const float* coef, const double* red,
                              int B, int N, int k, int Co, float* dpq, int64_t lddpq, void* stream);
 
+/* ---- BatchNorm(+act) on rows: backward, and the fused DGCNN tail ----------------------------
+ * Exact train-mode BN gradient for a per-point layer (conv_2d on [B,C,N,1],
+ * model/model_utils.py:8-32): with a = scale*G and red = (sum G, sum G*xhat) from
+ * sug_edgeconv_bwd_reduce (z := y, the BN input),
+ *   dy = a - (scale/rows) * (dbeta + xhat*dgamma).   a: dense [rows,C]. */
+int sug_bn_bwd_apply(const float* a, const float* y, int64_t ldy, const float* coef,
+                     const double* red, int64_t rows, int C, float* dy, int64_t lddy, void* stream);
+
+/* BatchNorm1d -> LeakyReLU(slope) -> max over N | mean over N  (model/Model.py:112-116),
+ * one read of y [B,N,C]; coef from sug_bn_finalize.  out_max/out_mean [B,C], arg [B,C] = row of
+ * the (first) maximum. */
+int sug_bn_act_pool_fwd(const float* y, int64_t ldy, const float* coef, int B, int N, int C,
+                        float slope, float* out_max, float* out_mean, int32_t* arg, void* stream);
+/* Backward of the above including the BN statistics terms: dy [B,N,C] (row stride lddy),
+ * red[0:C] = dbeta, red[C:2C] = dgamma (fp64).  train = 0: statistics are constants (eval mode).
+ * ws: SUG_STATS_BLOCKS*2*C floats. B <= SUG_STATS_BLOCKS. */
+int sug_bn_act_pool_bwd(const float* y, int64_t ldy, const float* coef, const float* gmax,
+                        const float* gmean, const int32_t* arg, int B, int N, int C, float slope,
+                        int train, double* red, float* ws, float* dy, int64_t lddy, void* stream);
+
 /* ---- Gaussian multi-kernel MMD --------------------------------------------------
  * replaces _mix_rbf_kernel + _mmd2(biased=True), model/mmd.py:239-254, :274-312.
  * Z = [X;Y] : [2m, D] rows (ld = ldz).  e_ij = n_i - 2<z_i,z_j> + n_j with n the

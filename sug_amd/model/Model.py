@@ -118,8 +118,8 @@ class DGCNN(nn.Module):
         x3 = self.conv3.edge_rows(x2, nb(x2, 2))                      # [B,N,128]
         x4 = self.conv4.edge_rows(x3, nb(x3, 3))                      # [B,N,256]
         x5 = F.linear(torch.cat((x1, x2, x3, x4), dim=2), self.conv5.weight.squeeze(-1))
-        x5 = F.leaky_relu(_bn_rows(self.bn5, x5), negative_slope=0.2)
-        feat = torch.cat((x5.max(dim=1)[0], x5.mean(dim=1)), 1)
+        # bn5 -> leaky_relu(0.2) -> adaptive max | avg pool (Model.py:113-116), fused
+        feat = torch.cat(ops.bn_act_pool(x5, self.bn5, 0.2), 1)
         node_fea = node_fea.transpose(1, 2).unsqueeze(-1)             # [B,64(ch),64(node),1]
         if node:
             return feat, node_fea, None

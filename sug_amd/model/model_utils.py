@@ -15,6 +15,11 @@ from . import point_utils
 _ACT_SLOPE = {'relu': 0.0, 'leakyrelu': 0.01}      # nn.LeakyReLU() default slope, model_utils.py:27
 
 
+def OWN_BN(bn):
+    """Debug hook: which BatchNorm layers use the library's BN kernels (default: all)."""
+    return True
+
+
 def _bn_rows(bn, y):
     """Train/eval BatchNorm of a [..., C] rows tensor with the module's parameters."""
     shp = y.shape
@@ -44,6 +49,8 @@ class conv_2d(nn.Module):
     def rows(self, x):
         """x [..., Cin] -> [..., Cout]: per-point GEMM + BN over all leading dims + act."""
         y = F.linear(x, self.weight2d(), self.conv[0].bias)
+        if self.activation in _ACT_SLOPE and OWN_BN(self.conv[1]):
+            return ops.bn_act_rows(y, self.conv[1], _ACT_SLOPE[self.activation])
         return self.conv[2](_bn_rows(self.conv[1], y))
 
     def forward(self, x):

@@ -263,6 +263,115 @@ def affine_act(z, coef, slope, out=None):
     return out.view(*z.shape)
 
 
+def col_stats(y2):
+    """y2 [rows, C] (row stride ld) -> fp64 [2C] = column sums, column sums of squares."""
+    rows, C = y2.shape
+    stats = torch.empty(2 * C, dtype=torch.float64, device=y2.device)
+    ws = torch.empty(STATS_BLOCKS * 2 * C, dtype=torch.float32, device=y2.device)
+    check(lib().sug_col_stats(_p(y2), y2.stride(0), rows, C, _p(stats), _p(ws), _st()), 'sug_col_stats')
+    return stats
+
+
+class _BNActRows(torch.autograd.Function):
+    """act(BatchNorm(y)) over the rows of y [rows, C]; act = LeakyReLU(slope) (0: ReLU, 1: none).
+    Train mode uses batch statistics and updates the running ones like nn.BatchNorm."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, running_mean, running_var, training, slope, eps, momentum):
+        _need_gpu(y, gamma)
+        C = y.shape[-1]
+        y2 = y.reshape(-1, C)
+        if y2.stride(1) != 1 or y2.stride(0) != C:
+            y2 = y2.contiguous()
+        rows = y2.shape[0]
+        g, b = gamma.detach().contiguous(), beta.detach().contiguous()
+        if training:
+            coef = bn_coef(col_stats(y2), g, b, rows, eps, momentum, running_mean, running_var)
+        else:
+            coef = eval_coef(g, b, running_mean, running_var, eps)
+        out = affine_act(y2, coef, slope)
+        if any(ctx.needs_input_grad[i] for i in (0, 1, 2)):
+            ctx.save_for_backward(y2, coef)
+            ctx.meta = (rows, C, float(slope), bool(training), tuple(y.shape))
+        return out.view(y.shape)
+
+    @staticmethod
+    def backward(ctx, gout):
+        y2, coef = ctx.saved_tensors
+        rows, C, slope, training, shape = ctx.meta
+        dev = gout.device
+        g2 = gout.reshape(rows, C)
+        if g2.stride(1) != 1:
+            g2 = g2.contiguous()
+        a = torch.empty(rows, C, dtype=torch.float32, device=dev)
+        red = torch.empty(2 * C, dtype=torch.float64, device=dev)
+        ws = torch.empty(STATS_BLOCKS * 2 * C, dtype=torch.float32, device=dev)
+        check(lib().sug_edgeconv_bwd_reduce(_p(g2), g2.stride(0), _p(y2), _p(coef), rows, C, slope, _p(a), _p(red),
+                                            _p(ws), _st()), 'sug_edgeconv_bwd_reduce')
+        if training:
+            dy = torch.empty(rows, C, dtype=torch.float32, device=dev)
+            check(lib().sug_bn_bwd_apply(_p(a), _p(y2), C, _p(coef), _p(red), rows, C, _p(dy), C, _st()),
+                  'sug_bn_bwd_apply')
+        else:
+            dy = a
+        return dy.view(shape), red[C:].float(), red[:C].float(), None, None, None, None, None, None
+
+
+def bn_act_rows(y, bn, slope):
+    """bn: an nn.BatchNorm{1,2}d module whose parameters / running buffers are used."""
+    if bn.training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return _BNActRows.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, slope, bn.eps,
+                            bn.momentum)
+
+
+class _BNActPool(torch.autograd.Function):
+    """y [B,N,C] -> (max_n, mean_n) of LeakyReLU(slope)(BatchNorm(y)); one read of y forward,
+    two backward (sug_bn_act_pool_*)."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, running_mean, running_var, training, slope, eps, momentum):
+        _need_gpu(y, gamma)
+        y, B, N, C, ld = _rows3(y)
+        g, b = gamma.detach().contiguous(), beta.detach().contiguous()
+        if training:
+            stats = col_stats(y.view(B * N, C) if ld == C else y.reshape(B * N, C))
+            coef = bn_coef(stats, g, b, B * N, eps, momentum, running_mean, running_var)
+        else:
+            coef = eval_coef(g, b, running_mean, running_var, eps)
+        omax = torch.empty(B, C, dtype=torch.float32, device=y.device)
+        omean = torch.empty(B, C, dtype=torch.float32, device=y.device)
+        arg = torch.empty(B, C, dtype=torch.int32, device=y.device)
+        check(lib().sug_bn_act_pool_fwd(_p(y), ld, _p(coef), B, N, C, float(slope), _p(omax), _p(omean), _p(arg),
+                                        _st()), 'sug_bn_act_pool_fwd')
+        ctx.save_for_backward(y, coef, arg)
+        ctx.meta = (B, N, C, ld, float(slope), bool(training))
+        ctx.mark_non_differentiable(arg)
+        return omax, omean
+
+    @staticmethod
+    def backward(ctx, gmax, gmean):
+        y, coef, arg = ctx.saved_tensors
+        B, N, C, ld, slope, training = ctx.meta
+        dev = y.device
+        gmax, gmean = gmax.contiguous(), gmean.contiguous()
+        red = torch.empty(2 * C, dtype=torch.float64, device=dev)
+        ws = torch.empty(STATS_BLOCKS * 2 * C, dtype=torch.float32, device=dev)
+        dy = torch.empty(B, N, C, dtype=torch.float32, device=dev)
+        check(lib().sug_bn_act_pool_bwd(_p(y), ld, _p(coef), _p(gmax), _p(gmean), _p(arg), B, N, C, slope,
+                                        1 if training else 0, _p(red), _p(ws), _p(dy), C, _st()),
+              'sug_bn_act_pool_bwd')
+        return dy, red[C:].float(), red[:C].float(), None, None, None, None, None, None
+
+
+def bn_act_pool(y, bn, slope):
+    """(max over points, mean over points) of act(bn(y)), y [B,N,C]."""
+    if bn.training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return _BNActPool.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, slope, bn.eps,
+                            bn.momentum)
+
+
 # ----------------------------------------------------------------------------- EdgeConv
 class _EdgeConv(torch.autograd.Function):
     """BN(train or eval) + LeakyReLU + max over k of y = P[idx] + Q, see include/sug_amd.h."""

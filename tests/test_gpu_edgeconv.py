@@ -65,3 +65,63 @@ def test_edgeconv_is_deterministic():
         outs.append((y.detach().clone(), xi.grad.clone()))
     assert torch.equal(outs[0][0], outs[1][0])
     assert torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize('C,rows_shape,slope,train', [(64, (3, 500), 0.0, True), (512, (2, 256), 0.01, True),
+                                                      (12, (1000,), 1.0, True), (128, (4, 64), 0.0, False)])
+def test_bn_act_rows_vs_torch(C, rows_shape, slope, train):
+    """Own BN(+LeakyReLU/ReLU) on rows, forward/backward/running stats, vs torch's F.batch_norm (fp32 reference)."""
+    import torch.nn.functional as F
+    from sug_amd import ops
+    g = torch.Generator().manual_seed(C)
+    y = (torch.randn(*rows_shape, C, generator=g) * 2 + 0.5).cuda()
+    probe = torch.randn(*rows_shape, C, generator=g).cuda()
+    bn_a, bn_b = torch.nn.BatchNorm1d(C).cuda().train(train), torch.nn.BatchNorm1d(C).cuda().train(train)
+    with torch.no_grad():
+        w = 1 + 0.3 * torch.randn(C, generator=g)
+        w[::5] = -w[::5]
+        for bn in (bn_a, bn_b):
+            bn.weight.copy_(w.cuda()); bn.bias.copy_(torch.randn(C, generator=g).cuda() if bn is bn_a else bn_a.bias)
+            bn.running_mean.fill_(0.1); bn.running_var.fill_(1.3)
+    ya, yb = y.clone().requires_grad_(True), y.clone().requires_grad_(True)
+    out_a = ops.bn_act_rows(ya, bn_a, slope)
+    ref = F.batch_norm(yb.reshape(-1, C), bn_b.running_mean, bn_b.running_var, bn_b.weight, bn_b.bias, train, 0.1, 1e-5)
+    ref = F.leaky_relu(ref, slope).view_as(yb) if slope != 1.0 else ref.view_as(yb)
+    (out_a * probe).sum().backward()
+    (ref * probe).sum().backward()
+    torch.testing.assert_close(out_a, ref, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(ya.grad, yb.grad, rtol=1e-3, atol=2e-4)
+    torch.testing.assert_close(bn_a.weight.grad, bn_b.weight.grad, rtol=1e-3, atol=1e-2)
+    torch.testing.assert_close(bn_a.bias.grad, bn_b.bias.grad, rtol=1e-3, atol=1e-2)
+    torch.testing.assert_close(bn_a.running_mean, bn_b.running_mean, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(bn_a.running_var, bn_b.running_var, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('B,N,C,train', [(3, 200, 64, True), (2, 1024, 512, True), (2, 100, 70, False)])
+def test_bn_act_pool_vs_torch(B, N, C, train):
+    """Fused bn5 -> leaky_relu(0.2) -> max|mean pooling vs the torch fp32 composition."""
+    import torch.nn.functional as F
+    from sug_amd import ops
+    g = torch.Generator().manual_seed(N + C)
+    y = (torch.randn(B, N, C, generator=g) + 0.3).cuda()
+    pm, pa = torch.randn(B, C, generator=g).cuda(), torch.randn(B, C, generator=g).cuda()
+    bn_a, bn_b = torch.nn.BatchNorm1d(C).cuda().train(train), torch.nn.BatchNorm1d(C).cuda().train(train)
+    with torch.no_grad():
+        w = 1 + 0.3 * torch.randn(C, generator=g)
+        w[::4] = -w[::4]
+        for bn in (bn_a, bn_b):
+            bn.weight.copy_(w.cuda())
+            bn.running_var.fill_(0.8)
+    ya, yb = y.clone().requires_grad_(True), y.clone().requires_grad_(True)
+    mx, mean = ops.bn_act_pool(ya, bn_a, 0.2)
+    r = F.leaky_relu(F.batch_norm(yb.reshape(-1, C), bn_b.running_mean, bn_b.running_var, bn_b.weight, bn_b.bias,
+                                  train, 0.1, 1e-5), 0.2).view(B, N, C)
+    rmx, rmean = r.max(dim=1)[0], r.mean(dim=1)
+    ((mx * pm).sum() + (mean * pa).sum()).backward()
+    ((rmx * pm).sum() + (rmean * pa).sum()).backward()
+    torch.testing.assert_close(mx, rmx, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(mean, rmean, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(ya.grad, yb.grad, rtol=1e-3, atol=1e-5)
+    torch.testing.assert_close(bn_a.weight.grad, bn_b.weight.grad, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(bn_a.bias.grad, bn_b.bias.grad, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(bn_a.running_var, bn_b.running_var, rtol=1e-5, atol=1e-6)
