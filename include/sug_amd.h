@@ -178,12 +178,13 @@ int sug_bn_bwd_apply(const float* a, const float* y, int64_t ldy, const float* c
 
 /* BatchNorm1d -> LeakyReLU(slope) -> max over N | mean over N  (model/Model.py:112-116),
  * one read of y [B,N,C]; coef from sug_bn_finalize.  out_max/out_mean [B,C], arg [B,C] = row of
- * the (first) maximum. */
+ * the (first) maximum.  ws: workspace of 12*B*C floats (per-chunk partial max/sum/arg). */
 int sug_bn_act_pool_fwd(const float* y, int64_t ldy, const float* coef, int B, int N, int C,
-                        float slope, float* out_max, float* out_mean, int32_t* arg, void* stream);
+                        float slope, float* out_max, float* out_mean, int32_t* arg, float* ws,
+                        void* stream);
 /* Backward of the above including the BN statistics terms: dy [B,N,C] (row stride lddy),
  * red[0:C] = dbeta, red[C:2C] = dgamma (fp64).  train = 0: statistics are constants (eval mode).
- * ws: SUG_STATS_BLOCKS*2*C floats. B <= SUG_STATS_BLOCKS. */
+ * ws: SUG_STATS_BLOCKS*2*C floats. B <= SUG_STATS_BLOCKS/4. */
 int sug_bn_act_pool_bwd(const float* y, int64_t ldy, const float* coef, const float* gmax,
                         const float* gmean, const int32_t* arg, int B, int N, int C, float slope,
                         int train, double* red, float* ws, float* dy, int64_t lddy, void* stream);

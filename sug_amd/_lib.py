@@ -36,7 +36,7 @@ SIGNATURES = {
     'sug_edgeconv_bwd_scatter': [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32,
                                  _vp, _i64, _vp],
     'sug_bn_bwd_apply': [_vp, _vp, _i64, _vp, _vp, _i64, _i32, _vp, _i64, _vp],
-    'sug_bn_act_pool_fwd': [_vp, _i64, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp],
+    'sug_bn_act_pool_fwd': [_vp, _i64, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp],
     'sug_bn_act_pool_bwd': [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp, _i64, _vp],
     'sug_mmd_rbf': [_vp, _i64, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp],
     'sug_chamfer': [_vp, _vp, _i32, _i32, _i32, _vp, _vp],

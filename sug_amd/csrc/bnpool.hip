@@ -9,6 +9,32 @@
 
 namespace {
 
+// float4 variant of bn_bwd_apply_kernel (C % 4 == 0, aligned rows)
+__global__ __launch_bounds__(256) void bn_bwd_apply_vec4_kernel(const float* __restrict__ a,
+                                                                const float* __restrict__ y, int64_t ldy,
+                                                                const float* __restrict__ coef,
+                                                                const double* __restrict__ red,
+                                                                int64_t rows, int C, float invM,
+                                                                float* __restrict__ dy, int64_t lddy) {
+  const int C4 = C >> 2;
+  const int64_t total = rows * C4;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int c = (int)(e % C4) * 4;
+    const int64_t r = e / C4;
+    const float4 av = *reinterpret_cast<const float4*>(a + r * C + c);
+    const float4 yv = *reinterpret_cast<const float4*>(y + r * ldy + c);
+    const float4 sc = *reinterpret_cast<const float4*>(coef + c);
+    const float4 mean = *reinterpret_cast<const float4*>(coef + 2 * C + c);
+    const float4 rstd = *reinterpret_cast<const float4*>(coef + 3 * C + c);
+    float4 o;
+    o.x = av.x - sc.x * invM * ((float)red[c + 0] + (yv.x - mean.x) * rstd.x * (float)red[C + c + 0]);
+    o.y = av.y - sc.y * invM * ((float)red[c + 1] + (yv.y - mean.y) * rstd.y * (float)red[C + c + 1]);
+    o.z = av.z - sc.z * invM * ((float)red[c + 2] + (yv.z - mean.z) * rstd.z * (float)red[C + c + 2]);
+    o.w = av.w - sc.w * invM * ((float)red[c + 3] + (yv.w - mean.w) * rstd.w * (float)red[C + c + 3]);
+    *reinterpret_cast<float4*>(dy + r * lddy + c) = o;
+  }
+}
+
 // dy = a - (scale/M) * (dbeta + xhat * dgamma),  a = scale * G  (exact BN gradient)
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ a,
                                                            const float* __restrict__ y, int64_t ldy,
@@ -26,96 +52,164 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   }
 }
 
-// One workgroup: 64 channels x all N rows of one cloud (4 row phases, LDS combine).
-__global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(const float* __restrict__ y, int64_t ldy,
-                                                              const float* __restrict__ coef, int N,
-                                                              int C, float slope,
-                                                              float* __restrict__ omax,
-                                                              float* __restrict__ omean,
-                                                              int32_t* __restrict__ arg) {
-  __shared__ float s_m[4][64];
-  __shared__ float s_s[4][64];
-  __shared__ int s_a[4][64];
-  const int b = blockIdx.y;
-  const int cl = threadIdx.x & 63, ph = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
-  float best = -INFINITY, sum = 0.f;
-  int bi = 0;
+constexpr int NS = 4;      // row chunks per cloud (more workgroups -> more loads in flight)
+
+__device__ __forceinline__ float lrelu(float u, float slope) { return u > 0.f ? u : u * slope; }
+
+// Workgroup = 64 channels (16 float4 lanes) x 16 row-lanes over one of NS row chunks of a
+// cloud.  Partials per (b, chunk, c): max, arg, sum -> pool_combine_kernel.  Scalar fallback
+// (C % 4 != 0) uses 64 scalar lanes x 4 row-lanes through the same code path (VEC = 1).
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_act_pool_part_kernel(const float* __restrict__ y, int64_t ldy,
+                                                               const float* __restrict__ coef, int N,
+                                                               int C, float slope,
+                                                               float* __restrict__ pmax,
+                                                               float* __restrict__ psum,
+                                                               int32_t* __restrict__ parg) {
+  constexpr int LX = 64 / VEC, LY = 256 / LX;
+  __shared__ float s_m[LY][64];
+  __shared__ float s_s[LY][64];
+  __shared__ int s_a[LY][64];
+  const int b = blockIdx.y, ch = blockIdx.z;
+  const int lx = threadIdx.x % LX, ly = threadIdx.x / LX;
+  const int c = blockIdx.x * 64 + lx * VEC;
+  const int n0 = (int)((int64_t)N * ch / NS), n1 = (int)((int64_t)N * (ch + 1) / NS);
+  float best[VEC], sum[VEC];
+  int bi[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) { best[v] = -INFINITY; sum[v] = 0.f; bi[v] = n0; }
   if (c < C) {
-    const float sc = coef[c], sh = coef[C + c];
+    float sc[VEC], sh[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) { sc[v] = coef[c + v]; sh[v] = coef[C + c + v]; }
     const float* p = y + (int64_t)b * N * ldy + c;
-    for (int n = ph; n < N; n += 4) {
-      float u = fmaf(sc, p[(int64_t)n * ldy], sh);
-      u = u > 0.f ? u : u * slope;
-      sum += u;
-      if (u > best) {
-        best = u;
-        bi = n;
+#pragma unroll 4
+    for (int n = n0 + ly; n < n1; n += LY) {
+      float val[VEC];
+      if constexpr (VEC == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(p + (int64_t)n * ldy);
+        val[0] = t.x; val[1] = t.y; val[2] = t.z; val[3] = t.w;
+      } else {
+        val[0] = p[(int64_t)n * ldy];
+      }
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        const float u = lrelu(fmaf(sc[v], val[v], sh[v]), slope);
+        sum[v] += u;
+        if (u > best[v]) { best[v] = u; bi[v] = n; }
       }
     }
   }
-  s_m[ph][cl] = best;
-  s_s[ph][cl] = sum;
-  s_a[ph][cl] = bi;
-  __syncthreads();
-  if (ph == 0 && c < C) {
-    float m = s_m[0][cl], s = s_s[0][cl];
-    int a = s_a[0][cl];
 #pragma unroll
-    for (int i = 1; i < 4; ++i) {
-      s += s_s[i][cl];
-      const float mi = s_m[i][cl];
-      const int ai = s_a[i][cl];
-      if (mi > m || (mi == m && ai < a)) {      // first maximum, like torch.max
-        m = mi;
-        a = ai;
+  for (int v = 0; v < VEC; ++v) {
+    s_m[ly][lx * VEC + v] = best[v];
+    s_s[ly][lx * VEC + v] = sum[v];
+    s_a[ly][lx * VEC + v] = bi[v];
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int cc = blockIdx.x * 64 + threadIdx.x;
+    if (cc < C) {
+      float m = s_m[0][threadIdx.x], sm = s_s[0][threadIdx.x];
+      int a = s_a[0][threadIdx.x];
+      for (int i = 1; i < LY; ++i) {
+        sm += s_s[i][threadIdx.x];
+        const float mi = s_m[i][threadIdx.x];
+        const int ai = s_a[i][threadIdx.x];
+        if (mi > m || (mi == m && ai < a)) { m = mi; a = ai; }    // first maximum, like torch.max
       }
+      const int64_t o = ((int64_t)b * NS + ch) * C + cc;
+      pmax[o] = m; psum[o] = sm; parg[o] = a;
     }
-    omax[(int64_t)b * C + c] = m;
-    omean[(int64_t)b * C + c] = s / (float)N;
-    arg[(int64_t)b * C + c] = a;
   }
 }
 
-// G[b,n,c] = act'(u) * (gmean[b,c]/N + gmax[b,c]*[n == arg[b,c]]);  per-WG partial sums of G and
-// G*xhat into ws (ordered combine by sug's reduce_partials), layout as col_reduce_kernel.
+__global__ __launch_bounds__(256) void pool_combine_kernel(const float* __restrict__ pmax,
+                                                           const float* __restrict__ psum,
+                                                           const int32_t* __restrict__ parg, int B, int N,
+                                                           int C, float* __restrict__ omax,
+                                                           float* __restrict__ omean,
+                                                           int32_t* __restrict__ arg) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)B * C) return;
+  const int b = (int)(e / C), c = (int)(e % C);
+  float m = -INFINITY, sm = 0.f;
+  int a = 0;
+  for (int ch = 0; ch < NS; ++ch) {      // ascending chunks: ties keep the lower row
+    const int64_t o = ((int64_t)b * NS + ch) * C + c;
+    sm += psum[o];
+    if (pmax[o] > m) { m = pmax[o]; a = parg[o]; }
+  }
+  omax[e] = m; omean[e] = sm / (float)N; arg[e] = a;
+}
+
+// G[b,n,c] = act'(u) * (gmean[b,c]/N + gmax[b,c]*[n == arg[b,c]]);  partial sums of G and G*xhat
+// per (cloud, chunk) into ws rows (ordered fp64 combine by reduce_rows_kernel).
+template <int VEC>
 __global__ __launch_bounds__(256) void pool_bwd_reduce_kernel(const float* __restrict__ y, int64_t ldy,
                                                               const float* __restrict__ coef,
                                                               const float* __restrict__ gmax,
                                                               const float* __restrict__ gmean,
                                                               const int32_t* __restrict__ arg, int N,
                                                               int C, float slope, float* __restrict__ ws) {
-  __shared__ float s_g[4][64];
-  __shared__ float s_x[4][64];
-  const int b = blockIdx.y;
-  const int cl = threadIdx.x & 63, ph = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
-  float sg = 0.f, sx = 0.f;
+  constexpr int LX = 64 / VEC, LY = 256 / LX;
+  __shared__ float s_g[LY][64];
+  __shared__ float s_x[LY][64];
+  const int b = blockIdx.y, ch = blockIdx.z;
+  const int lx = threadIdx.x % LX, ly = threadIdx.x / LX;
+  const int c = blockIdx.x * 64 + lx * VEC;
+  const int n0 = (int)((int64_t)N * ch / NS), n1 = (int)((int64_t)N * (ch + 1) / NS);
+  float sg[VEC], sx[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) { sg[v] = 0.f; sx[v] = 0.f; }
   if (c < C) {
-    const float sc = coef[c], sh = coef[C + c], mean = coef[2 * C + c], rstd = coef[3 * C + c];
-    const float gm = gmean[(int64_t)b * C + c] / (float)N, gx = gmax[(int64_t)b * C + c];
-    const int am = arg[(int64_t)b * C + c];
+    float sc[VEC], sh[VEC], mean[VEC], rstd[VEC], gm[VEC], gx[VEC];
+    int am[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      sc[v] = coef[c + v]; sh[v] = coef[C + c + v]; mean[v] = coef[2 * C + c + v]; rstd[v] = coef[3 * C + c + v];
+      gm[v] = gmean[(int64_t)b * C + c + v] / (float)N;
+      gx[v] = gmax[(int64_t)b * C + c + v];
+      am[v] = arg[(int64_t)b * C + c + v];
+    }
     const float* p = y + (int64_t)b * N * ldy + c;
-    for (int n = ph; n < N; n += 4) {
-      const float yv = p[(int64_t)n * ldy];
-      const float u = fmaf(sc, yv, sh);
-      const float g = (u > 0.f ? 1.f : slope) * (gm + (n == am ? gx : 0.f));
-      sg += g;
-      sx = fmaf(g, (yv - mean) * rstd, sx);
+#pragma unroll 4
+    for (int n = n0 + ly; n < n1; n += LY) {
+      float val[VEC];
+      if constexpr (VEC == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(p + (int64_t)n * ldy);
+        val[0] = t.x; val[1] = t.y; val[2] = t.z; val[3] = t.w;
+      } else {
+        val[0] = p[(int64_t)n * ldy];
+      }
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        const float u = fmaf(sc[v], val[v], sh[v]);
+        const float g = (u > 0.f ? 1.f : slope) * (gm[v] + (n == am[v] ? gx[v] : 0.f));
+        sg[v] += g;
+        sx[v] = fmaf(g, (val[v] - mean[v]) * rstd[v], sx[v]);
+      }
     }
   }
-  s_g[ph][cl] = sg;
-  s_x[ph][cl] = sx;
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    s_g[ly][lx * VEC + v] = sg[v];
+    s_x[ly][lx * VEC + v] = sx[v];
+  }
   __syncthreads();
-  if (ph == 0 && c < C) {
-    const float tg = ((s_g[0][cl] + s_g[1][cl]) + s_g[2][cl]) + s_g[3][cl];
-    const float tx = ((s_x[0][cl] + s_x[1][cl]) + s_x[2][cl]) + s_x[3][cl];
-    float* w = ws + (size_t)blockIdx.y * 2 * C;      // one partial row per cloud
-    w[c] = tg;
-    w[C + c] = tx;
+  if (threadIdx.x < 64) {
+    const int cc = blockIdx.x * 64 + threadIdx.x;
+    if (cc < C) {
+      float tg = 0.f, tx = 0.f;
+      for (int i = 0; i < LY; ++i) { tg += s_g[i][threadIdx.x]; tx += s_x[i][threadIdx.x]; }
+      float* w = ws + ((size_t)b * NS + ch) * 2 * C;
+      w[cc] = tg;
+      w[C + cc] = tx;
+    }
   }
 }
 
+template <int VEC>
 __global__ __launch_bounds__(256) void pool_bwd_apply_kernel(const float* __restrict__ y, int64_t ldy,
                                                              const float* __restrict__ coef,
                                                              const double* __restrict__ red,
@@ -124,18 +218,33 @@ __global__ __launch_bounds__(256) void pool_bwd_apply_kernel(const float* __rest
                                                              const int32_t* __restrict__ arg, int B,
                                                              int N, int C, float slope, float invM,
                                                              float* __restrict__ dy, int64_t lddy) {
-  const int64_t total = (int64_t)B * N * C;
+  const int CV = C / VEC;
+  const int64_t total = (int64_t)B * N * CV;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-    const int c = (int)(e % C);
-    const int64_t r = e / C;
+    const int c = (int)(e % CV) * VEC;
+    const int64_t r = e / CV;
     const int b = (int)(r / N), n = (int)(r - (int64_t)b * N);
-    const float sc = coef[c];
-    const float yv = y[r * ldy + c];
-    const float u = fmaf(sc, yv, coef[C + c]);
-    const float g = (u > 0.f ? 1.f : slope) *
-                    (gmean[(int64_t)b * C + c] / (float)N + (n == arg[(int64_t)b * C + c] ? gmax[(int64_t)b * C + c] : 0.f));
-    const float xhat = (yv - coef[2 * C + c]) * coef[3 * C + c];
-    dy[r * lddy + c] = sc * (g - invM * ((float)red[c] + xhat * (float)red[C + c]));
+    float val[VEC], out[VEC];
+    if constexpr (VEC == 4) {
+      const float4 t = *reinterpret_cast<const float4*>(y + r * ldy + c);
+      val[0] = t.x; val[1] = t.y; val[2] = t.z; val[3] = t.w;
+    } else {
+      val[0] = y[r * ldy + c];
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      const float sc = coef[c + v];
+      const float u = fmaf(sc, val[v], coef[C + c + v]);
+      const float g = (u > 0.f ? 1.f : slope) * (gmean[(int64_t)b * C + c + v] / (float)N +
+                                                 (n == arg[(int64_t)b * C + c + v] ? gmax[(int64_t)b * C + c + v] : 0.f));
+      const float xhat = (val[v] - coef[2 * C + c + v]) * coef[3 * C + c + v];
+      out[v] = sc * (g - invM * ((float)red[c + v] + xhat * (float)red[C + c + v]));
+    }
+    if constexpr (VEC == 4) {
+      *reinterpret_cast<float4*>(dy + r * lddy + c) = make_float4(out[0], out[1], out[2], out[3]);
+    } else {
+      dy[r * lddy + c] = out[0];
+    }
   }
 }
 
@@ -171,20 +280,41 @@ extern "C" int sug_bn_bwd_apply(const float* a, const float* y, int64_t ldy, con
                                 void* stream) {
   SUG_REQUIRE(a && y && coef && red && dy, "sug_bn_bwd_apply: null pointer");
   SUG_REQUIRE(rows > 0 && C > 0 && ldy >= C && lddy >= C, "sug_bn_bwd_apply: bad shape");
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(rows * C)), dim3(256), 0, (hipStream_t)stream, a, y,
-                     ldy, coef, red, rows, C, (float)(1.0 / (double)rows), dy, lddy);
+  const bool vec = (C % 4 == 0) && (ldy % 4 == 0) && (lddy % 4 == 0) && ((uintptr_t)a % 16 == 0) &&
+                   ((uintptr_t)y % 16 == 0) && ((uintptr_t)dy % 16 == 0) && ((uintptr_t)coef % 16 == 0);
+  if (vec)
+    hipLaunchKernelGGL(bn_bwd_apply_vec4_kernel, dim3(ew_grid(rows * C / 4)), dim3(256), 0, (hipStream_t)stream, a,
+                       y, ldy, coef, red, rows, C, (float)(1.0 / (double)rows), dy, lddy);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(rows * C)), dim3(256), 0, (hipStream_t)stream, a, y,
+                       ldy, coef, red, rows, C, (float)(1.0 / (double)rows), dy, lddy);
   SUG_LAUNCH_CHECK("sug_bn_bwd_apply");
   return SUG_OK;
 }
 
+static bool vec4_ok(const float* y, int64_t ld, int C) {
+  return (C % 4 == 0) && (ld % 4 == 0) && ((uintptr_t)y % 16 == 0);
+}
+
 extern "C" int sug_bn_act_pool_fwd(const float* y, int64_t ldy, const float* coef, int B, int N, int C,
                                    float slope, float* out_max, float* out_mean, int32_t* arg,
-                                   void* stream) {
-  SUG_REQUIRE(y && coef && out_max && out_mean && arg, "sug_bn_act_pool_fwd: null pointer");
+                                   float* ws, void* stream) {
+  SUG_REQUIRE(y && coef && out_max && out_mean && arg && ws, "sug_bn_act_pool_fwd: null pointer");
   SUG_REQUIRE(B > 0 && N > 0 && C > 0 && ldy >= C && B <= 65535, "sug_bn_act_pool_fwd: bad shape");
-  hipLaunchKernelGGL(bn_act_pool_fwd_kernel, dim3(sug_divup(C, 64), B), dim3(256), 0, (hipStream_t)stream,
-                     y, ldy, coef, N, C, slope, out_max, out_mean, arg);
+  hipStream_t st = (hipStream_t)stream;
+  const size_t part = (size_t)B * NS * C;
+  float* pmax = ws;
+  float* psum = ws + part;
+  int32_t* parg = reinterpret_cast<int32_t*>(ws + 2 * part);
+  dim3 grid(sug_divup(C, 64), B, NS);
+  if (vec4_ok(y, ldy, C))
+    hipLaunchKernelGGL((bn_act_pool_part_kernel<4>), grid, dim3(256), 0, st, y, ldy, coef, N, C, slope, pmax, psum, parg);
+  else
+    hipLaunchKernelGGL((bn_act_pool_part_kernel<1>), grid, dim3(256), 0, st, y, ldy, coef, N, C, slope, pmax, psum, parg);
   SUG_LAUNCH_CHECK("sug_bn_act_pool_fwd");
+  hipLaunchKernelGGL(pool_combine_kernel, dim3(sug_divup((int64_t)B * C, 256)), dim3(256), 0, st, pmax, psum, parg,
+                     B, N, C, out_max, out_mean, arg);
+  SUG_LAUNCH_CHECK("sug_bn_act_pool_fwd(combine)");
   return SUG_OK;
 }
 
@@ -193,16 +323,25 @@ extern "C" int sug_bn_act_pool_bwd(const float* y, int64_t ldy, const float* coe
                                    float slope, int train, double* red, float* ws, float* dy,
                                    int64_t lddy, void* stream) {
   SUG_REQUIRE(y && coef && gmax && gmean && arg && red && ws && dy, "sug_bn_act_pool_bwd: null pointer");
-  SUG_REQUIRE(B > 0 && N > 0 && C > 0 && ldy >= C && lddy >= C && B <= SUG_STATS_BLOCKS,
-              "sug_bn_act_pool_bwd: bad shape (B must be <= %d)", SUG_STATS_BLOCKS);
+  SUG_REQUIRE(B > 0 && N > 0 && C > 0 && ldy >= C && lddy >= C && B * NS <= SUG_STATS_BLOCKS,
+              "sug_bn_act_pool_bwd: bad shape (B must be <= %d)", SUG_STATS_BLOCKS / NS);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(pool_bwd_reduce_kernel, dim3(sug_divup(C, 64), B), dim3(256), 0, st, y, ldy, coef, gmax,
-                     gmean, arg, N, C, slope, ws);
+  const bool vec = vec4_ok(y, ldy, C) && vec4_ok(dy, lddy, C);
+  dim3 grid(sug_divup(C, 64), B, NS);
+  if (vec)
+    hipLaunchKernelGGL((pool_bwd_reduce_kernel<4>), grid, dim3(256), 0, st, y, ldy, coef, gmax, gmean, arg, N, C, slope, ws);
+  else
+    hipLaunchKernelGGL((pool_bwd_reduce_kernel<1>), grid, dim3(256), 0, st, y, ldy, coef, gmax, gmean, arg, N, C, slope, ws);
   SUG_LAUNCH_CHECK("sug_bn_act_pool_bwd(reduce)");
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3(sug_divup(2 * C, 16)), dim3(256), 0, st, ws, B, 2 * C, red);
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(sug_divup(2 * C, 16)), dim3(256), 0, st, ws, B * NS, 2 * C, red);
   SUG_LAUNCH_CHECK("sug_bn_act_pool_bwd(combine)");
-  hipLaunchKernelGGL(pool_bwd_apply_kernel, dim3(ew_grid((int64_t)B * N * C)), dim3(256), 0, st, y, ldy, coef,
-                     red, gmax, gmean, arg, B, N, C, slope, train ? (float)(1.0 / ((double)B * N)) : 0.f, dy, lddy);
+  const float invM = train ? (float)(1.0 / ((double)B * N)) : 0.f;
+  if (vec)
+    hipLaunchKernelGGL((pool_bwd_apply_kernel<4>), dim3(ew_grid((int64_t)B * N * C / 4)), dim3(256), 0, st, y, ldy,
+                       coef, red, gmax, gmean, arg, B, N, C, slope, invM, dy, lddy);
+  else
+    hipLaunchKernelGGL((pool_bwd_apply_kernel<1>), dim3(ew_grid((int64_t)B * N * C)), dim3(256), 0, st, y, ldy, coef,
+                       red, gmax, gmean, arg, B, N, C, slope, invM, dy, lddy);
   SUG_LAUNCH_CHECK("sug_bn_act_pool_bwd(apply)");
   return SUG_OK;
 }

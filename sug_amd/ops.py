@@ -342,8 +342,9 @@ class _BNActPool(torch.autograd.Function):
         omax = torch.empty(B, C, dtype=torch.float32, device=y.device)
         omean = torch.empty(B, C, dtype=torch.float32, device=y.device)
         arg = torch.empty(B, C, dtype=torch.int32, device=y.device)
+        ws = torch.empty(12 * B * C, dtype=torch.float32, device=y.device)
         check(lib().sug_bn_act_pool_fwd(_p(y), ld, _p(coef), B, N, C, float(slope), _p(omax), _p(omean), _p(arg),
-                                        _st()), 'sug_bn_act_pool_fwd')
+                                        _p(ws), _st()), 'sug_bn_act_pool_fwd')
         ctx.save_for_backward(y, coef, arg)
         ctx.meta = (B, N, C, ld, float(slope), bool(training))
         ctx.mark_non_differentiable(arg)
