@@ -168,6 +168,27 @@ int sug_edgeconv_bwd_scatter(const float* a, const uint8_t* arg, const float* s1
                              const int32_t* rev_ent, const float* coef, const double* red,
                              int B, int N, int k, int Co, float* dpq, int64_t lddpq, void* stream);
 
+/* ---- SA-node module glue (adapt_layer_off, model/model_utils.py:103-128) --------------------
+ * off[b,s,:] = mean_j tanh(proj[b,g_j,:] - proj[b,f,:]) * (loc[b,g_j,:] - loc[b,f,:]),
+ * nloc = loc[b,f,:] + off, with f = fidx[b,s], g_j = gidx[b,s,j], proj = fea . W_pred_offset^T
+ * ([B,N,3]; :110-119).  Backward: dproj [B,N,3] (zero-initialised by the caller, atomics). */
+int sug_node_offset_fwd(const float* proj, const float* loc, const int32_t* fidx,
+                        const int32_t* gidx, int B, int N, int S, int ns, float* off, float* nloc,
+                        void* stream);
+int sug_node_offset_bwd(const float* proj, const float* loc, const int32_t* fidx,
+                        const int32_t* gidx, const float* goff, int B, int N, int S, int ns,
+                        float* dproj, void* stream);
+/* out[b,n,:] = [ fea[b,n,0:C1] | sum_t w_t * node[b, idx3[b,n,t], 0:C2] ] with the inverse-distance
+ * weights of upsample_inter (model/point_utils.py:156-162) from the 3-NN distances d3.
+ * Backward (g = d out): dnode [B,S,C2] and dnloc [B,S,3] (both zero-initialised by the caller,
+ * atomics); dnloc carries d3's gradient through d = |xyz - nloc|^2; d fea is g[:, :, 0:C1]. */
+int sug_interp3_cat_fwd(const float* fea, int64_t ldf, int C1, const float* node,
+                        const int32_t* idx3, const float* d3, int B, int N, int S, int C2,
+                        float* out, int64_t ldo, void* stream);
+int sug_interp3_cat_bwd(const float* g, int64_t ldg, int C1, const float* node, const int32_t* idx3,
+                        const float* d3, const float* xyz, const float* nloc, int B, int N, int S,
+                        int C2, float* dnode, float* dnloc, void* stream);
+
 /* ---- BatchNorm(+act) on rows: backward, and the fused DGCNN tail ----------------------------
  * Exact train-mode BN gradient for a per-point layer (conv_2d on [B,C,N,1],
  * model/model_utils.py:8-32): with a = scale*G and red = (sum G, sum G*xhat) from

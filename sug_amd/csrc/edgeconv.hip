@@ -20,7 +20,7 @@ __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<floa
 template <int NCH>
 __global__ __launch_bounds__(256) void edgeconv_fwd_kernel(
     const float* __restrict__ pq, int64_t ldpq, const int32_t* __restrict__ idx,
-    const float* __restrict__ gamma, int64_t BN, int N, int k, int Co, int LPP,
+    const float* __restrict__ gamma, int64_t BN, int N, int k, int Co, int LPP, int bpc,
     float* __restrict__ z, uint8_t* __restrict__ arg, float* __restrict__ s1,
     float* __restrict__ ws) {
   extern __shared__ __attribute__((aligned(16))) float s_red[];  // [256/LPP][2*Co] per-slot partial sums
@@ -35,8 +35,16 @@ __global__ __launch_bounds__(256) void edgeconv_fwd_kernel(
     const int ch = ch0 + u * LPP;
     gs[u] = ch < nchunk ? ld4(gamma + ch * 4) : make_float4(1, 1, 1, 1);
   }
-  for (int64_t p = (int64_t)blockIdx.x * ppb + slot; p < BN; p += (int64_t)gridDim.x * ppb) {
-    const int64_t b = p / N;
+  // XCD-aware work mapping: workgroups are dealt round-robin over the 8 XCDs, so the ones with
+  // equal blockIdx % 8 share an L2.  All `bpc` workgroups of a cloud get the same residue:
+  // a cloud's P matrix (N*Co*4 B <= 1 MB) then stays in one 4 MB L2 instead of being pulled
+  // through every XCD (placement only affects speed).
+  const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+  const int64_t b = (int64_t)(jb / bpc) * 8 + xcd;
+  const int lb = jb % bpc;
+  const int64_t B_ = BN / N;
+  for (int n = lb * ppb + slot; b < B_ && n < N; n += bpc * ppb) {
+    const int64_t p = b * N + n;
     const int32_t* ir = idx + p * k;
     const float* base = pq + b * N * ldpq;
 #pragma unroll
@@ -48,19 +56,35 @@ __global__ __launch_bounds__(256) void edgeconv_fwd_kernel(
       int jx = 0, jy = 0, jz = 0, jw = 0;
       float sx = 0, sy = 0, sz = 0, sw = 0, qx = 0, qy = 0, qz = 0, qw = 0;
       const bool px = gs[u].x >= 0.f, py = gs[u].y >= 0.f, pz = gs[u].z >= 0.f, pw = gs[u].w >= 0.f;
-#pragma unroll 4
-      for (int j = 0; j < k; ++j) {
-        int nb = ir[j];
-        nb = nb < 0 ? 0 : (nb >= N ? N - 1 : nb);
-        const float4 pv = ld4(base + (int64_t)nb * ldpq + ch * 4);
-        const float yx = __fadd_rn(pv.x, q.x), yy = __fadd_rn(pv.y, q.y);
-        const float yz = __fadd_rn(pv.z, q.z), yw = __fadd_rn(pv.w, q.w);
-        sx += yx; sy += yy; sz += yz; sw += yw;
-        qx = fmaf(yx, yx, qx); qy = fmaf(yy, yy, qy); qz = fmaf(yz, yz, qz); qw = fmaf(yw, yw, qw);
-        if (j == 0 || (px ? yx > bx : yx < bx)) { bx = yx; jx = j; }
-        if (j == 0 || (py ? yy > by : yy < by)) { by = yy; jy = j; }
-        if (j == 0 || (pz ? yz > bz : yz < bz)) { bz = yz; jz = j; }
-        if (j == 0 || (pw ? yw > bw : yw < bw)) { bw = yw; jw = j; }
+      // The gathers are latency-bound (L2 hits, waves mostly waiting): fetch a batch of GB
+      // neighbour indices first, then issue all GB row gathers back to back, then reduce --
+      // two memory round trips per batch instead of two per neighbour group.
+      constexpr int GB = 10;
+      for (int j0 = 0; j0 < k; j0 += GB) {
+        int nb[GB];
+        float4 pv[GB];
+#pragma unroll
+        for (int t = 0; t < GB; ++t) {
+          const int j = j0 + t;
+          int v = (j < k) ? ir[j] : 0;
+          nb[t] = v < 0 ? 0 : (v >= N ? N - 1 : v);
+        }
+#pragma unroll
+        for (int t = 0; t < GB; ++t) pv[t] = ld4(base + (int64_t)nb[t] * ldpq + ch * 4);
+#pragma unroll
+        for (int t = 0; t < GB; ++t) {
+          const int j = j0 + t;
+          if (j < k) {
+            const float yx = __fadd_rn(pv[t].x, q.x), yy = __fadd_rn(pv[t].y, q.y);
+            const float yz = __fadd_rn(pv[t].z, q.z), yw = __fadd_rn(pv[t].w, q.w);
+            sx += yx; sy += yy; sz += yz; sw += yw;
+            qx = fmaf(yx, yx, qx); qy = fmaf(yy, yy, qy); qz = fmaf(yz, yz, qz); qw = fmaf(yw, yw, qw);
+            if (j == 0 || (px ? yx > bx : yx < bx)) { bx = yx; jx = j; }
+            if (j == 0 || (py ? yy > by : yy < by)) { by = yy; jy = j; }
+            if (j == 0 || (pz ? yz > bz : yz < bz)) { bz = yz; jz = j; }
+            if (j == 0 || (pw ? yw > bw : yw < bw)) { bw = yw; jw = j; }
+          }
+        }
       }
       const int64_t o = p * Co + ch * 4;
       st4(z + o, make_float4(bx, by, bz, bw));
@@ -277,15 +301,19 @@ __global__ __launch_bounds__(256) void edgeconv_bwd_scatter_kernel(
     const float* __restrict__ a, const uint8_t* __restrict__ arg, const float* __restrict__ s1,
     const float* __restrict__ pq, int64_t ldpq, const int32_t* __restrict__ rev_off,
     const int32_t* __restrict__ rev_ent, const float* __restrict__ coef,
-    const double* __restrict__ red, int64_t BN, int N, int k, int Co, int LPP, float invM,
+    const double* __restrict__ red, int64_t BN, int N, int k, int Co, int LPP, int bpc, float invM,
     float* __restrict__ dpq, int64_t lddpq) {
   const int nchunk = Co >> 2;
   const int ppb = 256 / LPP;
   const int slot = threadIdx.x / LPP, ch0 = threadIdx.x % LPP;
   const float kf = (float)k;
-  for (int64_t p = (int64_t)blockIdx.x * ppb + slot; p < BN; p += (int64_t)gridDim.x * ppb) {
-    const int64_t b = p / N;
-    const int m = (int)(p - b * N);
+  // XCD-aware mapping as in edgeconv_fwd_kernel: a cloud's a / arg / Q rows stay in one L2
+  const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+  const int64_t b = (int64_t)(jb / bpc) * 8 + xcd;
+  const int lb = jb % bpc;
+  const int64_t B_ = BN / N;
+  for (int m = lb * ppb + slot; b < B_ && m < N; m += bpc * ppb) {
+    const int64_t p = b * N + m;
     const int32_t* offp = rev_off + b * (N + 1) + m;
     const int off = offp[0], cnt = offp[1] - offp[0];
     const int32_t* ent = rev_ent + b * (int64_t)N * k + off;
@@ -303,17 +331,31 @@ __global__ __launch_bounds__(256) void edgeconv_bwd_scatter_kernel(
       const float fx = sc.x * invM, fy = sc.y * invM, fz = sc.z * invM, fw = sc.w * invM;
       const float hx = fx * rstd.x * dgx, hy = fy * rstd.y * dgy, hz = fz * rstd.z * dgz, hw = fw * rstd.w * dgw;
       float ax = 0, ay = 0, az = 0, aw = 0;
-      for (int t = 0; t < cnt; ++t) {
-        const int e = ent[t];
-        const int n = e / k, j = e - n * k;
-        const int64_t o = (rowb + n) * Co + c;
-        const float4 av = ld4(a + o);
-        const uint32_t aj = *reinterpret_cast<const uint32_t*>(arg + o);
-        const float4 qv = ld4(pq + (rowb + n) * ldpq + Co + c);
-        ax += ((int)(aj & 255u) == j ? av.x : 0.f) - hx * qv.x;
-        ay += ((int)((aj >> 8) & 255u) == j ? av.y : 0.f) - hy * qv.y;
-        az += ((int)((aj >> 16) & 255u) == j ? av.z : 0.f) - hz * qv.z;
-        aw += ((int)(aj >> 24) == j ? av.w : 0.f) - hw * qv.w;
+      constexpr int GB = 8;      // entries per batch: indices first, then all row loads in flight
+      for (int t0 = 0; t0 < cnt; t0 += GB) {
+        int en[GB];
+        float4 av[GB], qv[GB];
+        uint32_t aj[GB];
+#pragma unroll
+        for (int t = 0; t < GB; ++t) en[t] = (t0 + t < cnt) ? ent[t0 + t] : -1;
+#pragma unroll
+        for (int t = 0; t < GB; ++t) {
+          const int n = en[t] >= 0 ? en[t] / k : 0;
+          const int64_t o = (rowb + n) * Co + c;
+          av[t] = ld4(a + o);
+          aj[t] = *reinterpret_cast<const uint32_t*>(arg + o);
+          qv[t] = ld4(pq + (rowb + n) * ldpq + Co + c);
+        }
+#pragma unroll
+        for (int t = 0; t < GB; ++t) {
+          if (en[t] >= 0) {
+            const int n = en[t] / k, j = en[t] - n * k;
+            ax += ((int)(aj[t] & 255u) == j ? av[t].x : 0.f) - hx * qv[t].x;
+            ay += ((int)((aj[t] >> 8) & 255u) == j ? av[t].y : 0.f) - hy * qv[t].y;
+            az += ((int)((aj[t] >> 16) & 255u) == j ? av[t].z : 0.f) - hz * qv[t].z;
+            aw += ((int)(aj[t] >> 24) == j ? av[t].w : 0.f) - hw * qv[t].w;
+          }
+        }
       }
       const float4 pm = ld4(pq + p * ldpq + c);
       const float cf = (float)cnt;
@@ -361,16 +403,20 @@ extern "C" int sug_edgeconv_fwd(const float* pq, int64_t ldpq, const int32_t* id
   const int nch = sug_divup(Co >> 2, lpp);
   const int64_t BN = (int64_t)B * N;
   const int ppb = 256 / lpp;
-  int grid = sug_divup(BN, ppb);
-  if (grid > SUG_STATS_BLOCKS) grid = SUG_STATS_BLOCKS;
+  // grid = 8 XCD residues x ceil(B/8) clouds per residue x bpc workgroups per cloud (<= SUG_STATS_BLOCKS)
+  const int cpx = sug_divup(B, 8);
+  int bpc = sug_divup(N, ppb);
+  if (bpc > SUG_STATS_BLOCKS / (8 * cpx)) bpc = SUG_STATS_BLOCKS / (8 * cpx);
+  SUG_REQUIRE(bpc >= 1, "sug_edgeconv_fwd: B=%d too large", B);
+  const int grid = 8 * cpx * bpc;
   const size_t sh = (size_t)ppb * 2 * Co * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   if (nch == 1)
-    hipLaunchKernelGGL((edgeconv_fwd_kernel<1>), dim3(grid), dim3(256), sh, st, pq, ldpq, idx, gamma, BN, N, k, Co, lpp, z, arg, s1, ws);
+    hipLaunchKernelGGL((edgeconv_fwd_kernel<1>), dim3(grid), dim3(256), sh, st, pq, ldpq, idx, gamma, BN, N, k, Co, lpp, bpc, z, arg, s1, ws);
   else if (nch == 2)
-    hipLaunchKernelGGL((edgeconv_fwd_kernel<2>), dim3(grid), dim3(256), sh, st, pq, ldpq, idx, gamma, BN, N, k, Co, lpp, z, arg, s1, ws);
+    hipLaunchKernelGGL((edgeconv_fwd_kernel<2>), dim3(grid), dim3(256), sh, st, pq, ldpq, idx, gamma, BN, N, k, Co, lpp, bpc, z, arg, s1, ws);
   else
-    hipLaunchKernelGGL((edgeconv_fwd_kernel<4>), dim3(grid), dim3(256), sh, st, pq, ldpq, idx, gamma, BN, N, k, Co, lpp, z, arg, s1, ws);
+    hipLaunchKernelGGL((edgeconv_fwd_kernel<4>), dim3(grid), dim3(256), sh, st, pq, ldpq, idx, gamma, BN, N, k, Co, lpp, bpc, z, arg, s1, ws);
   SUG_LAUNCH_CHECK("sug_edgeconv_fwd");
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(sug_divup(2 * Co, 16)), dim3(256), 0, st, ws, grid, 2 * Co, stats);
   SUG_LAUNCH_CHECK("sug_edgeconv_fwd(reduce)");
@@ -483,16 +529,18 @@ extern "C" int sug_edgeconv_bwd_scatter(const float* a, const uint8_t* arg, cons
   const int nch = sug_divup(Co >> 2, lpp);
   const int64_t BN = (int64_t)B * N;
   const int ppb = 256 / lpp;
-  int grid = sug_divup(BN, ppb);
-  if (grid > 4096) grid = 4096;
+  const int cpx = sug_divup(B, 8);
+  int bpc = sug_divup(N, ppb);
+  while (bpc > 1 && (int64_t)8 * cpx * bpc > 8192) bpc = (bpc + 1) / 2;
+  const int grid = 8 * cpx * bpc;
   const float invM = (float)(1.0 / ((double)BN * k));
   hipStream_t st = (hipStream_t)stream;
   if (nch == 1)
-    hipLaunchKernelGGL((edgeconv_bwd_scatter_kernel<1>), dim3(grid), dim3(256), 0, st, a, arg, s1, pq, ldpq, rev_off, rev_ent, coef, red, BN, N, k, Co, lpp, invM, dpq, lddpq);
+    hipLaunchKernelGGL((edgeconv_bwd_scatter_kernel<1>), dim3(grid), dim3(256), 0, st, a, arg, s1, pq, ldpq, rev_off, rev_ent, coef, red, BN, N, k, Co, lpp, bpc, invM, dpq, lddpq);
   else if (nch == 2)
-    hipLaunchKernelGGL((edgeconv_bwd_scatter_kernel<2>), dim3(grid), dim3(256), 0, st, a, arg, s1, pq, ldpq, rev_off, rev_ent, coef, red, BN, N, k, Co, lpp, invM, dpq, lddpq);
+    hipLaunchKernelGGL((edgeconv_bwd_scatter_kernel<2>), dim3(grid), dim3(256), 0, st, a, arg, s1, pq, ldpq, rev_off, rev_ent, coef, red, BN, N, k, Co, lpp, bpc, invM, dpq, lddpq);
   else
-    hipLaunchKernelGGL((edgeconv_bwd_scatter_kernel<4>), dim3(grid), dim3(256), 0, st, a, arg, s1, pq, ldpq, rev_off, rev_ent, coef, red, BN, N, k, Co, lpp, invM, dpq, lddpq);
+    hipLaunchKernelGGL((edgeconv_bwd_scatter_kernel<4>), dim3(grid), dim3(256), 0, st, a, arg, s1, pq, ldpq, rev_off, rev_ent, coef, red, BN, N, k, Co, lpp, bpc, invM, dpq, lddpq);
   SUG_LAUNCH_CHECK("sug_edgeconv_bwd_scatter");
   return SUG_OK;
 }

@@ -41,6 +41,10 @@ class conv_2d(nn.Module):
         self.conv = nn.Sequential(nn.Conv2d(in_ch, out_ch, kernel_size=kernel, bias=bias),
                                   nn.BatchNorm2d(out_ch), act)
         self.activation = activation
+        # opt-in (SUGStep): reuse the [W1 ; W2-W1] split across the forwards of one step
+        # (one backward over all of them); cleared by the owner after backward
+        self.cache_weight_split = False
+        self._wcat = None
 
     def weight2d(self):
         w = self.conv[0].weight
@@ -65,7 +69,12 @@ class conv_2d(nn.Module):
         B, N, C = x.shape
         W = self.weight2d()
         assert W.shape[1] == 2 * C
-        Wcat = torch.cat((W[:, :C], W[:, C:] - W[:, :C]), dim=0)          # [2Co, C]
+        key = (W._version, torch.is_grad_enabled())
+        if self.cache_weight_split and self._wcat is not None and self._wcat[0] == key:
+            Wcat = self._wcat[1]                                          # same weights, same step
+        else:
+            Wcat = torch.cat((W[:, :C], W[:, C:] - W[:, :C]), dim=0)      # [2Co, C]
+            self._wcat = (key, Wcat) if self.cache_weight_split else None
         pq = F.linear(x.reshape(B * N, C), Wcat)
         bias = self.conv[0].bias
         if bias is not None:                                              # bias rides on the Q half
@@ -162,18 +171,25 @@ class adapt_layer_off(nn.Module):
         fidx = ops.fps(loc, S, start)                                 # [B,S]
         f_loc = ops.gather_rows(loc, fidx)                            # [B,S,3]
         gidx = ops.ball_query(loc, f_loc, 0.3, 64)                    # [B,S,64]
-        # pred_offset on (fea_j - fea_c) is linear before the tanh: project once, gather after
+        # pred_offset on (fea_j - fea_c) is linear before the tanh: project once (one GEMM), then
+        # gather / tanh / weight / mean in one kernel (sug_node_offset_*)
         w_off = self.pred_offset[0].weight.view(self.offset_dim, -1)
         proj = F.linear(fea, w_off)                                   # [B,N,3]
-        sem = torch.tanh(ops.gather_rows(proj, gidx) - ops.gather_rows(proj, fidx).unsqueeze(2))
-        g_loc = ops.gather_rows(loc, gidx) - f_loc.unsqueeze(2)       # [B,S,64,3]
-        node_off = (sem * g_loc).mean(dim=2)                          # [B,S,3]
-        n_loc = f_loc + node_off
+        if self.offset_dim == 3 and gidx.shape[2] == S:
+            node_off, n_loc = ops.node_offset(proj, loc, fidx, gidx)  # [B,S,3] each
+        else:
+            sem = torch.tanh(ops.gather_rows(proj, gidx) - ops.gather_rows(proj, fidx).unsqueeze(2))
+            g_loc = ops.gather_rows(loc, gidx) - f_loc.unsqueeze(2)
+            node_off = (sem * g_loc).mean(dim=2)
+            n_loc = f_loc + node_off
         gidx2 = ops.knn_query(loc, n_loc, 64)                         # 64-NN of the moved nodes
         res = self.residual.rows(fea)
         node_fea = ops.group_max(res, gidx2)                          # [B,S,64]
-        interp = point_utils.interpolate_rows(loc, n_loc, node_fea, 3)
-        return torch.cat((fea, interp), dim=2), node_fea, node_off
+        if fea.shape[2] % 4 == 0 and node_fea.shape[2] % 4 == 0:
+            out = ops.interp3_cat(fea, node_fea, loc, n_loc)          # cat(fea, 3-NN interpolation)
+        else:
+            out = torch.cat((fea, point_utils.interpolate_rows(loc, n_loc, node_fea, 3)), dim=2)
+        return out, node_fea, node_off
 
     def forward(self, input_fea, input_loc):
         """input_fea [B,64,N,1], input_loc [B,3,N] -> (output_fea [B,128,N,1], node_fea [B,64,S,1],

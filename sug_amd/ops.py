@@ -232,6 +232,77 @@ def group_max(feat, idx):
     return _GroupMax.apply(feat, idx)
 
 
+# ----------------------------------------------------------------------------- SA-node glue
+class _NodeOffset(torch.autograd.Function):
+    """(node_off, node_loc) of adapt_layer_off from the projected features (sug_node_offset_*)."""
+
+    @staticmethod
+    def forward(ctx, proj, loc, fidx, gidx):
+        _need_gpu(proj, loc, fidx, gidx)
+        proj, loc = proj.contiguous(), loc.detach().contiguous()
+        fidx, gidx = _i32(fidx).contiguous(), _i32(gidx).contiguous()
+        B, N, _ = proj.shape
+        S, ns = gidx.shape[1], gidx.shape[2]
+        off = torch.empty(B, S, 3, dtype=torch.float32, device=proj.device)
+        nloc = torch.empty(B, S, 3, dtype=torch.float32, device=proj.device)
+        check(lib().sug_node_offset_fwd(_p(proj), _p(loc), _p(fidx), _p(gidx), B, N, S, ns, _p(off), _p(nloc), _st()),
+              'sug_node_offset_fwd')
+        ctx.save_for_backward(proj, loc, fidx, gidx)
+        return off, nloc
+
+    @staticmethod
+    def backward(ctx, goff, gnloc):
+        proj, loc, fidx, gidx = ctx.saved_tensors
+        B, N, _ = proj.shape
+        S, ns = gidx.shape[1], gidx.shape[2]
+        g = (goff + gnloc).contiguous()                 # nloc = loc[f] + off
+        dproj = torch.zeros_like(proj)
+        check(lib().sug_node_offset_bwd(_p(proj), _p(loc), _p(fidx), _p(gidx), _p(g), B, N, S, ns, _p(dproj), _st()),
+              'sug_node_offset_bwd')
+        return dproj, None, None, None
+
+
+def node_offset(proj, loc, fidx, gidx):
+    """proj [B,N,3], loc [B,N,3], fidx [B,S], gidx [B,S,ns] -> (node_off [B,S,3], node_loc [B,S,3])."""
+    return _NodeOffset.apply(proj, loc, fidx, gidx)
+
+
+class _Interp3Cat(torch.autograd.Function):
+    """cat(fea, inverse-distance 3-NN interpolation of the node features) in one kernel; the
+    backward also carries the distance gradient back to the node positions."""
+
+    @staticmethod
+    def forward(ctx, fea, node, xyz, nloc):
+        _need_gpu(fea, node, xyz, nloc)
+        fea, B, N, C1, ldf = _rows3(fea)
+        node = node.contiguous()
+        xyz, nlocd = xyz.detach().contiguous(), nloc.detach().contiguous()
+        S, C2 = node.shape[1], node.shape[2]
+        idx3, d3 = three_nn_raw(xyz, nlocd)
+        out = torch.empty(B, N, C1 + C2, dtype=torch.float32, device=fea.device)
+        check(lib().sug_interp3_cat_fwd(_p(fea), ldf, C1, _p(node), _p(idx3), _p(d3), B, N, S, C2, _p(out),
+                                        C1 + C2, _st()), 'sug_interp3_cat_fwd')
+        ctx.save_for_backward(node, idx3, d3, xyz, nlocd)
+        ctx.meta = (B, N, S, C1, C2)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        node, idx3, d3, xyz, nloc = ctx.saved_tensors
+        B, N, S, C1, C2 = ctx.meta
+        g = g.contiguous()
+        dnode = torch.zeros_like(node)
+        dnloc = torch.zeros_like(nloc)
+        check(lib().sug_interp3_cat_bwd(_p(g), C1 + C2, C1, _p(node), _p(idx3), _p(d3), _p(xyz), _p(nloc), B, N, S,
+                                        C2, _p(dnode), _p(dnloc), _st()), 'sug_interp3_cat_bwd')
+        return g[:, :, :C1], dnode, None, dnloc
+
+
+def interp3_cat(fea, node, xyz, nloc):
+    """fea [B,N,C1], node [B,S,C2], xyz [B,N,3], nloc [B,S,3] -> [B,N,C1+C2]."""
+    return _Interp3Cat.apply(fea, node, xyz, nloc)
+
+
 # ----------------------------------------------------------------------------- BN helpers
 def bn_coef(stats, gamma, beta, count, eps, momentum, running_mean, running_var):
     C = gamma.numel()
@@ -314,7 +385,8 @@ class _BNActRows(torch.autograd.Function):
                   'sug_bn_bwd_apply')
         else:
             dy = a
-        return dy.view(shape), red[C:].float(), red[:C].float(), None, None, None, None, None, None
+        rf = red.float()
+        return dy.view(shape), rf[C:], rf[:C], None, None, None, None, None, None
 
 
 def bn_act_rows(y, bn, slope):
@@ -362,7 +434,8 @@ class _BNActPool(torch.autograd.Function):
         check(lib().sug_bn_act_pool_bwd(_p(y), ld, _p(coef), _p(gmax), _p(gmean), _p(arg), B, N, C, slope,
                                         1 if training else 0, _p(red), _p(ws), _p(dy), C, _st()),
               'sug_bn_act_pool_bwd')
-        return dy, red[C:].float(), red[:C].float(), None, None, None, None, None, None
+        rf = red.float()
+        return dy, rf[C:], rf[:C], None, None, None, None, None, None
 
 
 def bn_act_pool(y, bn, slope):
@@ -424,9 +497,8 @@ class _EdgeConv(torch.autograd.Function):
                      lambda: lib().sug_edgeconv_bwd_scatter(_p(a), _p(arg), _p(s1), _p(pq), ld, _p(off), _p(ent),
                                                             _p(coef), _p(red_used), B, N, k, Co, _p(dpq), 2 * Co,
                                                             _st())), 'sug_edgeconv_bwd_scatter')
-        dbeta = red[:Co].float()
-        dgamma = red[Co:].float()
-        return dpq, None, dgamma, dbeta, None, None, None, None, None, None
+        rf = red.float()
+        return dpq, None, rf[Co:], rf[:Co], None, None, None, None, None, None
 
 
 def edgeconv_bn_act_max(pq, idx, gamma, beta, running_mean, running_var, training, slope, eps=1e-5, momentum=0.1):

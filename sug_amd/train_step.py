@@ -131,6 +131,9 @@ class SUGStep:
         self.share_prefix = share_prefix and hasattr(model.g, 'share_prefix')
         if hasattr(model.g, 'share_prefix'):
             model.g.share_prefix = self.share_prefix
+        self._split_layers = [m for m in model.modules() if hasattr(m, 'cache_weight_split')]
+        for m in self._split_layers:
+            m.cache_weight_split = bool(share_prefix)
         self.methods = dict(METHODS)
         if methods:
             self.methods.update(methods)
@@ -263,6 +266,8 @@ class SUGStep:
         loss.backward()
         if self.share_prefix:
             self.model.g.clear_prefix_cache()
+        for m in self._split_layers:
+            m._wcat = None
         if self.world > 1:
             allreduce_grads_(self.model.parameters(), self.world)
         self.optimizer_dis.step()

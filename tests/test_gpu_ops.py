@@ -242,3 +242,37 @@ def test_chamfer_vs_oracle():
     dm = ((pa[:, :, None] - pb[:, None]) ** 2).sum(-1)
     ref = dm.min(2)[0].mean(1) + dm.min(1)[0].mean(1)
     torch.testing.assert_close(d.cpu(), ref, rtol=1e-5, atol=1e-7)
+
+
+def test_adapt_layer_fused_glue_vs_oracle():
+    """adapt_layer_off.rows (fused node-offset + interp3/concat kernels, forward and backward)
+    against the oracle's adapt_layer_off on identical weights and FPS start."""
+    from sug_amd.model.model_utils import adapt_layer_off
+    g = torch.Generator().manual_seed(21)
+    B, N = 3, 512
+    loc = O.synth_clouds(B, N, g).squeeze(-1)                       # [B,3,N]
+    fea = torch.randn(B, 64, N, 1, generator=g)
+    m = adapt_layer_off()
+    sd = O.fill_params({k: tuple(v.shape) for k, v in m.state_dict().items()}, 3)
+    m.load_state_dict(sd)
+    m = m.cuda().train()
+    start = torch.randint(0, N, (B,), generator=g)
+    p = O.as_params({'a.' + k: v for k, v in sd.items()})
+    fo = fea.clone().requires_grad_(True)
+    out_o, node_o, off_o = O.adapt_layer_off(p, 'a.', fo, loc, True, start)
+    probe = torch.randn(out_o.shape, generator=g)
+    pn = torch.randn(node_o.shape, generator=g)
+    ((out_o * probe).sum() + (node_o * pn).sum() + off_o.sum()).backward()
+    from sug_amd import ops
+    ops.START_PROVIDER = lambda b, n: start
+    try:
+        fg = fea.cuda().requires_grad_(True)
+        out, node, off = m(fg, loc.cuda())
+    finally:
+        ops.START_PROVIDER = None
+    ((out * probe.cuda()).sum() + (node * pn.cuda()).sum() + off.sum()).backward()
+    torch.testing.assert_close(off.detach().cpu(), off_o.detach(), rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(node.detach().cpu(), node_o.detach(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(out.detach().cpu(), out_o.detach(), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(fg.grad.cpu(), fo.grad, rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(m.pred_offset[0].weight.grad.cpu(), p['a.pred_offset.0.weight'].grad, rtol=2e-3, atol=2e-3)
