@@ -10,6 +10,7 @@
 
 namespace {
 
+// One wave per node (b,s); lanes run over the ns neighbours, wave shuffle reduction.
 __global__ __launch_bounds__(256) void node_offset_fwd_kernel(const float* __restrict__ proj,
                                                               const float* __restrict__ loc,
                                                               const int32_t* __restrict__ fidx,
@@ -17,8 +18,9 @@ __global__ __launch_bounds__(256) void node_offset_fwd_kernel(const float* __res
                                                               int S, int ns, int total,
                                                               float* __restrict__ off,
                                                               float* __restrict__ nloc) {
-  const int e = blockIdx.x * 256 + threadIdx.x;       // (b, s)
+  const int e = blockIdx.x * 4 + (threadIdx.x >> 6);  // (b, s)
   if (e >= total) return;
+  const int lane = threadIdx.x & 63;
   const int b = e / S;
   const float* pb = proj + (int64_t)b * N * 3;
   const float* lb = loc + (int64_t)b * N * 3;
@@ -28,17 +30,20 @@ __global__ __launch_bounds__(256) void node_offset_fwd_kernel(const float* __res
   const float lcx = lb[f * 3 + 0], lcy = lb[f * 3 + 1], lcz = lb[f * 3 + 2];
   float ax = 0.f, ay = 0.f, az = 0.f;
   const int32_t* g = gidx + (int64_t)e * ns;
-  for (int j = 0; j < ns; ++j) {
-    int n = g[j];
+  for (int j = lane; j < ns; j += 64) {
+    const int n = g[j];
     if (n < 0 || n >= N) continue;                    // zero-hit rows of the ball query
     ax += tanhf(pb[n * 3 + 0] - pcx) * (lb[n * 3 + 0] - lcx);
     ay += tanhf(pb[n * 3 + 1] - pcy) * (lb[n * 3 + 1] - lcy);
     az += tanhf(pb[n * 3 + 2] - pcz) * (lb[n * 3 + 2] - lcz);
   }
-  const float inv = 1.0f / (float)ns;
-  ax *= inv; ay *= inv; az *= inv;
-  off[e * 3 + 0] = ax; off[e * 3 + 1] = ay; off[e * 3 + 2] = az;
-  nloc[e * 3 + 0] = lcx + ax; nloc[e * 3 + 1] = lcy + ay; nloc[e * 3 + 2] = lcz + az;
+  ax = wave_sum_f(ax); ay = wave_sum_f(ay); az = wave_sum_f(az);
+  if (lane == 0) {
+    const float inv = 1.0f / (float)ns;
+    ax *= inv; ay *= inv; az *= inv;
+    off[e * 3 + 0] = ax; off[e * 3 + 1] = ay; off[e * 3 + 2] = az;
+    nloc[e * 3 + 0] = lcx + ax; nloc[e * 3 + 1] = lcy + ay; nloc[e * 3 + 2] = lcz + az;
+  }
 }
 
 // dproj[g_j] += g * d_j * (1 - t^2) / ns ; dproj[f] -= sum_j (same)   (dproj zero-initialised)
@@ -49,8 +54,9 @@ __global__ __launch_bounds__(256) void node_offset_bwd_kernel(const float* __res
                                                               const float* __restrict__ goff, int N,
                                                               int S, int ns, int total,
                                                               float* __restrict__ dproj) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (e >= total) return;
+  const int lane = threadIdx.x & 63;
   const int b = e / S;
   const float* pb = proj + (int64_t)b * N * 3;
   const float* lb = loc + (int64_t)b * N * 3;
@@ -63,8 +69,8 @@ __global__ __launch_bounds__(256) void node_offset_bwd_kernel(const float* __res
   const float gx = goff[e * 3 + 0] * inv, gy = goff[e * 3 + 1] * inv, gz = goff[e * 3 + 2] * inv;
   float cx = 0.f, cy = 0.f, cz = 0.f;
   const int32_t* g = gidx + (int64_t)e * ns;
-  for (int j = 0; j < ns; ++j) {
-    int n = g[j];
+  for (int j = lane; j < ns; j += 64) {
+    const int n = g[j];
     if (n < 0 || n >= N) continue;
     const float tx = tanhf(pb[n * 3 + 0] - pcx), ty = tanhf(pb[n * 3 + 1] - pcy), tz = tanhf(pb[n * 3 + 2] - pcz);
     const float vx = gx * (lb[n * 3 + 0] - lcx) * (1.f - tx * tx);
@@ -73,7 +79,10 @@ __global__ __launch_bounds__(256) void node_offset_bwd_kernel(const float* __res
     atomicAdd(&db[n * 3 + 0], vx); atomicAdd(&db[n * 3 + 1], vy); atomicAdd(&db[n * 3 + 2], vz);
     cx += vx; cy += vy; cz += vz;
   }
-  atomicAdd(&db[f * 3 + 0], -cx); atomicAdd(&db[f * 3 + 1], -cy); atomicAdd(&db[f * 3 + 2], -cz);
+  cx = wave_sum_f(cx); cy = wave_sum_f(cy); cz = wave_sum_f(cz);
+  if (lane == 0) {
+    atomicAdd(&db[f * 3 + 0], -cx); atomicAdd(&db[f * 3 + 1], -cy); atomicAdd(&db[f * 3 + 2], -cz);
+  }
 }
 
 // 16 lanes x float4 per point (C2 = 64 interpolated channels); generic C2 % 4 == 0 via a loop.
@@ -106,69 +115,79 @@ __global__ __launch_bounds__(256) void interp3_cat_fwd_kernel(const float* __res
   }
 }
 
-// g: gradient of out [B,N,C1+C2] (row stride ldg).  dnode += w_t*g_interp (atomics),
+// g: gradient of out [B,N,C1+C2] (row stride ldg).  dnode += w_t*g_interp,
 // dd_t = -(r_t^2/R) * <g_interp, node_t - interp>  (0 where d_t was clamped), and through
-// d_t = |q - c_t|^2:  dnloc[idx_t] += dd_t * 2*(nloc[idx_t] - xyz[n])  (atomics).
+// d_t = |q - c_t|^2:  dnloc[idx_t] += dd_t * 2*(nloc[idx_t] - xyz[n]).
+// One workgroup = one cloud x one chunk of its points; the cloud's node gradients [S,C2]
+// (16 KB at 64x64) and node-position gradients accumulate in LDS (every node receives ~48
+// contributions per channel: global atomics would serialise) and are flushed once.
 __global__ __launch_bounds__(256) void interp3_cat_bwd_kernel(const float* __restrict__ g, int64_t ldg,
                                                               int C1, const float* __restrict__ node,
                                                               const int32_t* __restrict__ idx3,
                                                               const float* __restrict__ d3,
                                                               const float* __restrict__ xyz,
                                                               const float* __restrict__ nloc, int N,
-                                                              int S, int C2, int64_t BN,
+                                                              int S, int C2, int chunks,
                                                               float* __restrict__ dnode,
                                                               float* __restrict__ dnloc) {
-  const int64_t p = (int64_t)blockIdx.x * 16 + threadIdx.x / 16;
-  const bool live = p < BN;
-  const int64_t pc = live ? p : 0;
-  const int lane = threadIdx.x & 15;
-  const int64_t b = pc / N;
-  const float d0 = d3[pc * 3 + 0], d1 = d3[pc * 3 + 1], d2 = d3[pc * 3 + 2];
-  const float r0 = 1.0f / fmaxf(d0, 1e-10f), r1 = 1.0f / fmaxf(d1, 1e-10f), r2 = 1.0f / fmaxf(d2, 1e-10f);
-  const float R = (r0 + r1) + r2;
-  const float w0 = r0 / R, w1 = r1 / R, w2 = r2 / R;
-  const int i0 = idx3[pc * 3 + 0], i1 = idx3[pc * 3 + 1], i2 = idx3[pc * 3 + 2];
-  const float* n0 = node + (b * S + i0) * C2;
-  const float* n1 = node + (b * S + i1) * C2;
-  const float* n2 = node + (b * S + i2) * C2;
-  float* dn0 = dnode + (b * S + i0) * C2;
-  float* dn1 = dnode + (b * S + i1) * C2;
-  float* dn2 = dnode + (b * S + i2) * C2;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-  if (live) {
-    for (int c = lane * 4; c < C2; c += 64) {
-      const float4 gv = *reinterpret_cast<const float4*>(g + p * ldg + C1 + c);
-      const float4 a = *reinterpret_cast<const float4*>(n0 + c), bq = *reinterpret_cast<const float4*>(n1 + c),
-                   cq = *reinterpret_cast<const float4*>(n2 + c);
-      const float gg[4] = {gv.x, gv.y, gv.z, gv.w};
-      const float aa[4] = {a.x, a.y, a.z, a.w}, bb[4] = {bq.x, bq.y, bq.z, bq.w}, cc[4] = {cq.x, cq.y, cq.z, cq.w};
+  extern __shared__ float s_acc[];               // [S*C2] node grads | [S*3] node-position grads
+  float* s_dn = s_acc;
+  float* s_dl = s_acc + S * C2;
+  const int b = blockIdx.y, ck = blockIdx.x;
+  for (int i = threadIdx.x; i < S * C2 + S * 3; i += 256) s_acc[i] = 0.f;
+  __syncthreads();
+  const int lane = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int n0 = (int)((int64_t)N * ck / chunks), n1 = (int)((int64_t)N * (ck + 1) / chunks);
+  const float* nodeb = node + (int64_t)b * S * C2;
+  for (int n = n0 + grp; n < n1 + 15; n += 16) {   // all 16 lanes of a group share n (uniform trip count)
+    const bool live = n < n1;
+    const int64_t p = (int64_t)b * N + (live ? n : n0);
+    const float d0 = d3[p * 3 + 0], d1 = d3[p * 3 + 1], d2 = d3[p * 3 + 2];
+    const float r0 = 1.0f / fmaxf(d0, 1e-10f), r1 = 1.0f / fmaxf(d1, 1e-10f), r2 = 1.0f / fmaxf(d2, 1e-10f);
+    const float R = (r0 + r1) + r2;
+    const float w0 = r0 / R, w1 = r1 / R, w2 = r2 / R;
+    const int i0 = idx3[p * 3 + 0], i1 = idx3[p * 3 + 1], i2 = idx3[p * 3 + 2];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    if (live) {
+      for (int c = lane * 4; c < C2; c += 64) {
+        const float4 gv = *reinterpret_cast<const float4*>(g + p * ldg + C1 + c);
+        const float4 a = *reinterpret_cast<const float4*>(nodeb + i0 * C2 + c);
+        const float4 bq = *reinterpret_cast<const float4*>(nodeb + i1 * C2 + c);
+        const float4 cq = *reinterpret_cast<const float4*>(nodeb + i2 * C2 + c);
+        const float gg[4] = {gv.x, gv.y, gv.z, gv.w};
+        const float aa[4] = {a.x, a.y, a.z, a.w}, bb[4] = {bq.x, bq.y, bq.z, bq.w}, cc[4] = {cq.x, cq.y, cq.z, cq.w};
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const float o = (aa[v] * w0 + bb[v] * w1) + cc[v] * w2;
-        s0 += gg[v] * (aa[v] - o); s1 += gg[v] * (bb[v] - o); s2 += gg[v] * (cc[v] - o);
-        atomicAdd(&dn0[c + v], w0 * gg[v]);
-        atomicAdd(&dn1[c + v], w1 * gg[v]);
-        atomicAdd(&dn2[c + v], w2 * gg[v]);
+        for (int v = 0; v < 4; ++v) {
+          const float o = (aa[v] * w0 + bb[v] * w1) + cc[v] * w2;
+          s0 += gg[v] * (aa[v] - o); s1 += gg[v] * (bb[v] - o); s2 += gg[v] * (cc[v] - o);
+          atomicAdd(&s_dn[i0 * C2 + c + v], w0 * gg[v]);
+          atomicAdd(&s_dn[i1 * C2 + c + v], w1 * gg[v]);
+          atomicAdd(&s_dn[i2 * C2 + c + v], w2 * gg[v]);
+        }
       }
     }
-  }
 #pragma unroll
-  for (int o = 8; o > 0; o >>= 1) {
-    s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o);
+    for (int o = 8; o > 0; o >>= 1) {
+      s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o);
+    }
+    if (live && lane < 3) {
+      const float sv = lane == 0 ? s0 : (lane == 1 ? s1 : s2);
+      const float d = lane == 0 ? d0 : (lane == 1 ? d1 : d2);
+      const float r = lane == 0 ? r0 : (lane == 1 ? r1 : r2);
+      const int i = lane == 0 ? i0 : (lane == 1 ? i1 : i2);
+      const float dd = (d < 1e-10f) ? 0.f : -(r * r / R) * sv;     // clamp region: no gradient
+      const float* q = xyz + p * 3;
+      const float* cpos = nloc + ((int64_t)b * S + i) * 3;
+      atomicAdd(&s_dl[i * 3 + 0], dd * 2.f * (cpos[0] - q[0]));
+      atomicAdd(&s_dl[i * 3 + 1], dd * 2.f * (cpos[1] - q[1]));
+      atomicAdd(&s_dl[i * 3 + 2], dd * 2.f * (cpos[2] - q[2]));
+    }
   }
-  if (live && lane < 3) {
-    const float s = lane == 0 ? s0 : (lane == 1 ? s1 : s2);
-    const float d = lane == 0 ? d0 : (lane == 1 ? d1 : d2);
-    const float r = lane == 0 ? r0 : (lane == 1 ? r1 : r2);
-    const int i = lane == 0 ? i0 : (lane == 1 ? i1 : i2);
-    const float dd = (d < 1e-10f) ? 0.f : -(r * r / R) * s;       // clamp region: no gradient
-    const float* q = xyz + p * 3;
-    const float* cpos = nloc + (b * S + i) * 3;
-    float* dc = dnloc + (b * S + i) * 3;
-    atomicAdd(&dc[0], dd * 2.f * (cpos[0] - q[0]));
-    atomicAdd(&dc[1], dd * 2.f * (cpos[1] - q[1]));
-    atomicAdd(&dc[2], dd * 2.f * (cpos[2] - q[2]));
-  }
+  __syncthreads();
+  float* dnb = dnode + (int64_t)b * S * C2;
+  float* dlb = dnloc + (int64_t)b * S * 3;
+  for (int i = threadIdx.x; i < S * C2; i += 256) atomicAdd(&dnb[i], s_dn[i]);
+  for (int i = threadIdx.x; i < S * 3; i += 256) atomicAdd(&dlb[i], s_dl[i]);
 }
 
 }  // namespace
@@ -179,7 +198,7 @@ extern "C" int sug_node_offset_fwd(const float* proj, const float* loc, const in
   SUG_REQUIRE(proj && loc && fidx && gidx && off && nloc, "sug_node_offset_fwd: null pointer");
   SUG_REQUIRE(B > 0 && N > 0 && S > 0 && ns > 0, "sug_node_offset_fwd: bad shape");
   const int total = B * S;
-  hipLaunchKernelGGL(node_offset_fwd_kernel, dim3(sug_divup(total, 256)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(node_offset_fwd_kernel, dim3(sug_divup(total, 4)), dim3(256), 0, (hipStream_t)stream,
                      proj, loc, fidx, gidx, N, S, ns, total, off, nloc);
   SUG_LAUNCH_CHECK("sug_node_offset_fwd");
   return SUG_OK;
@@ -191,7 +210,7 @@ extern "C" int sug_node_offset_bwd(const float* proj, const float* loc, const in
   SUG_REQUIRE(proj && loc && fidx && gidx && goff && dproj, "sug_node_offset_bwd: null pointer");
   SUG_REQUIRE(B > 0 && N > 0 && S > 0 && ns > 0, "sug_node_offset_bwd: bad shape");
   const int total = B * S;
-  hipLaunchKernelGGL(node_offset_bwd_kernel, dim3(sug_divup(total, 256)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(node_offset_bwd_kernel, dim3(sug_divup(total, 4)), dim3(256), 0, (hipStream_t)stream,
                      proj, loc, fidx, gidx, goff, N, S, ns, total, dproj);
   SUG_LAUNCH_CHECK("sug_node_offset_bwd");
   return SUG_OK;
@@ -221,9 +240,13 @@ extern "C" int sug_interp3_cat_bwd(const float* g, int64_t ldg, int C1, const fl
   SUG_REQUIRE(B > 0 && N > 0 && S >= 3 && C2 > 0 && C1 % 4 == 0 && C2 % 4 == 0 && ldg % 4 == 0 &&
                   ldg >= C1 + C2 && ((uintptr_t)g % 16 == 0) && ((uintptr_t)node % 16 == 0),
               "sug_interp3_cat_bwd: bad shape / alignment");
-  const int64_t BN = (int64_t)B * N;
-  hipLaunchKernelGGL(interp3_cat_bwd_kernel, dim3(sug_divup(BN, 16)), dim3(256), 0, (hipStream_t)stream, g, ldg,
-                     C1, node, idx3, d3, xyz, nloc, N, S, C2, BN, dnode, dnloc);
+  const size_t sh = (size_t)(S * C2 + S * 3) * sizeof(float);
+  SUG_REQUIRE(sh <= 64 * 1024 && B <= 65535, "sug_interp3_cat_bwd: S*C2=%d too large for the LDS accumulator", S * C2);
+  int chunks = 512 / B;                      // ~512 workgroups in total
+  if (chunks < 1) chunks = 1;
+  if (chunks > sug_divup(N, 64)) chunks = sug_divup(N, 64);
+  hipLaunchKernelGGL(interp3_cat_bwd_kernel, dim3(chunks, B), dim3(256), sh, (hipStream_t)stream, g, ldg, C1, node,
+                     idx3, d3, xyz, nloc, N, S, C2, chunks, dnode, dnloc);
   SUG_LAUNCH_CHECK("sug_interp3_cat_bwd");
   return SUG_OK;
 }
