@@ -168,6 +168,15 @@ int sug_edgeconv_bwd_scatter(const float* a, const uint8_t* arg, const float* s1
                              const int32_t* rev_ent, const float* coef, const double* red,
                              int B, int N, int k, int Co, float* dpq, int64_t lddpq, void* stream);
 
+/* ---- weight gradient of a per-point linear layer ----------------------------------------------
+ * dw[M,N] = g^T . x, g [R,M] (row stride ldg), x [R,N] (row stride ldx): the backward of every
+ * 1x1 conv of the encoders (conv_2d / Conv1d, model/model_utils.py:13, model/Model.py:68-70)
+ * w.r.t. its weight, R = B*N rows.  Split over row chunks, fp32 MFMA, ordered combine
+ * (bit-reproducible).  ws: sug_linear_dw_workspace(R,M,N) floats. */
+int64_t sug_linear_dw_workspace(int64_t R, int M, int N);
+int sug_linear_dw(const float* g, int64_t ldg, const float* x, int64_t ldx, int64_t R, int M, int N,
+                  float* dw, float* ws, void* stream);
+
 /* ---- SA-node module glue (adapt_layer_off, model/model_utils.py:103-128) --------------------
  * off[b,s,:] = mean_j tanh(proj[b,g_j,:] - proj[b,f,:]) * (loc[b,g_j,:] - loc[b,f,:]),
  * nloc = loc[b,f,:] + off, with f = fidx[b,s], g_j = gidx[b,s,j], proj = fea . W_pred_offset^T

@@ -35,6 +35,7 @@ SIGNATURES = {
     'sug_edgeconv_bwd_reduce': [_vp, _i64, _vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp],
     'sug_edgeconv_bwd_scatter': [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32,
                                  _vp, _i64, _vp],
+    'sug_linear_dw': [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp],
     'sug_node_offset_fwd': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
     'sug_node_offset_bwd': [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp],
     'sug_interp3_cat_fwd': [_vp, _i64, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp],
@@ -65,6 +66,8 @@ def lib():
             fn = getattr(L, name)
             fn.argtypes = args
             fn.restype = ctypes.c_int
+        L.sug_linear_dw_workspace.restype = ctypes.c_int64
+        L.sug_linear_dw_workspace.argtypes = [_i64, _i32, _i32]
         L.sug_last_error.restype = ctypes.c_char_p
         L.sug_last_error.argtypes = []
         L.sug_abi_version.restype = ctypes.c_int

@@ -1,0 +1,115 @@
+// Weight gradient of a per-point linear layer: dW[M,N] = g^T . x over R rows (R = B*N = 32768 at
+// C2, M/N = 3..512).  rocBLAS runs these "K = R, tiny output" GEMMs at ~140 us regardless of
+// size (few output tiles -> few workgroups, each walking all of K); here K is split over row
+// chunks so thousands of waves stream g and x once at HBM rate:
+//   workgroup = (row chunk, 64x64 output super-tile); each of its 4 waves owns a quarter of the
+//   chunk's rows and 2x2 tiles of v_mfma_f32_32x32x2_f32 (K = 2 rows per MFMA: lanes 0-31 carry
+//   row r, lanes 32-63 row r+1; operands are plain coalesced 128-B row segments of g and x, no
+//   LDS staging); waves combine through LDS in a fixed order; per-chunk partials are summed by
+//   an ordered second kernel (bit-reproducible, no float atomics).
+// Algorithmic bytes 4*R*(M+N) + 4*M*N; FLOPs 2*R*M*N: HBM-bound for M,N <= 128.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void linear_dw_kernel(const float* __restrict__ g, int64_t ldg,
+                                                        const float* __restrict__ x, int64_t ldx,
+                                                        int64_t R, int M, int N, int rows_per_block,
+                                                        float* __restrict__ part) {
+  __shared__ float s_acc[3][4][16][64];          // waves 1..3 x (2x2 tiles) x 16 regs x 64 lanes
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int col = lane & 31, kh = lane >> 5;
+  const int i0 = blockIdx.y * 64, j0 = blockIdx.z * 64;
+  const int64_t rb0 = (int64_t)blockIdx.x * rows_per_block;
+  int64_t rb1 = rb0 + rows_per_block;
+  if (rb1 > R) rb1 = R;
+  const int per = rows_per_block / 4;            // rows_per_block is a multiple of 8
+  int64_t r0 = rb0 + (int64_t)wv * per, r1 = r0 + per;
+  if (r1 > rb1) r1 = rb1;
+  const bool ia0 = i0 + col < M, ia1 = i0 + 32 + col < M;
+  const bool jb0 = j0 + col < N, jb1 = j0 + 32 + col < N;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+#pragma unroll 4
+  for (int64_t r = r0; r < r1; r += 2) {
+    const int64_t row = r + kh;
+    const bool ok = row < r1;
+    const float* gr = g + row * ldg + i0 + col;
+    const float* xr = x + row * ldx + j0 + col;
+    const float a0 = (ok && ia0) ? gr[0] : 0.f, a1 = (ok && ia1) ? gr[32] : 0.f;
+    const float b0 = (ok && jb0) ? xr[0] : 0.f, b1 = (ok && jb1) ? xr[32] : 0.f;
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+  }
+  if (wv > 0) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s_acc[wv - 1][t][r][lane] = acc[t >> 1][t & 1][r];
+  }
+  __syncthreads();
+  if (wv == 0) {
+    float* p = part + (size_t)blockIdx.x * M * N;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int ti = i0 + (t >> 1) * 32, tj = j0 + (t & 1) * 32;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = ((acc[t >> 1][t & 1][r] + s_acc[0][t][r][lane]) + s_acc[1][t][r][lane]) + s_acc[2][t][r][lane];
+        const int i = ti + (r & 3) + 8 * (r >> 2) + 4 * kh, j = tj + col;
+        if (i < M && j < N) p[(size_t)i * N + j] = v;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void linear_dw_reduce_kernel(const float* __restrict__ part, int nchunk,
+                                                               int64_t MN, float* __restrict__ dw) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= MN) return;
+  double acc = 0.0;
+  for (int c = 0; c < nchunk; ++c) acc += (double)part[(size_t)c * MN + e];
+  dw[e] = (float)acc;
+}
+
+int plan_rows_per_block(int64_t R, int M, int N) {
+  const int tiles = sug_divup(M, 64) * sug_divup(N, 64);
+  int64_t nchunk = 2048 / tiles;                 // ~2048 workgroups in total
+  if (nchunk < 8) nchunk = 8;
+  int64_t rpb = (R + nchunk - 1) / nchunk;
+  if (rpb < 64) rpb = 64;
+  return (int)((rpb + 7) / 8 * 8);
+}
+
+}  // namespace
+
+extern "C" int64_t sug_linear_dw_workspace(int64_t R, int M, int N) {
+  if (R <= 0 || M <= 0 || N <= 0) return 0;
+  return (int64_t)sug_divup(R, plan_rows_per_block(R, M, N)) * M * N;
+}
+
+extern "C" int sug_linear_dw(const float* g, int64_t ldg, const float* x, int64_t ldx, int64_t R, int M,
+                             int N, float* dw, float* ws, void* stream) {
+  SUG_REQUIRE(g && x && dw && ws, "sug_linear_dw: null pointer");
+  SUG_REQUIRE(R > 0 && M > 0 && N > 0 && ldg >= M && ldx >= N, "sug_linear_dw: bad shape");
+  const int rpb = plan_rows_per_block(R, M, N);
+  const int nchunk = sug_divup(R, rpb);
+  SUG_REQUIRE(sug_divup(M, 64) <= 65535 && sug_divup(N, 64) <= 65535, "sug_linear_dw: output too large");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(linear_dw_kernel, dim3(nchunk, sug_divup(M, 64), sug_divup(N, 64)), dim3(256), 0, st, g, ldg, x,
+                     ldx, R, M, N, rpb, ws);
+  SUG_LAUNCH_CHECK("sug_linear_dw");
+  const int64_t MN = (int64_t)M * N;
+  hipLaunchKernelGGL(linear_dw_reduce_kernel, dim3(sug_divup(MN, 256)), dim3(256), 0, st, ws, nchunk, MN, dw);
+  SUG_LAUNCH_CHECK("sug_linear_dw(reduce)");
+  return SUG_OK;
+}

@@ -114,10 +114,10 @@ class DGCNN(nn.Module):
         nb = lambda f, i: gi[i] if gi[i] is not None else ops.knn(f, self.k)
         x1, x2 = self._prefix(x, loc, nb)                             # [B,N,64], [B,N,64]
         x_, node_fea, _ = self.node_fea_adapt.rows(x2, loc)           # [B,N,128], [B,64,64]
-        x2 = F.linear(x_, self.conv1d.weight.squeeze(-1), self.conv1d.bias)
+        x2 = ops.linear_rows(x_, self.conv1d.weight.squeeze(-1), self.conv1d.bias)
         x3 = self.conv3.edge_rows(x2, nb(x2, 2))                      # [B,N,128]
         x4 = self.conv4.edge_rows(x3, nb(x3, 3))                      # [B,N,256]
-        x5 = F.linear(torch.cat((x1, x2, x3, x4), dim=2), self.conv5.weight.squeeze(-1))
+        x5 = ops.linear_rows(torch.cat((x1, x2, x3, x4), dim=2), self.conv5.weight.squeeze(-1))
         # bn5 -> leaky_relu(0.2) -> adaptive max | avg pool (Model.py:113-116), fused
         feat = torch.cat(ops.bn_act_pool(x5, self.bn5, 0.2), 1)
         node_fea = node_fea.transpose(1, 2).unsqueeze(-1)             # [B,64(ch),64(node),1]

@@ -52,7 +52,7 @@ class conv_2d(nn.Module):
 
     def rows(self, x):
         """x [..., Cin] -> [..., Cout]: per-point GEMM + BN over all leading dims + act."""
-        y = F.linear(x, self.weight2d(), self.conv[0].bias)
+        y = ops.linear_rows(x, self.weight2d(), self.conv[0].bias)
         if self.activation in _ACT_SLOPE and OWN_BN(self.conv[1]):
             return ops.bn_act_rows(y, self.conv[1], _ACT_SLOPE[self.activation])
         return self.conv[2](_bn_rows(self.conv[1], y))
@@ -75,7 +75,7 @@ class conv_2d(nn.Module):
         else:
             Wcat = torch.cat((W[:, :C], W[:, C:] - W[:, :C]), dim=0)      # [2Co, C]
             self._wcat = (key, Wcat) if self.cache_weight_split else None
-        pq = F.linear(x.reshape(B * N, C), Wcat)
+        pq = ops.linear_rows(x.reshape(B * N, C), Wcat)
         bias = self.conv[0].bias
         if bias is not None:                                              # bias rides on the Q half
             pq = pq + torch.cat((torch.zeros_like(bias), bias))
@@ -174,7 +174,7 @@ class adapt_layer_off(nn.Module):
         # pred_offset on (fea_j - fea_c) is linear before the tanh: project once (one GEMM), then
         # gather / tanh / weight / mean in one kernel (sug_node_offset_*)
         w_off = self.pred_offset[0].weight.view(self.offset_dim, -1)
-        proj = F.linear(fea, w_off)                                   # [B,N,3]
+        proj = ops.linear_rows(fea, w_off)                            # [B,N,3]
         if self.offset_dim == 3 and gidx.shape[2] == S:
             node_off, n_loc = ops.node_offset(proj, loc, fidx, gidx)  # [B,S,3] each
         else:

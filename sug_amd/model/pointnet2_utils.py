@@ -87,7 +87,7 @@ class PointNetSetAbstraction(nn.Module):
         node = None
         for i, conv in enumerate(self.mlp_convs):                      # g: [B,S,ns,C] rows
             w = conv.weight.view(conv.weight.shape[0], -1)
-            g = ops.bn_act_rows(F.linear(g, w, conv.bias), self.mlp_bns[i], 0.0)
+            g = ops.bn_act_rows(ops.linear_rows(g, w, conv.bias), self.mlp_bns[i], 0.0)
             if adapt and i == 1:
                 node = g
         out = torch.max(g, dim=2)[0]

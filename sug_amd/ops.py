@@ -232,6 +232,52 @@ def group_max(feat, idx):
     return _GroupMax.apply(feat, idx)
 
 
+# ----------------------------------------------------------------------------- per-point linear
+class _LinearRows(torch.autograd.Function):
+    """y = x . W^T (+ b) over rows; the weight gradient g^T . x (K = rows = B*N, small output)
+    runs in sug_linear_dw instead of a rocBLAS GEMM that does not split K."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        y = torch.nn.functional.linear(x, weight, bias)
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        M, N = weight.shape
+        g2 = g.reshape(-1, M)
+        x2 = x.reshape(-1, N)
+        if g2.stride(1) != 1:
+            g2 = g2.contiguous()
+        if x2.stride(1) != 1:
+            x2 = x2.contiguous()
+        R = g2.shape[0]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = (g2 @ weight).view(x.shape)
+        if ctx.needs_input_grad[1]:
+            if M * N >= 512 * 256:          # large outputs: rocBLAS is efficient there
+                dw = g2.t() @ x2
+            else:
+                dw = torch.empty(M, N, dtype=torch.float32, device=g.device)
+                ws = torch.empty(int(lib().sug_linear_dw_workspace(R, M, N)), dtype=torch.float32, device=g.device)
+                check(lib().sug_linear_dw(_p(g2), g2.stride(0), _p(x2), x2.stride(0), R, M, N, _p(dw), _p(ws), _st()),
+                      'sug_linear_dw')
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = g2.sum(dim=0)
+        return dx, dw, db
+
+
+def linear_rows(x, weight, bias=None):
+    """F.linear for [..., Cin] rows with many rows and small Cin/Cout (the encoders' 1x1 convs)."""
+    if not x.is_cuda or x.dtype != torch.float32:
+        return torch.nn.functional.linear(x, weight, bias)
+    return _LinearRows.apply(x, weight, bias)
+
+
 # ----------------------------------------------------------------------------- SA-node glue
 class _NodeOffset(torch.autograd.Function):
     """(node_off, node_loc) of adapt_layer_off from the projected features (sug_node_offset_*)."""

@@ -11,7 +11,7 @@ from conftest import ROOT
 def _declared():
     src = open(os.path.join(ROOT, 'include', 'sug_amd.h')).read()
     src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
-    names = re.findall(r'\b(?:int|const char\*)\s+(sug_[a-z0-9_]+)\s*\(', src)
+    names = re.findall(r'\b(?:int|int64_t|const char\*)\s+(sug_[a-z0-9_]+)\s*\(', src)
     return sorted(set(names))
 
 
@@ -35,7 +35,7 @@ def test_library_built_and_exports_header_symbols():
 
 def test_ctypes_table_matches_header():
     from sug_amd import _lib
-    names = [n for n in _declared() if n not in ('sug_last_error', 'sug_abi_version')]
+    names = [n for n in _declared() if n not in ('sug_last_error', 'sug_abi_version', 'sug_linear_dw_workspace')]
     assert sorted(_lib.SIGNATURES) == names
     for n in names:
         assert len(_lib.SIGNATURES[n]) == _count_args(n), n
