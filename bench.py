@@ -109,6 +109,8 @@ def main():
                     help='EXPERIMENTAL: replay the step from a hipGraph (faults on ROCm 7.0/gfx950, see DESIGN.md)')
     ap.add_argument('--no-share-prefix', action='store_true',
                     help='recompute the kNN+conv1/conv2 stage in the node passes instead of sharing it (identical results)')
+    ap.add_argument('--no-pair', action='store_true',
+                    help='separate encoder passes for the source and the target batch (identical results)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -131,7 +133,7 @@ def main():
         for t in list(model.parameters()) + list(model.buffers()):
             dist.broadcast(t.data, 0)
     trainer = SUGStep(model, lr=1e-3, weight_decay=5e-5, share_prefix=not args.no_share_prefix,
-                      use_graph=args.graph)
+                      use_graph=args.graph, pair_domains=not args.no_pair)
     B, N = args.batch, args.npoints
     data, lab, data_t, lab_t = synth(B, N, 666 + rank, dev)
     torch.manual_seed(666 + rank)                       # FPS start draws, per rank (train_dg.py:78)
@@ -142,14 +144,15 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # Kernel events: in graph mode they are captured as event-record nodes (and read back for
-    # the last replayed step); in eager mode only the kNN kernels are instrumented because every
-    # event pair costs host time in a host-bound step.
-    ops.PROFILE_ONLY = None if trainer.use_graph else {'knn'}
+    # Kernel events: only the kNN kernels (the dominant hand-written kernel) are instrumented,
+    # because every event pair costs host time in a host-bound step.  Eager mode times them over
+    # the timed region; graph mode (events cannot be captured on ROCm) over its eager warm-up step.
+    ops.PROFILE_ONLY = {'knn'}
     for i in range(max(args.warmup, 3 if trainer.use_graph else 1)):
-        if trainer.use_graph and i == 1:
-            ops.PROFILE = {}                            # the capture happens inside this step
+        ops.PROFILE = {} if (trainer.use_graph and i == 0) else ops.PROFILE
         trainer.step(data, lab, data_t, lab_t)
+        if trainer.use_graph and i == 0:
+            graph_prof, ops.PROFILE = ops.PROFILE, None
     sync()
     if not trainer.use_graph:
         ops.PROFILE = {}
@@ -158,7 +161,7 @@ def main():
         losses = trainer.step(data, lab, data_t, lab_t)
     sync()
     dt = time.perf_counter() - t0
-    prof, ops.PROFILE = ops.PROFILE, None
+    prof, ops.PROFILE = (graph_prof if trainer.use_graph else ops.PROFILE), None
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -207,7 +210,7 @@ def main():
                                       '(2 sem + 2 node forwards, 3 soft-MMD, backward, 3 Adam)' % (args.model, N, B),
                           'global_batch': world * B, 'parallelism': 'dp%d' % world,
                           'launch': 'hipGraph replay of the whole step' if trainer.use_graph else 'eager',
-                          'share_prefix': trainer.share_prefix},
+                          'share_prefix': trainer.share_prefix, 'pair_domains': trainer.pair_domains},
                'roofline': roofline, 'cpu_baseline': cpu, 'losses': loss_vals,
                'kernels': {k: {kk: (round(vv, 5) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in kern.items()}}
         print(json.dumps(out))

@@ -72,21 +72,31 @@ __global__ __launch_bounds__(256) void linear_dw_kernel(const float* __restrict_
   }
 }
 
+// dw[e] = sum over chunks, 16 chunk-lanes x 16 elements per workgroup; fixed combination order.
 __global__ __launch_bounds__(256) void linear_dw_reduce_kernel(const float* __restrict__ part, int nchunk,
                                                                int64_t MN, float* __restrict__ dw) {
-  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= MN) return;
+  __shared__ double s_p[16][17];
+  const int el = threadIdx.x & 15, cl = threadIdx.x >> 4;
+  const int64_t e = (int64_t)blockIdx.x * 16 + el;
   double acc = 0.0;
-  for (int c = 0; c < nchunk; ++c) acc += (double)part[(size_t)c * MN + e];
-  dw[e] = (float)acc;
+  if (e < MN)
+    for (int c = cl; c < nchunk; c += 16) acc += (double)part[(size_t)c * MN + e];
+  s_p[cl][el] = acc;
+  __syncthreads();
+  if (cl == 0 && e < MN) {
+    double t = s_p[0][el];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) t += s_p[i][el];
+    dw[e] = (float)t;
+  }
 }
 
 int plan_rows_per_block(int64_t R, int M, int N) {
   const int tiles = sug_divup(M, 64) * sug_divup(N, 64);
-  int64_t nchunk = 2048 / tiles;                 // ~2048 workgroups in total
+  int64_t nchunk = 1024 / tiles;                 // ~1024 workgroups in total
   if (nchunk < 8) nchunk = 8;
   int64_t rpb = (R + nchunk - 1) / nchunk;
-  if (rpb < 64) rpb = 64;
+  if (rpb < 128) rpb = 128;
   return (int)((rpb + 7) / 8 * 8);
 }
 
@@ -109,7 +119,7 @@ extern "C" int sug_linear_dw(const float* g, int64_t ldg, const float* x, int64_
                      ldx, R, M, N, rpb, ws);
   SUG_LAUNCH_CHECK("sug_linear_dw");
   const int64_t MN = (int64_t)M * N;
-  hipLaunchKernelGGL(linear_dw_reduce_kernel, dim3(sug_divup(MN, 256)), dim3(256), 0, st, ws, nchunk, MN, dw);
+  hipLaunchKernelGGL(linear_dw_reduce_kernel, dim3(sug_divup(MN, 16)), dim3(256), 0, st, ws, nchunk, MN, dw);
   SUG_LAUNCH_CHECK("sug_linear_dw(reduce)");
   return SUG_OK;
 }

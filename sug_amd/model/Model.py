@@ -12,7 +12,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
-from .model_utils import conv_2d, fc_layer, transform_net, adapt_layer_off, _bn_rows
+from .model_utils import conv_2d, fc_layer, transform_net, adapt_layer_off, _bn_rows, bn_module
 from .pointnet2_utils import PointNetSetAbstraction
 
 K = 20      # model/Model.py:52
@@ -89,7 +89,7 @@ class DGCNN(nn.Module):
             x1 = self.conv1.edge_rows(loc, nb(loc, 0))
             return x1, self.conv2.edge_rows(x1, nb(x1, 1))
         ver = sum(p._version for m in (self.conv1, self.conv2) for p in m.parameters())
-        key = (x.data_ptr(), x._version, tuple(x.shape), torch.is_grad_enabled(), ver)
+        key = (x.data_ptr(), x._version, tuple(x.shape), torch.is_grad_enabled(), ver, ops.BN_GROUPS)
         hit = self._prefix_cache.get(key)
         if hit is not None:
             x1, x2, st1, st2 = hit
@@ -140,6 +140,10 @@ class Pointnet2_g(nn.Module):
         self.channel_redu = nn.Conv2d(512, 64, 1)
         self.dim_redu = nn.MaxPool1d(3, stride=8)
 
+    def fps_plan(self, N):
+        """Point counts of the farthest_point_sample calls of one forward, in call order."""
+        return [N, self.sa1.npoint]
+
     def forward(self, xyz, node=False):
         rows = xyz.squeeze(-1).transpose(1, 2).contiguous()           # [B,N,3(+3)]
         B = rows.shape[0]
@@ -176,7 +180,7 @@ class Pointnet_g(nn.Module):
         y = torch.bmm(y, self.trans_net2.rows(y))
         y, node_fea, node_off = self.conv3.rows(y, loc)
         y = self.conv5.rows(self.conv4.rows(y))
-        y = self.bn1(torch.max(y, dim=1)[0])
+        y = bn_module(self.bn1, torch.max(y, dim=1)[0])
         node_fea = node_fea.transpose(1, 2).unsqueeze(-1)
         node_off = node_off.transpose(1, 2)
         if node:
@@ -248,3 +252,30 @@ class Net_MDA(nn.Module):
         y1, sem_feature1 = self.c1(x, adapt=True)
         y2, sem_feature2 = self.c2(x, adapt=True)
         return y1, y2, sem_feature1, sem_feature2
+
+    def forward_pair(self, x_pair, node_adaptation=False):
+        """Both domains in one encoder pass (not in the reference; used by SUGStep).
+        x_pair = cat(source batch, target batch) [2B,3,N,1].  Equivalent to
+        forward(source, ...) followed by forward(target, ...): every BatchNorm computes its
+        statistics and updates its running buffers per domain half, source first
+        (ops.bn_groups), everything else is per cloud / per row.
+        semantic (default): ((y1,y2,f1,f2) of the source, (y1,y2,f1,f2) of the target);
+        node_adaptation:    (attention_s(source nodes), attention_t(target nodes))."""
+        B2 = x_pair.size(0)
+        assert B2 % 2 == 0
+        B = B2 // 2
+        queue = None
+        if ops.START_PROVIDER is None:
+            # CPU-generator draws in the reference's order: all FPS calls of the source forward,
+            # then all of the target forward
+            plan = self.g.fps_plan(x_pair.size(2)) if hasattr(self.g, 'fps_plan') else [x_pair.size(2)]
+            draws = [[torch.randint(0, n, (B,), dtype=torch.long) for n in plan] for _ in range(2)]
+            queue = [torch.cat((draws[0][c], draws[1][c])) for c in range(len(plan))]
+        with ops.bn_groups(2), ops.start_queue(queue):
+            x, feat_ori, _ = self.g(x_pair, node=True)
+        if node_adaptation:
+            f = feat_ori.contiguous().view(B2, -1)
+            return self.attention_s(f[:B]), self.attention_t(f[B:])
+        y1, f1 = self.c1(x, adapt=True)
+        y2, f2 = self.c2(x, adapt=True)
+        return (y1[:B], y2[:B], f1[:B], f2[:B]), (y1[B:], y2[B:], f1[B:], f2[B:])

@@ -20,8 +20,20 @@ def OWN_BN(bn):
     return True
 
 
+def bn_module(bn, y):
+    """Apply a torch BatchNorm module per domain group (ops.bn_groups), i.e. as the separate
+    forward calls of the reference would."""
+    if ops.BN_GROUPS == 1:
+        return bn(y)
+    return torch.cat([bn(c) for c in y.chunk(ops.BN_GROUPS, dim=0)], dim=0)
+
+
 def _bn_rows(bn, y):
     """Train/eval BatchNorm of a [..., C] rows tensor with the module's parameters."""
+    if ops.BN_GROUPS > 1:
+        G = ops.BN_GROUPS
+        with ops.bn_groups(1):
+            return torch.cat([_bn_rows(bn, c) for c in y.chunk(G, dim=0)], dim=0)
     shp = y.shape
     y2 = y.reshape(-1, shp[-1])
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
@@ -80,8 +92,7 @@ class conv_2d(nn.Module):
         if bias is not None:                                              # bias rides on the Q half
             pq = pq + torch.cat((torch.zeros_like(bias), bias))
         bn = self.conv[1]
-        if bn.training and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
+        ops._count_bn_call(bn)
         out, coef = ops.edgeconv_bn_act_max(pq.view(B, N, -1), idx, bn.weight, bn.bias, bn.running_mean,
                                             bn.running_var, bn.training, _ACT_SLOPE[self.activation],
                                             bn.eps, bn.momentum)
@@ -92,10 +103,11 @@ class conv_2d(nn.Module):
         (coef from edge_rows(..., return_stats=True)): what nn.BatchNorm2d would do again."""
         bn = self.conv[1]
         m = bn.momentum
-        bn.running_mean.mul_(1.0 - m).add_(coef[2] * m)
-        bn.running_var.mul_(1.0 - m).add_(coef[4] * m)
-        if bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
+        for c in (coef if coef.dim() == 3 else (coef,)):               # one update per domain group
+            bn.running_mean.mul_(1.0 - m).add_(c[2] * m)
+            bn.running_var.mul_(1.0 - m).add_(c[4] * m)
+            if bn.num_batches_tracked is not None:
+                bn.num_batches_tracked.add_(1)
 
 
 class fc_layer(nn.Module):

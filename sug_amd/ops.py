@@ -4,6 +4,7 @@ Tensors are plumbing here: device memory + the current HIP stream.  Every op
 requires fp32/int32 tensors on a HIP device and raises otherwise -- there is no
 CPU path.  Feature tensors are point-major rows [B,N,C].
 """
+import contextlib
 import ctypes
 
 import torch
@@ -26,18 +27,60 @@ PROFILE_ONLY = None
 START_PROVIDER = None
 
 
+# Domain groups of a batch: with BN_GROUPS = G the batch dimension holds G equal contiguous parts
+# (Net_MDA.forward_pair: source clouds then target clouds) that the reference sends through the
+# network in G separate forward calls.  Everything per-cloud / per-row is oblivious to that; the
+# BatchNorm ops compute statistics and update the running buffers per part, in order, so the
+# result is the one of G separate calls.
+BN_GROUPS = 1
+
+
+@contextlib.contextmanager
+def bn_groups(g):
+    global BN_GROUPS
+    old, BN_GROUPS = BN_GROUPS, int(g)
+    try:
+        yield
+    finally:
+        BN_GROUPS = old
+
+
+# Pre-drawn FPS starts (Net_MDA.forward_pair draws them in the reference's call order: every
+# farthest_point_sample of the source forward, then those of the target forward).
+START_QUEUE = None
+
+
+@contextlib.contextmanager
+def start_queue(q):
+    global START_QUEUE
+    old, START_QUEUE = START_QUEUE, (list(q) if q is not None else None)
+    try:
+        yield
+    finally:
+        START_QUEUE = old
+
+
 def draw_start(B, N):
     if START_PROVIDER is not None:
         return START_PROVIDER(B, N)
+    if START_QUEUE:
+        t = START_QUEUE.pop(0)
+        if t.numel() != B:
+            raise RuntimeError('FPS start plan does not match the encoder (%d starts for %d clouds)' % (t.numel(), B))
+        return t
+    G = BN_GROUPS
+    if G > 1 and B % G == 0:        # one CPU-generator draw per reference forward call
+        return torch.cat([torch.randint(0, N, (B // G,), dtype=torch.long) for _ in range(G)])
     return torch.randint(0, N, (B,), dtype=torch.long)
 
 
 def _timed(name, shape, call):
     if PROFILE is None or (PROFILE_ONLY is not None and not name.startswith(tuple(PROFILE_ONLY))):
         return call()
-    ext = torch.cuda.is_current_stream_capturing()
-    a = torch.cuda.Event(enable_timing=True, external=ext)
-    b = torch.cuda.Event(enable_timing=True, external=ext)
+    if torch.cuda.is_current_stream_capturing():        # timing events cannot be captured on ROCm
+        return call()
+    a = torch.cuda.Event(enable_timing=True)
+    b = torch.cuda.Event(enable_timing=True)
     a.record()
     r = call()
     b.record()
@@ -350,9 +393,9 @@ def interp3_cat(fea, node, xyz, nloc):
 
 
 # ----------------------------------------------------------------------------- BN helpers
-def bn_coef(stats, gamma, beta, count, eps, momentum, running_mean, running_var):
+def bn_coef(stats, gamma, beta, count, eps, momentum, running_mean, running_var, out=None):
     C = gamma.numel()
-    coef = torch.empty(5, C, dtype=torch.float32, device=gamma.device)
+    coef = torch.empty(5, C, dtype=torch.float32, device=gamma.device) if out is None else out
     check(lib().sug_bn_finalize(_p(stats), _p(gamma), _p(beta), C, float(count), eps, momentum,
                                 _p(running_mean), _p(running_var), _p(coef), _st()), 'sug_bn_finalize')
     return coef
@@ -380,11 +423,12 @@ def affine_act(z, coef, slope, out=None):
     return out.view(*z.shape)
 
 
-def col_stats(y2):
+def col_stats(y2, ws=None):
     """y2 [rows, C] (row stride ld) -> fp64 [2C] = column sums, column sums of squares."""
     rows, C = y2.shape
     stats = torch.empty(2 * C, dtype=torch.float64, device=y2.device)
-    ws = torch.empty(STATS_BLOCKS * 2 * C, dtype=torch.float32, device=y2.device)
+    if ws is None:
+        ws = torch.empty(STATS_BLOCKS * 2 * C, dtype=torch.float32, device=y2.device)
     check(lib().sug_col_stats(_p(y2), y2.stride(0), rows, C, _p(stats), _p(ws), _st()), 'sug_col_stats')
     return stats
 
@@ -394,53 +438,67 @@ class _BNActRows(torch.autograd.Function):
     Train mode uses batch statistics and updates the running ones like nn.BatchNorm."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, running_mean, running_var, training, slope, eps, momentum):
+    def forward(ctx, y, gamma, beta, running_mean, running_var, training, slope, eps, momentum, G):
         _need_gpu(y, gamma)
         C = y.shape[-1]
         y2 = y.reshape(-1, C)
         if y2.stride(1) != 1 or y2.stride(0) != C:
             y2 = y2.contiguous()
         rows = y2.shape[0]
+        if rows % G:
+            raise RuntimeError('bn_act_rows: %d rows do not split into %d domain groups' % (rows, G))
+        rg = rows // G
         g, b = gamma.detach().contiguous(), beta.detach().contiguous()
         if training:
-            coef = bn_coef(col_stats(y2), g, b, rows, eps, momentum, running_mean, running_var)
+            coef = torch.empty(G, 5, C, dtype=torch.float32, device=y.device)
+            ws = torch.empty(STATS_BLOCKS * 2 * C, dtype=torch.float32, device=y.device)
+            for i in range(G):
+                bn_coef(col_stats(y2[i * rg:(i + 1) * rg], ws), g, b, rg, eps, momentum, running_mean, running_var,
+                        out=coef[i])
         else:
-            coef = eval_coef(g, b, running_mean, running_var, eps)
-        out = affine_act(y2, coef, slope)
+            coef = eval_coef(g, b, running_mean, running_var, eps).unsqueeze(0).repeat(G, 1, 1)
+        out = torch.empty(rows, C, dtype=torch.float32, device=y.device)
+        for i in range(G):
+            affine_act(y2[i * rg:(i + 1) * rg], coef[i], slope, out=out[i * rg:(i + 1) * rg])
         if any(ctx.needs_input_grad[i] for i in (0, 1, 2)):
             ctx.save_for_backward(y2, coef)
-            ctx.meta = (rows, C, float(slope), bool(training), tuple(y.shape))
+            ctx.meta = (rows, C, float(slope), bool(training), tuple(y.shape), G)
         return out.view(y.shape)
 
     @staticmethod
     def backward(ctx, gout):
         y2, coef = ctx.saved_tensors
-        rows, C, slope, training, shape = ctx.meta
+        rows, C, slope, training, shape, G = ctx.meta
+        rg = rows // G
         dev = gout.device
         g2 = gout.reshape(rows, C)
         if g2.stride(1) != 1:
             g2 = g2.contiguous()
         a = torch.empty(rows, C, dtype=torch.float32, device=dev)
-        red = torch.empty(2 * C, dtype=torch.float64, device=dev)
+        red = torch.empty(G, 2 * C, dtype=torch.float64, device=dev)
         ws = torch.empty(STATS_BLOCKS * 2 * C, dtype=torch.float32, device=dev)
-        check(lib().sug_edgeconv_bwd_reduce(_p(g2), g2.stride(0), _p(y2), _p(coef), rows, C, slope, _p(a), _p(red),
-                                            _p(ws), _st()), 'sug_edgeconv_bwd_reduce')
-        if training:
-            dy = torch.empty(rows, C, dtype=torch.float32, device=dev)
-            check(lib().sug_bn_bwd_apply(_p(a), _p(y2), C, _p(coef), _p(red), rows, C, _p(dy), C, _st()),
-                  'sug_bn_bwd_apply')
-        else:
-            dy = a
-        rf = red.float()
-        return dy.view(shape), rf[C:], rf[:C], None, None, None, None, None, None
+        dy = torch.empty(rows, C, dtype=torch.float32, device=dev) if training else a
+        for i in range(G):
+            sl = slice(i * rg, (i + 1) * rg)
+            check(lib().sug_edgeconv_bwd_reduce(_p(g2[sl]), g2.stride(0), _p(y2[sl]), _p(coef[i]), rg, C, slope,
+                                                _p(a[sl]), _p(red[i]), _p(ws), _st()), 'sug_edgeconv_bwd_reduce')
+            if training:
+                check(lib().sug_bn_bwd_apply(_p(a[sl]), _p(y2[sl]), C, _p(coef[i]), _p(red[i]), rg, C, _p(dy[sl]), C,
+                                             _st()), 'sug_bn_bwd_apply')
+        rf = (red[0] if G == 1 else red.sum(0)).float()
+        return dy.view(shape), rf[C:], rf[:C], None, None, None, None, None, None, None
+
+
+def _count_bn_call(bn):
+    if bn.training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(BN_GROUPS)
 
 
 def bn_act_rows(y, bn, slope):
     """bn: an nn.BatchNorm{1,2}d module whose parameters / running buffers are used."""
-    if bn.training and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+    _count_bn_call(bn)
     return _BNActRows.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, slope, bn.eps,
-                            bn.momentum)
+                            bn.momentum, BN_GROUPS)
 
 
 class _BNActPool(torch.autograd.Function):
@@ -448,48 +506,60 @@ class _BNActPool(torch.autograd.Function):
     two backward (sug_bn_act_pool_*)."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, running_mean, running_var, training, slope, eps, momentum):
+    def forward(ctx, y, gamma, beta, running_mean, running_var, training, slope, eps, momentum, G):
         _need_gpu(y, gamma)
         y, B, N, C, ld = _rows3(y)
+        if B % G:
+            raise RuntimeError('bn_act_pool: %d clouds do not split into %d domain groups' % (B, G))
+        Bg = B // G
+        dev = y.device
         g, b = gamma.detach().contiguous(), beta.detach().contiguous()
         if training:
-            stats = col_stats(y.view(B * N, C) if ld == C else y.reshape(B * N, C))
-            coef = bn_coef(stats, g, b, B * N, eps, momentum, running_mean, running_var)
+            coef = torch.empty(G, 5, C, dtype=torch.float32, device=dev)
+            wss = torch.empty(STATS_BLOCKS * 2 * C, dtype=torch.float32, device=dev)
+            for i in range(G):
+                yg = y[i * Bg:(i + 1) * Bg]
+                stats = col_stats(yg.view(Bg * N, C) if ld == C else yg.reshape(Bg * N, C), wss)
+                bn_coef(stats, g, b, Bg * N, eps, momentum, running_mean, running_var, out=coef[i])
         else:
-            coef = eval_coef(g, b, running_mean, running_var, eps)
-        omax = torch.empty(B, C, dtype=torch.float32, device=y.device)
-        omean = torch.empty(B, C, dtype=torch.float32, device=y.device)
-        arg = torch.empty(B, C, dtype=torch.int32, device=y.device)
-        ws = torch.empty(12 * B * C, dtype=torch.float32, device=y.device)
-        check(lib().sug_bn_act_pool_fwd(_p(y), ld, _p(coef), B, N, C, float(slope), _p(omax), _p(omean), _p(arg),
-                                        _p(ws), _st()), 'sug_bn_act_pool_fwd')
+            coef = eval_coef(g, b, running_mean, running_var, eps).unsqueeze(0).repeat(G, 1, 1)
+        omax = torch.empty(B, C, dtype=torch.float32, device=dev)
+        omean = torch.empty(B, C, dtype=torch.float32, device=dev)
+        arg = torch.empty(B, C, dtype=torch.int32, device=dev)
+        ws = torch.empty(12 * Bg * C, dtype=torch.float32, device=dev)
+        for i in range(G):
+            sl = slice(i * Bg, (i + 1) * Bg)
+            check(lib().sug_bn_act_pool_fwd(_p(y[sl]), ld, _p(coef[i]), Bg, N, C, float(slope), _p(omax[sl]),
+                                            _p(omean[sl]), _p(arg[sl]), _p(ws), _st()), 'sug_bn_act_pool_fwd')
         ctx.save_for_backward(y, coef, arg)
-        ctx.meta = (B, N, C, ld, float(slope), bool(training))
+        ctx.meta = (B, N, C, ld, float(slope), bool(training), G)
         ctx.mark_non_differentiable(arg)
         return omax, omean
 
     @staticmethod
     def backward(ctx, gmax, gmean):
         y, coef, arg = ctx.saved_tensors
-        B, N, C, ld, slope, training = ctx.meta
+        B, N, C, ld, slope, training, G = ctx.meta
+        Bg = B // G
         dev = y.device
         gmax, gmean = gmax.contiguous(), gmean.contiguous()
-        red = torch.empty(2 * C, dtype=torch.float64, device=dev)
+        red = torch.empty(G, 2 * C, dtype=torch.float64, device=dev)
         ws = torch.empty(STATS_BLOCKS * 2 * C, dtype=torch.float32, device=dev)
         dy = torch.empty(B, N, C, dtype=torch.float32, device=dev)
-        check(lib().sug_bn_act_pool_bwd(_p(y), ld, _p(coef), _p(gmax), _p(gmean), _p(arg), B, N, C, slope,
-                                        1 if training else 0, _p(red), _p(ws), _p(dy), C, _st()),
-              'sug_bn_act_pool_bwd')
-        rf = red.float()
-        return dy, rf[C:], rf[:C], None, None, None, None, None, None
+        for i in range(G):
+            sl = slice(i * Bg, (i + 1) * Bg)
+            check(lib().sug_bn_act_pool_bwd(_p(y[sl]), ld, _p(coef[i]), _p(gmax[sl]), _p(gmean[sl]), _p(arg[sl]), Bg, N,
+                                            C, slope, 1 if training else 0, _p(red[i]), _p(ws), _p(dy[sl]), C, _st()),
+                  'sug_bn_act_pool_bwd')
+        rf = (red[0] if G == 1 else red.sum(0)).float()
+        return dy, rf[C:], rf[:C], None, None, None, None, None, None, None
 
 
 def bn_act_pool(y, bn, slope):
     """(max over points, mean over points) of act(bn(y)), y [B,N,C]."""
-    if bn.training and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+    _count_bn_call(bn)
     return _BNActPool.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, slope, bn.eps,
-                            bn.momentum)
+                            bn.momentum, BN_GROUPS)
 
 
 # ----------------------------------------------------------------------------- EdgeConv
@@ -497,60 +567,74 @@ class _EdgeConv(torch.autograd.Function):
     """BN(train or eval) + LeakyReLU + max over k of y = P[idx] + Q, see include/sug_amd.h."""
 
     @staticmethod
-    def forward(ctx, pq, idx, gamma, beta, running_mean, running_var, training, slope, eps, momentum):
+    def forward(ctx, pq, idx, gamma, beta, running_mean, running_var, training, slope, eps, momentum, G):
         _need_gpu(pq, idx, gamma)
         pq, B, N, C2, ld = _rows3(pq)
         Co = C2 // 2
         idx = _i32(idx).contiguous()
         k = idx.shape[2]
+        if B % G:
+            raise RuntimeError('edgeconv: %d clouds do not split into %d domain groups' % (B, G))
+        Bg = B // G
         dev = pq.device
         gamma_c, beta_c = gamma.detach().contiguous(), beta.detach().contiguous()
         need_bwd = any(ctx.needs_input_grad[i] for i in (0, 2, 3))
         z = torch.empty(B, N, Co, dtype=torch.float32, device=dev)
         arg = torch.empty(B, N, Co, dtype=torch.uint8, device=dev)
         s1 = torch.empty(B, N, Co, dtype=torch.float32, device=dev) if need_bwd else None
-        stats = torch.empty(2 * Co, dtype=torch.float64, device=dev)
+        stats = torch.empty(G, 2 * Co, dtype=torch.float64, device=dev)
         ws = torch.empty(STATS_BLOCKS * 2 * Co, dtype=torch.float32, device=dev)
-        check(_timed('edgeconv_fwd_Co%d' % Co, {'B': B, 'N': N, 'k': k, 'Co': Co},
-                     lambda: lib().sug_edgeconv_fwd(_p(pq), ld, _p(idx), _p(gamma_c), B, N, k, Co, _p(z), _p(arg),
-                                                    _p(s1), _p(stats), _p(ws), _st())), 'sug_edgeconv_fwd')
-        if training:
-            coef = bn_coef(stats, gamma_c, beta_c, B * N * k, eps, momentum, running_mean, running_var)
-        else:
-            coef = eval_coef(gamma_c, beta_c, running_mean, running_var, eps)
-        out = affine_act(z, coef, slope)
+        coef = torch.empty(G, 5, Co, dtype=torch.float32, device=dev)
+        if not training:
+            coef.copy_(eval_coef(gamma_c, beta_c, running_mean, running_var, eps))
+        out = torch.empty(B, N, Co, dtype=torch.float32, device=dev)
+        for i in range(G):
+            sl = slice(i * Bg, (i + 1) * Bg)
+            s1p = _p(s1[sl]) if need_bwd else None
+            check(_timed('edgeconv_fwd_Co%d' % Co, {'B': Bg, 'N': N, 'k': k, 'Co': Co},
+                         lambda: lib().sug_edgeconv_fwd(_p(pq[sl]), ld, _p(idx[sl]), _p(gamma_c), Bg, N, k, Co,
+                                                        _p(z[sl]), _p(arg[sl]), s1p, _p(stats[i]), _p(ws), _st())),
+                  'sug_edgeconv_fwd')
+            if training:
+                bn_coef(stats[i], gamma_c, beta_c, Bg * N * k, eps, momentum, running_mean, running_var, out=coef[i])
+            affine_act(z[sl], coef[i], slope, out=out[sl])
         if need_bwd:
             ctx.save_for_backward(pq, idx, z, arg, s1, coef)
-            ctx.meta = (B, N, k, Co, ld, float(slope), bool(training))
-        ctx.mark_non_differentiable(coef)
-        return out, coef
+            ctx.meta = (B, N, k, Co, ld, float(slope), bool(training), G)
+        coef_out = coef[0] if G == 1 else coef
+        ctx.mark_non_differentiable(coef_out)
+        return out, coef_out
 
     @staticmethod
     def backward(ctx, gout, _gcoef):
         pq, idx, z, arg, s1, coef = ctx.saved_tensors
-        B, N, k, Co, ld, slope, training = ctx.meta
+        B, N, k, Co, ld, slope, training, G = ctx.meta
+        Bg = B // G
         dev = gout.device
         gout = gout.contiguous()
         a = torch.empty(B, N, Co, dtype=torch.float32, device=dev)
-        red = torch.empty(2 * Co, dtype=torch.float64, device=dev)
+        red = torch.empty(G, 2 * Co, dtype=torch.float64, device=dev)
         ws = torch.empty(STATS_BLOCKS * 2 * Co, dtype=torch.float32, device=dev)
-        check(lib().sug_edgeconv_bwd_reduce(_p(gout), Co, _p(z), _p(coef), B * N, Co, slope, _p(a), _p(red),
-                                            _p(ws), _st()), 'sug_edgeconv_bwd_reduce')
         off, ent = knn_reverse(idx)
         dpq = torch.empty(B, N, 2 * Co, dtype=torch.float32, device=dev)
         red_used = red if training else torch.zeros_like(red)       # eval mode: statistics are constants
-        check(_timed('edgeconv_bwd_scatter_Co%d' % Co, {'B': B, 'N': N, 'k': k, 'Co': Co},
-                     lambda: lib().sug_edgeconv_bwd_scatter(_p(a), _p(arg), _p(s1), _p(pq), ld, _p(off), _p(ent),
-                                                            _p(coef), _p(red_used), B, N, k, Co, _p(dpq), 2 * Co,
-                                                            _st())), 'sug_edgeconv_bwd_scatter')
-        rf = red.float()
-        return dpq, None, rf[Co:], rf[:Co], None, None, None, None, None, None
+        for i in range(G):
+            sl = slice(i * Bg, (i + 1) * Bg)
+            check(lib().sug_edgeconv_bwd_reduce(_p(gout[sl]), Co, _p(z[sl]), _p(coef[i]), Bg * N, Co, slope, _p(a[sl]),
+                                                _p(red[i]), _p(ws), _st()), 'sug_edgeconv_bwd_reduce')
+            check(_timed('edgeconv_bwd_scatter_Co%d' % Co, {'B': Bg, 'N': N, 'k': k, 'Co': Co},
+                         lambda: lib().sug_edgeconv_bwd_scatter(_p(a[sl]), _p(arg[sl]), _p(s1[sl]), _p(pq[sl]), ld,
+                                                                _p(off[sl]), _p(ent[sl]), _p(coef[i]),
+                                                                _p(red_used[i]), Bg, N, k, Co, _p(dpq[sl]), 2 * Co,
+                                                                _st())), 'sug_edgeconv_bwd_scatter')
+        rf = (red[0] if G == 1 else red.sum(0)).float()
+        return dpq, None, rf[Co:], rf[:Co], None, None, None, None, None, None, None
 
 
 def edgeconv_bn_act_max(pq, idx, gamma, beta, running_mean, running_var, training, slope, eps=1e-5, momentum=0.1):
     """pq [B,N,2*Co] = x.[W1;W2-W1]^T, idx [B,N,k] -> (out [B,N,Co], coef [5,Co] = scale, shift,
-    batch mean, rstd, unbiased batch variance)."""
-    return _EdgeConv.apply(pq, idx, gamma, beta, running_mean, running_var, training, slope, eps, momentum)
+    batch mean, rstd, unbiased batch variance; [G,5,Co] under bn_groups(G > 1))."""
+    return _EdgeConv.apply(pq, idx, gamma, beta, running_mean, running_var, training, slope, eps, momentum, BN_GROUPS)
 
 
 # ----------------------------------------------------------------------------- MMD

@@ -124,8 +124,11 @@ class _StartFeeder:
 
 class SUGStep:
     def __init__(self, model, lr=1e-3, weight_decay=5e-5, lr_scaler=1.0, methods=None, criterion=None,
-                 global_mmd=True, fused_adam=None, share_prefix=True, use_graph=False):
+                 global_mmd=True, fused_adam=None, share_prefix=True, use_graph=False, pair_domains=True):
         self.model = model
+        # source and target batch go through the encoder as one 2B-cloud batch with per-domain
+        # BatchNorm statistics (Net_MDA.forward_pair): same results, half the launches
+        self.pair_domains = bool(pair_domains) and hasattr(model, 'forward_pair')
         # one backward over all four forwards of a step -> the encoder may share the stage in
         # front of the SA-node module between the semantic and node pass of a batch (exact)
         self.share_prefix = share_prefix and hasattr(model.g, 'share_prefix')
@@ -181,8 +184,13 @@ class SUGStep:
     def losses(self, data, label, data_t, label_t, mmd_on=True):
         M = self.methods
         model = self.model
-        pred_s1, pred_s2, sem_s1, sem_s2 = model(data, semantic_adaption=True)
-        pred_t1, pred_t2, sem_t1, sem_t2 = model(data_t, semantic_adaption=True)
+        pair = None
+        if self.pair_domains and data.shape == data_t.shape and model.training:
+            pair = torch.cat((data, data_t), dim=0)
+            (pred_s1, pred_s2, sem_s1, sem_s2), (pred_t1, pred_t2, sem_t1, sem_t2) = model.forward_pair(pair)
+        else:
+            pred_s1, pred_s2, sem_s1, sem_s2 = model(data, semantic_adaption=True)
+            pred_t1, pred_t2, sem_t1, sem_t2 = model(data_t, semantic_adaption=True)
         loss_s = 0.5 * self.criterion(pred_s1, label) + 0.5 * self.criterion(pred_s2, label)
         if M['ADV_WEIGHT'] > 0:
             loss_s = loss_s - M['ADV_WEIGHT'] * discrepancy(pred_t1, pred_t2)
@@ -194,8 +202,11 @@ class SUGStep:
         loss_cls = M['CLS_WEIGHT'] * loss
         if not mmd_on or M['MMD_WEIGHT'] <= 0:
             return loss_cls, None, None
-        feat_node_s = model(data, node_adaptation_s=True)
-        feat_node_t = model(data_t, node_adaptation_t=True)
+        if pair is not None:
+            feat_node_s, feat_node_t = model.forward_pair(pair, node_adaptation=True)
+        else:
+            feat_node_s = model(data, node_adaptation_s=True)
+            feat_node_t = model(data_t, node_adaptation_t=True)
         geo, sem = M['GEO_MMD'][0], M['SEM_MMD'][0]
         loss_geo = M['MMD_WEIGHT'] * geo['GEO_SCALE'] * self._mmd(label, feat_node_s, label_t, feat_node_t, geo, data, data_t)
         loss_sem = None

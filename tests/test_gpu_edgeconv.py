@@ -146,3 +146,74 @@ def test_linear_dw_vs_torch(R, M, N):
     W.grad = None
     (ops.linear_rows(x, W, b) * probe).sum().backward()
     assert torch.equal(g1, W.grad)
+
+
+class _BN:
+    """Minimal stand-in for an nn.BatchNorm module (parameters + running buffers)."""
+
+    def __init__(self, C, seed):
+        g = torch.Generator().manual_seed(seed)
+        self.weight = (torch.randn(C, generator=g)).cuda().requires_grad_(True)
+        self.bias = (torch.randn(C, generator=g) * 0.1).cuda().requires_grad_(True)
+        self.running_mean = torch.zeros(C).cuda()
+        self.running_var = torch.ones(C).cuda()
+        self.num_batches_tracked = torch.zeros((), dtype=torch.long).cuda()
+        self.training, self.eps, self.momentum = True, 1e-5, 0.1
+
+
+def _grouped_vs_separate(run, x, C, seed):
+    """run(x_part, bn) -> tuple of outputs.  Grouped (bn_groups(2)) must equal two calls bit for bit."""
+    from sug_amd import ops
+    res = []
+    for grouped in (False, True):
+        bn = _BN(C, seed)
+        xs = x.clone().requires_grad_(True)
+        if grouped:
+            with ops.bn_groups(2):
+                outs = run(xs, bn)
+        else:
+            h = xs.shape[0] // 2
+            o1, o2 = run(xs[:h], bn), run(xs[h:], bn)
+            outs = tuple(torch.cat((a, b), 0) for a, b in zip(o1, o2))
+        probe = [torch.randn(o.shape, generator=torch.Generator().manual_seed(5 + i)).cuda() for i, o in enumerate(outs)]
+        sum((o * p).sum() for o, p in zip(outs, probe)).backward()
+        res.append(([o.detach() for o in outs], xs.grad, bn.weight.grad, bn.bias.grad, bn.running_mean, bn.running_var,
+                    bn.num_batches_tracked))
+    for a, b in zip(res[0][0], res[1][0]):
+        assert torch.equal(a, b)
+    assert torch.equal(res[0][1], res[1][1]), float((res[0][1] - res[1][1]).abs().max())
+    for i in (2, 3):       # dgamma / dbeta: the two group sums are added in fp64 instead of fp32
+        torch.testing.assert_close(res[0][i], res[1][i], rtol=1e-5, atol=1e-5)
+    for i in (4, 5, 6):
+        assert torch.equal(res[0][i], res[1][i])
+
+
+@pytest.mark.parametrize('shape', [(8, 1, 128, 1024), (8, 256, 64), (4, 32, 16, 259)])
+def test_bn_act_rows_groups(shape):
+    from sug_amd import ops
+    x = torch.randn(*shape, generator=torch.Generator().manual_seed(1)).cuda()
+    _grouped_vs_separate(lambda t, bn: (ops.bn_act_rows(t, bn, 0.0),), x, shape[-1], 3)
+
+
+def test_bn_act_pool_groups():
+    from sug_amd import ops
+    x = torch.randn(8, 200, 512, generator=torch.Generator().manual_seed(2)).cuda()
+    _grouped_vs_separate(lambda t, bn: ops.bn_act_pool(t, bn, 0.2), x, 512, 4)
+
+
+def test_edgeconv_groups():
+    from sug_amd import ops
+    B, N, k, Co = 6, 256, 20, 64
+    g = torch.Generator().manual_seed(3)
+    pq = torch.randn(B, N, 2 * Co, generator=g).cuda()
+    idx = torch.randint(0, N, (B, N, k), generator=g).int().cuda()
+
+    # separate calls see views of one clone: tell the halves apart by address
+    class _Run:
+        def __call__(self, t, bn):
+            off = (t.data_ptr() - t._base.data_ptr()) // (t.element_size() * N * 2 * Co) if t._base is not None else 0
+            out, _ = ops.edgeconv_bn_act_max(t, idx[off:off + t.shape[0]], bn.weight, bn.bias, bn.running_mean,
+                                             bn.running_var, True, 0.01)
+            return (out,)
+
+    _grouped_vs_separate(_Run(), pq, Co, 5)

@@ -102,7 +102,7 @@ def test_prefix_sharing_is_exact():
             if isinstance(m, torch.nn.Dropout2d):
                 m.p = 0.0
         net = net.cuda().train()
-        tr = SUGStep(net, share_prefix=share, fused_adam=False)
+        tr = SUGStep(net, share_prefix=share, fused_adam=False, pair_domains=False)
         torch.manual_seed(seed)
         lc, lg, ls = tr.losses(G['data'].cuda(), G['label'].cuda(), G['data_t'].cuda(), G['label_t'].cuda())
         (lc + lg + ls).backward()
@@ -116,3 +116,52 @@ def test_prefix_sharing_is_exact():
         torch.testing.assert_close(res[1][1][k], res[0][1][k], rtol=1e-4, atol=3e-6 * gmax)
     for k in res[0][2]:
         assert torch.equal(res[0][2][k], res[1][2][k]), k
+
+
+@pytest.mark.parametrize('model_name', ['DGCNN', 'Pointnet', 'Pointnet2'])
+def test_pair_domains_match_separate_passes(model_name):
+    """SUGStep(pair_domains=True) sends cat(source, target) through the encoder once per pass kind
+    with per-domain BatchNorm statistics; losses, gradients and BN buffers must be those of the
+    reference's separate forward calls (GEMM shapes differ, so equality is to fp32 rounding)."""
+    from sug_amd.model.Model import Net_MDA
+    from sug_amd.train_step import SUGStep
+    G = load_golden('step_dgcnn.npz')
+    seed = G['seed']
+    res = []
+    for pair in (False, True):
+        net = Net_MDA(model_name)
+        net.load_state_dict(O.fill_params({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed))
+        for m in net.modules():
+            if isinstance(m, torch.nn.Dropout2d):
+                m.p = 0.0
+        net = net.cuda().train()
+        tr = SUGStep(net, fused_adam=False, pair_domains=pair)
+        assert tr.pair_domains == pair
+        torch.manual_seed(seed)
+        lc, lg, ls = tr.losses(G['data'].cuda(), G['label'].cuda(), G['data_t'].cuda(), G['label_t'].cuda())
+        (lc + lg + ls).backward()
+        res.append(([lc.item(), lg.item(), ls.item()],
+                    {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None},
+                    {k: v.clone() for k, v in net.state_dict().items() if 'running' in k or 'num_batches' in k}))
+    print(res[0][0], res[1][0])
+    for a, b in zip(res[0][0], res[1][0]):
+        assert abs(a - b) <= 2e-5 * max(1.0, abs(a)), (res[0][0], res[1][0])
+    assert res[0][1].keys() == res[1][1].keys()
+    gmax = max(float(g.abs().max()) for g in res[0][1].values())
+    worst = max(float((res[1][1][k] - res[0][1][k]).abs().max()) for k in res[0][1])
+    print('max grad diff %.3e of gmax %.3e' % (worst, gmax))
+    for k in res[0][1]:
+        a, b = res[0][1][k], res[1][1][k]
+        rel = float((a - b).norm() / (a.norm() + 1e-12))
+        if model_name == 'Pointnet2':
+            # ReLU heads: on this input one LayerNorm output of c2.mlp1 is +-1e-7, a GEMM of twice
+            # the rows rounds it to the other side of the ReLU kink (tools/diag_pair4.py) and that
+            # single element carries 5% of the gradient norm; the grouped BN kernels themselves are
+            # bit-identical to separate calls (test_gpu_edgeconv.py::test_*_groups).  Bounded in norm.
+            if 'mlp_convs' in k and k.endswith('.bias'):
+                continue            # a bias in front of BatchNorm: true gradient 0, only rounding noise
+            assert rel <= 1e-1, (k, rel)
+        else:
+            torch.testing.assert_close(b, a, rtol=2e-3, atol=2e-4 * gmax)
+    for k in res[0][2]:
+        torch.testing.assert_close(res[1][2][k].float(), res[0][2][k].float(), rtol=1e-5, atol=1e-6)
