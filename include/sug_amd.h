@@ -141,6 +141,13 @@ int sug_bn_finalize(const double* stats, const float* gamma, const float* beta, 
                     double count, float eps, float momentum, float* running_mean,
                     float* running_var, float* coef, void* stream);
 
+/* Replay of the running-statistics update for G more train-mode forwards over batches whose
+ * statistics are already in coef [G,5,C] (rows 2 and 4 of each group), in group order, with
+ * sug_bn_finalize's arithmetic: what nn.BatchNorm would do when the encoder prefix is evaluated
+ * again on the same batch (model/Model.py:88-92 run once per forward call). */
+int sug_bn_replay(const float* coef, int G, int C, float momentum, float* running_mean, float* running_var,
+                  void* stream);
+
 /* out[r,c] = act(scale[c]*z[r,c] + shift[c]), act = LeakyReLU(slope) (slope 0: ReLU,
  * slope 1: identity).  rows = B*N.  */
 int sug_affine_act(const float* z, int64_t ldz, const float* coef, int64_t rows, int C,
@@ -176,6 +183,20 @@ int sug_edgeconv_bwd_scatter(const float* a, const uint8_t* arg, const float* s1
 int64_t sug_linear_dw_workspace(int64_t R, int M, int N);
 int sug_linear_dw(const float* g, int64_t ldg, const float* x, int64_t ldx, int64_t R, int M, int N,
                   float* dw, float* ws, void* stream);
+
+/* ---- optimizer step ------------------------------------------------------------------------
+ * torch.optim.Adam (no amsgrad; L2 weight decay added to the gradient; bias correction; eps
+ * outside the square root) over T tensors in one launch per 384 tensors: the update of
+ * optimizer_g / optimizer_c / optimizer_dis, train_dg_single_gpu.py:193-203 and :333-335.
+ * table: device int64 [T,4] = {param ptr, exp_avg ptr, exp_avg_sq ptr, numel}; block_first:
+ * device + host copies of the int32 [T+1] prefix sum of ceil(numel / sug_adam_chunk());
+ * grads_host: HOST array of T device pointers (null = tensor without gradient, skipped);
+ * bias_corr1 = 1 - beta1^step, bias_corr2 = 1 - beta2^step.  Hyper-parameters are doubles and the
+ * derived constants (1 - beta, lr / bias_corr1) are rounded to fp32 once, as torch does. */
+int sug_adam_chunk(void);
+int sug_adam_step(const int64_t* table, const int32_t* block_first, const int32_t* block_first_host, int T,
+                  const void* const* grads_host, double lr, double beta1, double beta2, double eps,
+                  double weight_decay, double bias_corr1, double bias_corr2, void* stream);
 
 /* ---- SA-node module glue (adapt_layer_off, model/model_utils.py:103-128) --------------------
  * off[b,s,:] = mean_j tanh(proj[b,g_j,:] - proj[b,f,:]) * (loc[b,g_j,:] - loc[b,f,:]),

@@ -35,6 +35,8 @@ SIGNATURES = {
     'sug_edgeconv_bwd_reduce': [_vp, _i64, _vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp],
     'sug_edgeconv_bwd_scatter': [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32,
                                  _vp, _i64, _vp],
+    'sug_bn_replay': [_vp, _i32, _i32, _f32, _vp, _vp, _vp],
+    'sug_adam_step': [_vp, _vp, _vp, _i32, _vp, _f64, _f64, _f64, _f64, _f64, _f64, _f64, _vp],
     'sug_linear_dw': [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp],
     'sug_node_offset_fwd': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
     'sug_node_offset_bwd': [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp],
@@ -68,6 +70,8 @@ def lib():
             fn.restype = ctypes.c_int
         L.sug_linear_dw_workspace.restype = ctypes.c_int64
         L.sug_linear_dw_workspace.argtypes = [_i64, _i32, _i32]
+        L.sug_adam_chunk.restype = ctypes.c_int
+        L.sug_adam_chunk.argtypes = []
         L.sug_last_error.restype = ctypes.c_char_p
         L.sug_last_error.argtypes = []
         L.sug_abi_version.restype = ctypes.c_int

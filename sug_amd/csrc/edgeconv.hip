@@ -159,6 +159,23 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
   }
 }
 
+// The running-statistics update of G more train-mode forwards on batches whose statistics are
+// already known (coef rows 2 and 4), applied in group order with bn_finalize's arithmetic.
+__global__ __launch_bounds__(256) void bn_replay_kernel(const float* __restrict__ coef, int G, int C,
+                                                        float momentum, float* __restrict__ rmean,
+                                                        float* __restrict__ rvar) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float m = rmean[c], v = rvar[c];
+  for (int g = 0; g < G; ++g) {
+    const float* cg = coef + (size_t)g * 5 * C;
+    m = (1.f - momentum) * m + momentum * cg[2 * C + c];
+    v = (1.f - momentum) * v + momentum * cg[4 * C + c];
+  }
+  rmean[c] = m;
+  rvar[c] = v;
+}
+
 __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ z, int64_t ldz,
                                                          const float* __restrict__ coef, int64_t rows,
                                                          int C, float slope, float* __restrict__ out,
@@ -431,6 +448,16 @@ extern "C" int sug_bn_finalize(const double* stats, const float* gamma, const fl
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(sug_divup(C, 256)), dim3(256), 0, (hipStream_t)stream,
                      stats, gamma, beta, C, count, eps, momentum, running_mean, running_var, coef);
   SUG_LAUNCH_CHECK("sug_bn_finalize");
+  return SUG_OK;
+}
+
+extern "C" int sug_bn_replay(const float* coef, int G, int C, float momentum, float* running_mean,
+                             float* running_var, void* stream) {
+  SUG_REQUIRE(coef && running_mean && running_var, "sug_bn_replay: null pointer");
+  SUG_REQUIRE(G > 0 && C > 0, "sug_bn_replay: bad shape");
+  hipLaunchKernelGGL(bn_replay_kernel, dim3(sug_divup(C, 256)), dim3(256), 0, (hipStream_t)stream, coef, G, C,
+                     momentum, running_mean, running_var);
+  SUG_LAUNCH_CHECK("sug_bn_replay");
   return SUG_OK;
 }
 

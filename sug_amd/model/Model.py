@@ -271,11 +271,13 @@ class Net_MDA(nn.Module):
             plan = self.g.fps_plan(x_pair.size(2)) if hasattr(self.g, 'fps_plan') else [x_pair.size(2)]
             draws = [[torch.randint(0, n, (B,), dtype=torch.long) for n in plan] for _ in range(2)]
             queue = [torch.cat((draws[0][c], draws[1][c])) for c in range(len(plan))]
-        with ops.bn_groups(2), ops.start_queue(queue):
+        with ops.bn_groups(2), ops.start_queue(queue), ops.deferred_bn_counts():
             x, feat_ori, _ = self.g(x_pair, node=True)
+        halves = lambda t: t.reshape(2, B, -1).unbind(0)      # backward: one stack, no zero fills
         if node_adaptation:
-            f = feat_ori.contiguous().view(B2, -1)
-            return self.attention_s(f[:B]), self.attention_t(f[B:])
+            f_s, f_t = halves(feat_ori.contiguous())
+            return self.attention_s(f_s), self.attention_t(f_t)
         y1, f1 = self.c1(x, adapt=True)
         y2, f2 = self.c2(x, adapt=True)
-        return (y1[:B], y2[:B], f1[:B], f2[:B]), (y1[B:], y2[B:], f1[B:], f2[B:])
+        (y1s, y1t), (y2s, y2t), (f1s, f1t), (f2s, f2t) = halves(y1), halves(y2), halves(f1), halves(f2)
+        return (y1s, y2s, f1s, f2s), (y1t, y2t, f1t, f2t)

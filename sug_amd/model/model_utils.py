@@ -101,13 +101,7 @@ class conv_2d(nn.Module):
     def replay_bn_update(self, coef):
         """Apply the running-statistics update of one more train-mode forward on the same batch
         (coef from edge_rows(..., return_stats=True)): what nn.BatchNorm2d would do again."""
-        bn = self.conv[1]
-        m = bn.momentum
-        for c in (coef if coef.dim() == 3 else (coef,)):               # one update per domain group
-            bn.running_mean.mul_(1.0 - m).add_(c[2] * m)
-            bn.running_var.mul_(1.0 - m).add_(c[4] * m)
-            if bn.num_batches_tracked is not None:
-                bn.num_batches_tracked.add_(1)
+        ops.bn_replay(self.conv[1], coef)
 
 
 class fc_layer(nn.Module):

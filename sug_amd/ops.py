@@ -485,13 +485,53 @@ class _BNActRows(torch.autograd.Function):
             if training:
                 check(lib().sug_bn_bwd_apply(_p(a[sl]), _p(y2[sl]), C, _p(coef[i]), _p(red[i]), rg, C, _p(dy[sl]), C,
                                              _st()), 'sug_bn_bwd_apply')
-        rf = (red[0] if G == 1 else red.sum(0)).float()
+        rf = red[0].float() if G == 1 else red.sum(0, dtype=torch.float32)
         return dy.view(shape), rf[C:], rf[:C], None, None, None, None, None, None, None
 
 
-def _count_bn_call(bn):
+# num_batches_tracked increments: one tiny launch per BatchNorm call unless deferred; inside a
+# `deferred_bn_counts()` block they are collected and applied with one foreach add at the end.
+_PENDING_COUNTS = None
+
+
+@contextlib.contextmanager
+def deferred_bn_counts():
+    global _PENDING_COUNTS
+    if _PENDING_COUNTS is not None:          # nested: the outer block flushes
+        yield
+        return
+    _PENDING_COUNTS = {}
+    try:
+        yield
+    finally:
+        pend, _PENDING_COUNTS = _PENDING_COUNTS, None
+        by_inc = {}
+        for t, n in pend.values():
+            by_inc.setdefault(n, []).append(t)
+        for n, ts in by_inc.items():
+            torch._foreach_add_(ts, n)
+
+
+def _count_bn_call(bn, n=None):
     if bn.training and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(BN_GROUPS)
+        n = BN_GROUPS if n is None else n
+        if _PENDING_COUNTS is not None:
+            t = bn.num_batches_tracked
+            old = _PENDING_COUNTS.get(id(t))
+            _PENDING_COUNTS[id(t)] = (t, n + (old[1] if old else 0))
+        else:
+            bn.num_batches_tracked.add_(n)
+
+
+def bn_replay(bn, coef):
+    """Running-statistics update of len(coef) more train-mode forwards with known batch statistics
+    (coef [5,C] or [G,5,C] from a BN op), in order (sug_bn_replay)."""
+    c3 = coef if coef.dim() == 3 else coef.unsqueeze(0)
+    c3 = c3 if c3.is_contiguous() else c3.contiguous()
+    G, _, C = c3.shape
+    check(lib().sug_bn_replay(_p(c3), G, C, float(bn.momentum), _p(bn.running_mean), _p(bn.running_var), _st()),
+          'sug_bn_replay')
+    _count_bn_call(bn, G)
 
 
 def bn_act_rows(y, bn, slope):
@@ -551,7 +591,7 @@ class _BNActPool(torch.autograd.Function):
             check(lib().sug_bn_act_pool_bwd(_p(y[sl]), ld, _p(coef[i]), _p(gmax[sl]), _p(gmean[sl]), _p(arg[sl]), Bg, N,
                                             C, slope, 1 if training else 0, _p(red[i]), _p(ws), _p(dy[sl]), C, _st()),
                   'sug_bn_act_pool_bwd')
-        rf = (red[0] if G == 1 else red.sum(0)).float()
+        rf = red[0].float() if G == 1 else red.sum(0, dtype=torch.float32)
         return dy, rf[C:], rf[:C], None, None, None, None, None, None, None
 
 
@@ -627,7 +667,7 @@ class _EdgeConv(torch.autograd.Function):
                                                                 _p(off[sl]), _p(ent[sl]), _p(coef[i]),
                                                                 _p(red_used[i]), Bg, N, k, Co, _p(dpq[sl]), 2 * Co,
                                                                 _st())), 'sug_edgeconv_bwd_scatter')
-        rf = (red[0] if G == 1 else red.sum(0)).float()
+        rf = red[0].float() if G == 1 else red.sum(0, dtype=torch.float32)
         return dpq, None, rf[Co:], rf[:Co], None, None, None, None, None, None, None
 
 

@@ -1,0 +1,95 @@
+"""Adam for the three optimizers of a SUG step (train_dg_single_gpu.py:193-203, :333-335).
+
+`Adam` is a torch.optim.Adam (same constructor arguments, same `state` layout, so
+state_dict()/load_state_dict() interoperate with torch's) whose step() runs in
+sug_adam_step: one launch per optimizer instead of torch's ~20 multi-tensor launches over
+~150 small tensors.  HIP tensors only -- like the rest of the library there is no CPU path."""
+import ctypes
+import math
+
+import torch
+
+from ._lib import lib, check
+
+
+class _Bucket:
+    __slots__ = ('params', 'steps', 'table', 'first_dev', 'first_host', 'hyper', 'step_val', 'T')
+
+
+class Adam(torch.optim.Adam):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0):
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, foreach=False, fused=False)
+        self._plan = None
+        self._plan_key = None
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._plan = None
+
+    def _hyper(self, g):
+        if g.get('amsgrad') or g.get('maximize') or g.get('capturable') or g.get('differentiable'):
+            raise RuntimeError('sug_amd.optim.Adam: amsgrad / maximize / capturable / differentiable are not supported')
+        lr = g['lr']
+        return (float(lr), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']), float(g['weight_decay']))
+
+    def _build(self, key):
+        chunk = lib().sug_adam_chunk()
+        buckets = {}
+        for g in self.param_groups:
+            hyper = self._hyper(g)
+            for p in g['params']:
+                if p.grad is None:
+                    continue
+                if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+                    raise RuntimeError('sug_amd.optim.Adam: contiguous fp32 HIP parameters only (no CPU path)')
+                st = self.state[p]
+                if len(st) == 0:
+                    st['step'] = torch.tensor(0.0, dtype=torch.float32)
+                    st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                if st['step'].is_cuda:
+                    st['step'] = st['step'].cpu()
+                buckets.setdefault((hyper, float(st['step']), p.device), []).append(p)
+        plan = []
+        for (hyper, step_val, dev), ps in buckets.items():
+            b = _Bucket()
+            b.params, b.hyper, b.step_val, b.T = ps, hyper, int(step_val), len(ps)
+            b.steps = [self.state[p]['step'] for p in ps]
+            rows, first = [], [0]
+            for p in ps:
+                st = self.state[p]
+                rows.append([p.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr(), p.numel()])
+                first.append(first[-1] + (p.numel() + chunk - 1) // chunk)
+            b.table = torch.tensor(rows, dtype=torch.int64).to(dev)
+            b.first_host = (ctypes.c_int32 * len(first))(*first)
+            b.first_dev = torch.tensor(first, dtype=torch.int32).to(dev)
+            plan.append(b)
+        self._plan, self._plan_key = plan, key
+        return plan
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if closure is not None:
+            raise RuntimeError('sug_amd.optim.Adam: closures are not supported')
+        key = (tuple(p.grad is not None for g in self.param_groups for p in g['params']),
+               tuple(self._hyper(g) for g in self.param_groups))
+        plan = self._plan if (self._plan is not None and key == self._plan_key) else self._build(key)
+        L = lib()
+        for b in plan:
+            b.step_val += 1
+            torch._foreach_add_(b.steps, 1.0)
+            ptrs = []
+            for p in b.params:
+                g = p.grad
+                if g.is_sparse or g.dtype != torch.float32:
+                    raise RuntimeError('sug_amd.optim.Adam: dense fp32 gradients only')
+                if not g.is_contiguous():
+                    g = p.grad = g.contiguous()
+                ptrs.append(g.data_ptr())
+            lr, b1, b2, eps, wd = b.hyper
+            stream = torch.cuda.current_stream(b.table.device).cuda_stream
+            check(L.sug_adam_step(b.table.data_ptr(), b.first_dev.data_ptr(), b.first_host, b.T,
+                                  (ctypes.c_void_p * b.T)(*ptrs), lr, b1, b2, eps, wd,
+                                  1.0 - math.pow(b1, b.step_val), 1.0 - math.pow(b2, b.step_val),
+                                  ctypes.c_void_p(stream)), 'sug_adam_step')
+        return None

@@ -143,11 +143,11 @@ class SUGStep:
         self.criterion = criterion if criterion is not None else nn.CrossEntropyLoss()
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.global_mmd = global_mmd and self.world > 1
+        # fused_adam: None/True -> sug_amd.optim.Adam (one launch per optimizer) on a HIP device;
+        # False -> torch.optim.Adam's default path (the parity tests' reference update)
         kw = {}
-        if fused_adam is None:
-            fused_adam = next(model.parameters()).is_cuda
-        if fused_adam:
-            kw['fused'] = True
+        on_gpu = next(model.parameters()).is_cuda
+        own_adam = on_gpu and (fused_adam is None or fused_adam) and not use_graph
         # EXPERIMENTAL hipGraph mode (off by default): the whole step (4 forwards, losses, backward,
         # 3 Adam updates) is captured once and replayed; an eager step of ~1200 launches is
         # host-bound.  On ROCm 7.0 / gfx950 back-to-back replays of this graph end in a GPU fault
@@ -162,12 +162,15 @@ class SUGStep:
         self._graph_epoch = None
         if self.use_graph:
             kw['capturable'] = True
+            kw['fused'] = True
+        from .optim import Adam as _SugAdam
+        AdamCls = _SugAdam if own_adam else torch.optim.Adam
         # train_dg_single_gpu.py:191-203
         params = [{'params': v} for k, v in model.g.named_parameters() if 'pred_offset' not in k]
-        self.optimizer_g = torch.optim.Adam(params, lr=lr, weight_decay=weight_decay, **kw)
-        self.optimizer_c = torch.optim.Adam([{'params': model.c1.parameters()}, {'params': model.c2.parameters()}],
+        self.optimizer_g = AdamCls(params, lr=lr, weight_decay=weight_decay, **kw)
+        self.optimizer_c = AdamCls([{'params': model.c1.parameters()}, {'params': model.c2.parameters()}],
                                             lr=lr, weight_decay=weight_decay, **kw)
-        self.optimizer_dis = torch.optim.Adam([{'params': model.g.parameters()},
+        self.optimizer_dis = AdamCls([{'params': model.g.parameters()},
                                                {'params': model.attention_s.parameters()},
                                                {'params': model.attention_t.parameters()}],
                                               lr=lr * lr_scaler, weight_decay=weight_decay, **kw)

@@ -1,13 +1,26 @@
 """The two helpers of utils/common_utils.py that model/mmd.py calls."""
+import weakref
+
 import torch
+
+# One step builds the one-hot of the same label tensor up to five times (three soft-MMD terms and
+# the SDA weights): remember it per live tensor object and version.
+_one_hot_cache = {}          # id(labels) -> (weakref to labels, key, one_hot)
 
 
 def create_one_hot_labels(original_labels, num_class=10):
     """utils/common_utils.py:161-164, built on the labels' own device (the reference builds
     it on the CPU and copies it over, model/mmd.py:61-62)."""
+    key = (original_labels._version, num_class)
+    hit = _one_hot_cache.get(id(original_labels))
+    if hit is not None and hit[0]() is original_labels and hit[1] == key:
+        return hit[2]
     n = original_labels.shape[0]
     one_hot = torch.zeros(n, num_class, device=original_labels.device)
     one_hot.scatter_(1, original_labels.view(-1, 1).long(), 1.0)
+    if len(_one_hot_cache) >= 16:
+        _one_hot_cache.clear()
+    _one_hot_cache[id(original_labels)] = (weakref.ref(original_labels), key, one_hot)
     return one_hot
 
 

@@ -276,3 +276,42 @@ def test_adapt_layer_fused_glue_vs_oracle():
     torch.testing.assert_close(out.detach().cpu(), out_o.detach(), rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(fg.grad.cpu(), fo.grad, rtol=1e-3, atol=1e-4)
     torch.testing.assert_close(m.pred_offset[0].weight.grad.cpu(), p['a.pred_offset.0.weight'].grad, rtol=2e-3, atol=2e-3)
+
+
+def test_adam_multi_tensor_vs_torch():
+    """sug_amd.optim.Adam (sug_adam_step) against torch.optim.Adam: same update, same state layout."""
+    from sug_amd.optim import Adam
+    g = torch.Generator().manual_seed(11)
+    shapes = [(7,), (64, 3, 1, 1), (4097,), (512, 512), (1000, 33), (1,), (4096,), (3, 5, 7)]
+    mine = [torch.randn(*s, generator=g).cuda().requires_grad_(True) for s in shapes]
+    ref = [p.detach().clone().requires_grad_(True) for p in mine]
+    groups = lambda ps: [{'params': ps[:3]}, {'params': ps[3:6], 'lr': 3e-3}, {'params': ps[6:]}]
+    om = Adam(groups(mine), lr=1e-3, weight_decay=5e-5)
+    ot = torch.optim.Adam(groups(ref), lr=1e-3, weight_decay=5e-5)
+    for it in range(4):
+        for i, (a, b) in enumerate(zip(mine, ref)):
+            if it == 2 and i == 1:          # a tensor without gradient in one step: skipped, its step count lags
+                a.grad = b.grad = None
+                continue
+            gr = torch.randn(a.shape, generator=g).cuda() * (10.0 ** (i % 3 - 1))
+            a.grad, b.grad = gr.clone(), gr.clone()
+        om.step()
+        ot.step()
+    for a, b in zip(mine, ref):
+        torch.testing.assert_close(a, b, rtol=2e-6, atol=2e-7)
+    sm, st = om.state_dict(), ot.state_dict()
+    assert sm['state'].keys() == st['state'].keys()
+    for k in sm['state']:
+        assert float(sm['state'][k]['step']) == float(st['state'][k]['step'])
+        for name in ('exp_avg', 'exp_avg_sq'):          # fp32 rounding (torch contracts to FMA, this build does not)
+            want = st['state'][k][name]
+            torch.testing.assert_close(sm['state'][k][name], want, rtol=2e-6, atol=1e-6 * float(want.abs().max()))
+    ot.load_state_dict(sm)                  # torch's Adam accepts the state ...
+    om.load_state_dict(st)                  # ... and the other way round
+    for a, b in zip(mine, ref):
+        gr = torch.randn(a.shape, generator=g).cuda()
+        a.grad, b.grad = gr.clone(), gr.clone()
+    om.step()
+    ot.step()
+    for a, b in zip(mine, ref):
+        torch.testing.assert_close(a, b, rtol=2e-6, atol=2e-7)

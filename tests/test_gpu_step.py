@@ -23,7 +23,7 @@ def test_two_training_steps_match_reference():
     net = net.cuda().train()
     methods = {'GEO_MMD': [{'NAME': 'SOFT_MMD', 'LABEL_SCALE': 50, 'GEO_SCALE': 1}],
                'SEM_MMD': [{'NAME': 'SOFT_MMD', 'LABEL_SCALE': 5, 'SEM_WEIGHTS': 'none', 'LABEL_WEIGHT': 0.5, 'SEM_SCALE': 1}]}
-    tr = SUGStep(net, lr=1e-3, weight_decay=5e-5, methods=methods, fused_adam=False)
+    tr = SUGStep(net, lr=1e-3, weight_decay=5e-5, methods=methods)        # defaults: paired domains, sug_amd.optim.Adam
     data, data_t = G['data'].cuda(), G['data_t'].cuda()
     lab, lab_t = G['label'].cuda(), G['label_t'].cuda()
     torch.manual_seed(seed)
