@@ -253,6 +253,19 @@ int sug_bn_act_pool_bwd(const float* y, int64_t ldy, const float* coef, const fl
 int sug_mmd_rbf(const float* z, int64_t ldz, int m, int D, const float* w,
                 const float* neg_gamma, int nsigma, double* sums, float* wt, void* stream);
 
+/* Backward of sug_mmd_rbf for 2m <= 128: dz[i,:] = gscale[0] * 2 * (rowsum(wt)[i]*z[i,:] - (wt.z)[i,:])
+ * (the autograd of model/mmd.py:239-312 w.r.t. the features); gscale: device scalar = dL/dmmd2. */
+int sug_mmd_rbf_bwd(const float* z, int64_t ldz, const float* wt, int m, int D, const float* gscale,
+                    float* dz, int64_t lddz, void* stream);
+
+/* SDA sample weights from class probabilities: prob_weights_soft + distance2weights,
+ * model/mmd.py:134-148 and :178-202 (the reference computes them on the CPU with scipy's kl_div).
+ * pred_* [m,10] logits (row strides lds/ldt), label_* int64 [m]; method 0 "none", 1 "naive_inverse",
+ * 2 "exp_inverse", 3 "mean2one"; weights [m]. */
+int sug_sda_prob_weights(const float* pred_s, int64_t lds, const float* pred_t, int64_t ldt,
+                         const int64_t* label_s, const int64_t* label_t, int m, int num_class,
+                         float label_weight, int method, float* weights, void* stream);
+
 /* Chamfer distance per cloud pair (SDA geometric weights; geometric_weights(),
  * model/mmd.py:107-131 -- third-party op in the reference, parity unpinned):
  * out[b] = mean_i min_j |a_i-b_j|^2 + mean_j min_i |a_i-b_j|^2, direct-form distance.

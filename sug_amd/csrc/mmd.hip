@@ -112,6 +112,103 @@ __global__ __launch_bounds__(256) void chamfer_dir_kernel(const float* __restric
   if ((threadIdx.x & (WAVE - 1)) == 0) atomicAdd(&out[b], s / (float)N);
 }
 
+
+// dZ[i,:] = scale * 2 * (rowsum(wt)[i] * Z[i,:] - sum_j wt[i,j] Z[j,:]) for small 2m (<= 128 rows):
+// workgroup = (64 columns of D) x 4 row groups; Z columns through LDS, wt rows broadcast.
+__global__ __launch_bounds__(256) void mmd_bwd_kernel(const float* __restrict__ z, int64_t ldz,
+                                                      const float* __restrict__ wt, int M2, int D,
+                                                      const float* __restrict__ gscale,
+                                                      float* __restrict__ dz, int64_t lddz) {
+  extern __shared__ float s_z[];                 // [M2][64]
+  const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int d = blockIdx.x * 64 + c;
+  for (int j = rg; j < M2; j += 4) s_z[j * 64 + c] = d < D ? z[(int64_t)j * ldz + d] : 0.f;
+  __syncthreads();
+  if (d >= D) return;
+  const float g2 = 2.f * gscale[0];
+  for (int i = rg; i < M2; i += 4) {
+    const float* w = wt + (int64_t)i * M2;
+    float rs = 0.f, acc = 0.f;
+    for (int j = 0; j < M2; ++j) {
+      const float wij = w[j];
+      rs += wij;
+      acc = fmaf(wij, s_z[j * 64 + c], acc);
+    }
+    dz[(int64_t)i * lddz + d] = g2 * (rs * s_z[i * 64 + c] - acc);
+  }
+}
+
+// SDA sample weights from class probabilities (prob_weights_soft + distance2weights,
+// model/mmd.py:134-148, :178-202): one workgroup, thread per sample row.
+//   a = [softmax(pred_s) | onehot(label_s) * lw] + 1e-8, normalised by its global sum (b likewise);
+//   dist_i = sum_c 0.5*kl(a,b) + 0.5*kl(b,a), kl(x,y) = x log(x/y) - x + y;
+//   method 0 none, 1 naive_inverse, 2 exp_inverse, 3 mean2one (1/mean truncated to an integer).
+__global__ __launch_bounds__(256) void sda_prob_weights_kernel(const float* __restrict__ ps, int64_t lds,
+                                                               const float* __restrict__ pt, int64_t ldt,
+                                                               const int64_t* __restrict__ ls,
+                                                               const int64_t* __restrict__ lt, int m, float lw,
+                                                               int method, float* __restrict__ out) {
+  constexpr int NC = 10;
+  __shared__ double s_red[4][2];
+  __shared__ double s_tot[2];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  auto block_sum2 = [&](double a, double b, double& ra, double& rb) {
+    a = wave_sum_d(a);
+    b = wave_sum_d(b);
+    __syncthreads();
+    if (lane == 0) { s_red[wv][0] = a; s_red[wv][1] = b; }
+    __syncthreads();
+    ra = ((s_red[0][0] + s_red[1][0]) + s_red[2][0]) + s_red[3][0];
+    rb = ((s_red[0][1] + s_red[1][1]) + s_red[2][1]) + s_red[3][1];
+  };
+  auto row_probs = [&](const float* p, float* q) {        // fp32 softmax as torch: exp(x - max) / sum
+    float mx = p[0];
+    for (int c = 1; c < NC; ++c) mx = fmaxf(mx, p[c]);
+    float sum = 0.f;
+    for (int c = 0; c < NC; ++c) { q[c] = expf(p[c] - mx); sum += q[c]; }
+    for (int c = 0; c < NC; ++c) q[c] = q[c] / sum;
+  };
+  // pass 1: global sums of (a + eps), (b + eps)
+  double sa = 0.0, sb = 0.0;
+  for (int i = threadIdx.x; i < m; i += 256) {
+    float q[NC];
+    row_probs(ps + (int64_t)i * lds, q);
+    for (int c = 0; c < NC; ++c) sa += (double)(q[c] + 1e-8f) + (double)(((int)ls[i] == c ? lw : 0.f) + 1e-8f);
+    row_probs(pt + (int64_t)i * ldt, q);
+    for (int c = 0; c < NC; ++c) sb += (double)(q[c] + 1e-8f) + (double)(((int)lt[i] == c ? lw : 0.f) + 1e-8f);
+  }
+  double ta, tb;
+  block_sum2(sa, sb, ta, tb);
+  const float fa = (float)ta, fb = (float)tb;
+  // pass 2: distances (kept in out[]), and their sum / the sum of the inverse weights
+  double dsum = 0.0, wsum = 0.0;
+  for (int i = threadIdx.x; i < m; i += 256) {
+    float qa[NC], qb[NC];
+    row_probs(ps + (int64_t)i * lds, qa);
+    row_probs(pt + (int64_t)i * ldt, qb);
+    float dist = 0.f;
+    for (int c = 0; c < 2 * NC; ++c) {
+      const float av = c < NC ? qa[c] : ((int)ls[i] == c - NC ? lw : 0.f);
+      const float bv = c < NC ? qb[c] : ((int)lt[i] == c - NC ? lw : 0.f);
+      const float x = (av + 1e-8f) / fa, y = (bv + 1e-8f) / fb;
+      const float k1 = x * logf(x / y) - x + y, k2 = y * logf(y / x) - y + x;
+      dist += k1 * 0.5f + k2 * 0.5f;
+    }
+    out[i] = dist;
+    dsum += (double)dist;
+    wsum += method == 1 ? (double)(1.f / (dist + 1e-8f)) : (method == 2 ? (double)expf(-dist) : 0.0);
+  }
+  double td, tw;
+  block_sum2(dsum, wsum, td, tw);
+  if (method == 0) return;
+  const float mean = (float)(td / (double)m);
+  const float scale = (float)(int)(1.f / mean);           // .type(torch.int): truncation
+  for (int i = threadIdx.x; i < m; i += 256) {
+    const float dist = out[i];
+    out[i] = method == 1 ? (1.f / (dist + 1e-8f)) / (float)tw : (method == 2 ? expf(-dist) / (float)tw : dist * scale);
+  }
+}
+
 }  // namespace
 
 extern "C" int sug_mmd_rbf(const float* z, int64_t ldz, int m, int D, const float* w,
@@ -134,5 +231,28 @@ extern "C" int sug_chamfer(const float* a, const float* b, int B, int N, int M, 
   hipLaunchKernelGGL(chamfer_dir_kernel, dim3(sug_divup(N, 256), B), dim3(256), (size_t)M * 3 * sizeof(float), st, a, b, N, M, out);
   hipLaunchKernelGGL(chamfer_dir_kernel, dim3(sug_divup(M, 256), B), dim3(256), (size_t)N * 3 * sizeof(float), st, b, a, M, N, out);
   SUG_LAUNCH_CHECK("sug_chamfer");
+  return SUG_OK;
+}
+
+extern "C" int sug_mmd_rbf_bwd(const float* z, int64_t ldz, const float* wt, int m, int D, const float* gscale,
+                               float* dz, int64_t lddz, void* stream) {
+  SUG_REQUIRE(z && wt && gscale && dz, "sug_mmd_rbf_bwd: null pointer");
+  SUG_REQUIRE(m > 0 && 2 * m <= 128 && D > 0 && ldz >= D && lddz >= D, "sug_mmd_rbf_bwd: bad shape (2m <= 128)");
+  const int M2 = 2 * m;
+  hipLaunchKernelGGL(mmd_bwd_kernel, dim3(sug_divup(D, 64)), dim3(256), (size_t)M2 * 64 * sizeof(float),
+                     (hipStream_t)stream, z, ldz, wt, M2, D, gscale, dz, lddz);
+  SUG_LAUNCH_CHECK("sug_mmd_rbf_bwd");
+  return SUG_OK;
+}
+
+extern "C" int sug_sda_prob_weights(const float* pred_s, int64_t lds, const float* pred_t, int64_t ldt,
+                                    const int64_t* label_s, const int64_t* label_t, int m, int num_class,
+                                    float label_weight, int method, float* weights, void* stream) {
+  SUG_REQUIRE(pred_s && pred_t && label_s && label_t && weights, "sug_sda_prob_weights: null pointer");
+  SUG_REQUIRE(m > 0 && num_class == 10 && lds >= 10 && ldt >= 10, "sug_sda_prob_weights: bad shape (10 classes)");
+  SUG_REQUIRE(method >= 0 && method <= 3, "sug_sda_prob_weights: unknown weighting method");
+  hipLaunchKernelGGL(sda_prob_weights_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pred_s, lds, pred_t, ldt,
+                     label_s, label_t, m, label_weight, method, weights);
+  SUG_LAUNCH_CHECK("sug_sda_prob_weights");
   return SUG_OK;
 }

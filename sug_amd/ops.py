@@ -643,6 +643,7 @@ class _EdgeConv(torch.autograd.Function):
             ctx.meta = (B, N, k, Co, ld, float(slope), bool(training), G)
         coef_out = coef[0] if G == 1 else coef
         ctx.mark_non_differentiable(coef_out)
+        ctx.set_materialize_grads(False)
         return out, coef_out
 
     @staticmethod
@@ -650,8 +651,10 @@ class _EdgeConv(torch.autograd.Function):
         pq, idx, z, arg, s1, coef = ctx.saved_tensors
         B, N, k, Co, ld, slope, training, G = ctx.meta
         Bg = B // G
+        if gout is None:
+            return (None,) * 11
         dev = gout.device
-        gout = gout.contiguous()
+        gout, _, _, _, ldg = _rows3(gout)                           # a column slice of a wider buffer is fine
         a = torch.empty(B, N, Co, dtype=torch.float32, device=dev)
         red = torch.empty(G, 2 * Co, dtype=torch.float64, device=dev)
         ws = torch.empty(STATS_BLOCKS * 2 * Co, dtype=torch.float32, device=dev)
@@ -660,7 +663,7 @@ class _EdgeConv(torch.autograd.Function):
         red_used = red if training else torch.zeros_like(red)       # eval mode: statistics are constants
         for i in range(G):
             sl = slice(i * Bg, (i + 1) * Bg)
-            check(lib().sug_edgeconv_bwd_reduce(_p(gout[sl]), Co, _p(z[sl]), _p(coef[i]), Bg * N, Co, slope, _p(a[sl]),
+            check(lib().sug_edgeconv_bwd_reduce(_p(gout[sl]), ldg, _p(z[sl]), _p(coef[i]), Bg * N, Co, slope, _p(a[sl]),
                                                 _p(red[i]), _p(ws), _st()), 'sug_edgeconv_bwd_reduce')
             check(_timed('edgeconv_bwd_scatter_Co%d' % Co, {'B': Bg, 'N': N, 'k': k, 'Co': Co},
                          lambda: lib().sug_edgeconv_bwd_scatter(_p(a[sl]), _p(arg[sl]), _p(s1[sl]), _p(pq[sl]), ld,
@@ -711,6 +714,13 @@ class _MixRbfMMD2(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         Z, wt = ctx.saved_tensors
+        M2, D = Z.shape
+        if M2 <= 128:
+            gs = g.detach().to(device=Z.device, dtype=torch.float32).reshape(1)
+            dZ = torch.empty(M2, D, dtype=torch.float32, device=Z.device)
+            check(lib().sug_mmd_rbf_bwd(_p(Z), Z.stride(0), _p(wt), M2 // 2, D, _p(gs), _p(dZ), D, _st()),
+                  'sug_mmd_rbf_bwd')
+            return dZ, None, None, None
         dZ = 2.0 * (wt.sum(dim=1, keepdim=True) * Z - wt @ Z)
         return g * dZ, None, None, None
 
@@ -718,6 +728,28 @@ class _MixRbfMMD2(torch.autograd.Function):
 def mix_rbf_mmd2_rows(Z, m, sample_weights=None, sigmas=SIGMA_LIST):
     """Z = cat(X, Y) [2m, D] -> biased MMD^2 (0-d tensor)."""
     return _MixRbfMMD2.apply(Z, m, sample_weights, tuple(sigmas))
+
+
+_SDA_METHODS = {'none': 0, 'naive_inverse': 1, 'exp_inverse': 2, 'mean2one': 3}
+
+
+def sda_prob_weights(pred_s, pred_t, label_s, label_t, label_weight, method):
+    """SDA weights [m] from logits [m,10] and labels [m] (prob_weights_soft + distance2weights,
+    model/mmd.py:134-148, :178-202) in one kernel."""
+    _need_gpu(pred_s, pred_t, label_s, label_t)
+    if method not in _SDA_METHODS:
+        raise RuntimeError('Not supported weighting method %s' % method)
+    ps = pred_s.detach().reshape(-1, 10).float()
+    pt = pred_t.detach().reshape(-1, 10).float()
+    ps = ps if ps.stride(1) == 1 else ps.contiguous()
+    pt = pt if pt.stride(1) == 1 else pt.contiguous()
+    ls, lt = label_s.reshape(-1).long().contiguous(), label_t.reshape(-1).long().contiguous()
+    m = ps.shape[0]
+    out = torch.empty(m, dtype=torch.float32, device=ps.device)
+    check(lib().sug_sda_prob_weights(_p(ps), ps.stride(0), _p(pt), pt.stride(0), _p(ls), _p(lt), m, 10,
+                                     float(label_weight), _SDA_METHODS[method], _p(out), _st()),
+          'sug_sda_prob_weights')
+    return out
 
 
 def chamfer(a, b):

@@ -77,3 +77,17 @@ def test_mmd_vs_oracle_sizes(m, D):
     # MMD of a sample with itself is exactly 0 in the biased estimator (size-independent property)
     Zs = torch.cat((X, X), 0).cuda()
     assert abs(float(ops.mix_rbf_mmd2_rows(Zs, m))) < 1e-6
+
+
+@pytest.mark.parametrize('m', [8, 32, 300])
+@pytest.mark.parametrize('meth', ['none', 'naive_inverse', 'exp_inverse', 'mean2one'])
+def test_sda_prob_weights_kernel_vs_oracle(m, meth):
+    """sug_sda_prob_weights against the oracle's prob_weights_soft on random logits / labels."""
+    from sug_amd.model import mmd
+    g = torch.Generator().manual_seed(m)
+    ps, pt = torch.randn(m, 10, generator=g) * 2, torch.randn(m, 10, generator=g) * 2
+    ls, lt = torch.randint(0, 10, (m,), generator=g), torch.randint(0, 10, (m,), generator=g)
+    want = O.prob_weights_soft(ps, pt, ls, lt, 0.5, meth)
+    got = mmd.prob_weights_soft(ps.cuda(), pt.cuda(), ls.cuda(), lt.cuda(), 0.5, meth)
+    assert got.shape == want.shape
+    torch.testing.assert_close(got.cpu(), want, rtol=2e-4, atol=1e-7)
