@@ -15,20 +15,24 @@
 // flight under the MFMA chain).  LDS rows are stored de-interleaved [even feats | odd feats]
 // so one ds_read_b128 feeds the A operand of four consecutive k-steps (lanes 0-31 supply
 // k=2s, lanes 32-63 k=2s+1); row stride C+4 floats keeps the b128 reads conflict-free.
-// Selection (what bounds this kernel): two sweeps -- see knn_mfma_kernel.
+// Selection: one sweep with a lazily refreshed threshold -- see knn_mfma_kernel.
 //
 // Algorithmic bytes 4*C*N + 4*N*k per cloud; FLOPs N^2*(2C+3): compute bound.
 #include "common.h"
 #include <type_traits>
 
 #ifdef SUG_KNN_STAMP      // diagnostic build only (tools/bench_knn.py): per-phase cycle stamps of block 0
-__device__ unsigned long long g_knn_stamp[8];
+__device__ unsigned long long g_knn_stamp[16];
 extern "C" int sug_debug_read_stamps(unsigned long long* host) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_knn_stamp), sizeof(g_knn_stamp));
 }
 #define STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_knn_stamp[i] = clock64(); } while (0)
+#define ACC_BEGIN() const unsigned long long _t0 = clock64()
+#define ACC_END(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_knn_stamp[i] += clock64() - _t0; } while (0)
 #else
 #define STAMP(i)
+#define ACC_BEGIN()
+#define ACC_END(i)
 #endif
 
 namespace {
@@ -177,21 +181,29 @@ __device__ __forceinline__ unsigned long long pack_key(float s, int j) {
 
 // Ring capacity per lane (entries of 8 B): the LDS budget is 160 KB per workgroup.
 template <int CP>
-struct RingCap { static constexpr int value = (CP == 128) ? 48 : 64; };
+struct RingCap { static constexpr int value = (CP == 128) ? 48 : 64; };   // multiples of 16
 
-// One sweep over the candidates, branch-free per candidate:
-//  * the K best SCORES of a lane stay sorted in registers: inserting s into a descending list
-//    is new[t] = med3(old[t-1], old[t], s), one v_med3_f32 per slot, no indices;
-//  * a candidate that beats the current K-th score (i.e. enters the list) is also appended,
-//    with its index, to a per-lane LDS ring by a predicated store (a rejected candidate writes
-//    the dummy slot CAP).  Every member of the final top-K is in the ring; about
-//    K(1+ln(n/K)) ~ 85 entries pass per lane over a cloud, so the ring (CAP ~ 64) is
-//    compacted -- keep score > tau plus the first ties at tau, tau = current K-th score --
-//    only a few times, all waves of the workgroup in the same iteration (a wave compacting
-//    alone would stall the others at the per-tile barrier).
+// One sweep over the candidates; per candidate only  score -> compare -> predicated append:
+//  * a candidate whose score beats `thr` is appended, with its index, to a per-lane LDS ring by a
+//    predicated store (a rejected candidate writes the dummy slot CAP).  `thr` is the lane's K-th
+//    best score AS OF THE LAST REFRESH: slightly stale, never too high, so the ring always holds
+//    a superset of the lane's top-K.  That is ~7 VALU ops per candidate, which hides under the
+//    next tile's MFMA chain (2-4 MFMAs = 128-256 cycles per candidate slot).
+//  * refresh: the K best SCORES of a lane stay sorted in registers; inserting s into a descending
+//    list is new[t] = med3(old[t-1], old[t], s), one v_med3_f32 per slot.  The chain runs only
+//    over the ring entries appended since the last refresh (not over every candidate), whenever
+//    some lane of the workgroup has RP of them pending; then thr = v[K-1] is exact again.  About
+//    K(1+ln(n/K)) + staleness ~ 100-150 entries pass per lane over a cloud instead of 512.
+//  * the ring (CAP ~ 64) is compacted -- keep score > tau plus the first ties at tau, tau = the
+//    exact K-th score right after a refresh -- only a few times; all waves of the workgroup
+//    refresh / compact in the same iteration (a wave doing it alone would stall the others at
+//    the per-tile barrier).
 // The <= K survivors of a lane and of its partner lane (l ^ 32, same query, other half of the
 // candidates) are then ranked by counting: position = number of better keys among the 2K.
 // Same result as a sorted (score desc, index asc) scan of all N candidates.
+#ifndef SUG_KNN_RP
+#define SUG_KNN_RP 24      // measured 8/12/16/24 (tools/bench_knn.py): fewer, larger refreshes win
+#endif
 template <int CP, int K>
 __global__ __launch_bounds__(256, 1) void knn_mfma_kernel(const float* __restrict__ x, int64_t ldx,
                                                           int N, int k, int32_t* __restrict__ idx) {
@@ -236,9 +248,44 @@ __global__ __launch_bounds__(256, 1) void knn_mfma_kernel(const float* __restric
   float v[K];
 #pragma unroll
   for (int t = 0; t < K; ++t) v[t] = -INFINITY;
-  int cnt = 0;
+  int cnt = 0, done = 0;            // ring entries; how many of them the med3 chain has seen
+  float thr = -INFINITY;            // v[K-1] as of the last refresh
   float2* ring = s_ring + threadIdx.x;
 
+  auto chain = [&](float sc) {
+#pragma unroll
+    for (int u = K - 1; u > 0; --u) v[u] = __builtin_amdgcn_fmed3f(v[u - 1], v[u], sc);
+    v[0] = fmaxf(v[0], sc);
+  };
+  // Bring the sorted scores up to date with the ring: entries [done, cnt) of every lane, the loop
+  // running to the wave-wide maximum (padding with -inf is a no-op for the chain).
+  auto refresh = [&]() {
+    auto fetch = [&](int i, float (&sc)[4]) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = i + u < CAP ? i + u : CAP;
+        const float r = ring[e * 256].x;
+        sc[u] = (i + u < cnt) ? r : -INFINITY;
+      }
+    };
+    float nx[4];
+    fetch(done, nx);
+    for (int i = done; __any(i < cnt); i += 4) {
+      float sc[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) sc[u] = nx[u];
+      fetch(i + 4, nx);                       // next batch in flight under this batch's chain
+#pragma unroll
+      for (int u = 0; u < 4; ++u) chain(sc[u]);
+    }
+    done = cnt;
+    thr = v[K - 1];
+  };
+
+  // Compaction reads a batch of 16 entries into registers before it writes any of them back
+  // (writes only go to positions <= the ones already read), so the LDS reads of a batch are in
+  // flight together instead of one read -> write round trip per entry.
+  static_assert(CAP % 16 == 0, "ring capacity must be a multiple of the compaction batch");
   // Exact compaction: keep entries with score > tau and the first (K - #strict) entries equal
   // to tau, in order (<= K entries remain).
   auto compact = [&]() {
@@ -247,16 +294,20 @@ __global__ __launch_bounds__(256, 1) void knn_mfma_kernel(const float* __restric
 #pragma unroll 8
     for (int i = 0; i < CAP; ++i) ns += (i < cnt && ring[i * 256].x > tau) ? 1 : 0;
     int room = K - ns, out = 0;
-#pragma unroll 8
-    for (int i = 0; i < CAP; ++i) {
-      const float2 e = ring[i * 256];
-      const bool live = i < cnt;
-      const bool strict = live && e.x > tau;
-      const bool tie = live && e.x == tau && room > 0 && e.x > -INFINITY;
-      const bool keep = strict || tie;
-      ring[(keep ? out : CAP) * 256] = e;
-      out += keep ? 1 : 0;
-      room -= tie ? 1 : 0;
+    for (int i0 = 0; i0 < CAP && __any(i0 < cnt); i0 += 16) {
+      float2 e[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) e[u] = ring[(i0 + u) * 256];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const bool live = i0 + u < cnt;
+        const bool strict = live && e[u].x > tau;
+        const bool tie = live && e[u].x == tau && room > 0 && e[u].x > -INFINITY;
+        const bool keep = strict || tie;
+        ring[(keep ? out : CAP) * 256] = e[u];
+        out += keep ? 1 : 0;
+        room -= tie ? 1 : 0;
+      }
     }
     cnt = out;
   };
@@ -264,20 +315,24 @@ __global__ __launch_bounds__(256, 1) void knn_mfma_kernel(const float* __restric
   auto compact_fast = [&]() {
     const float tau = v[K - 1];
     int out = 0;
-#pragma unroll 8
-    for (int i = 0; i < CAP; ++i) {
-      const float2 e = ring[i * 256];
-      const bool keep = (i < cnt) && (e.x >= tau) && (e.x > -INFINITY);
-      ring[(keep ? out : CAP) * 256] = e;
-      out += keep ? 1 : 0;
+    for (int i0 = 0; i0 < CAP && __any(i0 < cnt); i0 += 16) {
+      float2 e[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) e[u] = ring[(i0 + u) * 256];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const bool keep = (i0 + u < cnt) && (e[u].x >= tau) && (e[u].x > -INFINITY);
+        ring[(keep ? out : CAP) * 256] = e[u];
+        out += keep ? 1 : 0;
+      }
     }
     cnt = out;
   };
 
 #define SUG_SB() __builtin_amdgcn_sched_barrier(0)
   // One pipeline step: the MFMA chain of the NEXT tile (matrix pipe) is issued in pieces
-  // between the pieces of the CURRENT tile's selection (VALU): per candidate slot c,
-  //   [mfma] score + ring append [mfma] med3 upper half [mfma] med3 lower half [mfma]
+  // between the CURRENT tile's candidates (VALU): per candidate slot c,
+  //   [mfma] score + compare + ring append [mfma x (P-1)]
   // with the source order pinned by sched_barrier(0) -- left alone, hipcc emits the whole
   // dependent MFMA chain first and the in-order wave then cannot overlap anything.
   constexpr int NM = HALF;                       // k-steps (MFMAs) per tile
@@ -314,26 +369,12 @@ __global__ __launch_bounds__(256, 1) void knn_mfma_kernel(const float* __restric
       SUG_SB();
       // pairwise_distance = -xx - inner - xx^T, inner = -2*dot (model_utils.py:179-181)
       const float s = __fsub_rn(__fsub_rn(-nn[c], __fmul_rn(-2.0f, acc_cur[c])), ni);
-      const bool enters = s > v[K - 1];
+      const bool enters = s > thr;
       ring[(enters ? cnt : CAP) * 256] = make_float2(s, __int_as_float(jbase + 8 * (c >> 2) + (c & 3)));
       cnt += enters ? 1 : 0;
       SUG_SB();
       if constexpr (P >= 2) acc_next = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c * P + 1], bq[c * P + 1], acc_next, 0, 0, 0);
-      SUG_SB();
-#pragma unroll
-      for (int u = K - 1; u >= K / 2; --u) v[u] = __builtin_amdgcn_fmed3f(v[u - 1], v[u], s);
-      // pin the results here: hipcc otherwise sinks half of the chain out of the pipelined block
-#pragma unroll
-      for (int u = K - 1; u >= K / 2; --u) asm volatile("" : "+v"(v[u]));
-      SUG_SB();
       if constexpr (P >= 3) acc_next = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c * P + 2], bq[c * P + 2], acc_next, 0, 0, 0);
-      SUG_SB();
-#pragma unroll
-      for (int u = K / 2 - 1; u > 0; --u) v[u] = __builtin_amdgcn_fmed3f(v[u - 1], v[u], s);
-      v[0] = fmaxf(v[0], s);
-#pragma unroll
-      for (int u = K / 2 - 1; u >= 0; --u) asm volatile("" : "+v"(v[u]));
-      SUG_SB();
       if constexpr (P >= 4) acc_next = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c * P + 3], bq[c * P + 3], acc_next, 0, 0, 0);
       SUG_SB();
     }
@@ -357,20 +398,37 @@ __global__ __launch_bounds__(256, 1) void knn_mfma_kernel(const float* __restric
     for (int t = 0; t < ntile; ++t) {
       // (the last iteration's MFMA chain runs on a stale buffer; its result is never used)
       f32x16 acc_next;
+      { ACC_BEGIN();
       step(acc_cur, acc_next, tbuf(t + 1) + qj * RS + h * HALF, nbuf(t) + 4 * h, t * TJ + 4 * h);
+      ACC_END(8); }
+      { ACC_BEGIN();
       if (t + 2 < ntile) tile_store<CP>(tr, tbuf(t + 2), nbuf(t + 2), N, (t + 2) * TJ);
-      // block-wide decision inside the per-tile barrier: compact when a ring could overflow
-      const int need = __syncthreads_or(cnt > CAP - 16);
+      ACC_END(9); }
+      ACC_BEGIN();
+      // block-wide decision inside the per-tile barrier: bit 0 = a ring could overflow during
+      // the next tile (compact), bit 1 = a lane has SUG_KNN_RP entries the chain has not seen
+      const int need = __syncthreads_or((cnt > CAP - 16 ? 1 : 0) | (cnt - done >= SUG_KNN_RP ? 2 : 0));
+      ACC_END(10);
       if (t + 3 < ntile) tile_load<CP>(tr, xb, ldx, N, (t + 3) * TJ);
-      if (need) {
+      { ACC_BEGIN();
+      if (need) refresh();
+      ACC_END(11); }
+      { ACC_BEGIN();
+      if (need & 1) {
         compact_fast();
         if (__syncthreads_or(cnt > CAP - 16)) compact();      // degenerate clouds: many exact ties
+        done = cnt;
       }
+      ACC_END(12); }
+#ifdef SUG_KNN_STAMP
+      if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { g_knn_stamp[13] += need ? 1 : 0; g_knn_stamp[14] += (need & 1); }
+#endif
       acc_cur = acc_next;
     }
   }
 #undef SUG_SB
   STAMP(2);
+  refresh();
   compact();
   STAMP(3);
 
@@ -398,6 +456,13 @@ __global__ __launch_bounds__(256, 1) void knn_mfma_kernel(const float* __restric
     }
     if (key[i] != 0ull && rank < k && q < N) o[rank] = 0x7fffffff - (int)(unsigned int)(key[i] & 0xffffffffull);
   }
+  // fewer than k comparable candidates (NaN features, N < k): point the remaining slots at the
+  // query itself so that downstream gathers stay in range
+  int nvalid = 0;
+#pragma unroll
+  for (int u = 0; u < K; ++u) nvalid += (key[u] != 0ull ? 1 : 0) + (pk[u] != 0ull ? 1 : 0);
+  if (h == 0 && q < N)
+    for (int r = nvalid; r < k; ++r) o[r] = q;
   STAMP(5);
 }
 

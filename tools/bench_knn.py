@@ -33,22 +33,31 @@ def time_knn(L, x, k, iters=20):
     return a.elapsed_time(b) / iters * 1e3
 
 
+_prev = [0] * 16
+
+
 def stamps(L):
-    buf = (ctypes.c_ulonglong * 8)()
+    buf = (ctypes.c_ulonglong * 16)()
     L.sug_debug_read_stamps(buf)
     v = list(buf)
     names = ['query staging', 'sweep (mfma+med3+ring)', 'final compact', 'build keys', 'rank+store']
-    return ', '.join('%s %d' % (n, v[i + 1] - v[i]) for i, n in enumerate(names))
+    global _prev
+    d = [a - b for a, b in zip(v, _prev)]
+    _prev = v
+    L6 = 6.0   # accumulators add up over the 3 warm-up + 3 timed launches
+    acc = 'per launch: step %d, tile_store %d, barrier_or %d, refresh %d (x%.1f), compact %d (x%.1f)' % (d[8] / L6, d[9] / L6, d[10] / L6, d[11] / L6, d[13] / L6, d[12] / L6, d[14] / L6)
+    return ', '.join('%s %d' % (n, v[i + 1] - v[i]) for i, n in enumerate(names)) + ' | ' + acc
 
 
 if __name__ == '__main__':
     torch.manual_seed(0)
-    variants = [('full', [])]
+    variants = [('rp8', ['-DSUG_KNN_RP=8']), ('rp12', []), ('rp16', ['-DSUG_KNN_RP=16']), ('rp24', ['-DSUG_KNN_RP=24'])]
     libs = [(t, build(t, d)) for t, d in variants]
-    for C in (3, 64, 128):
-        x = torch.randn(32, 1024, C, device='cuda')
-        print('C=%3d ' % C + '  '.join('%s %7.1f us' % (t, time_knn(L, x, 20)) for t, L in libs))
-    S = build('stamp', ['-DSUG_KNN_STAMP=1'])
+    for B in (32, 64):
+        for C in (3, 64, 128):
+            x = torch.randn(B, 1024, C, device='cuda')
+            print('B=%d C=%3d ' % (B, C) + '  '.join('%s %7.1f us' % (t, time_knn(L, x, 20)) for t, L in libs))
+    S = build('stamp', ['-DSUG_KNN_STAMP=1', '-DSUG_KNN_RP=16'])
     for C in (3, 64, 128):
         x = torch.randn(32, 1024, C, device='cuda')
         us = time_knn(S, x, 20, iters=3)
