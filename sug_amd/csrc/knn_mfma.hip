@@ -330,6 +330,18 @@ __global__ __launch_bounds__(256, 1) void knn_mfma_kernel(const float* __restric
   };
 
 #define SUG_SB() __builtin_amdgcn_sched_barrier(0)
+#ifndef SUG_KNN_ABL
+#define SUG_KNN_REFRESH_MASK 3
+#define SUG_KNN_COMPACT_MASK 1
+#else
+#define SUG_KNN_REFRESH_MASK 4
+#define SUG_KNN_COMPACT_MASK 4
+#endif
+#ifdef SUG_KNN_STAMP
+#define SUG_KNN_COUNT(need) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { g_knn_stamp[13] += (need) ? 1 : 0; g_knn_stamp[14] += ((need) & 1); } } while (0)
+#else
+#define SUG_KNN_COUNT(need)
+#endif
   // One pipeline step: the MFMA chain of the NEXT tile (matrix pipe) is issued in pieces
   // between the CURRENT tile's candidates (VALU): per candidate slot c,
   //   [mfma] score + compare + ring append [mfma x (P-1)]
@@ -356,6 +368,10 @@ __global__ __launch_bounds__(256, 1) void knn_mfma_kernel(const float* __restric
         av[4 * g + 0] = a4.x; av[4 * g + 1] = a4.y; av[4 * g + 2] = a4.z; av[4 * g + 3] = a4.w;
       }
     }
+    // keep the operand loads HERE: hipcc otherwise sinks the norm loads into the candidate loop,
+    // where every s_waitcnt lgkmcnt(0) also drains the ring stores in flight
+#pragma unroll
+    for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(nn[r]));
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc_next[r] = 0.f;
     if constexpr (CP == 4) {
@@ -369,9 +385,16 @@ __global__ __launch_bounds__(256, 1) void knn_mfma_kernel(const float* __restric
       SUG_SB();
       // pairwise_distance = -xx - inner - xx^T, inner = -2*dot (model_utils.py:179-181)
       const float s = __fsub_rn(__fsub_rn(-nn[c], __fmul_rn(-2.0f, acc_cur[c])), ni);
+#if defined(SUG_KNN_ABL) && SUG_KNN_ABL == 1      // ablation: no selection at all
+      thr = fmaxf(thr, s);
+#else
       const bool enters = s > thr;
       ring[(enters ? cnt : CAP) * 256] = make_float2(s, __int_as_float(jbase + 8 * (c >> 2) + (c & 3)));
       cnt += enters ? 1 : 0;
+#endif
+#if defined(SUG_KNN_ABL) && SUG_KNN_ABL == 2      // ablation: append only, never refresh / compact
+      cnt = cnt > CAP - 17 ? 0 : cnt;
+#endif
       SUG_SB();
       if constexpr (P >= 2) acc_next = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c * P + 1], bq[c * P + 1], acc_next, 0, 0, 0);
       if constexpr (P >= 3) acc_next = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c * P + 2], bq[c * P + 2], acc_next, 0, 0, 0);
@@ -382,49 +405,56 @@ __global__ __launch_bounds__(256, 1) void knn_mfma_kernel(const float* __restric
 
   // Software pipeline over candidate tiles (3 LDS buffers, one barrier per tile):
   //   iteration t:  MFMA chain of tile t+1 (matrix pipe)  ||  selection of tile t (VALU)
-  //                 registers of tile t+2 -> LDS, global loads of tile t+3 in flight.
+  //                 registers of tile t+2 -> LDS; global loads of tiles t+3 and t+4 in flight
+  //                 (two staging register sets: a load has two iterations to land).
   {
-    TileRegs<CP> tr;
+    TileRegs<CP> tra, trb;                      // tile t+2 lives in tra for even t, trb for odd t
     auto tbuf = [&](int t) { return s_tile + (t % 3) * TJ * RS; };
     auto nbuf = [&](int t) { return s_norm + (t % 3) * TJ; };
-    tile_load<CP>(tr, xb, ldx, N, 0);
-    tile_store<CP>(tr, tbuf(0), nbuf(0), N, 0);
+    tile_load<CP>(tra, xb, ldx, N, 0);
+    tile_store<CP>(tra, tbuf(0), nbuf(0), N, 0);
     __syncthreads();
-    if (ntile > 1) tile_load<CP>(tr, xb, ldx, N, TJ);
+    if (ntile > 1) tile_load<CP>(trb, xb, ldx, N, TJ);
+    if (ntile > 2) tile_load<CP>(tra, xb, ldx, N, 2 * TJ);
     f32x16 acc_cur = score_tile<CP>(tbuf(0) + qj * RS + h * HALF, bq);
-    if (ntile > 1) tile_store<CP>(tr, tbuf(1), nbuf(1), N, TJ);
+    if (ntile > 1) tile_store<CP>(trb, tbuf(1), nbuf(1), N, TJ);
     __syncthreads();
-    if (ntile > 2) tile_load<CP>(tr, xb, ldx, N, 2 * TJ);
-    for (int t = 0; t < ntile; ++t) {
-      // (the last iteration's MFMA chain runs on a stale buffer; its result is never used)
-      f32x16 acc_next;
-      { ACC_BEGIN();
-      step(acc_cur, acc_next, tbuf(t + 1) + qj * RS + h * HALF, nbuf(t) + 4 * h, t * TJ + 4 * h);
-      ACC_END(8); }
-      { ACC_BEGIN();
-      if (t + 2 < ntile) tile_store<CP>(tr, tbuf(t + 2), nbuf(t + 2), N, (t + 2) * TJ);
-      ACC_END(9); }
-      ACC_BEGIN();
-      // block-wide decision inside the per-tile barrier: bit 0 = a ring could overflow during
-      // the next tile (compact), bit 1 = a lane has SUG_KNN_RP entries the chain has not seen
-      const int need = __syncthreads_or((cnt > CAP - 16 ? 1 : 0) | (cnt - done >= SUG_KNN_RP ? 2 : 0));
-      ACC_END(10);
-      if (t + 3 < ntile) tile_load<CP>(tr, xb, ldx, N, (t + 3) * TJ);
-      { ACC_BEGIN();
-      if (need) refresh();
-      ACC_END(11); }
-      { ACC_BEGIN();
-      if (need & 1) {
-        compact_fast();
-        if (__syncthreads_or(cnt > CAP - 16)) compact();      // degenerate clouds: many exact ties
-        done = cnt;
-      }
-      ACC_END(12); }
-#ifdef SUG_KNN_STAMP
-      if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { g_knn_stamp[13] += need ? 1 : 0; g_knn_stamp[14] += (need & 1); }
-#endif
-      acc_cur = acc_next;
+    if (ntile > 3) tile_load<CP>(trb, xb, ldx, N, 3 * TJ);
+    // (a macro, not a lambda: a lambda calling the lambdas above keeps their captured state --
+    // cnt, v[], the ring pointer -- in a closure object in scratch memory)
+    // per tile: (the last iteration's MFMA chain runs on a stale buffer; its result is never used)
+    //   block-wide decision inside the per-tile barrier: bit 0 = a ring could overflow during the
+    //   next tile (compact), bit 1 = a lane has SUG_KNN_RP entries the chain has not seen
+#define SUG_KNN_BODY(T, TR) do { \
+      f32x16 acc_next; \
+      { ACC_BEGIN(); \
+      step(acc_cur, acc_next, tbuf((T) + 1) + qj * RS + h * HALF, nbuf((T)) + 4 * h, (T) * TJ + 4 * h); \
+      ACC_END(8); } \
+      { ACC_BEGIN(); \
+      if ((T) + 2 < ntile) tile_store<CP>(TR, tbuf((T) + 2), nbuf((T) + 2), N, ((T) + 2) * TJ); \
+      ACC_END(9); } \
+      ACC_BEGIN(); \
+      const int need = __syncthreads_or((cnt > CAP - 16 ? 1 : 0) | (cnt - done >= SUG_KNN_RP ? 2 : 0)); \
+      ACC_END(10); \
+      if ((T) + 4 < ntile) tile_load<CP>(TR, xb, ldx, N, ((T) + 4) * TJ); \
+      { ACC_BEGIN(); \
+      if (need & SUG_KNN_REFRESH_MASK) refresh(); \
+      ACC_END(11); } \
+      { ACC_BEGIN(); \
+      if (need & SUG_KNN_COMPACT_MASK) { \
+        compact_fast(); \
+        if (__syncthreads_or(cnt > CAP - 16)) compact(); /* degenerate clouds: many exact ties */ \
+        done = cnt; \
+      } \
+      ACC_END(12); } \
+      SUG_KNN_COUNT(need); \
+      acc_cur = acc_next; \
+    } while (0)
+    for (int t = 0; t < ntile; t += 2) {
+      SUG_KNN_BODY(t, tra);
+      if (t + 1 < ntile) SUG_KNN_BODY(t + 1, trb);
     }
+#undef SUG_KNN_BODY
   }
 #undef SUG_SB
   STAMP(2);

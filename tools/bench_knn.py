@@ -51,7 +51,7 @@ def stamps(L):
 
 if __name__ == '__main__':
     torch.manual_seed(0)
-    variants = [('rp8', ['-DSUG_KNN_RP=8']), ('rp12', []), ('rp16', ['-DSUG_KNN_RP=16']), ('rp24', ['-DSUG_KNN_RP=24'])]
+    variants = [('full', []), ('no-select', ['-DSUG_KNN_ABL=1']), ('append-only', ['-DSUG_KNN_ABL=2'])]
     libs = [(t, build(t, d)) for t, d in variants]
     for B in (32, 64):
         for C in (3, 64, 128):
