@@ -14,6 +14,43 @@ namespace {
 constexpr int TI = 16;
 constexpr int DK = 64;
 
+// Kernel value, its derivative coefficient and the contribution of pair (i,j) to the three sums.
+__device__ __forceinline__ void pair_epilogue(int i, int j, int m, float g, float ni, float nj,
+                                              const float* __restrict__ w, const float* __restrict__ neg_gamma,
+                                              int ns, float* __restrict__ wt, float& kxx, float& kyy, float& kxy) {
+  const int M2 = 2 * m;
+  {
+    // exponent = Z_norm_sqr - 2*ZZT + Z_norm_sqr.t()   (model/mmd.py:247)
+    const float e = __fadd_rn(__fsub_rn(ni, __fmul_rn(2.0f, g)), nj);
+    float K = 0.f, Kp = 0.f;
+    for (int s = 0; s < ns; ++s) {
+      const float ng = neg_gamma[s];
+      const float t = expf(__fmul_rn(ng, e));
+      K += t;
+      Kp = fmaf(ng, t, Kp);
+    }
+    const float inv_m2 = 1.0f / ((float)m * (float)m);
+    float cf;  // symmetrised coefficient c_ij + c_ji of K_ij in mmd2
+    if (i < m && j < m) {
+      kxx = K;
+      cf = 2.0f * inv_m2;
+    } else if (i >= m && j >= m) {
+      kyy = K;
+      cf = 2.0f * inv_m2;
+    } else if (i < m) {  // i in X, j in Y: weight belongs to column j-m
+      const float wj = w ? w[j - m] : 1.0f;
+      kxy = wj * K;
+      cf = -2.0f * wj * inv_m2;
+    } else {  // i in Y, j in X (mirror; contributes to wt only)
+      const float wi = w ? w[i - m] : 1.0f;
+      cf = -2.0f * wi * inv_m2;
+    }
+    // e_ii is identically 0: no gradient, and keeping cf*Kp_ii (huge) on the diagonal would
+    // cancel catastrophically in dZ = 2*(diag(rowsum(wt)) - wt).Z
+    if (wt) wt[(int64_t)i * M2 + j] = (i == j) ? 0.f : cf * Kp;
+  }
+}
+
 __global__ __launch_bounds__(256) void mmd_rbf_kernel(const float* __restrict__ z, int64_t ldz, int m,
                                                       int D, const float* __restrict__ w,
                                                       const float* __restrict__ neg_gamma, int ns,
@@ -47,36 +84,53 @@ __global__ __launch_bounds__(256) void mmd_rbf_kernel(const float* __restrict__ 
     }
   }
   float kxx = 0.f, kyy = 0.f, kxy = 0.f;
-  if (i < M2 && j < M2) {
-    // exponent = Z_norm_sqr - 2*ZZT + Z_norm_sqr.t()   (model/mmd.py:247)
-    const float e = __fadd_rn(__fsub_rn(ni, __fmul_rn(2.0f, g)), nj);
-    float K = 0.f, Kp = 0.f;
-    for (int s = 0; s < ns; ++s) {
-      const float ng = neg_gamma[s];
-      const float t = expf(__fmul_rn(ng, e));
-      K += t;
-      Kp = fmaf(ng, t, Kp);
-    }
-    const float inv_m2 = 1.0f / ((float)m * (float)m);
-    float cf;  // symmetrised coefficient c_ij + c_ji of K_ij in mmd2
-    if (i < m && j < m) {
-      kxx = K;
-      cf = 2.0f * inv_m2;
-    } else if (i >= m && j >= m) {
-      kyy = K;
-      cf = 2.0f * inv_m2;
-    } else if (i < m) {  // i in X, j in Y: weight belongs to column j-m
-      const float wj = w ? w[j - m] : 1.0f;
-      kxy = wj * K;
-      cf = -2.0f * wj * inv_m2;
-    } else {  // i in Y, j in X (mirror; contributes to wt only)
-      const float wi = w ? w[i - m] : 1.0f;
-      cf = -2.0f * wi * inv_m2;
-    }
-    // e_ii is identically 0: no gradient, and keeping cf*Kp_ii (huge) on the diagonal would
-    // cancel catastrophically in dZ = 2*(diag(rowsum(wt)) - wt).Z
-    if (wt) wt[(int64_t)i * M2 + j] = (i == j) ? 0.f : cf * Kp;
+  if (i < M2 && j < M2) pair_epilogue(i, j, m, g, ni, nj, w, neg_gamma, ns, wt, kxx, kyy, kxy);
+  double dxx = wave_sum_d((double)kxx), dyy = wave_sum_d((double)kyy), dxy = wave_sum_d((double)kxy);
+  if ((threadIdx.x & (WAVE - 1)) == 0) {
+    atomicAdd(&s_sum[0], dxx);
+    atomicAdd(&s_sum[1], dyy);
+    atomicAdd(&s_sum[2], dxy);
   }
+  __syncthreads();
+  if (threadIdx.x < 3) atomicAdd(&sums[threadIdx.x], s_sum[threadIdx.x]);
+}
+
+
+// Few rows, many features (2m <= 128, e.g. the node features: 64 x 4106): 4x4 pair tiles, the 16
+// lanes of a pair split D (stride 16, straight from global / L2) and their partial chains are
+// combined by a fixed xor tree -- for i == j the three partial chains are identical lane by lane,
+// so e_ii is still exactly 0.  (2m/4)^2 workgroups instead of (2m/16)^2.
+__global__ __launch_bounds__(256) void mmd_rbf_small_kernel(const float* __restrict__ z, int64_t ldz, int m,
+                                                            int D, const float* __restrict__ w,
+                                                            const float* __restrict__ neg_gamma, int ns,
+                                                            double* __restrict__ sums,
+                                                            float* __restrict__ wt) {
+  __shared__ double s_sum[3];
+  const int M2 = 2 * m;
+  const int l16 = threadIdx.x & 15, pr = threadIdx.x >> 4;
+  const int i = blockIdx.y * 4 + (pr >> 2), j = blockIdx.x * 4 + (pr & 3);
+  if (threadIdx.x < 3) s_sum[threadIdx.x] = 0.0;
+  __syncthreads();
+  float g = 0.f, ni = 0.f, nj = 0.f;
+  if (i < M2 && j < M2) {
+    const float* zi = z + (int64_t)i * ldz;
+    const float* zj = z + (int64_t)j * ldz;
+#pragma unroll 4
+    for (int d = l16; d < D; d += 16) {
+      const float a = zi[d], b = zj[d];
+      g = fmaf(a, b, g);
+      ni = fmaf(a, a, ni);
+      nj = fmaf(b, b, nj);
+    }
+  }
+#pragma unroll
+  for (int o = 8; o >= 1; o >>= 1) {
+    g += __shfl_xor(g, o);
+    ni += __shfl_xor(ni, o);
+    nj += __shfl_xor(nj, o);
+  }
+  float kxx = 0.f, kyy = 0.f, kxy = 0.f;
+  if (l16 == 0 && i < M2 && j < M2) pair_epilogue(i, j, m, g, ni, nj, w, neg_gamma, ns, wt, kxx, kyy, kxy);
   double dxx = wave_sum_d((double)kxx), dyy = wave_sum_d((double)kyy), dxy = wave_sum_d((double)kxy);
   if ((threadIdx.x & (WAVE - 1)) == 0) {
     atomicAdd(&s_sum[0], dxx);
@@ -216,9 +270,15 @@ extern "C" int sug_mmd_rbf(const float* z, int64_t ldz, int m, int D, const floa
   SUG_REQUIRE(z && neg_gamma && sums, "sug_mmd_rbf: null pointer");
   SUG_REQUIRE(m > 0 && D > 0 && ldz >= D, "sug_mmd_rbf: bad shape m=%d D=%d", m, D);
   SUG_REQUIRE(nsigma >= 1 && nsigma <= 8, "sug_mmd_rbf: nsigma=%d", nsigma);
-  const int T = sug_divup(2 * m, TI);
-  hipLaunchKernelGGL(mmd_rbf_kernel, dim3(T, T), dim3(256), 0, (hipStream_t)stream, z, ldz, m, D, w,
-                     neg_gamma, nsigma, sums, wt);
+  if (2 * m <= 128 && D >= 256) {      // few rows, long rows: split D across lanes for parallelism
+    const int T4 = sug_divup(2 * m, 4);
+    hipLaunchKernelGGL(mmd_rbf_small_kernel, dim3(T4, T4), dim3(256), 0, (hipStream_t)stream, z, ldz, m, D, w,
+                       neg_gamma, nsigma, sums, wt);
+  } else {
+    const int T = sug_divup(2 * m, TI);
+    hipLaunchKernelGGL(mmd_rbf_kernel, dim3(T, T), dim3(256), 0, (hipStream_t)stream, z, ldz, m, D, w,
+                       neg_gamma, nsigma, sums, wt);
+  }
   SUG_LAUNCH_CHECK("sug_mmd_rbf");
   return SUG_OK;
 }
