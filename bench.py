@@ -15,6 +15,7 @@ on the stream it is launched on; `cpu_baseline` times the CPU oracle (oracle/ref
 the restatement of the reference's algorithm) on a bounded sample of the same workload.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -49,10 +50,10 @@ def kernel_model(name, shape):
     if name.startswith('knn'):
         C = shape['C']
         return {'bytes': B * (4 * C * N + 4 * N * k), 'flops': B * N * N * (2 * C + 3)}
-    if name.startswith('edgeconv_fwd'):
+    if name.startswith(('edgeconv_fwd', 'edgeconv_layer_fwd')):     # layer call: + stats fold + affine pass
         Co = shape['Co']            # read PQ (8Co) + idx (4k); write z (4Co) + arg (Co) + s1 (4Co)
         return {'bytes': B * N * (8 * Co + 4 * k + 9 * Co), 'flops': B * N * k * Co * 6}
-    if name.startswith('edgeconv_bwd'):
+    if name.startswith(('edgeconv_bwd', 'edgeconv_layer_bwd')):     # layer call: + reverse lists + BN sums
         Co = shape['Co']            # read a, arg, s1, PQ, rev lists; write dPQ (8Co)
         return {'bytes': B * N * (4 * Co + Co + 4 * Co + 8 * Co + 8 * Co + 4 * k + 4), 'flops': B * N * k * Co * 4}
     return {'bytes': 0, 'flops': 0}
@@ -154,6 +155,11 @@ def main():
         if trainer.use_graph and i == 0:
             graph_prof, ops.PROFILE = ops.PROFILE, None
     sync()
+    # The interpreter's full (generation-2) collection walks every object torch has created so
+    # far: a ~70 ms pause that otherwise lands somewhere in the first 20 steps.  Collect now and
+    # freeze the survivors (what a long-running training loop reaches after its first minutes).
+    gc.collect()
+    gc.freeze()
     if not trainer.use_graph:
         ops.PROFILE = {}
     t0 = time.perf_counter()

@@ -240,6 +240,49 @@ int sug_bn_act_pool_bwd(const float* y, int64_t ldy, const float* coef, const fl
                         const float* gmean, const int32_t* arg, int B, int N, int C, float slope,
                         int train, double* red, float* ws, float* dy, int64_t lddy, void* stream);
 
+/* ---- layer-level entry points ---------------------------------------------------------------
+ * One call per BatchNorm-carrying layer, chaining the kernels above for `groups` equal contiguous
+ * parts of the batch (the domains the reference sends through the network in separate forward
+ * calls: statistics, normalisation and running-buffer updates are per part, in order).  coef is
+ * [groups,5,C]: written in training mode, read in eval mode (caller fills it from the running
+ * buffers).  stats: fp64 [2C] scratch; ws: SUG_STATS_BLOCKS*2*C floats.
+ *
+ * EdgeConv layer = get_graph_feature + conv_2d + max over k (model_utils.py:188-210, :8-32,
+ * Model.py:88-109): z/arg/s1 as sug_edgeconv_fwd, out [B,N,Co] (row stride ldo). */
+int sug_edgeconv_layer_fwd(const float* pq, int64_t ldpq, const int32_t* idx, const float* gamma,
+                           const float* beta, int B, int N, int k, int Co, int groups, int training,
+                           float eps, float momentum, float slope, float* running_mean,
+                           float* running_var, float* z, uint8_t* arg, float* s1, float* coef,
+                           float* out, int64_t ldo, double* stats, float* ws, void* stream);
+/* Its backward: reverse neighbour lists (rev_off [B,N+1], rev_ent [B,N*k], scratch), per-group BN
+ * sums red [groups+1, 2Co] (row g: dbeta | dgamma; the spare last row must be zero when
+ * training = 0), a [B,N,Co] scratch, dpq [B,N,2Co] (row stride lddpq). */
+int sug_edgeconv_layer_bwd(const float* gout, int64_t ldg, const float* z, const uint8_t* arg,
+                           const float* s1, const float* pq, int64_t ldpq, const int32_t* idx,
+                           const float* coef, int B, int N, int k, int Co, int groups, int training,
+                           float slope, float* a, double* red, int32_t* rev_off, int32_t* rev_ent,
+                           float* dpq, int64_t lddpq, float* ws, void* stream);
+/* conv_2d / Conv1d + BatchNorm + (Leaky)ReLU on rows (model_utils.py:8-32, pointnet2_utils.py:195-198):
+ * out = act(BN(y)), y [rows,C]. */
+int sug_bn_act_rows_fwd(const float* y, int64_t ldy, int64_t rows, int C, int groups, const float* gamma,
+                        const float* beta, int training, float eps, float momentum, float slope,
+                        float* running_mean, float* running_var, float* coef, float* out, int64_t ldo,
+                        double* stats, float* ws, void* stream);
+/* Backward: a [rows,C] scratch (= dy when training = 0), red [groups,2C], dy [rows,C]; y dense. */
+int sug_bn_act_rows_bwd(const float* gout, int64_t ldg, const float* y, int64_t ldy, const float* coef,
+                        int64_t rows, int C, int groups, int training, float slope, float* a, double* red,
+                        float* dy, float* ws, void* stream);
+/* bn5 -> LeakyReLU -> max | mean over the points (Model.py:112-116) per group; ws_pool: 12*(B/groups)*C floats. */
+int sug_bn_act_pool_layer_fwd(const float* y, int64_t ldy, int B, int N, int C, int groups,
+                              const float* gamma, const float* beta, int training, float eps, float momentum,
+                              float slope, float* running_mean, float* running_var, float* coef,
+                              float* out_max, float* out_mean, int32_t* arg, double* stats, float* ws_stats,
+                              float* ws_pool, void* stream);
+int sug_bn_act_pool_layer_bwd(const float* y, int64_t ldy, const float* coef, const float* gmax,
+                              const float* gmean, const int32_t* arg, int B, int N, int C, int groups,
+                              float slope, int training, double* red, float* ws, float* dy, int64_t lddy,
+                              void* stream);
+
 /* ---- Gaussian multi-kernel MMD --------------------------------------------------
  * replaces _mix_rbf_kernel + _mmd2(biased=True), model/mmd.py:239-254, :274-312.
  * Z = [X;Y] : [2m, D] rows (ld = ldz).  e_ij = n_i - 2<z_i,z_j> + n_j with n the

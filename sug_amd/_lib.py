@@ -35,6 +35,17 @@ SIGNATURES = {
     'sug_edgeconv_bwd_reduce': [_vp, _i64, _vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp],
     'sug_edgeconv_bwd_scatter': [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32,
                                  _vp, _i64, _vp],
+    'sug_edgeconv_layer_fwd': [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _vp, _vp,
+                               _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp],
+    'sug_edgeconv_layer_bwd': [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32,
+                               _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
+    'sug_bn_act_rows_fwd': [_vp, _i64, _i64, _i32, _i32, _vp, _vp, _i32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _i64,
+                            _vp, _vp, _vp],
+    'sug_bn_act_rows_bwd': [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp],
+    'sug_bn_act_pool_layer_fwd': [_vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _f32, _f32, _f32, _vp, _vp, _vp,
+                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    'sug_bn_act_pool_layer_bwd': [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp,
+                                  _i64, _vp],
     'sug_bn_replay': [_vp, _i32, _i32, _f32, _vp, _vp, _vp],
     'sug_mmd_rbf_bwd': [_vp, _i64, _vp, _i32, _i32, _vp, _vp, _i64, _vp],
     'sug_sda_prob_weights': [_vp, _i64, _vp, _i64, _vp, _vp, _i32, _i32, _f32, _i32, _vp, _vp],

@@ -1,0 +1,130 @@
+// Layer-level entry points: one C call per BatchNorm-carrying layer of the encoders, looping
+// over the domain groups of the batch (source clouds, then target clouds: the reference's
+// separate forward calls) and chaining the kernels of the finer-grained entry points.  Nothing
+// new is computed here; the point is one host call (and no tensor slicing in the binding) per
+// layer instead of 4-8.  Host-only translation unit.
+#include <stdint.h>
+#include "../../include/sug_amd.h"
+
+void sug_set_error(const char* fmt, ...);
+#define LAYER_REQUIRE(cond, ...) do { if (!(cond)) { sug_set_error(__VA_ARGS__); return SUG_ERR_ARG; } } while (0)
+#define LAYER_TRY(call) do { const int rc_ = (call); if (rc_ != SUG_OK) return rc_; } while (0)
+
+extern "C" int sug_edgeconv_layer_fwd(const float* pq, int64_t ldpq, const int32_t* idx, const float* gamma,
+                                      const float* beta, int B, int N, int k, int Co, int groups, int training,
+                                      float eps, float momentum, float slope, float* running_mean,
+                                      float* running_var, float* z, uint8_t* arg, float* s1, float* coef,
+                                      float* out, int64_t ldo, double* stats, float* ws, void* stream) {
+  LAYER_REQUIRE(groups >= 1 && B > 0 && B % groups == 0, "sug_edgeconv_layer_fwd: B=%d does not split into %d groups", B, groups);
+  LAYER_REQUIRE(coef && out && z && arg && stats, "sug_edgeconv_layer_fwd: null pointer");
+  const int Bg = B / groups;
+  const int64_t rows = (int64_t)Bg * N;
+  for (int g = 0; g < groups; ++g) {
+    const int64_t r0 = (int64_t)g * rows;
+    float* cg = coef + (int64_t)g * 5 * Co;
+    LAYER_TRY(sug_edgeconv_fwd(pq + r0 * ldpq, ldpq, idx + r0 * k, gamma, Bg, N, k, Co, z + r0 * Co, arg + r0 * Co,
+                               s1 ? s1 + r0 * Co : nullptr, stats, ws, stream));
+    if (training)
+      LAYER_TRY(sug_bn_finalize(stats, gamma, beta, Co, (double)rows * k, eps, momentum, running_mean, running_var, cg,
+                                stream));
+    LAYER_TRY(sug_affine_act(z + r0 * Co, Co, cg, rows, Co, slope, out + r0 * ldo, ldo, stream));
+  }
+  return SUG_OK;
+}
+
+extern "C" int sug_edgeconv_layer_bwd(const float* gout, int64_t ldg, const float* z, const uint8_t* arg,
+                                      const float* s1, const float* pq, int64_t ldpq, const int32_t* idx,
+                                      const float* coef, int B, int N, int k, int Co, int groups, int training,
+                                      float slope, float* a, double* red, int32_t* rev_off, int32_t* rev_ent,
+                                      float* dpq, int64_t lddpq, float* ws, void* stream) {
+  LAYER_REQUIRE(groups >= 1 && B > 0 && B % groups == 0, "sug_edgeconv_layer_bwd: B=%d does not split into %d groups", B, groups);
+  LAYER_REQUIRE(red && a && rev_off && rev_ent, "sug_edgeconv_layer_bwd: null pointer");
+  const int Bg = B / groups;
+  const int64_t rows = (int64_t)Bg * N;
+  LAYER_TRY(sug_knn_reverse(idx, B, N, k, rev_off, rev_ent, stream));
+  for (int g = 0; g < groups; ++g) {
+    const int64_t r0 = (int64_t)g * rows;
+    const float* cg = coef + (int64_t)g * 5 * Co;
+    double* rg = red + (int64_t)g * 2 * Co;                  // per group: dbeta | dgamma
+    LAYER_TRY(sug_edgeconv_bwd_reduce(gout + r0 * ldg, ldg, z + r0 * Co, cg, rows, Co, slope, a + r0 * Co, rg, ws, stream));
+    // eval mode: the statistics are constants, the scatter must see zero BN sums (red + groups*2Co: a
+    // caller-zeroed spare row)
+    const double* ru = training ? rg : red + (int64_t)groups * 2 * Co;
+    LAYER_TRY(sug_edgeconv_bwd_scatter(a + r0 * Co, arg + r0 * Co, s1 + r0 * Co, pq + r0 * ldpq, ldpq,
+                                       rev_off + (int64_t)g * Bg * (N + 1), rev_ent + (int64_t)g * Bg * N * k, cg, ru,
+                                       Bg, N, k, Co, dpq + r0 * lddpq, lddpq, stream));
+  }
+  return SUG_OK;
+}
+
+extern "C" int sug_bn_act_rows_fwd(const float* y, int64_t ldy, int64_t rows, int C, int groups,
+                                   const float* gamma, const float* beta, int training, float eps, float momentum,
+                                   float slope, float* running_mean, float* running_var, float* coef, float* out,
+                                   int64_t ldo, double* stats, float* ws, void* stream) {
+  LAYER_REQUIRE(groups >= 1 && rows > 0 && rows % groups == 0, "sug_bn_act_rows_fwd: %lld rows do not split into %d groups",
+                (long long)rows, groups);
+  LAYER_REQUIRE(coef && out, "sug_bn_act_rows_fwd: null pointer");
+  const int64_t rg = rows / groups;
+  for (int g = 0; g < groups; ++g) {
+    float* cg = coef + (int64_t)g * 5 * C;
+    if (training) {
+      LAYER_TRY(sug_col_stats(y + g * rg * ldy, ldy, rg, C, stats, ws, stream));
+      LAYER_TRY(sug_bn_finalize(stats, gamma, beta, C, (double)rg, eps, momentum, running_mean, running_var, cg, stream));
+    }
+    LAYER_TRY(sug_affine_act(y + g * rg * ldy, ldy, cg, rg, C, slope, out + g * rg * ldo, ldo, stream));
+  }
+  return SUG_OK;
+}
+
+extern "C" int sug_bn_act_rows_bwd(const float* gout, int64_t ldg, const float* y, int64_t ldy, const float* coef,
+                                   int64_t rows, int C, int groups, int training, float slope, float* a,
+                                   double* red, float* dy, float* ws, void* stream) {
+  LAYER_REQUIRE(groups >= 1 && rows > 0 && rows % groups == 0, "sug_bn_act_rows_bwd: %lld rows do not split into %d groups",
+                (long long)rows, groups);
+  LAYER_REQUIRE(ldy == C, "sug_bn_act_rows_bwd: y must be dense");
+  const int64_t rg = rows / groups;
+  for (int g = 0; g < groups; ++g) {
+    const float* cg = coef + (int64_t)g * 5 * C;
+    double* rd = red + (int64_t)g * 2 * C;
+    LAYER_TRY(sug_edgeconv_bwd_reduce(gout + g * rg * ldg, ldg, y + g * rg * C, cg, rg, C, slope, a + g * rg * C, rd, ws,
+                                      stream));
+    if (training)
+      LAYER_TRY(sug_bn_bwd_apply(a + g * rg * C, y + g * rg * C, C, cg, rd, rg, C, dy + g * rg * C, C, stream));
+  }
+  return SUG_OK;
+}
+
+extern "C" int sug_bn_act_pool_layer_fwd(const float* y, int64_t ldy, int B, int N, int C, int groups,
+                                         const float* gamma, const float* beta, int training, float eps,
+                                         float momentum, float slope, float* running_mean, float* running_var,
+                                         float* coef, float* out_max, float* out_mean, int32_t* arg, double* stats,
+                                         float* ws_stats, float* ws_pool, void* stream) {
+  LAYER_REQUIRE(groups >= 1 && B > 0 && B % groups == 0, "sug_bn_act_pool_layer_fwd: B=%d does not split into %d groups", B, groups);
+  const int Bg = B / groups;
+  const int64_t rg = (int64_t)Bg * N;
+  for (int g = 0; g < groups; ++g) {
+    float* cg = coef + (int64_t)g * 5 * C;
+    const float* yg = y + g * rg * ldy;
+    if (training) {
+      LAYER_TRY(sug_col_stats(yg, ldy, rg, C, stats, ws_stats, stream));
+      LAYER_TRY(sug_bn_finalize(stats, gamma, beta, C, (double)rg, eps, momentum, running_mean, running_var, cg, stream));
+    }
+    LAYER_TRY(sug_bn_act_pool_fwd(yg, ldy, cg, Bg, N, C, slope, out_max + (int64_t)g * Bg * C, out_mean + (int64_t)g * Bg * C,
+                                  arg + (int64_t)g * Bg * C, ws_pool, stream));
+  }
+  return SUG_OK;
+}
+
+extern "C" int sug_bn_act_pool_layer_bwd(const float* y, int64_t ldy, const float* coef, const float* gmax,
+                                         const float* gmean, const int32_t* arg, int B, int N, int C, int groups,
+                                         float slope, int training, double* red, float* ws, float* dy, int64_t lddy,
+                                         void* stream) {
+  LAYER_REQUIRE(groups >= 1 && B > 0 && B % groups == 0, "sug_bn_act_pool_layer_bwd: B=%d does not split into %d groups", B, groups);
+  const int Bg = B / groups;
+  const int64_t rg = (int64_t)Bg * N;
+  for (int g = 0; g < groups; ++g)
+    LAYER_TRY(sug_bn_act_pool_bwd(y + g * rg * ldy, ldy, coef + (int64_t)g * 5 * C, gmax + (int64_t)g * Bg * C,
+                                  gmean + (int64_t)g * Bg * C, arg + (int64_t)g * Bg * C, Bg, N, C, slope, training,
+                                  red + (int64_t)g * 2 * C, ws, dy + g * rg * lddy, lddy, stream));
+  return SUG_OK;
+}

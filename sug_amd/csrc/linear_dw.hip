@@ -37,7 +37,6 @@ __global__ __launch_bounds__(256) void linear_dw_kernel(const float* __restrict_
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-#pragma unroll 4
   for (int64_t r = r0; r < r1; r += 2) {
     const int64_t row = r + kh;
     const bool ok = row < r1;

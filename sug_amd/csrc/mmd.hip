@@ -204,7 +204,6 @@ __global__ __launch_bounds__(256) void sda_prob_weights_kernel(const float* __re
                                                                int method, float* __restrict__ out) {
   constexpr int NC = 10;
   __shared__ double s_red[4][2];
-  __shared__ double s_tot[2];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   auto block_sum2 = [&](double a, double b, double& ra, double& rb) {
     a = wave_sum_d(a);

@@ -93,7 +93,8 @@ def _p(t):
 
 
 def _st():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # raw handle of the current stream; torch.cuda.current_stream() builds a Stream object (~10 us)
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
 
 
 def _need_gpu(*ts):
@@ -447,19 +448,18 @@ class _BNActRows(torch.autograd.Function):
         rows = y2.shape[0]
         if rows % G:
             raise RuntimeError('bn_act_rows: %d rows do not split into %d domain groups' % (rows, G))
-        rg = rows // G
+        dev = y.device
         g, b = gamma.detach().contiguous(), beta.detach().contiguous()
         if training:
-            coef = torch.empty(G, 5, C, dtype=torch.float32, device=y.device)
-            ws = torch.empty(STATS_BLOCKS * 2 * C, dtype=torch.float32, device=y.device)
-            for i in range(G):
-                bn_coef(col_stats(y2[i * rg:(i + 1) * rg], ws), g, b, rg, eps, momentum, running_mean, running_var,
-                        out=coef[i])
+            coef = torch.empty(G, 5, C, dtype=torch.float32, device=dev)
         else:
             coef = eval_coef(g, b, running_mean, running_var, eps).unsqueeze(0).repeat(G, 1, 1)
-        out = torch.empty(rows, C, dtype=torch.float32, device=y.device)
-        for i in range(G):
-            affine_act(y2[i * rg:(i + 1) * rg], coef[i], slope, out=out[i * rg:(i + 1) * rg])
+        out = torch.empty(rows, C, dtype=torch.float32, device=dev)
+        stats = torch.empty(2 * C, dtype=torch.float64, device=dev)
+        ws = torch.empty(STATS_BLOCKS * 2 * C, dtype=torch.float32, device=dev)
+        check(lib().sug_bn_act_rows_fwd(_p(y2), C, rows, C, G, _p(g), _p(b), 1 if training else 0, eps, momentum,
+                                        float(slope), _p(running_mean), _p(running_var), _p(coef), _p(out), C,
+                                        _p(stats), _p(ws), _st()), 'sug_bn_act_rows_fwd')
         if any(ctx.needs_input_grad[i] for i in (0, 1, 2)):
             ctx.save_for_backward(y2, coef)
             ctx.meta = (rows, C, float(slope), bool(training), tuple(y.shape), G)
@@ -469,7 +469,6 @@ class _BNActRows(torch.autograd.Function):
     def backward(ctx, gout):
         y2, coef = ctx.saved_tensors
         rows, C, slope, training, shape, G = ctx.meta
-        rg = rows // G
         dev = gout.device
         g2 = gout.reshape(rows, C)
         if g2.stride(1) != 1:
@@ -478,13 +477,8 @@ class _BNActRows(torch.autograd.Function):
         red = torch.empty(G, 2 * C, dtype=torch.float64, device=dev)
         ws = torch.empty(STATS_BLOCKS * 2 * C, dtype=torch.float32, device=dev)
         dy = torch.empty(rows, C, dtype=torch.float32, device=dev) if training else a
-        for i in range(G):
-            sl = slice(i * rg, (i + 1) * rg)
-            check(lib().sug_edgeconv_bwd_reduce(_p(g2[sl]), g2.stride(0), _p(y2[sl]), _p(coef[i]), rg, C, slope,
-                                                _p(a[sl]), _p(red[i]), _p(ws), _st()), 'sug_edgeconv_bwd_reduce')
-            if training:
-                check(lib().sug_bn_bwd_apply(_p(a[sl]), _p(y2[sl]), C, _p(coef[i]), _p(red[i]), rg, C, _p(dy[sl]), C,
-                                             _st()), 'sug_bn_bwd_apply')
+        check(lib().sug_bn_act_rows_bwd(_p(g2), g2.stride(0), _p(y2), C, _p(coef), rows, C, G, 1 if training else 0,
+                                        slope, _p(a), _p(red), _p(dy), _p(ws), _st()), 'sug_bn_act_rows_bwd')
         rf = red[0].float() if G == 1 else red.sum(0, dtype=torch.float32)
         return dy.view(shape), rf[C:], rf[:C], None, None, None, None, None, None, None
 
@@ -551,26 +545,22 @@ class _BNActPool(torch.autograd.Function):
         y, B, N, C, ld = _rows3(y)
         if B % G:
             raise RuntimeError('bn_act_pool: %d clouds do not split into %d domain groups' % (B, G))
-        Bg = B // G
         dev = y.device
         g, b = gamma.detach().contiguous(), beta.detach().contiguous()
         if training:
             coef = torch.empty(G, 5, C, dtype=torch.float32, device=dev)
-            wss = torch.empty(STATS_BLOCKS * 2 * C, dtype=torch.float32, device=dev)
-            for i in range(G):
-                yg = y[i * Bg:(i + 1) * Bg]
-                stats = col_stats(yg.view(Bg * N, C) if ld == C else yg.reshape(Bg * N, C), wss)
-                bn_coef(stats, g, b, Bg * N, eps, momentum, running_mean, running_var, out=coef[i])
         else:
             coef = eval_coef(g, b, running_mean, running_var, eps).unsqueeze(0).repeat(G, 1, 1)
         omax = torch.empty(B, C, dtype=torch.float32, device=dev)
         omean = torch.empty(B, C, dtype=torch.float32, device=dev)
         arg = torch.empty(B, C, dtype=torch.int32, device=dev)
-        ws = torch.empty(12 * Bg * C, dtype=torch.float32, device=dev)
-        for i in range(G):
-            sl = slice(i * Bg, (i + 1) * Bg)
-            check(lib().sug_bn_act_pool_fwd(_p(y[sl]), ld, _p(coef[i]), Bg, N, C, float(slope), _p(omax[sl]),
-                                            _p(omean[sl]), _p(arg[sl]), _p(ws), _st()), 'sug_bn_act_pool_fwd')
+        stats = torch.empty(2 * C, dtype=torch.float64, device=dev)
+        wss = torch.empty(STATS_BLOCKS * 2 * C, dtype=torch.float32, device=dev)
+        wsp = torch.empty(12 * (B // G) * C, dtype=torch.float32, device=dev)
+        check(lib().sug_bn_act_pool_layer_fwd(_p(y), ld, B, N, C, G, _p(g), _p(b), 1 if training else 0, eps, momentum,
+                                              float(slope), _p(running_mean), _p(running_var), _p(coef), _p(omax),
+                                              _p(omean), _p(arg), _p(stats), _p(wss), _p(wsp), _st()),
+              'sug_bn_act_pool_layer_fwd')
         ctx.save_for_backward(y, coef, arg)
         ctx.meta = (B, N, C, ld, float(slope), bool(training), G)
         ctx.mark_non_differentiable(arg)
@@ -580,17 +570,14 @@ class _BNActPool(torch.autograd.Function):
     def backward(ctx, gmax, gmean):
         y, coef, arg = ctx.saved_tensors
         B, N, C, ld, slope, training, G = ctx.meta
-        Bg = B // G
         dev = y.device
         gmax, gmean = gmax.contiguous(), gmean.contiguous()
         red = torch.empty(G, 2 * C, dtype=torch.float64, device=dev)
         ws = torch.empty(STATS_BLOCKS * 2 * C, dtype=torch.float32, device=dev)
         dy = torch.empty(B, N, C, dtype=torch.float32, device=dev)
-        for i in range(G):
-            sl = slice(i * Bg, (i + 1) * Bg)
-            check(lib().sug_bn_act_pool_bwd(_p(y[sl]), ld, _p(coef[i]), _p(gmax[sl]), _p(gmean[sl]), _p(arg[sl]), Bg, N,
-                                            C, slope, 1 if training else 0, _p(red[i]), _p(ws), _p(dy[sl]), C, _st()),
-                  'sug_bn_act_pool_bwd')
+        check(lib().sug_bn_act_pool_layer_bwd(_p(y), ld, _p(coef), _p(gmax), _p(gmean), _p(arg), B, N, C, G, slope,
+                                              1 if training else 0, _p(red), _p(ws), _p(dy), C, _st()),
+              'sug_bn_act_pool_layer_bwd')
         rf = red[0].float() if G == 1 else red.sum(0, dtype=torch.float32)
         return dy, rf[C:], rf[:C], None, None, None, None, None, None, None
 
@@ -615,29 +602,24 @@ class _EdgeConv(torch.autograd.Function):
         k = idx.shape[2]
         if B % G:
             raise RuntimeError('edgeconv: %d clouds do not split into %d domain groups' % (B, G))
-        Bg = B // G
         dev = pq.device
         gamma_c, beta_c = gamma.detach().contiguous(), beta.detach().contiguous()
         need_bwd = any(ctx.needs_input_grad[i] for i in (0, 2, 3))
         z = torch.empty(B, N, Co, dtype=torch.float32, device=dev)
         arg = torch.empty(B, N, Co, dtype=torch.uint8, device=dev)
         s1 = torch.empty(B, N, Co, dtype=torch.float32, device=dev) if need_bwd else None
-        stats = torch.empty(G, 2 * Co, dtype=torch.float64, device=dev)
+        stats = torch.empty(2 * Co, dtype=torch.float64, device=dev)
         ws = torch.empty(STATS_BLOCKS * 2 * Co, dtype=torch.float32, device=dev)
         coef = torch.empty(G, 5, Co, dtype=torch.float32, device=dev)
         if not training:
             coef.copy_(eval_coef(gamma_c, beta_c, running_mean, running_var, eps))
         out = torch.empty(B, N, Co, dtype=torch.float32, device=dev)
-        for i in range(G):
-            sl = slice(i * Bg, (i + 1) * Bg)
-            s1p = _p(s1[sl]) if need_bwd else None
-            check(_timed('edgeconv_fwd_Co%d' % Co, {'B': Bg, 'N': N, 'k': k, 'Co': Co},
-                         lambda: lib().sug_edgeconv_fwd(_p(pq[sl]), ld, _p(idx[sl]), _p(gamma_c), Bg, N, k, Co,
-                                                        _p(z[sl]), _p(arg[sl]), s1p, _p(stats[i]), _p(ws), _st())),
-                  'sug_edgeconv_fwd')
-            if training:
-                bn_coef(stats[i], gamma_c, beta_c, Bg * N * k, eps, momentum, running_mean, running_var, out=coef[i])
-            affine_act(z[sl], coef[i], slope, out=out[sl])
+        check(_timed('edgeconv_layer_fwd_Co%d' % Co, {'B': B, 'N': N, 'k': k, 'Co': Co},
+                     lambda: lib().sug_edgeconv_layer_fwd(_p(pq), ld, _p(idx), _p(gamma_c), _p(beta_c), B, N, k, Co, G,
+                                                          1 if training else 0, eps, momentum, float(slope),
+                                                          _p(running_mean), _p(running_var), _p(z), _p(arg), _p(s1),
+                                                          _p(coef), _p(out), Co, _p(stats), _p(ws), _st())),
+              'sug_edgeconv_layer_fwd')
         if need_bwd:
             ctx.save_for_backward(pq, idx, z, arg, s1, coef)
             ctx.meta = (B, N, k, Co, ld, float(slope), bool(training), G)
@@ -650,27 +632,23 @@ class _EdgeConv(torch.autograd.Function):
     def backward(ctx, gout, _gcoef):
         pq, idx, z, arg, s1, coef = ctx.saved_tensors
         B, N, k, Co, ld, slope, training, G = ctx.meta
-        Bg = B // G
         if gout is None:
             return (None,) * 11
         dev = gout.device
         gout, _, _, _, ldg = _rows3(gout)                           # a column slice of a wider buffer is fine
         a = torch.empty(B, N, Co, dtype=torch.float32, device=dev)
-        red = torch.empty(G, 2 * Co, dtype=torch.float64, device=dev)
+        # per-group dbeta | dgamma, plus a zero row the scatter reads in eval mode (statistics constant)
+        red = (torch.empty if training else torch.zeros)(G + 1, 2 * Co, dtype=torch.float64, device=dev)
         ws = torch.empty(STATS_BLOCKS * 2 * Co, dtype=torch.float32, device=dev)
-        off, ent = knn_reverse(idx)
+        off = torch.empty(B, N + 1, dtype=torch.int32, device=dev)
+        ent = torch.empty(B, N * k, dtype=torch.int32, device=dev)
         dpq = torch.empty(B, N, 2 * Co, dtype=torch.float32, device=dev)
-        red_used = red if training else torch.zeros_like(red)       # eval mode: statistics are constants
-        for i in range(G):
-            sl = slice(i * Bg, (i + 1) * Bg)
-            check(lib().sug_edgeconv_bwd_reduce(_p(gout[sl]), ldg, _p(z[sl]), _p(coef[i]), Bg * N, Co, slope, _p(a[sl]),
-                                                _p(red[i]), _p(ws), _st()), 'sug_edgeconv_bwd_reduce')
-            check(_timed('edgeconv_bwd_scatter_Co%d' % Co, {'B': Bg, 'N': N, 'k': k, 'Co': Co},
-                         lambda: lib().sug_edgeconv_bwd_scatter(_p(a[sl]), _p(arg[sl]), _p(s1[sl]), _p(pq[sl]), ld,
-                                                                _p(off[sl]), _p(ent[sl]), _p(coef[i]),
-                                                                _p(red_used[i]), Bg, N, k, Co, _p(dpq[sl]), 2 * Co,
-                                                                _st())), 'sug_edgeconv_bwd_scatter')
-        rf = red[0].float() if G == 1 else red.sum(0, dtype=torch.float32)
+        check(_timed('edgeconv_layer_bwd_Co%d' % Co, {'B': B, 'N': N, 'k': k, 'Co': Co},
+                     lambda: lib().sug_edgeconv_layer_bwd(_p(gout), ldg, _p(z), _p(arg), _p(s1), _p(pq), ld, _p(idx),
+                                                          _p(coef), B, N, k, Co, G, 1 if training else 0, slope, _p(a),
+                                                          _p(red), _p(off), _p(ent), _p(dpq), 2 * Co, _p(ws), _st())),
+              'sug_edgeconv_layer_bwd')
+        rf = red[0].float() if G == 1 else red[:G].sum(0, dtype=torch.float32)
         return dpq, None, rf[Co:], rf[:Co], None, None, None, None, None, None, None
 
 

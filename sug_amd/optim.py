@@ -87,7 +87,7 @@ class Adam(torch.optim.Adam):
                     g = p.grad = g.contiguous()
                 ptrs.append(g.data_ptr())
             lr, b1, b2, eps, wd = b.hyper
-            stream = torch.cuda.current_stream(b.table.device).cuda_stream
+            stream = torch._C._cuda_getCurrentRawStream(b.table.device.index)
             check(L.sug_adam_step(b.table.data_ptr(), b.first_dev.data_ptr(), b.first_host, b.T,
                                   (ctypes.c_void_p * b.T)(*ptrs), lr, b1, b2, eps, wd,
                                   1.0 - math.pow(b1, b.step_val), 1.0 - math.pow(b2, b.step_val),
