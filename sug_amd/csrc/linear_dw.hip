@@ -72,6 +72,72 @@ __global__ __launch_bounds__(256) void linear_dw_kernel(const float* __restrict_
 }
 
 // dw[e] = sum over chunks, 16 chunk-lanes x 16 elements per workgroup; fixed combination order.
+// Large outputs (M, N >= 128): one wave per workgroup owns a 128x128 output tile (4x4 MFMA tiles,
+// 256 accumulator registers) over its row chunk: 8 coalesced 128-B loads feed 16 MFMAs, twice the
+// arithmetic intensity of the 64x64 kernel, and no cross-wave combine.
+__global__ __launch_bounds__(64) void linear_dw_big_kernel(const float* __restrict__ g, int64_t ldg,
+                                                           const float* __restrict__ x, int64_t ldx,
+                                                           int64_t R, int M, int N, int rows_per_block,
+                                                           float* __restrict__ part) {
+  const int lane = threadIdx.x;
+  const int col = lane & 31, kh = lane >> 5;
+  const int i0 = blockIdx.y * 128, j0 = blockIdx.z * 128;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  int64_t r1 = r0 + rows_per_block;
+  if (r1 > R) r1 = R;
+  bool ia[4], jb[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    ia[t] = i0 + 32 * t + col < M;
+    jb[t] = j0 + 32 * t + col < N;
+  }
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  // one wave per SIMD: nothing else hides the load latency, so the operands of the next ST-1 row
+  // pairs are in flight while the 16 MFMAs of a row pair are issued (rows past r1 load as zeros)
+  auto fetch = [&](int64_t r, float (&av)[4], float (&bv)[4]) {
+    const int64_t row = r + kh;
+    const bool ok = row < r1;
+    const float* gr = g + row * ldg + i0 + col;
+    const float* xr = x + row * ldx + j0 + col;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      av[t] = (ok && ia[t]) ? gr[32 * t] : 0.f;
+      bv[t] = (ok && jb[t]) ? xr[32 * t] : 0.f;
+    }
+  };
+  constexpr int ST = 4;                       // row pairs in flight ahead of the MFMAs
+  float av[ST][4], bv[ST][4];
+#pragma unroll
+  for (int s = 0; s < ST - 1; ++s) fetch(r0 + 2 * s, av[s], bv[s]);
+  for (int64_t r = r0; r < r1; r += 2 * ST) {
+#pragma unroll
+    for (int s = 0; s < ST; ++s) {
+      fetch(r + 2 * (s + ST - 1), av[(s + ST - 1) % ST], bv[(s + ST - 1) % ST]);
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][a], bv[s][b], acc[a][b], 0, 0, 0);
+    }
+  }
+  float* p = part + (size_t)blockIdx.x * M * N;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = i0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * kh, j = j0 + 32 * b + col;
+        if (i < M && j < N) p[(size_t)i * N + j] = acc[a][b][r];
+      }
+}
+
 __global__ __launch_bounds__(256) void linear_dw_reduce_kernel(const float* __restrict__ part, int nchunk,
                                                                int64_t MN, float* __restrict__ dw) {
   __shared__ double s_p[16][17];
@@ -90,8 +156,10 @@ __global__ __launch_bounds__(256) void linear_dw_reduce_kernel(const float* __re
   }
 }
 
+bool use_big(int M, int N) { return M >= 128 && N >= 128; }
+
 int plan_rows_per_block(int64_t R, int M, int N) {
-  const int tiles = sug_divup(M, 64) * sug_divup(N, 64);
+  const int tiles = use_big(M, N) ? sug_divup(M, 128) * sug_divup(N, 128) : sug_divup(M, 64) * sug_divup(N, 64);
   int64_t nchunk = 1024 / tiles;                 // ~1024 workgroups in total
   if (nchunk < 8) nchunk = 8;
   int64_t rpb = (R + nchunk - 1) / nchunk;
@@ -114,8 +182,12 @@ extern "C" int sug_linear_dw(const float* g, int64_t ldg, const float* x, int64_
   const int nchunk = sug_divup(R, rpb);
   SUG_REQUIRE(sug_divup(M, 64) <= 65535 && sug_divup(N, 64) <= 65535, "sug_linear_dw: output too large");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(linear_dw_kernel, dim3(nchunk, sug_divup(M, 64), sug_divup(N, 64)), dim3(256), 0, st, g, ldg, x,
-                     ldx, R, M, N, rpb, ws);
+  if (use_big(M, N))
+    hipLaunchKernelGGL(linear_dw_big_kernel, dim3(nchunk, sug_divup(M, 128), sug_divup(N, 128)), dim3(64), 0, st, g, ldg,
+                       x, ldx, R, M, N, rpb, ws);
+  else
+    hipLaunchKernelGGL(linear_dw_kernel, dim3(nchunk, sug_divup(M, 64), sug_divup(N, 64)), dim3(256), 0, st, g, ldg, x,
+                       ldx, R, M, N, rpb, ws);
   SUG_LAUNCH_CHECK("sug_linear_dw");
   const int64_t MN = (int64_t)M * N;
   hipLaunchKernelGGL(linear_dw_reduce_kernel, dim3(sug_divup(MN, 16)), dim3(256), 0, st, ws, nchunk, MN, dw);

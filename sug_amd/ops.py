@@ -303,7 +303,7 @@ class _LinearRows(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = (g2 @ weight).view(x.shape)
         if ctx.needs_input_grad[1]:
-            if M * N >= 512 * 256:          # large outputs: rocBLAS is efficient there
+            if M * N > 512 * 512:           # larger outputs than any encoder layer: rocBLAS
                 dw = g2.t() @ x2
             else:
                 dw = torch.empty(M, N, dtype=torch.float32, device=g.device)

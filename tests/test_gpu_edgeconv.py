@@ -128,7 +128,7 @@ def test_bn_act_pool_vs_torch(B, N, C, train):
 
 
 @pytest.mark.parametrize('R,M,N', [(32768, 64, 64), (32768, 128, 3), (32768, 3, 64), (4096, 512, 128), (1000, 70, 33),
-                                   (131072, 64, 131)])
+                                   (131072, 64, 131), (8192, 512, 512), (3000, 130, 259), (65536, 256, 128)])
 def test_linear_dw_vs_torch(R, M, N):
     """Split-K MFMA weight-gradient kernel vs a torch fp64 reference; bit-reproducible."""
     from sug_amd import ops
