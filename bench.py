@@ -201,6 +201,18 @@ def main():
                 roofline = {'kernel': dom, 'bound': 'hbm', 'achieved': kd['GBps'], 'peak': HBM_PEAK_GBS,
                             'unit': 'GB/s', 'frac': kd['GBps'] / HBM_PEAK_GBS, 'traffic': None}
             roofline['avg_launch_ms'] = kd['avg_ms']
+            # HBM bytes per launch from the committed PMC passes (not collectable inside this
+            # process): only for the shape they were taken on
+            try:
+                pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles',
+                                                  'r01_pmc_traffic.json'))).get(dom)
+                shp = prof[dom][0][2]
+                if pmc and all(pmc[k] == shp[k] for k in ('B', 'N', 'k')):
+                    roofline['traffic'] = pmc['traffic_bytes']
+                    roofline['traffic_note'] = 'bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE; ' \
+                                               'algorithmic %d' % ai['bytes']
+            except (OSError, ValueError, KeyError):
+                pass
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cps, secs = cpu_baseline(args.cpu_batch, N, args.cpu_steps)

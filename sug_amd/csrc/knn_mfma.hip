@@ -26,9 +26,9 @@ __device__ unsigned long long g_knn_stamp[16];
 extern "C" int sug_debug_read_stamps(unsigned long long* host) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_knn_stamp), sizeof(g_knn_stamp));
 }
-#define STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_knn_stamp[i] = clock64(); } while (0)
+#define STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_knn_stamp[i] = clock64(); } while (0)
 #define ACC_BEGIN() const unsigned long long _t0 = clock64()
-#define ACC_END(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_knn_stamp[i] += clock64() - _t0; } while (0)
+#define ACC_END(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_knn_stamp[i] += clock64() - _t0; } while (0)
 #else
 #define STAMP(i)
 #define ACC_BEGIN()
@@ -206,7 +206,7 @@ struct RingCap { static constexpr int value = (CP == 128) ? 48 : 64; };   // mul
 #endif
 template <int CP, int K>
 __global__ __launch_bounds__(256, 1) void knn_mfma_kernel(const float* __restrict__ x, int64_t ldx,
-                                                          int N, int k, int32_t* __restrict__ idx) {
+                                                          int B, int N, int k, int32_t* __restrict__ idx) {
   constexpr int RS = CP + 4;
   constexpr int HALF = CP / 2;
   constexpr int CAP = RingCap<CP>::value;
@@ -216,11 +216,24 @@ __global__ __launch_bounds__(256, 1) void knn_mfma_kernel(const float* __restric
   float* s_norm = s_tile + 3 * TJ * RS;                           // [3][TJ] (+pad)
   float2* s_ring = reinterpret_cast<float2*>(s_norm + 4 * TJ);    // [CAP+1][256] (score, index bits)
 
-  const int b = blockIdx.y;
+  // Workgroup -> (cloud, query block).  Consecutive workgroup ids go round-robin over the 8 XCDs
+  // (each with its own L2): give all query blocks of a cloud the same id % 8, so the cloud is
+  // fetched through the fabric once per XCD-resident group instead of once per workgroup
+  // (PMC: 140 MB -> ~algorithmic per launch at C=64, 64 clouds).
+  const int nq = (N + 127) / 128;
+  int b, qb;
+  if ((B & 7) == 0) {
+    const int grp = blockIdx.x / (8 * nq), rem = blockIdx.x % (8 * nq);
+    b = grp * 8 + (rem & 7);
+    qb = rem >> 3;
+  } else {
+    b = blockIdx.x / nq;
+    qb = blockIdx.x % nq;
+  }
   const float* xb = x + (int64_t)b * N * ldx;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int qj = lane & 31, h = lane >> 5;
-  const int q0 = blockIdx.x * 128;
+  const int q0 = qb * 128;
 
   STAMP(0);
   // ---- query operands: stage the wave's 32 query rows through the tile buffers
@@ -338,7 +351,7 @@ __global__ __launch_bounds__(256, 1) void knn_mfma_kernel(const float* __restric
 #define SUG_KNN_COMPACT_MASK 4
 #endif
 #ifdef SUG_KNN_STAMP
-#define SUG_KNN_COUNT(need) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { g_knn_stamp[13] += (need) ? 1 : 0; g_knn_stamp[14] += ((need) & 1); } } while (0)
+#define SUG_KNN_COUNT(need) do { if (blockIdx.x == 0 && threadIdx.x == 0) { g_knn_stamp[13] += (need) ? 1 : 0; g_knn_stamp[14] += ((need) & 1); } } while (0)
 #else
 #define SUG_KNN_COUNT(need)
 #endif
@@ -506,8 +519,8 @@ int launch(const float* x, int64_t ldx, int B, int N, int k, int32_t* idx, hipSt
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     attr_set = true;
   }
-  dim3 grid(sug_divup(N, 128), B);
-  hipLaunchKernelGGL((knn_mfma_kernel<CP, K>), grid, dim3(256), sh, st, x, ldx, N, k, idx);
+  dim3 grid(sug_divup(N, 128) * B);
+  hipLaunchKernelGGL((knn_mfma_kernel<CP, K>), grid, dim3(256), sh, st, x, ldx, B, N, k, idx);
   SUG_LAUNCH_CHECK("sug_knn(mfma)");
   return SUG_OK;
 }
