@@ -141,6 +141,18 @@ int sug_bn_finalize(const double* stats, const float* gamma, const float* beta, 
                     double count, float eps, float momentum, float* running_mean,
                     float* running_var, float* coef, void* stream);
 
+/* Fused forms used by the layer entry points: the producer's per-workgroup partial statistics are
+ * folded (same fixed order) and turned into coef / running-buffer updates by one kernel.
+ * sug_edgeconv_fwd_bn = sug_edgeconv_fwd + sug_bn_finalize (count = B*N*k);
+ * sug_col_stats_bn    = sug_col_stats   + sug_bn_finalize (count = rows). */
+int sug_edgeconv_fwd_bn(const float* pq, int64_t ldpq, const int32_t* idx, const float* gamma,
+                        const float* beta, int B, int N, int k, int Co, float eps, float momentum,
+                        float* running_mean, float* running_var, float* z, uint8_t* arg, float* s1,
+                        float* coef, float* ws, void* stream);
+int sug_col_stats_bn(const float* y, int64_t ldy, int64_t rows, int C, const float* gamma, const float* beta,
+                     float eps, float momentum, float* running_mean, float* running_var, float* coef,
+                     float* ws, void* stream);
+
 /* Replay of the running-statistics update for G more train-mode forwards over batches whose
  * statistics are already in coef [G,5,C] (rows 2 and 4 of each group), in group order, with
  * sug_bn_finalize's arithmetic: what nn.BatchNorm would do when the encoder prefix is evaluated

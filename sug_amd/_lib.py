@@ -46,6 +46,9 @@ SIGNATURES = {
                                   _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     'sug_bn_act_pool_layer_bwd': [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp,
                                   _i64, _vp],
+    'sug_edgeconv_fwd_bn': [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp,
+                            _vp, _vp],
+    'sug_col_stats_bn': [_vp, _i64, _i64, _i32, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp],
     'sug_bn_replay': [_vp, _i32, _i32, _f32, _vp, _vp, _vp],
     'sug_mmd_rbf_bwd': [_vp, _i64, _vp, _i32, _i32, _vp, _vp, _i64, _vp],
     'sug_sda_prob_weights': [_vp, _i64, _vp, _i64, _vp, _vp, _i32, _i32, _f32, _i32, _vp, _vp],

@@ -159,6 +159,52 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
   }
 }
 
+// reduce_partials + bn_finalize in one launch: a workgroup folds the partial rows of 8 channels
+// (their sum and sum-of-squares columns c and C+c, same 16-way strided fixed order as
+// reduce_partials_kernel) and writes the BN coefficients / running statistics of those channels.
+__global__ __launch_bounds__(256) void stats_finalize_kernel(const float* __restrict__ ws, int nblk, int C,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, double count,
+                                                             float eps, float momentum, float* __restrict__ rmean,
+                                                             float* __restrict__ rvar, float* __restrict__ coef) {
+  __shared__ double s_p[16][17];
+  __shared__ double s_tot[16];
+  const int cl = threadIdx.x & 15, p = threadIdx.x >> 4;
+  const int ch = blockIdx.x * 8 + (cl & 7);                 // cl < 8: sum column, cl >= 8: sum of squares
+  const int col = (cl < 8) ? ch : C + ch;
+  const int W = 2 * C;
+  double acc = 0.0;
+  if (ch < C) {
+#pragma unroll 8
+    for (int b = p; b < nblk; b += 16) acc += (double)ws[(size_t)b * W + col];
+  }
+  s_p[p][cl] = acc;
+  __syncthreads();
+  if (p == 0) {
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += s_p[i][cl];
+    s_tot[cl] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < 8 && ch < C) {
+    const int c = ch;
+    const double mean = s_tot[threadIdx.x] / count;
+    double var = s_tot[8 + threadIdx.x] / count - mean * mean;
+    if (var < 0) var = 0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float scale = gamma[c] * rstd;
+    coef[c] = scale;
+    coef[C + c] = beta[c] - (float)mean * scale;
+    coef[2 * C + c] = (float)mean;
+    coef[3 * C + c] = rstd;
+    const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+    coef[4 * C + c] = (float)unb;
+    if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+    if (rvar) rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+  }
+}
+
 // The running-statistics update of G more train-mode forwards on batches whose statistics are
 // already known (coef rows 2 and 4), applied in group order with bn_finalize's arithmetic.
 __global__ __launch_bounds__(256) void bn_replay_kernel(const float* __restrict__ coef, int G, int C,
@@ -406,10 +452,11 @@ inline int col_width(int C) {
 
 }  // namespace
 
-extern "C" int sug_edgeconv_fwd(const float* pq, int64_t ldpq, const int32_t* idx, const float* gamma,
-                                int B, int N, int k, int Co, float* z, uint8_t* arg, float* s1,
-                                double* stats, float* ws, void* stream) {
-  SUG_REQUIRE(pq && idx && gamma && z && arg && stats && ws, "sug_edgeconv_fwd: null pointer");
+// producer only: per-workgroup partial rows in ws, their number in *nblk
+static int edgeconv_fwd_partials(const float* pq, int64_t ldpq, const int32_t* idx, const float* gamma, int B, int N,
+                                 int k, int Co, float* z, uint8_t* arg, float* s1, float* ws, int* nblk,
+                                 void* stream) {
+  SUG_REQUIRE(pq && idx && gamma && z && arg && ws, "sug_edgeconv_fwd: null pointer");
   SUG_REQUIRE(B > 0 && N > 0 && k > 0 && k <= 255, "sug_edgeconv_fwd: bad shape B=%d N=%d k=%d", B, N, k);
   SUG_REQUIRE(Co > 0 && Co % 4 == 0 && Co <= 1024, "sug_edgeconv_fwd: Co=%d must be a multiple of 4, <= 1024", Co);
   SUG_REQUIRE(ldpq >= 2 * Co && ldpq % 4 == 0, "sug_edgeconv_fwd: ldpq=%lld", (long long)ldpq);
@@ -435,8 +482,35 @@ extern "C" int sug_edgeconv_fwd(const float* pq, int64_t ldpq, const int32_t* id
   else
     hipLaunchKernelGGL((edgeconv_fwd_kernel<4>), dim3(grid), dim3(256), sh, st, pq, ldpq, idx, gamma, BN, N, k, Co, lpp, bpc, z, arg, s1, ws);
   SUG_LAUNCH_CHECK("sug_edgeconv_fwd");
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(sug_divup(2 * Co, 16)), dim3(256), 0, st, ws, grid, 2 * Co, stats);
+  *nblk = grid;
+  return SUG_OK;
+}
+
+extern "C" int sug_edgeconv_fwd(const float* pq, int64_t ldpq, const int32_t* idx, const float* gamma,
+                                int B, int N, int k, int Co, float* z, uint8_t* arg, float* s1,
+                                double* stats, float* ws, void* stream) {
+  SUG_REQUIRE(stats, "sug_edgeconv_fwd: null pointer");
+  int grid = 0;
+  const int rc = edgeconv_fwd_partials(pq, ldpq, idx, gamma, B, N, k, Co, z, arg, s1, ws, &grid, stream);
+  if (rc != SUG_OK) return rc;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(sug_divup(2 * Co, 16)), dim3(256), 0, (hipStream_t)stream, ws, grid,
+                     2 * Co, stats);
   SUG_LAUNCH_CHECK("sug_edgeconv_fwd(reduce)");
+  return SUG_OK;
+}
+
+// EdgeConv forward + BatchNorm coefficients (batch statistics folded and finalised in one launch)
+extern "C" int sug_edgeconv_fwd_bn(const float* pq, int64_t ldpq, const int32_t* idx, const float* gamma,
+                                   const float* beta, int B, int N, int k, int Co, float eps, float momentum,
+                                   float* running_mean, float* running_var, float* z, uint8_t* arg, float* s1,
+                                   float* coef, float* ws, void* stream) {
+  SUG_REQUIRE(beta && coef, "sug_edgeconv_fwd_bn: null pointer");
+  int grid = 0;
+  const int rc = edgeconv_fwd_partials(pq, ldpq, idx, gamma, B, N, k, Co, z, arg, s1, ws, &grid, stream);
+  if (rc != SUG_OK) return rc;
+  hipLaunchKernelGGL(stats_finalize_kernel, dim3(sug_divup(Co, 8)), dim3(256), 0, (hipStream_t)stream, ws, grid, Co,
+                     gamma, beta, (double)B * N * k, eps, momentum, running_mean, running_var, coef);
+  SUG_LAUNCH_CHECK("sug_edgeconv_fwd_bn(finalize)");
   return SUG_OK;
 }
 
@@ -525,6 +599,21 @@ extern "C" int sug_col_stats(const float* y, int64_t ldy, int64_t rows, int C, d
   SUG_LAUNCH_CHECK("sug_col_stats");
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(sug_divup(2 * C, 16)), dim3(256), 0, st, ws, grid, 2 * C, stats);
   SUG_LAUNCH_CHECK("sug_col_stats(reduce)");
+  return SUG_OK;
+}
+
+// Column statistics of y [rows,C] + BatchNorm coefficients in two launches (sug_col_stats + sug_bn_finalize fused)
+extern "C" int sug_col_stats_bn(const float* y, int64_t ldy, int64_t rows, int C, const float* gamma,
+                                const float* beta, float eps, float momentum, float* running_mean,
+                                float* running_var, float* coef, float* ws, void* stream) {
+  SUG_REQUIRE(y && gamma && beta && coef && ws, "sug_col_stats_bn: null pointer");
+  SUG_REQUIRE(rows > 0 && C > 0 && C <= 4096 && ldy >= C, "sug_col_stats_bn: bad shape");
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = launch_col_reduce<0>(y, ldy, nullptr, nullptr, rows, C, 0.f, nullptr, ws, st);
+  SUG_LAUNCH_CHECK("sug_col_stats_bn");
+  hipLaunchKernelGGL(stats_finalize_kernel, dim3(sug_divup(C, 8)), dim3(256), 0, st, ws, grid, C, gamma, beta,
+                     (double)rows, eps, momentum, running_mean, running_var, coef);
+  SUG_LAUNCH_CHECK("sug_col_stats_bn(finalize)");
   return SUG_OK;
 }
 

@@ -22,11 +22,13 @@ extern "C" int sug_edgeconv_layer_fwd(const float* pq, int64_t ldpq, const int32
   for (int g = 0; g < groups; ++g) {
     const int64_t r0 = (int64_t)g * rows;
     float* cg = coef + (int64_t)g * 5 * Co;
-    LAYER_TRY(sug_edgeconv_fwd(pq + r0 * ldpq, ldpq, idx + r0 * k, gamma, Bg, N, k, Co, z + r0 * Co, arg + r0 * Co,
-                               s1 ? s1 + r0 * Co : nullptr, stats, ws, stream));
     if (training)
-      LAYER_TRY(sug_bn_finalize(stats, gamma, beta, Co, (double)rows * k, eps, momentum, running_mean, running_var, cg,
-                                stream));
+      LAYER_TRY(sug_edgeconv_fwd_bn(pq + r0 * ldpq, ldpq, idx + r0 * k, gamma, beta, Bg, N, k, Co, eps, momentum,
+                                    running_mean, running_var, z + r0 * Co, arg + r0 * Co,
+                                    s1 ? s1 + r0 * Co : nullptr, cg, ws, stream));
+    else
+      LAYER_TRY(sug_edgeconv_fwd(pq + r0 * ldpq, ldpq, idx + r0 * k, gamma, Bg, N, k, Co, z + r0 * Co, arg + r0 * Co,
+                                 s1 ? s1 + r0 * Co : nullptr, stats, ws, stream));
     LAYER_TRY(sug_affine_act(z + r0 * Co, Co, cg, rows, Co, slope, out + r0 * ldo, ldo, stream));
   }
   return SUG_OK;
@@ -67,10 +69,9 @@ extern "C" int sug_bn_act_rows_fwd(const float* y, int64_t ldy, int64_t rows, in
   const int64_t rg = rows / groups;
   for (int g = 0; g < groups; ++g) {
     float* cg = coef + (int64_t)g * 5 * C;
-    if (training) {
-      LAYER_TRY(sug_col_stats(y + g * rg * ldy, ldy, rg, C, stats, ws, stream));
-      LAYER_TRY(sug_bn_finalize(stats, gamma, beta, C, (double)rg, eps, momentum, running_mean, running_var, cg, stream));
-    }
+    if (training)
+      LAYER_TRY(sug_col_stats_bn(y + g * rg * ldy, ldy, rg, C, gamma, beta, eps, momentum, running_mean, running_var, cg,
+                                 ws, stream));
     LAYER_TRY(sug_affine_act(y + g * rg * ldy, ldy, cg, rg, C, slope, out + g * rg * ldo, ldo, stream));
   }
   return SUG_OK;
@@ -105,10 +106,9 @@ extern "C" int sug_bn_act_pool_layer_fwd(const float* y, int64_t ldy, int B, int
   for (int g = 0; g < groups; ++g) {
     float* cg = coef + (int64_t)g * 5 * C;
     const float* yg = y + g * rg * ldy;
-    if (training) {
-      LAYER_TRY(sug_col_stats(yg, ldy, rg, C, stats, ws_stats, stream));
-      LAYER_TRY(sug_bn_finalize(stats, gamma, beta, C, (double)rg, eps, momentum, running_mean, running_var, cg, stream));
-    }
+    if (training)
+      LAYER_TRY(sug_col_stats_bn(yg, ldy, rg, C, gamma, beta, eps, momentum, running_mean, running_var, cg, ws_stats,
+                                 stream));
     LAYER_TRY(sug_bn_act_pool_fwd(yg, ldy, cg, Bg, N, C, slope, out_max + (int64_t)g * Bg * C, out_mean + (int64_t)g * Bg * C,
                                   arg + (int64_t)g * Bg * C, ws_pool, stream));
   }
