@@ -119,8 +119,15 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        # SUG_BENCH_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks
+        # (ranks then share devices; RCCL refuses that).  The measured configuration is nccl = RCCL.
+        backend = os.environ.get('SUG_BENCH_BACKEND', 'nccl')
+        local = local % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local)
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     dev = torch.device('cuda', local)
 
     from sug_amd import ops, _lib

@@ -35,16 +35,24 @@ def discrepancy(out1, out2):
     return torch.mean(torch.abs(F.softmax(out1, dim=-1) - F.softmax(out2, dim=-1)))
 
 
+def _all_gather_rows(x):
+    world = dist.get_world_size()
+    x = x.contiguous()
+    out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    if dist.get_backend() == 'gloo' and x.is_cuda:        # rehearsal only: gloo gathers device tensors as a list
+        parts = list(out.chunk(world, dim=0))
+        dist.all_gather(parts, x)
+    else:
+        dist.all_gather_into_tensor(out, x)
+    return out
+
+
 class _AllGatherRows(torch.autograd.Function):
     """cat over ranks along dim 0; backward sums every rank's gradient for the local slice."""
 
     @staticmethod
     def forward(ctx, x):
-        world = dist.get_world_size()
-        x = x.contiguous()
-        out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-        dist.all_gather_into_tensor(out, x)
-        return out
+        return _all_gather_rows(x)
 
     @staticmethod
     def backward(ctx, g):
@@ -66,9 +74,7 @@ def gather_rows_ddp(x):
         return x
     if x.requires_grad:
         return _AllGatherRows.apply(x)
-    out = torch.empty((dist.get_world_size() * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-    dist.all_gather_into_tensor(out, x.contiguous())
-    return out
+    return _all_gather_rows(x)
 
 
 def allreduce_grads_(params, world):
@@ -82,9 +88,9 @@ def allreduce_grads_(params, world):
     dist.all_reduce(flat)
     flat.div_(world)
     off = 0
-    for p in ps:
+    for p in ps:                    # the averaged gradients stay in the flat buffer: no copy back
         n = p.numel()
-        p.grad.copy_(flat[off:off + n].view_as(p))
+        p.grad = flat[off:off + n].view_as(p)
         off += n
 
 
