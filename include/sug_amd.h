@@ -85,6 +85,10 @@ int sug_ball_query(const float* xyz, const float* query, int B, int N, int S,
  * dist_out may be NULL; else [B,S,k]. */
 int sug_knn_query(const float* xyz, const float* query, int B, int N, int S,
                   int k, int32_t* idx_out, float* dist_out, void* stream);
+/* Same selection on the direct-form distance sum((q - p)^2) of the Point Transformer path:
+ * `square_distance(...).argsort()[:, :, :k]`, Ptran_transformer.py:32-33, PTran_utils.py:117-119. */
+int sug_knn_query_direct(const float* xyz, const float* query, int B, int N, int S, int k,
+                         int32_t* idx_out, float* dist_out, void* stream);
 
 /* ---- 3 nearest of few candidates for many queries --------------------------
  * replaces the sort + [:3] of upsample_inter(), model/point_utils.py:153-155

@@ -14,6 +14,7 @@ Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
 """
 import math
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -325,12 +326,74 @@ def pointnet2_g(p, pre, x, training=True, starts=(None, None)):
     return l3_pts.view(B, 1024), node, None
 
 
-def pointnet_c(p, pre, x, dgcnn, adapt=False, drop_p=0.0, training=True):
-    """Pointnet_c.forward, model/Model.py:436-449 (PTran_flag False). Dropout2d on a 2-D
-    input acts element-wise; parity runs use drop_p=0."""
+# ---------------------------------------------------------------------------------------------
+# Point Transformer encoder (config C5): model/Ptran_transformer.py, model/PTran_utils.py,
+# PTran_g model/Model.py:285-337
+# ---------------------------------------------------------------------------------------------
+def sqdist_direct(src, dst):
+    """square_distance_Ptrans point_utils.py:43-57 = square_distance PTran_utils.py:22-36:
+    sum((src - dst)^2) -- NOT the expanded form of the other encoders. [B,N,C],[B,M,C] -> [B,N,M]."""
+    return torch.sum((src[:, :, None] - dst[:, None]) ** 2, dim=-1)
+
+
+def transformer_block(p, pre, xyz, feats, k=16):
+    """TransformerBlock.forward, Ptran_transformer.py:31-45: kNN by argsort of direct-form
+    distances, vector attention softmax_k(gamma(q - k + delta)/sqrt(d)) * (v + delta)."""
+    lin = lambda name, t, bias=True: F.linear(t, p[pre + name + '.weight'], p[pre + name + '.bias'] if bias else None)
+    knn = sqdist_direct(xyz, xyz).argsort()[:, :, :k]
+    knn_xyz = gather_cl(xyz, knn)
+    x = lin('fc1', feats)
+    q = lin('w_qs', x, False)
+    kk = gather_cl(lin('w_ks', x, False), knn)
+    v = gather_cl(lin('w_vs', x, False), knn)
+    pos = lin('fc_delta.2', F.relu(lin('fc_delta.0', xyz[:, :, None] - knn_xyz)))
+    attn = lin('fc_gamma.2', F.relu(lin('fc_gamma.0', q[:, :, None] - kk + pos)))
+    attn = F.softmax(attn / np.sqrt(kk.size(-1)), dim=-2)
+    res = torch.einsum('bmnf,bmnf->bmf', attn, v + pos)
+    return lin('fc2', res) + feats
+
+
+def transition_down(p, pre, xyz, points, npoint, nsample, training=True, start=None):
+    """TransitionDown = PTran_utils.PointNetSetAbstraction(knn=True) :158-199 with
+    sample_and_group(knn=True) :99-136: FPS, kNN by argsort, [xyz_j - xyz_c | feat_j], 2 x
+    (1x1 conv, BN, ReLU), max over the group."""
+    B = xyz.shape[0]
+    fidx = fps_cl(xyz, npoint, start)
+    new_xyz = gather_cl(xyz, fidx)
+    idx = sqdist_direct(new_xyz, xyz).argsort()[:, :, :nsample]
+    g = torch.cat([gather_cl(xyz, idx) - new_xyz.view(B, npoint, 1, 3), gather_cl(points, idx)], dim=-1)
+    g = g.permute(0, 3, 2, 1)
+    for i in range(2):
+        g = F.conv2d(g, p[pre + 'mlp_convs.%d.weight' % i], p[pre + 'mlp_convs.%d.bias' % i])
+        g = F.relu(_bn(p, pre + 'mlp_bns.%d.' % i, g, training))
+    return new_xyz, torch.max(g, 2)[0].transpose(1, 2)
+
+
+def ptran_g(p, pre, x, training=True, starts=(None, None, None, None)):
+    """PTran_g.forward, model/Model.py:316-337. x [B,3,N,1] -> (feat [B,512], node_fea [B,64,64])."""
+    x_ = x.squeeze(-1).permute(0, 2, 1)
+    xyz = x_[..., :3]
+    x1 = F.linear(F.relu(F.linear(x_, p[pre + 'fc1.0.weight'], p[pre + 'fc1.0.bias'])),
+                  p[pre + 'fc1.2.weight'], p[pre + 'fc1.2.bias'])
+    points = transformer_block(p, pre + 'transformer1.', xyz, x1)
+    feats = [(xyz, points)]
+    for i in range(4):
+        xyz, points = transition_down(p, pre + 'transition_downs.%d.sa.' % i, xyz, points, 1024 // 4 ** (i + 1), 16,
+                                      training, starts[i])
+        points = transformer_block(p, pre + 'transformers.%d.' % i, xyz, points)
+        feats.append((xyz, points))
+    node = F.conv1d(feats[2][1], p[pre + 'conv1d.weight'], p[pre + 'conv1d.bias'], stride=2)
+    return points.mean(1), node, None
+
+
+def pointnet_c(p, pre, x, dgcnn, adapt=False, drop_p=0.0, training=True, ptran=False):
+    """Pointnet_c.forward, model/Model.py:436-449 (mlp1 is skipped under PTran_flag). Dropout2d
+    on a 2-D input acts element-wise; parity runs use drop_p=0."""
     act = 'leakyrelu' if dgcnn else 'relu'
-    y = fc_ln_act(p, pre + 'mlp1.', x, act)
-    y = F.dropout(y, drop_p, training)
+    y = x
+    if not ptran:
+        y = fc_ln_act(p, pre + 'mlp1.', x, act)
+        y = F.dropout(y, drop_p, training)
     y = fc_ln_act(p, pre + 'mlp2.', y, act)
     mid = y
     y = F.dropout(y, drop_p, training)
@@ -357,6 +420,8 @@ def net_mda(p, model_name, x, training=True, starts=None, drop_p=0.0, mid_feat=F
                                 knn_override=knn_override)
     elif model_name == 'Pointnet2':
         feat, node, _ = pointnet2_g(p, 'g.', x, training, starts or (None, None))
+    elif model_name == 'PTran':
+        feat, node, _ = ptran_g(p, 'g.', x, training, starts or (None,) * 4)
     else:
         raise NotImplementedError(model_name)
     B = node.size(0)
@@ -365,12 +430,12 @@ def net_mda(p, model_name, x, training=True, starts=None, drop_p=0.0, mid_feat=F
     if node_adaptation_s or node_adaptation_t:
         pre = 'attention_s.' if node_adaptation_s else 'attention_t.'
         return calayer(p, pre, node.contiguous().view(B, -1, 1, 1), training)
-    dg = model_name == 'DGCNN'
+    dg, pt = model_name == 'DGCNN', model_name == 'PTran'
     if not semantic_adaption:
-        return (pointnet_c(p, 'c1.', feat, dg, False, drop_p, training),
-                pointnet_c(p, 'c2.', feat, dg, False, drop_p, training))
-    y1, s1 = pointnet_c(p, 'c1.', feat, dg, True, drop_p, training)
-    y2, s2 = pointnet_c(p, 'c2.', feat, dg, True, drop_p, training)
+        return (pointnet_c(p, 'c1.', feat, dg, False, drop_p, training, pt),
+                pointnet_c(p, 'c2.', feat, dg, False, drop_p, training, pt))
+    y1, s1 = pointnet_c(p, 'c1.', feat, dg, True, drop_p, training, pt)
+    y2, s2 = pointnet_c(p, 'c2.', feat, dg, True, drop_p, training, pt)
     return y1, y2, s1, s2
 
 

@@ -23,6 +23,7 @@ SIGNATURES = {
     'sug_fps': [_vp, _vp, _i32, _i32, _i32, _vp, _vp],
     'sug_ball_query': [_vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp, _vp],
     'sug_knn_query': [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
+    'sug_knn_query_direct': [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
     'sug_three_nn': [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
     'sug_gather_rows': [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp],
     'sug_scatter_add_rows': [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp],

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void ball_query_kernel(const float* __restrict
 // k nearest candidates for few queries (full-sort semantics): one wave per query,
 // the N distances live in registers (NPL per lane), k rounds of wave arg-min.
 // ---------------------------------------------------------------------------
-template <int NPL>
+template <int NPL, bool DIRECT>
 __global__ __launch_bounds__(256) void knn_query_kernel(const float* __restrict__ xyz,
                                                         const float* __restrict__ qry, int N, int S,
                                                         int k, int32_t* __restrict__ idx_out,
@@ -143,7 +143,9 @@ __global__ __launch_bounds__(256) void knn_query_kernel(const float* __restrict_
     const int j = p * WAVE + lane;
     if (j < N) {
       const float x = pb[j * 3 + 0], y = pb[j * 3 + 1], z = pb[j * 3 + 2];
-      d[p] = sqdist_expanded(dot3(qx, qy, qz, x, y, z), nq, sq3(x, y, z));
+      // DIRECT: sum((q - p)^2) as square_distance_Ptrans (point_utils.py:43-57 / PTran_utils.py:22-36);
+      // otherwise the expanded form of square_distance (point_utils.py:112-131)
+      d[p] = DIRECT ? sq3(qx - x, qy - y, qz - z) : sqdist_expanded(dot3(qx, qy, qz, x, y, z), nq, sq3(x, y, z));
     } else {
       d[p] = INFINITY;
     }
@@ -276,8 +278,9 @@ extern "C" int sug_ball_query(const float* xyz, const float* query, int B, int N
   return SUG_OK;
 }
 
-extern "C" int sug_knn_query(const float* xyz, const float* query, int B, int N, int S, int k,
-                             int32_t* idx_out, float* dist_out, void* stream) {
+template <bool DIRECT>
+static int launch_knn_query(const float* xyz, const float* query, int B, int N, int S, int k, int32_t* idx_out,
+                            float* dist_out, void* stream) {
   SUG_REQUIRE(xyz && query && idx_out, "sug_knn_query: null pointer");
   SUG_REQUIRE(B > 0 && N > 0 && S > 0, "sug_knn_query: bad shape");
   SUG_REQUIRE(k >= 1 && k <= 64 && k <= N, "sug_knn_query: need 1 <= k <= min(64,N), got %d", k);
@@ -287,17 +290,27 @@ extern "C" int sug_knn_query(const float* xyz, const float* query, int B, int N,
   hipStream_t st = (hipStream_t)stream;
   const int npl = sug_divup(N, WAVE);
   if (npl <= 4)
-    hipLaunchKernelGGL((knn_query_kernel<4>), grid, dim3(256), 0, st, xyz, query, N, S, k, idx_out, dist_out);
+    hipLaunchKernelGGL((knn_query_kernel<4, DIRECT>), grid, dim3(256), 0, st, xyz, query, N, S, k, idx_out, dist_out);
   else if (npl <= 8)
-    hipLaunchKernelGGL((knn_query_kernel<8>), grid, dim3(256), 0, st, xyz, query, N, S, k, idx_out, dist_out);
+    hipLaunchKernelGGL((knn_query_kernel<8, DIRECT>), grid, dim3(256), 0, st, xyz, query, N, S, k, idx_out, dist_out);
   else if (npl <= 16)
-    hipLaunchKernelGGL((knn_query_kernel<16>), grid, dim3(256), 0, st, xyz, query, N, S, k, idx_out, dist_out);
+    hipLaunchKernelGGL((knn_query_kernel<16, DIRECT>), grid, dim3(256), 0, st, xyz, query, N, S, k, idx_out, dist_out);
   else if (npl <= 32)
-    hipLaunchKernelGGL((knn_query_kernel<32>), grid, dim3(256), 0, st, xyz, query, N, S, k, idx_out, dist_out);
+    hipLaunchKernelGGL((knn_query_kernel<32, DIRECT>), grid, dim3(256), 0, st, xyz, query, N, S, k, idx_out, dist_out);
   else
-    hipLaunchKernelGGL((knn_query_kernel<64>), grid, dim3(256), 0, st, xyz, query, N, S, k, idx_out, dist_out);
+    hipLaunchKernelGGL((knn_query_kernel<64, DIRECT>), grid, dim3(256), 0, st, xyz, query, N, S, k, idx_out, dist_out);
   SUG_LAUNCH_CHECK("sug_knn_query");
   return SUG_OK;
+}
+
+extern "C" int sug_knn_query(const float* xyz, const float* query, int B, int N, int S, int k,
+                             int32_t* idx_out, float* dist_out, void* stream) {
+  return launch_knn_query<false>(xyz, query, B, N, S, k, idx_out, dist_out, stream);
+}
+
+extern "C" int sug_knn_query_direct(const float* xyz, const float* query, int B, int N, int S, int k,
+                                    int32_t* idx_out, float* dist_out, void* stream) {
+  return launch_knn_query<true>(xyz, query, B, N, S, k, idx_out, dist_out, stream);
 }
 
 extern "C" int sug_three_nn(const float* query, const float* cand, int B, int N, int S,

@@ -14,6 +14,8 @@ import torch.nn.functional as F
 from .. import ops
 from .model_utils import conv_2d, fc_layer, transform_net, adapt_layer_off, _bn_rows, bn_module
 from .pointnet2_utils import PointNetSetAbstraction
+from . import PTran_utils
+from .Ptran_transformer import TransformerBlock
 
 K = 20      # model/Model.py:52
 
@@ -188,6 +190,62 @@ class Pointnet_g(nn.Module):
         return y, node_fea
 
 
+class TransitionDown(nn.Module):
+    """model/Model.py:285-292."""
+
+    def __init__(self, k, nneighbor, channels):
+        super().__init__()
+        self.sa = PTran_utils.PointNetSetAbstraction(k, 0, nneighbor, channels[0], channels[1:], group_all=False,
+                                                     knn=True)
+
+    def forward(self, xyz, points):
+        return self.sa(xyz, points)
+
+
+class PTran_g(nn.Module):
+    """Point Transformer encoder (model/Model.py:295-337): 5 transformer blocks, 4 transition-down
+    stages (FPS to 256/64/16/4 points -- the schedule is fixed to npoints=1024 as in the reference
+    even for N=2048 -- kNN-16 grouping, 2-layer MLP, max)."""
+
+    def __init__(self):
+        super(PTran_g, self).__init__()
+        npoints, nblocks, nneighbor, d_points = 1024, 4, 16, 3
+        transformer_dim = 512
+        self.fc1 = nn.Sequential(nn.Linear(d_points, 32), nn.ReLU(), nn.Linear(32, 32))
+        self.transformer1 = TransformerBlock(32, transformer_dim, nneighbor)
+        self.transition_downs = nn.ModuleList()
+        self.transformers = nn.ModuleList()
+        for i in range(nblocks):
+            channel = 32 * 2 ** (i + 1)
+            self.transition_downs.append(TransitionDown(npoints // 4 ** (i + 1), nneighbor,
+                                                        [channel // 2 + 3, channel, channel]))
+            self.transformers.append(TransformerBlock(channel, transformer_dim, nneighbor))
+        self.nblocks = nblocks
+        self.npoints = npoints
+        self.conv1d = nn.Conv1d(64, 64, 1, stride=2)
+
+    def fps_plan(self, N):
+        """Point counts of the farthest_point_sample calls of one forward, in call order."""
+        return [N] + [self.npoints // 4 ** (i + 1) for i in range(self.nblocks - 1)]
+
+    def forward(self, x, node=False):
+        """x [B,3,N,1] -> (feat [B,512], node_fea [B,64,64](, None))."""
+        x_ = x.squeeze(-1).permute(0, 2, 1).contiguous()              # [B,N,3]
+        xyz = x_[..., :3]
+        x1 = self.fc1(x_)
+        points = self.transformer1(xyz, x1)[0]
+        xyz_and_feats = [(xyz, points)]
+        for i in range(self.nblocks):
+            xyz, points = self.transition_downs[i](xyz, points)
+            points = self.transformers[i](xyz, points)[0]
+            xyz_and_feats.append((xyz, points))
+        node_features = self.conv1d(xyz_and_feats[2][1])              # [B,64 points,128] -> [B,64,64]
+        points = points.mean(1)
+        if node:
+            return points, node_features, None
+        return points, node_features
+
+
 class Pointnet_c(nn.Module):
     """Classifier head (model/Model.py:412-449)."""
 
@@ -213,7 +271,7 @@ class Pointnet_c(nn.Module):
 
 
 class Net_MDA(nn.Module):
-    """model/Model.py:452-520.  model_name in {'Pointnet', 'Pointnet2', 'DGCNN'}."""
+    """model/Model.py:452-520.  model_name in {'Pointnet', 'Pointnet2', 'DGCNN', 'PTran'}."""
 
     def __init__(self, model_name='Pointnet'):
         super(Net_MDA, self).__init__()
@@ -226,6 +284,9 @@ class Net_MDA(nn.Module):
         elif model_name == 'DGCNN':
             self.g = DGCNN()
             self.dgcnn_flag = True
+        elif model_name == 'PTran':
+            self.g = PTran_g()
+            self.PTran_flag = True
         else:
             raise NotImplementedError("Unsupported model name")
         self.attention_s = CALayer(64 * 64)

@@ -164,15 +164,17 @@ def ball_query(xyz, query, radius, nsample):
     return out
 
 
-def knn_query(xyz, query, k, want_dist=False):
-    """k nearest of xyz [B,N,3] for each query [B,S,3] (sort semantics) -> idx [B,S,k]."""
+def knn_query(xyz, query, k, want_dist=False, direct=False):
+    """k nearest of xyz [B,N,3] for each query [B,S,3] (sort semantics) -> idx [B,S,k].
+    direct: distances as sum((q - p)^2) (Point Transformer path) instead of the expanded form."""
     _need_gpu(xyz, query)
     xyz, query = xyz.detach().contiguous(), query.detach().contiguous()
     B, N, _ = xyz.shape
     S = query.shape[1]
     idx = torch.empty(B, S, k, dtype=torch.int32, device=xyz.device)
     dist = torch.empty(B, S, k, dtype=torch.float32, device=xyz.device) if want_dist else None
-    check(lib().sug_knn_query(_p(xyz), _p(query), B, N, S, k, _p(idx), _p(dist), _st()), 'sug_knn_query')
+    fn = lib().sug_knn_query_direct if direct else lib().sug_knn_query
+    check(fn(_p(xyz), _p(query), B, N, S, k, _p(idx), _p(dist), _st()), 'sug_knn_query')
     return (idx, dist) if want_dist else idx
 
 

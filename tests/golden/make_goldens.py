@@ -243,7 +243,9 @@ def gen_model(name, B, N, seed, fname):
     p0 = _load(net, seed)
     _no_dropout(net)
     net.train()
-    n_fps = 2 if name == 'Pointnet2' else 1
+    fps_ranges = {'Pointnet2': [N, 512], 'PTran': [N, 256, 64, 16]}.get(name, [N])   # randint bounds of the FPS draws
+    n_fps = len(fps_ranges)
+    multi = n_fps > 1
     out = {'x': x, 'seed': seed}
 
     # pass 1: semantic heads, with gradients
@@ -272,7 +274,7 @@ def gen_model(name, B, N, seed, fname):
     p = O.as_params(p0)
     torch.manual_seed(seed + 1)
     starts = [None] * n_fps
-    o = O.net_mda(p, name, x, True, starts if name == 'Pointnet2' else None, semantic_adaption=True)
+    o = O.net_mda(p, name, x, True, starts if multi else None, semantic_adaption=True)
     for a, b, nm in zip(o, (y1, y2, s1, s2), ('y1', 'y2', 's1', 's2')):
         same(a, b, '%s %s' % (name, nm), 2e-6)
     oloss = sum((t * _probe(t.shape, 'probe%d' % i)).sum() for i, t in enumerate(o))
@@ -288,7 +290,7 @@ def gen_model(name, B, N, seed, fname):
     out['node_s'] = node_s
     torch.manual_seed(seed + 2)
     pd = {k: v.detach() for k, v in p.items()}
-    o_node = O.net_mda(pd, name, x, True, starts if name == 'Pointnet2' else None, node_adaptation_s=True)
+    o_node = O.net_mda(pd, name, x, True, starts if multi else None, node_adaptation_s=True)
     same(o_node, node_s, name + ' node_s', 2e-5)
     torch.manual_seed(seed + 3)
     feat, node = net(x, mid_feat=True)
@@ -297,8 +299,8 @@ def gen_model(name, B, N, seed, fname):
     # the FPS start draws of the three passes, in order
     for i, s in enumerate((seed + 1, seed + 2, seed + 3)):
         torch.manual_seed(s)
-        if name == 'Pointnet2':
-            out['start%d' % i] = torch.stack([torch.randint(0, N, (B,)), torch.randint(0, 512, (B,))])
+        if multi:
+            out['start%d' % i] = torch.stack([torch.randint(0, r, (B,)) for r in fps_ranges])
         else:
             out['start%d' % i] = torch.randint(0, N, (B,))
 
@@ -434,7 +436,7 @@ def gen_step():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['ops', 'mmd', 'pointnet_cls', 'dgcnn', 'pointnet', 'pointnet2', 'step']
+    which = sys.argv[1:] or ['ops', 'mmd', 'pointnet_cls', 'dgcnn', 'pointnet', 'pointnet2', 'ptran', 'step']
     if 'ops' in which:
         gen_ops()
     if 'mmd' in which:
@@ -447,5 +449,7 @@ if __name__ == '__main__':
         gen_model('Pointnet', 4, 1024, 12, 'model_pointnet.npz')
     if 'pointnet2' in which:
         gen_model('Pointnet2', 2, 2048, 13, 'model_pointnet2.npz')
+    if 'ptran' in which:
+        gen_model('PTran', 2, 1024, 14, 'model_ptran.npz')
     if 'step' in which:
         gen_step()

@@ -79,7 +79,8 @@ def run_passes(name, fname, knn_forced):
     return G, net, outs, loss
 
 
-@pytest.mark.parametrize('name,fname', [('Pointnet', 'model_pointnet.npz'), ('Pointnet2', 'model_pointnet2.npz')])
+@pytest.mark.parametrize('name,fname', [('Pointnet', 'model_pointnet.npz'), ('Pointnet2', 'model_pointnet2.npz'),
+                                        ('PTran', 'model_ptran.npz')])
 def test_encoder_parity(name, fname):
     G, net, (y1, y2, s1, s2), loss = run_passes(name, fname, False)
     seed = G['seed']

@@ -118,7 +118,7 @@ def test_prefix_sharing_is_exact():
         assert torch.equal(res[0][2][k], res[1][2][k]), k
 
 
-@pytest.mark.parametrize('model_name', ['DGCNN', 'Pointnet', 'Pointnet2'])
+@pytest.mark.parametrize('model_name', ['DGCNN', 'Pointnet', 'Pointnet2', 'PTran'])
 def test_pair_domains_match_separate_passes(model_name):
     """SUGStep(pair_domains=True) sends cat(source, target) through the encoder once per pass kind
     with per-domain BatchNorm statistics; losses, gradients and BN buffers must be those of the
@@ -153,7 +153,13 @@ def test_pair_domains_match_separate_passes(model_name):
     for k in res[0][1]:
         a, b = res[0][1][k], res[1][1][k]
         rel = float((a - b).norm() / (a.norm() + 1e-12))
-        if model_name == 'Pointnet2':
+        if model_name == 'PTran':
+            # ReLU stacks + atomically accumulated gather gradients: bounded in norm; a bias that only
+            # feeds a BatchNorm (transformer fc2 -> transition-down conv -> BN) has true gradient 0
+            if float(a.norm()) < 1e-3 * gmax:
+                continue
+            assert rel <= 2e-2, (k, rel)
+        elif model_name == 'Pointnet2':
             # ReLU heads: on this input one LayerNorm output of c2.mlp1 is +-1e-7, a GEMM of twice
             # the rows rounds it to the other side of the ReLU kink (tools/diag_pair4.py) and that
             # single element carries 5% of the gradient norm; the grouped BN kernels themselves are

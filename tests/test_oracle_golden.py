@@ -69,7 +69,7 @@ def test_pointnet_forward_oracle_vs_golden():
 
 
 @pytest.mark.parametrize('name,fname', [('DGCNN', 'model_dgcnn.npz'), ('Pointnet', 'model_pointnet.npz'),
-                                        ('Pointnet2', 'model_pointnet2.npz')])
+                                        ('Pointnet2', 'model_pointnet2.npz'), ('PTran', 'model_ptran.npz')])
 def test_mirror_has_reference_parameters(name, fname):
     """Same parameter / buffer names as the reference (so its checkpoints load): every name the
     reference produced a gradient or BN buffer for exists here, and the FPS start draws
@@ -83,7 +83,7 @@ def test_mirror_has_reference_parameters(name, fname):
     B, N = G['x'].shape[0], G['x'].shape[2]
     torch.manual_seed(G['seed'] + 1)
     first = torch.randint(0, N, (B,))
-    want = G['start0'][0] if name == 'Pointnet2' else G['start0']
+    want = G['start0'][0] if name in ('Pointnet2', 'PTran') else G['start0']
     assert torch.equal(first, want)
 
 
