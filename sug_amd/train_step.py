@@ -77,6 +77,28 @@ def gather_rows_ddp(x):
     return _all_gather_rows(x)
 
 
+def gather_rows_packed(tensors):
+    """gather_rows_ddp of several [m, w_i] tensors with ONE collective (one all-gather forward, one
+    reduce-scatter backward): the columns are packed side by side, gathered, and split again.
+    Integer tensors ride along as exact small floats.  Returns the gathered [world*m, w_i] tensors."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return list(tensors)
+    cols, meta = [], []
+    for t in tensors:
+        t2 = t.reshape(t.shape[0], -1)
+        meta.append((t2.shape[1], t.dtype, tuple(t.shape[1:])))
+        cols.append(t2 if t2.dtype == torch.float32 else t2.detach().to(torch.float32))
+    G = gather_rows_ddp(torch.cat(cols, dim=1))
+    out, off = [], 0
+    for w, dt, tail in meta:
+        g = G[:, off:off + w]
+        off += w
+        if dt != torch.float32:
+            g = g.round().to(dt)
+        out.append(g.reshape((G.shape[0],) + tail))
+    return out
+
+
 def allreduce_grads_(params, world):
     """Average gradients over ranks with a single flat all-reduce (RCCL over xGMI: one large
     message keeps all 7 links busy; SURVEY 2.2 -- 42 MiB for DGCNN).  Only parameters that
@@ -217,6 +239,15 @@ class SUGStep:
             feat_node_s = model(data, node_adaptation_s=True)
             feat_node_t = model(data_t, node_adaptation_t=True)
         geo, sem = M['GEO_MMD'][0], M['SEM_MMD'][0]
+        if self.global_mmd and sem['SEM_SCALE'] > 0 and not geo.get('GEO_WEIGHTS') and pred_s1.dim() == 2:
+            # everything the three MMD terms need crosses the ranks in one packed collective
+            (label_g, label_tg, fn_s, fn_t, s1, t1, s2, t2, p1s, p1t, p2s, p2t) = gather_rows_packed(
+                [label, label_t, feat_node_s, feat_node_t, sem_s1, sem_t1, sem_s2, sem_t2,
+                 pred_s1.detach(), pred_t1.detach(), pred_s2.detach(), pred_t2.detach()])
+            loss_geo = M['MMD_WEIGHT'] * geo['GEO_SCALE'] * mmd.mmd_cal(label_g, fn_s, label_tg, fn_t, geo)
+            l1 = sem['SEM_SCALE'] * mmd.mmd_cal(label_g, s1, label_tg, t1, sem, data_s=p1s, data_t=p1t)
+            l2 = sem['SEM_SCALE'] * mmd.mmd_cal(label_g, s2, label_tg, t2, sem, data_s=p2s, data_t=p2t)
+            return loss_cls, loss_geo, M['MMD_WEIGHT'] * (0.5 * l1 + 0.5 * l2)
         loss_geo = M['MMD_WEIGHT'] * geo['GEO_SCALE'] * self._mmd(label, feat_node_s, label_t, feat_node_t, geo, data, data_t)
         loss_sem = None
         if sem['SEM_SCALE'] > 0:

@@ -62,3 +62,44 @@ def test_sharded_mmd_and_grad_allreduce_match_single_process():
     for rank, g, _ in res:
         torch.testing.assert_close(g, W.grad, rtol=1e-4, atol=1e-6)
     assert torch.equal(res[0][1], res[1][1])
+
+
+def _worker_packed(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from sug_amd.train_step import gather_rows_ddp, gather_rows_packed
+    torch.manual_seed(1 + rank)
+    a = torch.randn(3, 5, requires_grad=True)
+    b = torch.randn(3, 2, 4, requires_grad=True)          # trailing dims are flattened and restored
+    lab = torch.randint(0, 10, (3,))
+    c = torch.randn(3, 7)                                  # no gradient
+    packed = gather_rows_packed([a, lab, b, c])
+    single = [gather_rows_ddp(a), gather_rows_ddp(lab), gather_rows_ddp(b), gather_rows_ddp(c)]
+    ok = all(torch.equal(x, y) for x, y in zip(packed, single)) and packed[1].dtype == lab.dtype
+    probe_a, probe_b = torch.randn(3 * world, 5, generator=torch.Generator().manual_seed(7)), \
+        torch.randn(3 * world, 2, 4, generator=torch.Generator().manual_seed(8))
+    ((packed[0] * probe_a).sum() + (packed[2] * probe_b).sum()).backward()
+    ga, gb = a.grad.clone(), b.grad.clone()
+    a.grad = b.grad = None
+    ((single[0] * probe_a).sum() + (single[2] * probe_b).sum()).backward()
+    ok = ok and torch.allclose(ga, a.grad) and torch.allclose(gb, b.grad)
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_packed_gather_equals_separate_gathers():
+    """gather_rows_packed (one collective per step for the three MMD terms) returns the tensors and
+    the gradients of one gather_rows_ddp per tensor."""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_packed, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res
