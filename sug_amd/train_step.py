@@ -116,6 +116,81 @@ def allreduce_grads_(params, world):
         off += n
 
 
+class GradReducer:
+    """Gradient averaging over ranks, overlapped with backward.
+
+    Parameters are split into buckets in the order their gradients become ready (for Net_MDA: heads
+    and attention layers first -- 38 of the 46 MB --, the encoder last).  A bucket's flat all-reduce
+    (one large message per bucket: RCCL spreads it over the 7 xGMI links) is issued from the
+    post-accumulate hook of its last parameter, while the rest of backward still runs; finish()
+    waits, divides by the world size and leaves every .grad as a view of the reduced flat buffer.
+    Which parameters receive a gradient is learned per `key` (e.g. MMD on / off) from a first,
+    non-overlapped step; any deviation later falls back to the synchronous path for that bucket."""
+
+    def __init__(self, buckets, world):
+        self.world = world
+        self.buckets = [[p for p in b if p.requires_grad] for b in buckets]
+        self.expected = {}                       # key -> [set of param ids per bucket]
+        self.key = None
+        self.active = False
+        for bi, ps in enumerate(self.buckets):
+            for p in ps:
+                p.register_post_accumulate_grad_hook(lambda q, bi=bi: self._ready(bi, q))
+
+    def begin(self, key):
+        """Call right before backward."""
+        n = len(self.buckets)
+        self.key = key
+        self.seen = [set() for _ in range(n)]
+        self.handles = [None] * n
+        self.flats = [None] * n
+        self.members = [None] * n
+        self.dirty = [False] * n
+        self.active = True
+
+    def _launch(self, bi, async_op):
+        ps = [p for p in self.buckets[bi] if p.grad is not None]
+        if not ps:
+            return
+        flat = torch.cat([p.grad.reshape(-1) for p in ps])
+        self.flats[bi], self.members[bi] = flat, ps
+        self.handles[bi] = dist.all_reduce(flat, async_op=async_op)
+
+    def _ready(self, bi, p):
+        if not self.active:
+            return
+        self.seen[bi].add(id(p))
+        exp = self.expected.get(self.key)
+        if exp is None:
+            return                                # learning step: everything happens in finish()
+        if self.flats[bi] is not None:
+            self.dirty[bi] = True                 # a gradient after the launch: redo this bucket in finish()
+        elif self.seen[bi] == exp[bi]:
+            self._launch(bi, async_op=True)
+
+    def finish(self):
+        """Call after backward, before the optimizers."""
+        self.active = False
+        for bi in range(len(self.buckets)):
+            if self.handles[bi] is not None and hasattr(self.handles[bi], 'wait'):
+                self.handles[bi].wait()
+            if self.flats[bi] is None or self.dirty[bi]:
+                self.flats[bi] = None
+                self._launch(bi, async_op=False)
+            flat = self.flats[bi]
+            if flat is None:
+                continue
+            flat.div_(self.world)
+            off = 0
+            for p in self.members[bi]:            # the averaged gradients stay in the flat buffer
+                n = p.numel()
+                p.grad = flat[off:off + n].view_as(p)
+                off += n
+        if self.key not in self.expected:
+            self.expected[self.key] = [set(s) for s in self.seen]
+        self.flats = self.members = self.handles = None
+
+
 class _StartFeeder:
     """FPS start indices for a replayable step: drawn from the CPU default generator in call
     order with the same (B, N) sequence as an eager step (so the random stream is the
@@ -171,6 +246,10 @@ class SUGStep:
         self.criterion = criterion if criterion is not None else nn.CrossEntropyLoss()
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.global_mmd = global_mmd and self.world > 1
+        self.reducer = None
+        if self.world > 1:
+            early = [p for m in (model.c1, model.c2, model.attention_s, model.attention_t) for p in m.parameters()]
+            self.reducer = GradReducer([early, list(model.g.parameters())], self.world)
         # fused_adam: None/True -> sug_amd.optim.Adam (one launch per optimizer) on a HIP device;
         # False -> torch.optim.Adam's default path (the parity tests' reference update)
         kw = {}
@@ -314,13 +393,15 @@ class SUGStep:
             loss = loss + loss_geo
         if loss_sem is not None:
             loss = loss + loss_sem
+        if self.reducer is not None:
+            self.reducer.begin(mmd_on)
         loss.backward()
         if self.share_prefix:
             self.model.g.clear_prefix_cache()
         for m in self._split_layers:
             m._wcat = None
-        if self.world > 1:
-            allreduce_grads_(self.model.parameters(), self.world)
+        if self.reducer is not None:
+            self.reducer.finish()
         self.optimizer_dis.step()
         self.optimizer_g.step()
         self.optimizer_c.step()

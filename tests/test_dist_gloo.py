@@ -103,3 +103,68 @@ def test_packed_gather_equals_separate_gathers():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok in res), res
+
+
+def _worker_reducer(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from sug_amd.train_step import GradReducer
+    torch.manual_seed(0)
+    enc = torch.nn.Linear(8, 8)
+    head = torch.nn.Linear(8, 4)
+    extra = torch.nn.Linear(8, 4)                 # only used when `use_extra` (like the attention layers with MMD on)
+    unused = torch.nn.Linear(3, 3)                # never receives a gradient
+    red = GradReducer([list(head.parameters()) + list(extra.parameters()) + list(unused.parameters()),
+                       list(enc.parameters())], world)
+    out = []
+    for step, use_extra in enumerate((True, True, False, True, False)):
+        torch.manual_seed(100 + 10 * step + rank)
+        x = torch.randn(5, 8)
+        for m in (enc, head, extra, unused):
+            m.zero_grad(set_to_none=True)
+        h = torch.relu(enc(x))
+        loss = head(h).square().mean() + (extra(h).abs().mean() if use_extra else 0.0)
+        red.begin(use_extra)
+        loss.backward()
+        red.finish()
+        out.append([None if p.grad is None else p.grad.numpy().copy() for m in (enc, head, extra, unused) for p in m.parameters()])
+    q.put((rank, out))                         # numpy: pickled by value (tensors would travel as shm handles)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_overlapped_buckets_match_plain_average():
+    """GradReducer (bucketed all-reduce issued from gradient hooks during backward) leaves the plain
+    cross-rank average in every .grad, through its learning step, overlapped steps and a change of
+    the set of parameters that receive gradients."""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_reducer, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # reference: both ranks' local gradients computed here, averaged
+    torch.manual_seed(0)
+    enc, head, extra, unused = torch.nn.Linear(8, 8), torch.nn.Linear(8, 4), torch.nn.Linear(8, 4), torch.nn.Linear(3, 3)
+    for step, use_extra in enumerate((True, True, False, True, False)):
+        grads = []
+        for rank in range(world):
+            torch.manual_seed(100 + 10 * step + rank)
+            x = torch.randn(5, 8)
+            for m in (enc, head, extra, unused):
+                m.zero_grad(set_to_none=True)
+            h = torch.relu(enc(x))
+            (head(h).square().mean() + (extra(h).abs().mean() if use_extra else 0.0)).backward()
+            grads.append([None if p.grad is None else p.grad.clone() for m in (enc, head, extra, unused) for p in m.parameters()])
+        for i, (g0, g1) in enumerate(zip(*grads)):
+            for rank in range(world):
+                got = res[rank][step][i]
+                if g0 is None:
+                    assert got is None
+                else:
+                    torch.testing.assert_close(torch.from_numpy(got), (g0 + g1) / world, rtol=1e-6, atol=1e-7)
