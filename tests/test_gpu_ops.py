@@ -315,3 +315,59 @@ def test_adam_multi_tensor_vs_torch():
     ot.step()
     for a, b in zip(mine, ref):
         torch.testing.assert_close(a, b, rtol=2e-6, atol=2e-7)
+
+
+@pytest.mark.parametrize('N,S,k', [(1024, 1024, 16), (256, 64, 16), (16, 4, 16), (300, 7, 5)])
+def test_knn_query_direct_form_vs_oracle(N, S, k):
+    """Point Transformer neighbours: argsort of sum((q - p)^2) (Ptran_transformer.py:32-33), bit-exact."""
+    from sug_amd import ops
+    g = torch.Generator().manual_seed(N + S + k)
+    xyz = torch.rand(2, N, 3, generator=g) * 2 - 1
+    qry = xyz[:, :S].contiguous() if S <= N else torch.rand(2, S, 3, generator=g)
+    want = O.sqdist_direct(qry, xyz).argsort()[:, :, :k]
+    got = ops.knn_query(xyz.cuda(), qry.cuda(), k, direct=True)
+    assert torch.equal(got.cpu().long(), want)
+
+
+def test_knn_full_size_properties():
+    """BASELINE size (64 clouds x 1024 points, C=64, k=20): size-independent properties of a kNN
+    list -- in range, no duplicates, the point itself first, scores non-increasing along k."""
+    from sug_amd import ops
+    x = torch.randn(64, 1024, 64, generator=torch.Generator().manual_seed(5)).cuda()
+    idx = ops.knn(x, 20).long()
+    assert int(idx.min()) >= 0 and int(idx.max()) < 1024
+    assert torch.equal(idx[:, :, 0], torch.arange(1024, device='cuda').expand(64, -1))
+    srt = idx.sort(dim=2)[0]
+    assert bool((srt[:, :, 1:] != srt[:, :, :-1]).all()), 'duplicate neighbour'
+    nbr = torch.gather(x.unsqueeze(1).expand(-1, 1024, -1, -1), 2, idx.unsqueeze(-1).expand(-1, -1, -1, 64))
+    d = ((nbr.double() - x.double().unsqueeze(2)) ** 2).sum(-1)
+    assert bool((d[:, :, 1:] >= d[:, :, :-1] - 1e-4).all()), 'neighbours not ordered by distance'
+    # idempotence: a second launch gives the same lists
+    assert torch.equal(ops.knn(x, 20).long(), idx)
+
+
+def test_knn_nan_features_stay_in_range():
+    """Clouds with NaN rows (a diverged training step): every slot still holds a valid index, so the
+    gathers downstream cannot fault; clean clouds of the same batch are unaffected."""
+    from sug_amd import ops
+    x = torch.randn(4, 256, 64, generator=torch.Generator().manual_seed(9))
+    clean = ops.knn(x.cuda(), 20)
+    x[1, 17] = float('nan')
+    x[2] = float('nan')
+    idx = ops.knn(x.cuda(), 20)
+    assert int(idx.min()) >= 0 and int(idx.max()) < 256
+    assert torch.equal(idx[0], clean[0]) and torch.equal(idx[3], clean[3])
+
+
+def test_bad_arguments_raise():
+    from sug_amd import ops
+    x = torch.randn(2, 64, 3).cuda()
+    with pytest.raises(RuntimeError):
+        ops.knn_query(x, x, 65)                       # k > 64
+    with pytest.raises(RuntimeError):
+        ops.knn(torch.randn(2, 64, 3), 4)             # CPU tensor: no fallback
+    with pytest.raises(RuntimeError):
+        ops.three_nn_raw(x, x[:, :2].contiguous())    # fewer than 3 candidates
+    with pytest.raises(RuntimeError):
+        with ops.bn_groups(2):
+            ops.bn_act_rows(torch.randn(3, 8).cuda(), torch.nn.BatchNorm1d(8).cuda(), 0.0)   # 3 rows, 2 groups
