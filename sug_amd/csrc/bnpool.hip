@@ -248,6 +248,55 @@ __global__ __launch_bounds__(256) void pool_bwd_apply_kernel(const float* __rest
   }
 }
 
+// Same, for C/4 dividing 256: a thread owns one float4 channel group of one cloud for its whole
+// life -- the nine per-channel constants are loaded once, no integer division per element -- and
+// streams over the points of its row chunk (pure read-y / write-dy traffic).
+__global__ __launch_bounds__(256) void pool_bwd_apply_rows_kernel(const float* __restrict__ y, int64_t ldy,
+                                                                  const float* __restrict__ coef,
+                                                                  const double* __restrict__ red,
+                                                                  const float* __restrict__ gmax,
+                                                                  const float* __restrict__ gmean,
+                                                                  const int32_t* __restrict__ arg, int N, int C,
+                                                                  int rows_per_block, float slope, float invM,
+                                                                  float* __restrict__ dy, int64_t lddy) {
+  const int CV = C >> 2;
+  const int b = blockIdx.y;
+  const int cg = threadIdx.x % CV, rl = threadIdx.x / CV, rstep = 256 / CV;
+  const int c = cg * 4;
+  float sc[4], sh[4], mu[4], rs[4], r0[4], r1[4], gme[4], gmx[4];
+  int am[4];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    sc[v] = coef[c + v];
+    sh[v] = coef[C + c + v];
+    mu[v] = coef[2 * C + c + v];
+    rs[v] = coef[3 * C + c + v];
+    r0[v] = (float)red[c + v];
+    r1[v] = (float)red[C + c + v];
+    gme[v] = gmean[(int64_t)b * C + c + v] / (float)N;
+    gmx[v] = gmax[(int64_t)b * C + c + v];
+    am[v] = arg[(int64_t)b * C + c + v];
+  }
+  const int n0 = blockIdx.x * rows_per_block;
+  const int n1 = n0 + rows_per_block < N ? n0 + rows_per_block : N;
+  const float* yb = y + (int64_t)b * N * ldy + c;
+  float* db = dy + (int64_t)b * N * lddy + c;
+#pragma unroll 4
+  for (int n = n0 + rl; n < n1; n += rstep) {
+    const float4 t = *reinterpret_cast<const float4*>(yb + (int64_t)n * ldy);
+    const float val[4] = {t.x, t.y, t.z, t.w};
+    float out[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const float u = fmaf(sc[v], val[v], sh[v]);
+      const float g = (u > 0.f ? 1.f : slope) * (gme[v] + (n == am[v] ? gmx[v] : 0.f));
+      const float xhat = (val[v] - mu[v]) * rs[v];
+      out[v] = sc[v] * (g - invM * (r0[v] + xhat * r1[v]));
+    }
+    *reinterpret_cast<float4*>(db + (int64_t)n * lddy) = make_float4(out[0], out[1], out[2], out[3]);
+  }
+}
+
 // out[i] = sum over rows (ascending, 16 strided partials) of ws[row][i] in fp64 (same scheme as
 // edgeconv.hip's reduce_partials_kernel).
 __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ ws, int nrow, int W,
@@ -336,7 +385,11 @@ extern "C" int sug_bn_act_pool_bwd(const float* y, int64_t ldy, const float* coe
   hipLaunchKernelGGL(reduce_rows_kernel, dim3(sug_divup(2 * C, 16)), dim3(256), 0, st, ws, B * NS, 2 * C, red);
   SUG_LAUNCH_CHECK("sug_bn_act_pool_bwd(combine)");
   const float invM = train ? (float)(1.0 / ((double)B * N)) : 0.f;
-  if (vec)
+  if (vec && (C / 4) <= 256 && 256 % (C / 4) == 0 && B <= 65535) {
+    const int rpb = 64 > 256 / (C / 4) ? 64 : 256 / (C / 4);
+    hipLaunchKernelGGL(pool_bwd_apply_rows_kernel, dim3(sug_divup(N, rpb), B), dim3(256), 0, st, y, ldy, coef, red, gmax,
+                       gmean, arg, N, C, rpb, slope, invM, dy, lddy);
+  } else if (vec)
     hipLaunchKernelGGL((pool_bwd_apply_kernel<4>), dim3(ew_grid((int64_t)B * N * C / 4)), dim3(256), 0, st, y, ldy,
                        coef, red, gmax, gmean, arg, B, N, C, slope, invM, dy, lddy);
   else

@@ -499,6 +499,9 @@ __global__ __launch_bounds__(256, 1) void knn_mfma_kernel(const float* __restric
     }
     if (key[i] != 0ull && rank < k && q < N) o[rank] = 0x7fffffff - (int)(unsigned int)(key[i] & 0xffffffffull);
   }
+#if defined(SUG_KNN_ABL) && SUG_KNN_ABL == 1
+  if (q < N && thr == 12345.678f) o[0] = 7;        // keeps the ablated score computation alive
+#endif
   // fewer than k comparable candidates (NaN features, N < k): point the remaining slots at the
   // query itself so that downstream gathers stay in range
   int nvalid = 0;
