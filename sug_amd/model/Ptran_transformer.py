@@ -1,8 +1,15 @@
-"""Point Transformer block (mirror of the reference's model/Ptran_transformer.py): kNN by
-direct-form distance (sug_knn_query_direct), neighbour gathers (sug_gather_rows), vector
-self-attention.  The 512-wide per-neighbour linears are library GEMMs on [B*n*k, d] rows; their
-weight gradients go through sug_linear_dw."""
-import numpy as np
+"""Point Transformer block on rows (host mirror of the reference's model/Ptran_transformer.py).
+
+Sub-module names and shapes follow the reference so its checkpoints load; the computation is
+organised around the library's kernels:
+
+  neighbours   sug_knn_query_direct   argsort of sum((q - p)^2), Ptran_transformer.py:32-33
+  gathers      sug_gather_rows        keys / values / coordinates of the k neighbours (+ scatter-add backward)
+  linears      rocBLAS forward / dx,  sug_linear_dw for every weight gradient (rows = B*n*k)
+  attention    softmax over the k neighbours of gamma(q - k + delta), applied to (v + delta)
+"""
+import math
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -10,36 +17,53 @@ import torch.nn.functional as F
 from .. import ops
 
 
-def _lin(layer, x):
-    return ops.linear_rows(x, layer.weight, layer.bias)
+def _two_layer(d_in, d_out):
+    return nn.Sequential(nn.Linear(d_in, d_out), nn.ReLU(), nn.Linear(d_out, d_out))
+
+
+def _apply(layer, rows):
+    """nn.Linear on [..., d] rows with the split-K weight-gradient kernel."""
+    return ops.linear_rows(rows, layer.weight, layer.bias)
+
+
+def _apply2(seq, rows):
+    """Linear -> ReLU -> Linear (the fc_delta / fc_gamma stacks)."""
+    return _apply(seq[2], F.relu(_apply(seq[0], rows)))
 
 
 class TransformerBlock(nn.Module):
+    """Vector self-attention over the k nearest neighbours of every point."""
+
     def __init__(self, d_points, d_model, k) -> None:
         super().__init__()
-        self.fc1 = nn.Linear(d_points, d_model)
-        self.fc2 = nn.Linear(d_model, d_points)
-        self.fc_delta = nn.Sequential(nn.Linear(3, d_model), nn.ReLU(), nn.Linear(d_model, d_model))
-        self.fc_gamma = nn.Sequential(nn.Linear(d_model, d_model), nn.ReLU(), nn.Linear(d_model, d_model))
-        self.w_qs = nn.Linear(d_model, d_model, bias=False)
-        self.w_ks = nn.Linear(d_model, d_model, bias=False)
-        self.w_vs = nn.Linear(d_model, d_model, bias=False)
         self.k = k
+        self.temperature = math.sqrt(d_model)
+        layers = {
+            'fc1': nn.Linear(d_points, d_model),            # lift the point features
+            'fc2': nn.Linear(d_model, d_points),            # and project the attended ones back
+            'fc_delta': _two_layer(3, d_model),             # position encoding of (x_i - x_j)
+            'fc_gamma': _two_layer(d_model, d_model),       # attention logits
+            'w_qs': nn.Linear(d_model, d_model, bias=False),
+            'w_ks': nn.Linear(d_model, d_model, bias=False),
+            'w_vs': nn.Linear(d_model, d_model, bias=False),
+        }
+        for name, layer in layers.items():
+            self.add_module(name, layer)
+
+    def neighbours(self, xyz):
+        """[B,n,3] -> int32 [B,n,min(k,n)]: an argsort over n < k columns has only n entries."""
+        return ops.knn_query(xyz, xyz, min(self.k, xyz.shape[1]), direct=True)
 
     def forward(self, xyz, features):
-        """xyz [B,n,3], features [B,n,f] -> (res [B,n,f], attn [B,n,k,d]); Ptran_transformer.py:31-45.
-        `argsort()[:, :, :k]` of n < k columns yields n neighbours: k_eff = min(k, n)."""
+        """xyz [B,n,3], features [B,n,f] -> (features' [B,n,f], attention [B,n,k,d])."""
         xyz = xyz.contiguous()
-        knn_idx = ops.knn_query(xyz, xyz, min(self.k, xyz.shape[1]), direct=True)      # [B,n,k]
-        knn_xyz = ops.gather_rows(xyz, knn_idx)
-        pre = features
-        x = _lin(self.fc1, features)
-        q = _lin(self.w_qs, x)
-        k = ops.gather_rows(_lin(self.w_ks, x), knn_idx)
-        v = ops.gather_rows(_lin(self.w_vs, x), knn_idx)
-        pos_enc = _lin(self.fc_delta[2], F.relu(_lin(self.fc_delta[0], xyz[:, :, None] - knn_xyz)))    # [B,n,k,d]
-        attn = _lin(self.fc_gamma[2], F.relu(_lin(self.fc_gamma[0], q[:, :, None] - k + pos_enc)))
-        attn = F.softmax(attn / np.sqrt(k.size(-1)), dim=-2)
-        res = torch.einsum('bmnf,bmnf->bmf', attn, v + pos_enc)
-        res = _lin(self.fc2, res) + pre
-        return res, attn
+        nbr = self.neighbours(xyz)
+        lifted = _apply(self.fc1, features)
+        query = _apply(self.w_qs, lifted).unsqueeze(2)                         # [B,n,1,d]
+        key = ops.gather_rows(_apply(self.w_ks, lifted), nbr)                  # [B,n,k,d]
+        value = ops.gather_rows(_apply(self.w_vs, lifted), nbr)
+        delta = _apply2(self.fc_delta, xyz.unsqueeze(2) - ops.gather_rows(xyz, nbr))
+        logits = _apply2(self.fc_gamma, query - key + delta)
+        attn = torch.softmax(logits / self.temperature, dim=2)                 # over the neighbours
+        mixed = (attn * (value + delta)).sum(dim=2)
+        return _apply(self.fc2, mixed) + features, attn
