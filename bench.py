@@ -44,6 +44,10 @@ def synth(B, N, seed, device):
     return [t.to(device) for t in (data, lab, data_t, lab_t)]
 
 
+BACKBONE = {'DGCNN': 'DGCNN EdgeConv backbone k=20', 'Pointnet': 'PointNet backbone', 'Pointnet2': 'PointNet++ backbone',
+            'PTran': 'Point Transformer backbone k=16'}
+
+
 def kernel_model(name, shape):
     """Algorithmic bytes / FLOPs of one launch (per-kernel table)."""
     B, N, k = shape['B'], shape['N'], shape['k']
@@ -231,8 +235,8 @@ def main():
                'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
                'data': 'synthetic',
-               'config': {'workload': '%s EdgeConv backbone, N=%d k=20, batch=%d per domain per GPU, MSA+SDA losses on '
-                                      '(2 sem + 2 node forwards, 3 soft-MMD, backward, 3 Adam)' % (args.model, N, B),
+               'config': {'workload': '%s, N=%d, batch=%d per domain per GPU, MSA+SDA losses on '
+                                      '(2 sem + 2 node forwards, 3 soft-MMD, backward, 3 Adam)' % (BACKBONE.get(args.model, args.model), N, B),
                           'global_batch': world * B, 'parallelism': 'dp%d' % world,
                           'launch': 'hipGraph replay of the whole step' if trainer.use_graph else 'eager',
                           'share_prefix': trainer.share_prefix, 'pair_domains': trainer.pair_domains},
