@@ -512,6 +512,221 @@ __global__ __launch_bounds__(256, 1) void knn_mfma_kernel(const float* __restric
   STAMP(5);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Two-pass variant (used for C = 3; selectable for C = 64): no ring, no refresh, no compaction.
+//   pass 1: the lane keeps only its K best SCORES, sorted, in registers (one v_med3_f32 per slot
+//           per candidate, interleaved with the next tile's MFMA chain) -> tau = exact K-th best
+//           score of the lane's half of the candidates, and how many ties at tau belong to the top K;
+//   pass 2: the same sweep again (bit-identical scores): a candidate with score > tau, or one of the
+//           first `room` candidates with score == tau, is appended with its index to a K-slot list
+//           in LDS (never more than K by construction, so no overflow handling).
+// The matrix pipe does the distance GEMM twice, but it was ~25% busy; in exchange LDS drops from
+// 159 KB to <= 67 KB per workgroup, two workgroups share a CU and hide each other's per-tile
+// latencies (barrier, LDS round trips, tile hand-off), and all block-wide decisions disappear.
+// The <= K entries of the two lanes of a query are merged by rank counting exactly as above.
+// ---------------------------------------------------------------------------------------------
+template <int CP, int K, int MODE>
+__device__ __forceinline__ void knn_sweep(const float* __restrict__ xb, int64_t ldx, int N, int ntile,
+                                          float* __restrict__ s_tile, float* __restrict__ s_norm,
+                                          const float (&bq)[CP / 2], float ni, int qj, int h, float (&v)[K],
+                                          float tau, int& room, int& cnt, float2* __restrict__ list) {
+  constexpr int RS = CP + 4;
+  constexpr int HALF = CP / 2;
+  constexpr int P = (CP == 4) ? 0 : HALF / 16;     // MFMAs issued per candidate slot
+  TileRegs<CP> tra, trb;
+  auto tbuf = [&](int t) { return s_tile + (t % 3) * TJ * RS; };
+  auto nbuf = [&](int t) { return s_norm + (t % 3) * TJ; };
+  __syncthreads();                                  // the buffers may still be read by the previous phase
+  tile_load<CP>(tra, xb, ldx, N, 0);
+  tile_store<CP>(tra, tbuf(0), nbuf(0), N, 0);
+  __syncthreads();
+  if (ntile > 1) tile_load<CP>(trb, xb, ldx, N, TJ);
+  if (ntile > 2) tile_load<CP>(tra, xb, ldx, N, 2 * TJ);
+  f32x16 acc_cur = score_tile<CP>(tbuf(0) + qj * RS + h * HALF, bq);
+  if (ntile > 1) tile_store<CP>(trb, tbuf(1), nbuf(1), N, TJ);
+  __syncthreads();
+  if (ntile > 3) tile_load<CP>(trb, xb, ldx, N, 3 * TJ);
+#define SUG_SB() __builtin_amdgcn_sched_barrier(0)
+#define SUG_KNN_TILE(T, TR) do { \
+    const float* arow = tbuf((T) + 1) + qj * RS + h * HALF; \
+    const float* nrm = nbuf((T)) + 4 * h; \
+    const int jbase = (T) * TJ + 4 * h; \
+    float nn[16]; \
+_Pragma("unroll") \
+    for (int g = 0; g < 4; ++g) { \
+      const float4 n4 = *reinterpret_cast<const float4*>(nrm + 8 * g); \
+      nn[4 * g + 0] = n4.x; nn[4 * g + 1] = n4.y; nn[4 * g + 2] = n4.z; nn[4 * g + 3] = n4.w; \
+    } \
+    float av[(CP == 4) ? 2 : HALF]; \
+    if constexpr (CP == 4) { \
+      const float2 a2 = *reinterpret_cast<const float2*>(arow); \
+      av[0] = a2.x; av[1] = a2.y; \
+    } else { \
+_Pragma("unroll") \
+      for (int g = 0; g < HALF / 4; ++g) { \
+        const float4 a4 = *reinterpret_cast<const float4*>(arow + 4 * g); \
+        av[4 * g + 0] = a4.x; av[4 * g + 1] = a4.y; av[4 * g + 2] = a4.z; av[4 * g + 3] = a4.w; \
+      } \
+    } \
+_Pragma("unroll") \
+    for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(nn[r])); \
+    f32x16 acc_next; \
+_Pragma("unroll") \
+    for (int r = 0; r < 16; ++r) acc_next[r] = 0.f; \
+    if constexpr (CP == 4) { \
+      acc_next = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bq[0], acc_next, 0, 0, 0); \
+      acc_next = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bq[1], acc_next, 0, 0, 0); \
+    } \
+    SUG_SB(); \
+_Pragma("unroll") \
+    for (int c = 0; c < 16; ++c) { \
+      if constexpr (P >= 1) acc_next = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c * P + 0], bq[c * P + 0], acc_next, 0, 0, 0); \
+      SUG_SB(); \
+      const float s = __fsub_rn(__fsub_rn(-nn[c], __fmul_rn(-2.0f, acc_cur[c])), ni); \
+      if constexpr (MODE == 0) { \
+_Pragma("unroll") \
+        for (int u = K - 1; u >= K / 2; --u) v[u] = __builtin_amdgcn_fmed3f(v[u - 1], v[u], s); \
+_Pragma("unroll") \
+        for (int u = K - 1; u >= K / 2; --u) asm volatile("" : "+v"(v[u])); \
+        SUG_SB(); \
+        if constexpr (P >= 2) acc_next = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c * P + 1], bq[c * P + 1], acc_next, 0, 0, 0); \
+        if constexpr (P >= 3) acc_next = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c * P + 2], bq[c * P + 2], acc_next, 0, 0, 0); \
+        SUG_SB(); \
+_Pragma("unroll") \
+        for (int u = K / 2 - 1; u > 0; --u) v[u] = __builtin_amdgcn_fmed3f(v[u - 1], v[u], s); \
+        v[0] = fmaxf(v[0], s); \
+_Pragma("unroll") \
+        for (int u = K / 2 - 1; u >= 0; --u) asm volatile("" : "+v"(v[u])); \
+        SUG_SB(); \
+        if constexpr (P >= 4) acc_next = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c * P + 3], bq[c * P + 3], acc_next, 0, 0, 0); \
+        SUG_SB(); \
+      } else { \
+        const bool tie = (s == tau) && (room > 0) && (s > -INFINITY); \
+        const bool keep = (s > tau) || tie; \
+        list[(keep ? cnt : K) * 256] = make_float2(s, __int_as_float(jbase + 8 * (c >> 2) + (c & 3))); \
+        cnt += keep ? 1 : 0; \
+        room -= tie ? 1 : 0; \
+        SUG_SB(); \
+        if constexpr (P >= 2) acc_next = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c * P + 1], bq[c * P + 1], acc_next, 0, 0, 0); \
+        if constexpr (P >= 3) acc_next = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c * P + 2], bq[c * P + 2], acc_next, 0, 0, 0); \
+        if constexpr (P >= 4) acc_next = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c * P + 3], bq[c * P + 3], acc_next, 0, 0, 0); \
+        SUG_SB(); \
+      } \
+    } \
+    if ((T) + 2 < ntile) tile_store<CP>(TR, tbuf((T) + 2), nbuf((T) + 2), N, ((T) + 2) * TJ); \
+    __syncthreads(); \
+    if ((T) + 4 < ntile) tile_load<CP>(TR, xb, ldx, N, ((T) + 4) * TJ); \
+    acc_cur = acc_next; \
+   \
+  } while (0)
+  for (int t = 0; t < ntile; t += 2) {          // (a macro body: selecting tra / trb at run time would spill them)
+    SUG_KNN_TILE(t, tra);
+    if (t + 1 < ntile) SUG_KNN_TILE(t + 1, trb);
+  }
+#undef SUG_KNN_TILE
+#undef SUG_SB
+}
+
+template <int CP, int K>
+__global__ __launch_bounds__(256, 2) void knn_mfma2p_kernel(const float* __restrict__ x, int64_t ldx, int B,
+                                                            int N, int k, int32_t* __restrict__ idx) {
+  constexpr int RS = CP + 4;
+  constexpr int HALF = CP / 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* s_tile = reinterpret_cast<float*>(smem);                 // [3][TJ][RS]
+  float* s_norm = s_tile + 3 * TJ * RS;                           // [3][TJ] (+pad)
+  float2* s_list = reinterpret_cast<float2*>(s_norm + 4 * TJ);    // [K+1][256] (score, index bits)
+
+  const int nq = (N + 127) / 128;
+  int b, qb;
+  if ((B & 7) == 0) {                                             // XCD-aware mapping, as above
+    const int grp = blockIdx.x / (8 * nq), rem = blockIdx.x % (8 * nq);
+    b = grp * 8 + (rem & 7);
+    qb = rem >> 3;
+  } else {
+    b = blockIdx.x / nq;
+    qb = blockIdx.x % nq;
+  }
+  const float* xb = x + (int64_t)b * N * ldx;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int qj = lane & 31, h = lane >> 5;
+  const int q0 = qb * 128;
+
+  float bq[HALF];
+  float ni = 0.f;
+  {
+    TileRegs<CP> tr;
+    for (int w = 0; w < 4; ++w) {
+      __syncthreads();
+      tile_load<CP>(tr, xb, ldx, N, q0 + w * TJ);
+      tile_store<CP>(tr, s_tile, s_norm, N, q0 + w * TJ);
+      __syncthreads();
+      if (w == wv) {
+        const float* qrow = s_tile + qj * RS + h * HALF;
+#pragma unroll
+        for (int e = 0; e < HALF; ++e) bq[e] = qrow[e];
+        ni = s_norm[qj];
+      }
+    }
+  }
+  const int ntile = (N + TJ - 1) / TJ;
+  float v[K];
+#pragma unroll
+  for (int t = 0; t < K; ++t) v[t] = -INFINITY;
+  float2* list = s_list + threadIdx.x;
+  int cnt = 0, room = 0;
+
+  knn_sweep<CP, K, 0>(xb, ldx, N, ntile, s_tile, s_norm, bq, ni, qj, h, v, 0.f, room, cnt, list);
+  const float tau = v[K - 1];
+#pragma unroll
+  for (int u = 0; u < K; ++u) room += (v[u] == tau) ? 1 : 0;     // ties at tau that belong to the top K
+  knn_sweep<CP, K, 1>(xb, ldx, N, ntile, s_tile, s_norm, bq, ni, qj, h, v, tau, room, cnt, list);
+
+  unsigned long long key[K];
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    const float2 e = list[i * 256];
+    key[i] = (i < cnt) ? pack_key(e.x, __float_as_int(e.y)) : 0ull;
+  }
+  const int q = q0 + wv * TJ + qj;
+  int32_t* o = idx + ((int64_t)b * N + (q < N ? q : 0)) * k;
+  unsigned long long pk[K];
+#pragma unroll
+  for (int u = 0; u < K; ++u) pk[u] = __shfl_xor(key[u], 32);
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    int rank = 0;
+#pragma unroll
+    for (int u = 0; u < K; ++u) {
+      rank += (key[u] > key[i]) ? 1 : 0;
+      rank += (pk[u] > key[i]) ? 1 : 0;
+    }
+    if (key[i] != 0ull && rank < k && q < N) o[rank] = 0x7fffffff - (int)(unsigned int)(key[i] & 0xffffffffull);
+  }
+  int nvalid = 0;
+#pragma unroll
+  for (int u = 0; u < K; ++u) nvalid += (key[u] != 0ull ? 1 : 0) + (pk[u] != 0ull ? 1 : 0);
+  if (h == 0 && q < N)
+    for (int r = nvalid; r < k; ++r) o[r] = q;                  // NaN features / N < k: stay in range
+}
+
+template <int CP, int K>
+int launch2p(const float* x, int64_t ldx, int B, int N, int k, int32_t* idx, hipStream_t st) {
+  constexpr int RS = CP + 4;
+  const size_t sh = (size_t)(3 * TJ * RS + 4 * TJ) * sizeof(float) + (size_t)(K + 1) * 256 * sizeof(float2);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_mfma2p_kernel<CP, K>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    attr_set = true;
+  }
+  dim3 grid(sug_divup(N, 128) * B);
+  hipLaunchKernelGGL((knn_mfma2p_kernel<CP, K>), grid, dim3(256), sh, st, x, ldx, B, N, k, idx);
+  SUG_LAUNCH_CHECK("sug_knn(mfma, two-pass)");
+  return SUG_OK;
+}
+
 template <int CP, int K>
 int launch(const float* x, int64_t ldx, int B, int N, int k, int32_t* idx, hipStream_t st) {
   constexpr int RS = CP + 4;
@@ -528,14 +743,36 @@ int launch(const float* x, int64_t ldx, int B, int N, int k, int32_t* idx, hipSt
   return SUG_OK;
 }
 
+// Which shapes take the two-pass kernel: 1 = C=3 only (default), 2 = C=3 and C=64, 0 = none.
+// Measured at 64 clouds (tools/bench_knn.py): C=3 113 vs 145 us (3 workgroups per CU);
+// C=64 248 vs 213 us -- the doubled MFMA work outweighs the co-residency of 2 workgroups.
+#ifndef SUG_KNN_TWO_PASS
+#define SUG_KNN_TWO_PASS 1
+#endif
+
 template <int K>
 int dispatch(const float* x, int64_t ldx, int B, int N, int C, int k, int32_t* idx, hipStream_t st) {
-  if (C == 3) return launch<4, K>(x, ldx, B, N, k, idx, st);
-  if (C == 64) return launch<64, K>(x, ldx, B, N, k, idx, st);
+  if (C == 3) return SUG_KNN_TWO_PASS >= 1 ? launch2p<4, K>(x, ldx, B, N, k, idx, st) : launch<4, K>(x, ldx, B, N, k, idx, st);
+  if (C == 64) return SUG_KNN_TWO_PASS >= 2 ? launch2p<64, K>(x, ldx, B, N, k, idx, st) : launch<64, K>(x, ldx, B, N, k, idx, st);
   return launch<128, K>(x, ldx, B, N, k, idx, st);
 }
 
 }  // namespace
+
+#ifdef SUG_KNN_STAMP
+// diagnostic: resident workgroups per CU of the two-pass kernel (tools/bench_knn.py)
+extern "C" int sug_debug_knn2p_occupancy(int C) {
+  int nb = -1;
+  if (C == 64) {
+    const size_t sh = (size_t)(3 * TJ * 68 + 4 * TJ) * sizeof(float) + (size_t)21 * 256 * sizeof(float2);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&knn_mfma2p_kernel<64, 20>), 256, sh);
+  } else {
+    const size_t sh = (size_t)(3 * TJ * 8 + 4 * TJ) * sizeof(float) + (size_t)21 * 256 * sizeof(float2);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&knn_mfma2p_kernel<4, 20>), 256, sh);
+  }
+  return nb;
+}
+#endif
 
 // Returns 1 if the MFMA path handles this shape/alignment (else the caller uses knn.hip).
 int sug_knn_mfma_supported(const float* x, int64_t ldx, int C, int k) {

@@ -51,13 +51,14 @@ def stamps(L):
 
 if __name__ == '__main__':
     torch.manual_seed(0)
-    variants = [('full', []), ('no-select', ['-DSUG_KNN_ABL=1']), ('append-only', ['-DSUG_KNN_ABL=2'])]
+    variants = [('default', []), ('two-pass', ['-DSUG_KNN_TWO_PASS=2']), ('single-pass', ['-DSUG_KNN_TWO_PASS=0'])]
     libs = [(t, build(t, d)) for t, d in variants]
     for B in (32, 64):
         for C in (3, 64, 128):
             x = torch.randn(B, 1024, C, device='cuda')
             print('B=%d C=%3d ' % (B, C) + '  '.join('%s %7.1f us' % (t, time_knn(L, x, 20)) for t, L in libs))
-    S = build('stamp', ['-DSUG_KNN_STAMP=1', '-DSUG_KNN_RP=16'])
+    S = build('stamp', ['-DSUG_KNN_STAMP=1'])
+    print('two-pass kernel: resident workgroups per CU  C=64: %d  C=3: %d' % (S.sug_debug_knn2p_occupancy(64), S.sug_debug_knn2p_occupancy(3)))
     for C in (3, 64, 128):
         x = torch.randn(32, 1024, C, device='cuda')
         us = time_knn(S, x, 20, iters=3)
