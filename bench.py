@@ -114,6 +114,8 @@ def main():
                     help='EXPERIMENTAL: replay the step from a hipGraph (faults on ROCm 7.0/gfx950, see DESIGN.md)')
     ap.add_argument('--no-share-prefix', action='store_true',
                     help='recompute the kNN+conv1/conv2 stage in the node passes instead of sharing it (identical results)')
+    ap.add_argument('--no-tuned-gemms', action='store_true',
+                    help='library GEMMs by the default heuristic instead of the recorded TunableOp choices (sug_amd/tuning)')
     ap.add_argument('--no-pair', action='store_true',
                     help='separate encoder passes for the source and the target batch (identical results)')
     args = ap.parse_args()
@@ -138,6 +140,10 @@ def main():
     from sug_amd.model.Model import Net_MDA
     from sug_amd.train_step import SUGStep
     _lib.lib()                                          # fail loudly if the HIP library is missing
+    tuned = False
+    if not args.no_tuned_gemms:
+        from sug_amd.tuning import enable_tuned_gemms
+        tuned = enable_tuned_gemms()
 
     torch.manual_seed(666)                              # train_dg_single_gpu.py:65
     model = Net_MDA(args.model).to(dev).train()
@@ -239,7 +245,8 @@ def main():
                                       '(2 sem + 2 node forwards, 3 soft-MMD, backward, 3 Adam)' % (BACKBONE.get(args.model, args.model), N, B),
                           'global_batch': world * B, 'parallelism': 'dp%d' % world,
                           'launch': 'hipGraph replay of the whole step' if trainer.use_graph else 'eager',
-                          'share_prefix': trainer.share_prefix, 'pair_domains': trainer.pair_domains},
+                          'share_prefix': trainer.share_prefix, 'pair_domains': trainer.pair_domains,
+                          'tuned_gemms': tuned},
                'roofline': roofline, 'cpu_baseline': cpu, 'losses': loss_vals,
                'kernels': {k: {kk: (round(vv, 5) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in kern.items()}}
         print(json.dumps(out))

@@ -1,0 +1,24 @@
+"""Tuned library-GEMM selection for the encoders' forward / input-gradient GEMMs.
+
+The dense GEMMs of the path are plain rocBLAS / hipBLASLt calls made by torch.  PyTorch's
+TunableOp can pick, per GEMM shape, the fastest solution of either library; `tunableop_gfx950.csv`
+holds the choices for the shapes of the C2 workload (DGCNN, 32 clouds per domain, N=1024), recorded
+on an MI355X with `tools/tune_gemms.py`.  `enable_tuned_gemms()` switches TunableOp on in look-up
+mode (no tuning at run time; unknown shapes fall back to the default heuristic).  The validator
+lines of the file pin the ROCm / library versions; on a different stack the table is ignored."""
+import os
+import tempfile
+
+TABLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tunableop_gfx950.csv')
+
+
+def enable_tuned_gemms(table=TABLE):
+    """Returns True if the table was loaded."""
+    import torch.cuda.tunable as tn
+    if not os.path.exists(table):
+        return False
+    tn.enable(True)
+    tn.tuning_enable(False)
+    # results written at exit go to a scratch file, never into the source tree
+    tn.set_filename(os.path.join(tempfile.gettempdir(), 'sug_amd_tunableop_%d.csv' % os.getpid()))
+    return bool(tn.read_file(table))
