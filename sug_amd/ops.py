@@ -279,6 +279,13 @@ def group_max(feat, idx):
 
 
 # ----------------------------------------------------------------------------- per-point linear
+# (rows, M, N) of weight gradients for which the TUNED library GEMM beats sug_linear_dw (filled by
+# sug_amd.tuning.enable_tuned_gemms from a measured table; empty = always the library's own kernel).
+DW_LIBRARY_SHAPES = set()
+DW_FORCE_LIBRARY = False        # tuning runs: every weight gradient through the library
+DW_SHAPE_LOG = None             # tuning runs: list collecting the (rows, M, N) seen
+
+
 class _LinearRows(torch.autograd.Function):
     """y = x . W^T (+ b) over rows; the weight gradient g^T . x (K = rows = B*N, small output)
     runs in sug_linear_dw instead of a rocBLAS GEMM that does not split K."""
@@ -305,8 +312,10 @@ class _LinearRows(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = (g2 @ weight).view(x.shape)
         if ctx.needs_input_grad[1]:
-            if M * N > 512 * 512:           # larger outputs than any encoder layer: rocBLAS
-                dw = g2.t() @ x2
+            if DW_SHAPE_LOG is not None:
+                DW_SHAPE_LOG.append((R, M, N))
+            if M * N > 512 * 512 or DW_FORCE_LIBRARY or (R, M, N) in DW_LIBRARY_SHAPES:
+                dw = g2.t() @ x2            # larger than any encoder layer, or the tuned library GEMM is faster
             else:
                 dw = torch.empty(M, N, dtype=torch.float32, device=g.device)
                 ws = torch.empty(int(lib().sug_linear_dw_workspace(R, M, N)), dtype=torch.float32, device=g.device)
