@@ -21,14 +21,26 @@ def _two_layer(d_in, d_out):
     return nn.Sequential(nn.Linear(d_in, d_out), nn.ReLU(), nn.Linear(d_out, d_out))
 
 
-def _apply(layer, rows):
-    """nn.Linear on [..., d] rows with the split-K weight-gradient kernel."""
+# Precision of the per-neighbour linears (rows = B*n*k, 512 wide: >95% of the block's FLOPs).
+# None: fp32, the parity mode (reference arithmetic).  torch.bfloat16 / torch.float16: operands are
+# rounded to 16 bits and the GEMMs run on the 16-bit MFMA path with fp32 accumulation (the C5
+# configuration of BASELINE.json); softmax, residuals, BatchNorm and all index work stay fp32.
+GEMM_DTYPE = None
+
+
+def _apply(layer, rows, wide=False):
+    """nn.Linear on [..., d] rows.  fp32: split-K weight-gradient kernel; `wide` rows (the k-expanded
+    tensors) may take the reduced-precision library GEMM when GEMM_DTYPE is set."""
+    if wide and GEMM_DTYPE is not None:
+        lo = GEMM_DTYPE
+        y = F.linear(rows.to(lo), layer.weight.to(lo), None if layer.bias is None else layer.bias.to(lo))
+        return y.float()
     return ops.linear_rows(rows, layer.weight, layer.bias)
 
 
 def _apply2(seq, rows):
-    """Linear -> ReLU -> Linear (the fc_delta / fc_gamma stacks)."""
-    return _apply(seq[2], F.relu(_apply(seq[0], rows)))
+    """Linear -> ReLU -> Linear (the fc_delta / fc_gamma stacks) on k-expanded rows."""
+    return _apply(seq[2], F.relu(_apply(seq[0], rows, wide=rows.shape[-1] >= 64)), wide=True)
 
 
 class TransformerBlock(nn.Module):
