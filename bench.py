@@ -111,7 +111,7 @@ def main():
     ap.add_argument('--cpu-steps', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--graph', action='store_true',
-                    help='EXPERIMENTAL: replay the step from a hipGraph (faults on ROCm 7.0/gfx950, see DESIGN.md)')
+                    help='replay the step from a hipGraph (opt-in; same speed as eager when the step is GPU-bound)')
     ap.add_argument('--no-share-prefix', action='store_true',
                     help='recompute the kNN+conv1/conv2 stage in the node passes instead of sharing it (identical results)')
     ap.add_argument('--no-tuned-gemms', action='store_true',

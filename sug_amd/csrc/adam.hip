@@ -18,7 +18,11 @@ __global__ __launch_bounds__(256) void adam_kernel(const int64_t* __restrict__ t
                                                    const int32_t* __restrict__ block_first,  // [T+1]
                                                    int t0, int T, GradPtrs gp, float step_size, float omb1,
                                                    float beta2, float omb2, float eps, float wd,
-                                                   float inv_bc2_sqrt) {
+                                                   float inv_bc2_sqrt, const float* __restrict__ dev_scalars) {
+  if (dev_scalars) {                              // capturable mode: written by adam_prepare_kernel
+    step_size = dev_scalars[0];
+    inv_bc2_sqrt = dev_scalars[1];
+  }
   const int b = blockIdx.x + block_first[t0];
   int lo = t0, hi = t0 + T;                       // block_first[lo] <= b < block_first[hi]
   while (hi - lo > 1) {
@@ -65,6 +69,16 @@ __global__ __launch_bounds__(256) void adam_kernel(const int64_t* __restrict__ t
   }
 }
 
+// Capturable mode (hipGraph replay): the step count lives on the device; one thread advances it and
+// derives lr / (1 - beta1^t) and 1 / sqrt(1 - beta2^t) for the update kernel of the same replay.
+__global__ void adam_prepare_kernel(int32_t* __restrict__ step, double lr, double beta1, double beta2,
+                                    float* __restrict__ scalars) {
+  const int t = step[0] + 1;
+  step[0] = t;
+  scalars[0] = (float)(lr / (1.0 - pow(beta1, (double)t)));
+  scalars[1] = (float)(1.0 / sqrt(1.0 - pow(beta2, (double)t)));
+}
+
 }  // namespace
 
 extern "C" int sug_adam_chunk(void) { return SUG_ADAM_CHUNK; }
@@ -84,8 +98,32 @@ extern "C" int sug_adam_step(const int64_t* table, const int32_t* block_first, c
     if (blocks <= 0) continue;
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, table, block_first, t0, tn, gp,
                        step_size, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
-                       (float)weight_decay, inv_bc2_sqrt);
+                       (float)weight_decay, inv_bc2_sqrt, (const float*)nullptr);
     SUG_LAUNCH_CHECK("sug_adam_step");
+  }
+  return SUG_OK;
+}
+
+extern "C" int sug_adam_step_capturable(const int64_t* table, const int32_t* block_first,
+                                        const int32_t* block_first_host, int T, const void* const* grads_host,
+                                        double lr, double beta1, double beta2, double eps, double weight_decay,
+                                        int32_t* step_dev, float* scalars_dev, void* stream) {
+  SUG_REQUIRE(table && block_first && block_first_host && grads_host && step_dev && scalars_dev,
+              "sug_adam_step_capturable: null pointer");
+  SUG_REQUIRE(T > 0, "sug_adam_step_capturable: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(1), 0, st, step_dev, lr, beta1, beta2, scalars_dev);
+  SUG_LAUNCH_CHECK("sug_adam_step_capturable(prepare)");
+  for (int t0 = 0; t0 < T; t0 += SUG_ADAM_ARGS) {
+    const int tn = T - t0 < SUG_ADAM_ARGS ? T - t0 : SUG_ADAM_ARGS;
+    GradPtrs gp;
+    for (int i = 0; i < SUG_ADAM_ARGS; ++i) gp.g[i] = i < tn ? (const float*)grads_host[t0 + i] : nullptr;
+    const int blocks = block_first_host[t0 + tn] - block_first_host[t0];
+    if (blocks <= 0) continue;
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, table, block_first, t0, tn, gp, 0.f,
+                       (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)weight_decay, 0.f,
+                       (const float*)scalars_dev);
+    SUG_LAUNCH_CHECK("sug_adam_step_capturable");
   }
   return SUG_OK;
 }

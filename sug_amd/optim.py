@@ -13,14 +13,17 @@ from ._lib import lib, check
 
 
 class _Bucket:
-    __slots__ = ('params', 'steps', 'table', 'first_dev', 'first_host', 'hyper', 'step_val', 'T')
+    __slots__ = ('params', 'steps', 'table', 'first_dev', 'first_host', 'hyper', 'step_val', 'T', 'step_dev', 'scalars')
 
 
 class Adam(torch.optim.Adam):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, graph_capturable=False):
+        """graph_capturable: the step count and bias corrections live on the device, so a step can be
+        captured in a hipGraph and replayed (state['step'] entries are then not maintained)."""
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, foreach=False, fused=False)
         self._plan = None
         self._plan_key = None
+        self._graph_capturable = bool(graph_capturable)
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
@@ -63,6 +66,8 @@ class Adam(torch.optim.Adam):
             b.table = torch.tensor(rows, dtype=torch.int64).to(dev)
             b.first_host = (ctypes.c_int32 * len(first))(*first)
             b.first_dev = torch.tensor(first, dtype=torch.int32).to(dev)
+            b.step_dev = torch.full((1,), b.step_val, dtype=torch.int32, device=dev)
+            b.scalars = torch.zeros(2, dtype=torch.float32, device=dev)
             plan.append(b)
         self._plan, self._plan_key = plan, key
         return plan
@@ -76,8 +81,9 @@ class Adam(torch.optim.Adam):
         plan = self._plan if (self._plan is not None and key == self._plan_key) else self._build(key)
         L = lib()
         for b in plan:
-            b.step_val += 1
-            torch._foreach_add_(b.steps, 1.0)
+            if not self._graph_capturable:
+                b.step_val += 1
+                torch._foreach_add_(b.steps, 1.0)
             ptrs = []
             for p in b.params:
                 g = p.grad
@@ -88,6 +94,12 @@ class Adam(torch.optim.Adam):
                 ptrs.append(g.data_ptr())
             lr, b1, b2, eps, wd = b.hyper
             stream = torch._C._cuda_getCurrentRawStream(b.table.device.index)
+            if self._graph_capturable:
+                check(L.sug_adam_step_capturable(b.table.data_ptr(), b.first_dev.data_ptr(), b.first_host, b.T,
+                                                 (ctypes.c_void_p * b.T)(*ptrs), lr, b1, b2, eps, wd,
+                                                 b.step_dev.data_ptr(), b.scalars.data_ptr(), ctypes.c_void_p(stream)),
+                      'sug_adam_step_capturable')
+                continue
             check(L.sug_adam_step(b.table.data_ptr(), b.first_dev.data_ptr(), b.first_host, b.T,
                                   (ctypes.c_void_p * b.T)(*ptrs), lr, b1, b2, eps, wd,
                                   1.0 - math.pow(b1, b.step_val), 1.0 - math.pow(b2, b.step_val),

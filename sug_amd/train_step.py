@@ -254,12 +254,13 @@ class SUGStep:
         # False -> torch.optim.Adam's default path (the parity tests' reference update)
         kw = {}
         on_gpu = next(model.parameters()).is_cuda
-        own_adam = on_gpu and (fused_adam is None or fused_adam) and not use_graph
-        # EXPERIMENTAL hipGraph mode (off by default): the whole step (4 forwards, losses, backward,
-        # 3 Adam updates) is captured once and replayed; an eager step of ~1200 launches is
-        # host-bound.  On ROCm 7.0 / gfx950 back-to-back replays of this graph end in a GPU fault
-        # inside a torch scatter kernel (root cause not found): do not enable
-        # outside a debugging session.  Single-GPU only.
+        own_adam = on_gpu and (fused_adam is None or fused_adam)
+        # hipGraph mode (opt-in): the whole step (forwards, losses, backward, 3 Adam updates) is
+        # captured once and replayed, FPS start indices fed through a static buffer.  Replay time
+        # equals the GPU-bound eager time (the step is GPU-bound on the boxes measured), so eager stays
+        # the default.  History: an early version of the step faulted inside a torch scatter kernel on
+        # its second replay; not reproduced since the pooling tail moved into bn_act_pool (3000 clean
+        # replays, tools/graph_soak.py).  Single-GPU only.
         self.use_graph = bool(use_graph) and self.world == 1 and next(model.parameters()).is_cuda
         self._graph = None
         self._tick = torch.zeros(1, device=next(model.parameters()).device) if self.use_graph else None
@@ -267,11 +268,14 @@ class SUGStep:
         self._static_in = None
         self._static_out = None
         self._graph_epoch = None
-        if self.use_graph:
-            kw['capturable'] = True
-            kw['fused'] = True
         from .optim import Adam as _SugAdam
         AdamCls = _SugAdam if own_adam else torch.optim.Adam
+        if self.use_graph:
+            if own_adam:
+                kw['graph_capturable'] = True           # step count / bias corrections on the device
+            else:
+                kw['capturable'] = True
+                kw['fused'] = True
         # train_dg_single_gpu.py:191-203
         params = [{'params': v} for k, v in model.g.named_parameters() if 'pred_offset' not in k]
         self.optimizer_g = AdamCls(params, lr=lr, weight_decay=weight_decay, **kw)
