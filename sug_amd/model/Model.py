@@ -88,9 +88,11 @@ class DGCNN(nn.Module):
     def clear_prefix_cache(self):
         self._prefix_cache = {}
 
-    def _prefix(self, x, loc, nb):
+    def _prefix(self, x, loc, nb, out1=None):
+        """kNN + conv1, kNN + conv2.  out1: where conv1's activations should be written (a column
+        slice of the conv5 input buffer); a cache hit returns the tensors of the earlier pass instead."""
         if not (self.share_prefix and self.training):
-            x1 = self.conv1.edge_rows(loc, nb(loc, 0))
+            x1 = self.conv1.edge_rows(loc, nb(loc, 0), out=out1)
             return x1, self.conv2.edge_rows(x1, nb(x1, 1))
         ver = sum(p._version for m in (self.conv1, self.conv2) for p in m.parameters())
         key = (x.data_ptr(), x._version, tuple(x.shape), torch.is_grad_enabled(), ver, ops.BN_GROUPS)
@@ -100,7 +102,7 @@ class DGCNN(nn.Module):
             self.conv1.replay_bn_update(st1)
             self.conv2.replay_bn_update(st2)
             return x1, x2
-        x1, st1 = self.conv1.edge_rows(loc, nb(loc, 0), return_stats=True)
+        x1, st1 = self.conv1.edge_rows(loc, nb(loc, 0), return_stats=True, out=out1)
         x2, st2 = self.conv2.edge_rows(x1, nb(x1, 1), return_stats=True)
         if len(self._prefix_cache) >= 4:            # a step has two inputs; never grow unbounded
             self._prefix_cache.clear()
@@ -116,12 +118,15 @@ class DGCNN(nn.Module):
         if knn_idx is not None:
             self._prefix_cache = {}
         nb = lambda f, i: gi[i] if gi[i] is not None else ops.knn(f, self.k)
-        x1, x2 = self._prefix(x, loc, nb)                             # [B,N,64], [B,N,64]
+        # conv5 consumes cat(x1, x2, x3, x4): the EdgeConv layers write their activations straight
+        # into the column slices of that [B,N,512] buffer instead of concatenating afterwards
+        cat_in = torch.empty(B, N, 512, dtype=torch.float32, device=x.device)
+        x1, x2 = self._prefix(x, loc, nb, out1=cat_in[:, :, 0:64])   # [B,N,64], [B,N,64]
         x_, node_fea, _ = self.node_fea_adapt.rows(x2, loc)           # [B,N,128], [B,64,64]
         x2 = ops.linear_rows(x_, self.conv1d.weight.squeeze(-1), self.conv1d.bias)
-        x3 = self.conv3.edge_rows(x2, nb(x2, 2))                      # [B,N,128]
-        x4 = self.conv4.edge_rows(x3, nb(x3, 3))                      # [B,N,256]
-        x5 = ops.linear_rows(torch.cat((x1, x2, x3, x4), dim=2), self.conv5.weight.squeeze(-1))
+        x3 = self.conv3.edge_rows(x2, nb(x2, 2), out=cat_in[:, :, 128:256])     # [B,N,128]
+        x4 = self.conv4.edge_rows(x3, nb(x3, 3), out=cat_in[:, :, 256:512])     # [B,N,256]
+        x5 = ops.linear_rows(ops.assemble_rows(cat_in, (x1, x2, x3, x4)), self.conv5.weight.squeeze(-1))
         # bn5 -> leaky_relu(0.2) -> adaptive max | avg pool (Model.py:113-116), fused
         feat = torch.cat(ops.bn_act_pool(x5, self.bn5, 0.2), 1)
         node_fea = node_fea.transpose(1, 2).unsqueeze(-1)             # [B,64(ch),64(node),1]

@@ -87,7 +87,7 @@ class conv_2d(nn.Module):
     def forward(self, x):
         return self.rows(x.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
 
-    def edge_rows(self, x, idx, return_stats=False):
+    def edge_rows(self, x, idx, return_stats=False, out=None):
         """Fused EdgeConv layer: max_k act(bn(W.[x_j - x_i ; x_i])) for x [B,N,C] rows and
         idx [B,N,k] (get_graph_feature + conv + max, model_utils.py:188-210, Model.py:88-94).
         W.[x_j-x_i; x_i] = W1.x_j + (W2-W1).x_i, so one [B*N,C]x[C,2Co] GEMM replaces the
@@ -110,7 +110,7 @@ class conv_2d(nn.Module):
         ops._count_bn_call(bn)
         out, coef = ops.edgeconv_bn_act_max(pq.view(B, N, -1), idx, bn.weight, bn.bias, bn.running_mean,
                                             bn.running_var, bn.training, _ACT_SLOPE[self.activation],
-                                            bn.eps, bn.momentum)
+                                            bn.eps, bn.momentum, out=out)
         return (out, coef) if return_stats else out
 
     def replay_bn_update(self, coef):

@@ -605,7 +605,7 @@ class _EdgeConv(torch.autograd.Function):
     """BN(train or eval) + LeakyReLU + max over k of y = P[idx] + Q, see include/sug_amd.h."""
 
     @staticmethod
-    def forward(ctx, pq, idx, gamma, beta, running_mean, running_var, training, slope, eps, momentum, G):
+    def forward(ctx, pq, idx, gamma, beta, running_mean, running_var, training, slope, eps, momentum, G, out_holder):
         _need_gpu(pq, idx, gamma)
         pq, B, N, C2, ld = _rows3(pq)
         Co = C2 // 2
@@ -624,12 +624,21 @@ class _EdgeConv(torch.autograd.Function):
         coef = torch.empty(G, 5, Co, dtype=torch.float32, device=dev)
         if not training:
             coef.copy_(eval_coef(gamma_c, beta_c, running_mean, running_var, eps))
-        out = torch.empty(B, N, Co, dtype=torch.float32, device=dev)
+        if out_holder is None:
+            out = torch.empty(B, N, Co, dtype=torch.float32, device=dev)
+        else:
+            # caller-provided destination (a column slice of a wider rows buffer, see assemble_rows);
+            # passed in a list so that autograd does not treat it as an input of this node
+            out = out_holder[0]
+            if tuple(out.shape) != (B, N, Co) or out.stride(2) != 1 or out.stride(0) != N * out.stride(1) \
+                    or out.dtype != torch.float32 or out.requires_grad:
+                raise RuntimeError('edgeconv: bad destination slice')
+        ldo = out.stride(1)
         check(_timed('edgeconv_layer_fwd_Co%d' % Co, {'B': B, 'N': N, 'k': k, 'Co': Co},
                      lambda: lib().sug_edgeconv_layer_fwd(_p(pq), ld, _p(idx), _p(gamma_c), _p(beta_c), B, N, k, Co, G,
                                                           1 if training else 0, eps, momentum, float(slope),
                                                           _p(running_mean), _p(running_var), _p(z), _p(arg), _p(s1),
-                                                          _p(coef), _p(out), Co, _p(stats), _p(ws), _st())),
+                                                          _p(coef), _p(out), ldo, _p(stats), _p(ws), _st())),
               'sug_edgeconv_layer_fwd')
         if need_bwd:
             ctx.save_for_backward(pq, idx, z, arg, s1, coef)
@@ -644,7 +653,7 @@ class _EdgeConv(torch.autograd.Function):
         pq, idx, z, arg, s1, coef = ctx.saved_tensors
         B, N, k, Co, ld, slope, training, G = ctx.meta
         if gout is None:
-            return (None,) * 11
+            return (None,) * 12
         dev = gout.device
         gout, _, _, _, ldg = _rows3(gout)                           # a column slice of a wider buffer is fine
         a = torch.empty(B, N, Co, dtype=torch.float32, device=dev)
@@ -660,13 +669,55 @@ class _EdgeConv(torch.autograd.Function):
                                                           _p(red), _p(off), _p(ent), _p(dpq), 2 * Co, _p(ws), _st())),
               'sug_edgeconv_layer_bwd')
         rf = red[0].float() if G == 1 else red[:G].sum(0, dtype=torch.float32)
-        return dpq, None, rf[Co:], rf[:Co], None, None, None, None, None, None, None
+        return dpq, None, rf[Co:], rf[:Co], None, None, None, None, None, None, None, None
 
 
-def edgeconv_bn_act_max(pq, idx, gamma, beta, running_mean, running_var, training, slope, eps=1e-5, momentum=0.1):
+def edgeconv_bn_act_max(pq, idx, gamma, beta, running_mean, running_var, training, slope, eps=1e-5, momentum=0.1,
+                        out=None):
     """pq [B,N,2*Co] = x.[W1;W2-W1]^T, idx [B,N,k] -> (out [B,N,Co], coef [5,Co] = scale, shift,
     batch mean, rstd, unbiased batch variance; [G,5,Co] under bn_groups(G > 1))."""
-    return _EdgeConv.apply(pq, idx, gamma, beta, running_mean, running_var, training, slope, eps, momentum, BN_GROUPS)
+    return _EdgeConv.apply(pq, idx, gamma, beta, running_mean, running_var, training, slope, eps, momentum, BN_GROUPS,
+                           None if out is None else [out])
+
+
+# ----------------------------------------------------------------------------- concat without copies
+class _AssembleRows(torch.autograd.Function):
+    """torch.cat(parts, dim=-1) for parts that (mostly) already live in column slices of `buf`
+    [..., sum(widths)]: producers were asked to write there (edgeconv_bn_act_max(out=...)); a part
+    stored elsewhere is copied in.  Backward hands every part its column slice of the gradient (views,
+    no copies).  `buf` is passed in a list: it is storage, not a differentiable input."""
+
+    @staticmethod
+    def forward(ctx, holder, *parts):
+        buf = holder[0]
+        off, widths = 0, []
+        for t in parts:
+            w = t.shape[-1]
+            dst = buf[..., off:off + w]
+            if not (t.data_ptr() == dst.data_ptr() and t.stride() == dst.stride() and t.shape == dst.shape):
+                # copy through an alias with its own version counter: an in-place op on a view of `buf`
+                # would invalidate (for autograd) the slices the producers already returned
+                alias = torch.empty(0, dtype=buf.dtype, device=buf.device).set_(
+                    buf.untyped_storage(), dst.storage_offset(), dst.shape, dst.stride())
+                alias.copy_(t)
+            widths.append(w)
+            off += w
+        if off != buf.shape[-1]:
+            raise RuntimeError('assemble_rows: parts cover %d of %d columns' % (off, buf.shape[-1]))
+        ctx.widths = widths
+        return buf.view(buf.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        out, off = [], 0
+        for w in ctx.widths:
+            out.append(g[..., off:off + w])
+            off += w
+        return (None,) + tuple(out)
+
+
+def assemble_rows(buf, parts):
+    return _AssembleRows.apply([buf], *parts)
 
 
 # ----------------------------------------------------------------------------- MMD
