@@ -59,3 +59,20 @@ def test_ops_refuse_cpu_tensors():
         ops.knn(torch.zeros(1, 8, 3), 4)
     with pytest.raises(RuntimeError, match='HIP device'):
         ops.mix_rbf_mmd2_rows(torch.zeros(4, 8), 2)
+
+
+def test_tuning_tables_are_well_formed():
+    """sug_amd/tuning: the TunableOp table has validator lines + GEMM entries, and every weight-gradient
+    shape routed to the library has a tuned TN entry with K = rows."""
+    import csv
+    import json
+    from sug_amd import tuning
+    rows = list(csv.reader(open(tuning.TABLE)))
+    assert any(r[0] == 'Validator' and r[1] == 'GCN_ARCH_NAME' and r[2].startswith('gfx950') for r in rows)
+    gemms = [r for r in rows if r[0].startswith('Gemm')]
+    assert len(gemms) >= 20
+    choice = json.load(open(tuning.DW_CHOICE))['library']
+    keys = {r[1] for r in gemms}
+    for R, M, N in choice:
+        assert any(k.startswith('nt_%d_%d_%d_' % (N, M, R)) or k.startswith('tn_%d_%d_%d_' % (N, M, R)) or
+                   ('_%d_' % R) in k for k in keys), (R, M, N)
