@@ -113,6 +113,121 @@ __global__ __launch_bounds__(256) void edgeconv_fwd_kernel(
   }
 }
 
+
+// LDS-resident variant.  The gathers of edgeconv_fwd_kernel are bound by L2 bandwidth: every point
+// pulls k full rows of P through L2 (k*4*Co bytes per point, 20x the matrix).  All neighbours of a
+// point lie in its own cloud, so a workgroup stages a 16-channel slice of the cloud's whole P matrix
+// in LDS (N x 64 B = 64 KB at N = 1024) and gathers from there: P leaves L2 once per slice, the
+// 20-fold reuse is served by LDS.  Workgroup = (cloud, 16-channel slice, part of the points);
+// 4 lanes per point, 64 points per pass; same per-point arithmetic (and tie rules) as above.
+// ws: one partial row per (cloud, part): row (b*psplit + part), only this slice's columns.
+template <int SW, int KK>
+__global__ __launch_bounds__(256) void edgeconv_fwd_lds_kernel(
+    const float* __restrict__ pq, int64_t ldpq, const int32_t* __restrict__ idx,
+    const float* __restrict__ gamma, int B, int N, int Co, int psplit,
+    float* __restrict__ z, uint8_t* __restrict__ arg, float* __restrict__ s1, float* __restrict__ ws) {
+  static_assert(KK % 4 == 0, "neighbour rows are fetched as int4");
+  extern __shared__ __attribute__((aligned(16))) float s_lds[];
+  float* s_p = s_lds;                          // [N][SW]
+  float* s_red = s_lds + (size_t)N * SW;       // [PPP][2*SW]
+  constexpr int LP = SW / 4;                   // lanes per point
+  constexpr int PPP = 256 / LP;                // points per pass
+  const int nslice = Co / SW;
+  const int per_cloud = nslice * psplit;
+  int b, r;
+  if ((B & 7) == 0) {                          // a cloud's workgroups share an XCD (its L2 holds P once)
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    b = (j / per_cloud) * 8 + xcd;
+    r = j % per_cloud;
+  } else {
+    b = blockIdx.x / per_cloud;
+    r = blockIdx.x % per_cloud;
+  }
+  const int sl = r % nslice, part = r / nslice;
+  const int c0 = sl * SW;
+  const float* base = pq + (int64_t)b * N * ldpq;
+  // LDS holds sign(gamma) * P: "max for gamma >= 0, min for gamma < 0" becomes a plain max of
+  // y' = sign*y = sign*P + sign*Q (sign flips are exact), and sum(y) = sign*sum(y'), sum(y^2) = sum(y'^2)
+  for (int e = threadIdx.x; e < N * LP; e += 256) {
+    const int n = e / LP, c4 = e % LP;
+    const float4 gf = ld4(gamma + c0 + c4 * 4);
+    float4 pv = ld4(base + (int64_t)n * ldpq + c0 + c4 * 4);
+    pv.x = gf.x >= 0.f ? pv.x : -pv.x; pv.y = gf.y >= 0.f ? pv.y : -pv.y;
+    pv.z = gf.z >= 0.f ? pv.z : -pv.z; pv.w = gf.w >= 0.f ? pv.w : -pv.w;
+    st4(s_p + n * SW + c4 * 4, pv);
+  }
+  const int lp = threadIdx.x % LP, slot = threadIdx.x / LP;
+  const float4 g4 = ld4(gamma + c0 + lp * 4);
+  const float4 sg = make_float4(g4.x >= 0.f ? 1.f : -1.f, g4.y >= 0.f ? 1.f : -1.f, g4.z >= 0.f ? 1.f : -1.f,
+                                g4.w >= 0.f ? 1.f : -1.f);
+  float4 a1 = make_float4(0, 0, 0, 0), a2 = make_float4(0, 0, 0, 0);
+  const int n_per = (N + psplit - 1) / psplit;
+  const int n_begin = part * n_per, n_end = (n_begin + n_per < N) ? n_begin + n_per : N;
+  // the neighbour list and the Q row of the NEXT point are fetched (global) while the current point
+  // gathers from LDS: a thread walks its points serially and few waves share a CU
+  int4 nv[KK / 4], nvn[KK / 4];
+  float4 q = make_float4(0, 0, 0, 0), qn = q;
+  auto fetch = [&](int n, int4 (&iv)[KK / 4], float4& qq) {
+    if (n < n_end) {
+      const int64_t p = (int64_t)b * N + n;
+      const int4* ir = reinterpret_cast<const int4*>(idx + p * KK);
+#pragma unroll
+      for (int t = 0; t < KK / 4; ++t) iv[t] = ir[t];
+      qq = ld4(pq + p * ldpq + Co + c0 + lp * 4);
+      qq.x *= sg.x; qq.y *= sg.y; qq.z *= sg.z; qq.w *= sg.w;
+    }
+  };
+  fetch(n_begin + slot, nv, q);
+  __syncthreads();
+  for (int n = n_begin + slot; n < n_end; n += PPP) {
+    fetch(n + PPP, nvn, qn);
+    float bx = 0, by = 0, bz = 0, bw = 0;
+    int jx = 0, jy = 0, jz = 0, jw = 0;
+    float sx = 0, sy = 0, sz = 0, sw = 0, qx = 0, qy = 0, qz = 0, qw = 0;
+#pragma unroll
+    for (int t = 0; t < KK / 4; ++t) {
+      const int m4[4] = {nv[t].x, nv[t].y, nv[t].z, nv[t].w};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = t * 4 + u;
+        const int m = min(max(m4[u], 0), N - 1);                      // clamp to the cloud (v_med3_i32)
+        const float4 pv = ld4(s_p + m * SW + lp * 4);
+        const float yx = __fadd_rn(pv.x, q.x), yy = __fadd_rn(pv.y, q.y);
+        const float yz = __fadd_rn(pv.z, q.z), yw = __fadd_rn(pv.w, q.w);
+        sx += yx; sy += yy; sz += yz; sw += yw;
+        qx = fmaf(yx, yx, qx); qy = fmaf(yy, yy, qy); qz = fmaf(yz, yz, qz); qw = fmaf(yw, yw, qw);
+        if (j == 0 || yx > bx) { bx = yx; jx = j; }                  // first maximum wins, as torch.max
+        if (j == 0 || yy > by) { by = yy; jy = j; }
+        if (j == 0 || yz > bz) { bz = yz; jz = j; }
+        if (j == 0 || yw > bw) { bw = yw; jw = j; }
+      }
+    }
+    // back to the true sign
+    bx *= sg.x; by *= sg.y; bz *= sg.z; bw *= sg.w;
+    sx *= sg.x; sy *= sg.y; sz *= sg.z; sw *= sg.w;
+    const int64_t o = ((int64_t)b * N + n) * Co + c0 + lp * 4;
+    st4(z + o, make_float4(bx, by, bz, bw));
+    *reinterpret_cast<uint32_t*>(arg + o) =
+        (uint32_t)jx | ((uint32_t)jy << 8) | ((uint32_t)jz << 16) | ((uint32_t)jw << 24);
+    if (s1) st4(s1 + o, make_float4(sx, sy, sz, sw));
+    a1.x += sx; a1.y += sy; a1.z += sz; a1.w += sw;
+    a2.x += qx; a2.y += qy; a2.z += qz; a2.w += qw;
+#pragma unroll
+    for (int t = 0; t < KK / 4; ++t) nv[t] = nvn[t];
+    q = qn;
+  }
+  // fixed-order reduction over the point slots (fp64), one partial row per (cloud, part)
+  st4(s_red + slot * 2 * SW + lp * 4, a1);
+  st4(s_red + slot * 2 * SW + SW + lp * 4, a2);
+  __syncthreads();
+  if (threadIdx.x < 2 * SW) {
+    double acc = 0.0;
+    for (int t = 0; t < PPP; ++t) acc += (double)s_red[t * 2 * SW + threadIdx.x];
+    const int col = threadIdx.x < SW ? c0 + threadIdx.x : Co + c0 + (threadIdx.x - SW);
+    ws[(size_t)(b * psplit + part) * 2 * Co + col] = (float)acc;
+  }
+}
+
 // out[i] = sum over workgroup rows of ws[row][i], in fp64, in a fixed order: 16 strided
 // partial sums per column (rows p, p+16, ...) combined in ascending p.  grid = ceil(W/16).
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ ws, int nblk,
@@ -463,6 +578,29 @@ static int edgeconv_fwd_partials(const float* pq, int64_t ldpq, const int32_t* i
   SUG_REQUIRE(((uintptr_t)pq % 16) == 0 && ((uintptr_t)z % 16) == 0 && ((uintptr_t)gamma % 16) == 0 &&
                   (!s1 || ((uintptr_t)s1 % 16) == 0) && ((uintptr_t)arg % 4) == 0,
               "sug_edgeconv_fwd: pointers must be 16-byte aligned");
+  hipStream_t st_ = (hipStream_t)stream;
+#ifndef SUG_EDGECONV_NO_LDS
+  // LDS-resident gathers when a 16-channel slice of one cloud's P matrix fits (N <= 2048)
+  if (k == 20 && Co % 16 == 0 && (size_t)N * 16 * 4 + 64 * 32 * 4 <= 150 * 1024 && B <= SUG_STATS_BLOCKS / 4 &&
+      ((uintptr_t)idx % 16) == 0) {
+    const int nslice = Co / 16;
+    int psplit = 512 / (B * nslice);
+    psplit = psplit < 1 ? 1 : (psplit > 4 ? 4 : psplit);
+    const size_t sh = (size_t)N * 16 * sizeof(float) + 64 * 32 * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&edgeconv_fwd_lds_kernel<16, 20>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+      attr_set = true;
+    }
+    const int grid = ((B & 7) == 0 ? B : B) * nslice * psplit;
+    hipLaunchKernelGGL((edgeconv_fwd_lds_kernel<16, 20>), dim3(grid), dim3(256), sh, st_, pq, ldpq, idx, gamma, B, N, Co,
+                       psplit, z, arg, s1, ws);
+    SUG_LAUNCH_CHECK("sug_edgeconv_fwd(lds)");
+    *nblk = B * psplit;
+    return SUG_OK;
+  }
+#endif
   const int lpp = lanes_per_point(Co);
   const int nch = sug_divup(Co >> 2, lpp);
   const int64_t BN = (int64_t)B * N;
