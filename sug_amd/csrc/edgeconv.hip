@@ -474,7 +474,9 @@ __global__ __launch_bounds__(256) void col_reduce_vec4_kernel(const float* __res
   }
 }
 
-template <int NCH>
+// KK: compile-time k (0 = run-time): the reverse entries encode (n, j) as n*k + j, and a division by
+// a run-time k costs ~20 instructions per entry and lane
+template <int NCH, int KK>
 __global__ __launch_bounds__(256) void edgeconv_bwd_scatter_kernel(
     const float* __restrict__ a, const uint8_t* __restrict__ arg, const float* __restrict__ s1,
     const float* __restrict__ pq, int64_t ldpq, const int32_t* __restrict__ rev_off,
@@ -484,7 +486,8 @@ __global__ __launch_bounds__(256) void edgeconv_bwd_scatter_kernel(
   const int nchunk = Co >> 2;
   const int ppb = 256 / LPP;
   const int slot = threadIdx.x / LPP, ch0 = threadIdx.x % LPP;
-  const float kf = (float)k;
+  const int kk = KK ? KK : k;
+  const float kf = (float)kk;
   // XCD-aware mapping as in edgeconv_fwd_kernel: a cloud's a / arg / Q rows stay in one L2
   const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
   const int64_t b = (int64_t)(jb / bpc) * 8 + xcd;
@@ -494,7 +497,7 @@ __global__ __launch_bounds__(256) void edgeconv_bwd_scatter_kernel(
     const int64_t p = b * N + m;
     const int32_t* offp = rev_off + b * (N + 1) + m;
     const int off = offp[0], cnt = offp[1] - offp[0];
-    const int32_t* ent = rev_ent + b * (int64_t)N * k + off;
+    const int32_t* ent = rev_ent + b * (int64_t)N * kk + off;
     const int64_t rowb = b * N;
 #pragma unroll
     for (int u = 0; u < NCH; ++u) {
@@ -518,7 +521,7 @@ __global__ __launch_bounds__(256) void edgeconv_bwd_scatter_kernel(
         for (int t = 0; t < GB; ++t) en[t] = (t0 + t < cnt) ? ent[t0 + t] : -1;
 #pragma unroll
         for (int t = 0; t < GB; ++t) {
-          const int n = en[t] >= 0 ? en[t] / k : 0;
+          const int n = en[t] >= 0 ? en[t] / kk : 0;
           const int64_t o = (rowb + n) * Co + c;
           av[t] = ld4(a + o);
           aj[t] = *reinterpret_cast<const uint32_t*>(arg + o);
@@ -527,7 +530,7 @@ __global__ __launch_bounds__(256) void edgeconv_bwd_scatter_kernel(
 #pragma unroll
         for (int t = 0; t < GB; ++t) {
           if (en[t] >= 0) {
-            const int n = en[t] / k, j = en[t] - n * k;
+            const int n = en[t] / kk, j = en[t] - n * kk;
             ax += ((int)(aj[t] & 255u) == j ? av[t].x : 0.f) - hx * qv[t].x;
             ay += ((int)((aj[t] >> 8) & 255u) == j ? av[t].y : 0.f) - hy * qv[t].y;
             az += ((int)((aj[t] >> 16) & 255u) == j ? av[t].z : 0.f) - hz * qv[t].z;
@@ -789,12 +792,16 @@ extern "C" int sug_edgeconv_bwd_scatter(const float* a, const uint8_t* arg, cons
   const int grid = 8 * cpx * bpc;
   const float invM = (float)(1.0 / ((double)BN * k));
   hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_SCATTER(NC) do { \
+    if (k == 20) hipLaunchKernelGGL((edgeconv_bwd_scatter_kernel<NC, 20>), dim3(grid), dim3(256), 0, st, a, arg, s1, pq, ldpq, rev_off, rev_ent, coef, red, BN, N, k, Co, lpp, bpc, invM, dpq, lddpq); \
+    else hipLaunchKernelGGL((edgeconv_bwd_scatter_kernel<NC, 0>), dim3(grid), dim3(256), 0, st, a, arg, s1, pq, ldpq, rev_off, rev_ent, coef, red, BN, N, k, Co, lpp, bpc, invM, dpq, lddpq); \
+  } while (0)
   if (nch == 1)
-    hipLaunchKernelGGL((edgeconv_bwd_scatter_kernel<1>), dim3(grid), dim3(256), 0, st, a, arg, s1, pq, ldpq, rev_off, rev_ent, coef, red, BN, N, k, Co, lpp, bpc, invM, dpq, lddpq);
+    LAUNCH_SCATTER(1);
   else if (nch == 2)
-    hipLaunchKernelGGL((edgeconv_bwd_scatter_kernel<2>), dim3(grid), dim3(256), 0, st, a, arg, s1, pq, ldpq, rev_off, rev_ent, coef, red, BN, N, k, Co, lpp, bpc, invM, dpq, lddpq);
+    LAUNCH_SCATTER(2);
   else
-    hipLaunchKernelGGL((edgeconv_bwd_scatter_kernel<4>), dim3(grid), dim3(256), 0, st, a, arg, s1, pq, ldpq, rev_off, rev_ent, coef, red, BN, N, k, Co, lpp, bpc, invM, dpq, lddpq);
+    LAUNCH_SCATTER(4);
   SUG_LAUNCH_CHECK("sug_edgeconv_bwd_scatter");
   return SUG_OK;
 }
