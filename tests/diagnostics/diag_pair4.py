@@ -1,5 +1,5 @@
 import sys, copy, torch
-sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')  # run from the repo root
 from conftest import load_golden
 from oracle import ref_cpu as O
 from sug_amd.model.Model import Net_MDA, Pointnet_c
