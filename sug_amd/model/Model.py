@@ -109,9 +109,11 @@ class DGCNN(nn.Module):
         self._prefix_cache[key] = (x1, x2, st1, st2)
         return x1, x2
 
-    def forward(self, x, node=False, knn_idx=None):
+    def forward(self, x, node=False, knn_idx=None, feat_grad=True):
         """x [B,3,N,1] -> (feat [B,1024], node_fea [B,64,64,1](, None)).
-        `knn_idx` (4 tensors [B,N,k]) overrides the neighbour graphs (tests: teacher forcing)."""
+        `knn_idx` (4 tensors [B,N,k]) overrides the neighbour graphs (tests: teacher forcing).
+        feat_grad=False: the caller discards `feat` (node-adaptation pass): the stage behind the
+        SA-node module still runs -- it updates BatchNorm running statistics -- but without autograd."""
         B, N = x.size(0), x.size(2)
         loc = x.squeeze(-1).transpose(1, 2).contiguous()              # [B,N,3] rows
         gi = knn_idx or [None] * 4
@@ -123,12 +125,13 @@ class DGCNN(nn.Module):
         cat_in = torch.empty(B, N, 512, dtype=torch.float32, device=x.device)
         x1, x2 = self._prefix(x, loc, nb, out1=cat_in[:, :, 0:64])   # [B,N,64], [B,N,64]
         x_, node_fea, _ = self.node_fea_adapt.rows(x2, loc)           # [B,N,128], [B,64,64]
-        x2 = ops.linear_rows(x_, self.conv1d.weight.squeeze(-1), self.conv1d.bias)
-        x3 = self.conv3.edge_rows(x2, nb(x2, 2), out=cat_in[:, :, 128:256])     # [B,N,128]
-        x4 = self.conv4.edge_rows(x3, nb(x3, 3), out=cat_in[:, :, 256:512])     # [B,N,256]
-        x5 = ops.linear_rows(ops.assemble_rows(cat_in, (x1, x2, x3, x4)), self.conv5.weight.squeeze(-1))
-        # bn5 -> leaky_relu(0.2) -> adaptive max | avg pool (Model.py:113-116), fused
-        feat = torch.cat(ops.bn_act_pool(x5, self.bn5, 0.2), 1)
+        with torch.set_grad_enabled(torch.is_grad_enabled() and feat_grad):
+            x2 = ops.linear_rows(x_, self.conv1d.weight.squeeze(-1), self.conv1d.bias)
+            x3 = self.conv3.edge_rows(x2, nb(x2, 2), out=cat_in[:, :, 128:256])     # [B,N,128]
+            x4 = self.conv4.edge_rows(x3, nb(x3, 3), out=cat_in[:, :, 256:512])     # [B,N,256]
+            x5 = ops.linear_rows(ops.assemble_rows(cat_in, (x1, x2, x3, x4)), self.conv5.weight.squeeze(-1))
+            # bn5 -> leaky_relu(0.2) -> adaptive max | avg pool (Model.py:113-116), fused
+            feat = torch.cat(ops.bn_act_pool(x5, self.bn5, 0.2), 1)
         node_fea = node_fea.transpose(1, 2).unsqueeze(-1)             # [B,64(ch),64(node),1]
         if node:
             return feat, node_fea, None
@@ -340,7 +343,10 @@ class Net_MDA(nn.Module):
             draws = [[torch.randint(0, n, (B,), dtype=torch.long) for n in plan] for _ in range(2)]
             queue = [torch.cat((draws[0][c], draws[1][c])) for c in range(len(plan))]
         with ops.bn_groups(2), ops.start_queue(queue), ops.deferred_bn_counts():
-            x, feat_ori, _ = self.g(x_pair, node=True)
+            if node_adaptation and isinstance(self.g, DGCNN):
+                x, feat_ori, _ = self.g(x_pair, node=True, feat_grad=False)     # only the node features are used
+            else:
+                x, feat_ori, _ = self.g(x_pair, node=True)
         halves = lambda t: t.reshape(2, B, -1).unbind(0)      # backward: one stack, no zero fills
         if node_adaptation:
             f_s, f_t = halves(feat_ori.contiguous())

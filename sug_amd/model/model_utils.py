@@ -96,12 +96,13 @@ class conv_2d(nn.Module):
         B, N, C = x.shape
         W = self.weight2d()
         assert W.shape[1] == 2 * C
-        key = (W._version, torch.is_grad_enabled())
-        if self.cache_weight_split and self._wcat is not None and self._wcat[0] == key:
-            Wcat = self._wcat[1]                                          # same weights, same step
+        grad = torch.is_grad_enabled()
+        hit = self._wcat if self.cache_weight_split else None
+        if hit is not None and hit[0] == W._version and (hit[1] or not grad):
+            Wcat = hit[2]                  # same weights, same step (a graph-attached copy also serves no_grad)
         else:
             Wcat = _SplitWeight.apply(W)                                  # [2Co, C] = [W1 ; W2-W1]
-            self._wcat = (key, Wcat) if self.cache_weight_split else None
+            self._wcat = (W._version, grad, Wcat) if self.cache_weight_split else None
         pq = ops.linear_rows(x.reshape(B * N, C), Wcat)
         bias = self.conv[0].bias
         if bias is not None:                                              # bias rides on the Q half
