@@ -130,8 +130,12 @@ class DGCNN(nn.Module):
             x3 = self.conv3.edge_rows(x2, nb(x2, 2), out=cat_in[:, :, 128:256])     # [B,N,128]
             x4 = self.conv4.edge_rows(x3, nb(x3, 3), out=cat_in[:, :, 256:512])     # [B,N,256]
             x5 = ops.linear_rows(ops.assemble_rows(cat_in, (x1, x2, x3, x4)), self.conv5.weight.squeeze(-1))
-            # bn5 -> leaky_relu(0.2) -> adaptive max | avg pool (Model.py:113-116), fused
-            feat = torch.cat(ops.bn_act_pool(x5, self.bn5, 0.2), 1)
+            if feat_grad:
+                # bn5 -> leaky_relu(0.2) -> adaptive max | avg pool (Model.py:113-116), fused
+                feat = torch.cat(ops.bn_act_pool(x5, self.bn5, 0.2), 1)
+            else:
+                ops.bn_update_stats(x5, self.bn5)        # the pooled feature is not used: buffers only
+                feat = None
         node_fea = node_fea.transpose(1, 2).unsqueeze(-1)             # [B,64(ch),64(node),1]
         if node:
             return feat, node_fea, None
@@ -306,7 +310,11 @@ class Net_MDA(nn.Module):
 
     def forward(self, x, constant=1, adaptation=False, node_vis=False, mid_feat=False, node_adaptation_s=False,
                 node_adaptation_t=False, semantic_adaption=False):
-        x, feat_ori, node_idx = self.g(x, node=True)
+        only_node = (node_adaptation_s or node_adaptation_t) and not (node_vis or mid_feat)
+        if only_node and isinstance(self.g, DGCNN):
+            x, feat_ori, node_idx = self.g(x, node=True, feat_grad=False)       # the pooled feature is not used
+        else:
+            x, feat_ori, node_idx = self.g(x, node=True)
         batch_size = feat_ori.size(0)
         if node_vis:
             return node_idx

@@ -593,6 +593,32 @@ class _BNActPool(torch.autograd.Function):
         return dy, rf[C:], rf[:C], None, None, None, None, None, None, None
 
 
+def bn_update_stats(y, bn):
+    """Train-mode BatchNorm side effect only: batch statistics of y [..., C] per domain group ->
+    running-buffer update (and num_batches_tracked); the normalised output is not produced.  For a
+    layer whose output is discarded but whose buffers the reference still updates."""
+    if not bn.training:
+        return
+    _need_gpu(y)
+    C = y.shape[-1]
+    y2 = y.detach().reshape(-1, C)
+    if y2.stride(1) != 1:
+        y2 = y2.contiguous()
+    rows, G = y2.shape[0], BN_GROUPS
+    if rows % G:
+        raise RuntimeError('bn_update_stats: %d rows do not split into %d domain groups' % (rows, G))
+    rg = rows // G
+    g, b = bn.weight.detach().contiguous(), bn.bias.detach().contiguous()
+    coef = torch.empty(5, C, dtype=torch.float32, device=y.device)
+    ws = torch.empty(STATS_BLOCKS * 2 * C, dtype=torch.float32, device=y.device)
+    for i in range(G):
+        yi = y2[i * rg:(i + 1) * rg]
+        check(lib().sug_col_stats_bn(_p(yi), yi.stride(0), rg, C, _p(g), _p(b), bn.eps, bn.momentum,
+                                     _p(bn.running_mean), _p(bn.running_var), _p(coef), _p(ws), _st()),
+              'sug_col_stats_bn')
+    _count_bn_call(bn)
+
+
 def bn_act_pool(y, bn, slope):
     """(max over points, mean over points) of act(bn(y)), y [B,N,C]."""
     _count_bn_call(bn)
