@@ -99,6 +99,25 @@ def cpu_baseline(B, N, steps=1):
     return 2 * B * steps / dt, dt
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, one process per
+    GPU (python -m torch.distributed.run, rendezvous on 127.0.0.1), BEFORE this process touches
+    the GPU; relay the ranks' output (rank 0 prints the JSON line) and return the child's exit
+    code.  The reference's DDP seam is train_dg.py:59-66, :216-217 (torch.distributed.launch)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC for RCCL on this driver
+    env.setdefault('OMP_NUM_THREADS', '8')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -120,7 +139,12 @@ def main():
                     help='separate encoder passes for the source and the target batch (identical results)')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        print('bench.py: --gpus %d but the launcher started %d rank(s); reporting n_gpus=%d'
+              % (args.gpus, world, world), file=sys.stderr)
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if world > 1:

@@ -7,7 +7,8 @@
  *   - the caller owns every buffer (device pointers), pre-allocates all outputs
  *     and scratch; kernels write in place and retain nothing;
  *   - every call is asynchronous on `stream` (a hipStream_t passed as void*),
- *     re-entrant, holds no global state, never synchronises, never allocates;
+ *     re-entrant, holds no global state, never synchronises, never allocates (the only process-wide note kept is, per device, that a
+ *     kernel's dynamic-LDS limit has been raised);
  *   - return 0 on success or a negative SUG_ERR_* code (never exit());
  *     sug_last_error() returns a thread-local message for the last failure;
  *   - feature tensors are point-major rows ("channel-last"): element (b,n,c) of

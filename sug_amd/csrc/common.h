@@ -30,6 +30,33 @@ int sug_knn_mfma(const float* x, int64_t ldx, int B, int N, int C, int k, int32_
 
 #define WAVE 64
 
+// Opt-in to more than 64 KB of dynamic LDS for one kernel.  The attribute is per DEVICE, so the
+// "already done" note is kept per device (atomics: two host threads racing here both set the same
+// value, which is harmless) and a failure is reported, not dropped.  This cache of a driver
+// attribute is the only state the library keeps besides the thread-local error string.
+#include <atomic>
+#define SUG_MAX_DEVICES 64
+struct SugLdsOptIn {
+  std::atomic<int> bytes[SUG_MAX_DEVICES];
+};
+template <typename KernelT>
+static inline int sug_allow_dynamic_lds(SugLdsOptIn& note, KernelT kernel, int bytes, const char* name) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SUG_MAX_DEVICES) {
+    sug_set_error("%s: cannot identify the current device", name);
+    return SUG_ERR_LAUNCH;
+  }
+  if (note.bytes[dev].load(std::memory_order_acquire) >= bytes) return SUG_OK;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) {
+    sug_set_error("%s: %d bytes of dynamic LDS refused on device %d: %s", name, bytes, dev, hipGetErrorString(e));
+    return SUG_ERR_LAUNCH;
+  }
+  note.bytes[dev].store(bytes, std::memory_order_release);
+  return SUG_OK;
+}
+
 static inline int sug_divup(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // |p|^2 as the CPU reference's torch.sum(x**2) over 3 channels: separately rounded

@@ -590,12 +590,8 @@ static int edgeconv_fwd_partials(const float* pq, int64_t ldpq, const int32_t* i
     int psplit = 512 / (B * nslice);
     psplit = psplit < 1 ? 1 : (psplit > 4 ? 4 : psplit);
     const size_t sh = (size_t)N * 16 * sizeof(float) + 64 * 32 * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&edgeconv_fwd_lds_kernel<16, 20>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-      attr_set = true;
-    }
+    static SugLdsOptIn note;
+    if (int rc = sug_allow_dynamic_lds(note, &edgeconv_fwd_lds_kernel<16, 20>, 150 * 1024, "sug_edgeconv_fwd(lds)")) return rc;
     const int grid = ((B & 7) == 0 ? B : B) * nslice * psplit;
     hipLaunchKernelGGL((edgeconv_fwd_lds_kernel<16, 20>), dim3(grid), dim3(256), sh, st_, pq, ldpq, idx, gamma, B, N, Co,
                        psplit, z, arg, s1, ws);

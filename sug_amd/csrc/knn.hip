@@ -294,12 +294,8 @@ extern "C" int sug_knn_reverse(const int32_t* idx, int B, int N, int k, int32_t*
   constexpr int BLOCK = 1024;
   size_t sh = (size_t)(2 * N + BLOCK + (size_t)N * k) * sizeof(int);
   SUG_REQUIRE(sh <= 160 * 1024, "sug_knn_reverse: N*k=%d too large for the LDS-resident build", N * k);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_reverse_kernel<BLOCK>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  static SugLdsOptIn note;
+  if (int rc = sug_allow_dynamic_lds(note, &knn_reverse_kernel<BLOCK>, 160 * 1024, "sug_knn_reverse")) return rc;
   hipLaunchKernelGGL((knn_reverse_kernel<BLOCK>), dim3(B), dim3(BLOCK), sh, (hipStream_t)stream, idx,
                      N, k, rev_off, rev_ent);
   SUG_LAUNCH_CHECK("sug_knn_reverse");

@@ -715,12 +715,8 @@ template <int CP, int K>
 int launch2p(const float* x, int64_t ldx, int B, int N, int k, int32_t* idx, hipStream_t st) {
   constexpr int RS = CP + 4;
   const size_t sh = (size_t)(3 * TJ * RS + 4 * TJ) * sizeof(float) + (size_t)(K + 1) * 256 * sizeof(float2);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_mfma2p_kernel<CP, K>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    attr_set = true;
-  }
+  static SugLdsOptIn note;
+  if (int rc = sug_allow_dynamic_lds(note, &knn_mfma2p_kernel<CP, K>, (int)sh, "sug_knn(mfma, two-pass)")) return rc;
   dim3 grid(sug_divup(N, 128) * B);
   hipLaunchKernelGGL((knn_mfma2p_kernel<CP, K>), grid, dim3(256), sh, st, x, ldx, B, N, k, idx);
   SUG_LAUNCH_CHECK("sug_knn(mfma, two-pass)");
@@ -731,12 +727,8 @@ template <int CP, int K>
 int launch(const float* x, int64_t ldx, int B, int N, int k, int32_t* idx, hipStream_t st) {
   constexpr int RS = CP + 4;
   const size_t sh = (size_t)(3 * TJ * RS + 4 * TJ) * sizeof(float) + (size_t)(RingCap<CP>::value + 1) * 256 * sizeof(float2);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_mfma_kernel<CP, K>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    attr_set = true;
-  }
+  static SugLdsOptIn note;
+  if (int rc = sug_allow_dynamic_lds(note, &knn_mfma_kernel<CP, K>, (int)sh, "sug_knn(mfma)")) return rc;
   dim3 grid(sug_divup(N, 128) * B);
   hipLaunchKernelGGL((knn_mfma_kernel<CP, K>), grid, dim3(256), sh, st, x, ldx, B, N, k, idx);
   SUG_LAUNCH_CHECK("sug_knn(mfma)");

@@ -328,8 +328,9 @@ class _LinearRows(torch.autograd.Function):
 
 def linear_rows(x, weight, bias=None):
     """F.linear for [..., Cin] rows with many rows and small Cin/Cout (the encoders' 1x1 convs)."""
-    if not x.is_cuda or x.dtype != torch.float32:
-        return torch.nn.functional.linear(x, weight, bias)
+    _need_gpu(x, weight)
+    if x.dtype != torch.float32:
+        raise RuntimeError('sug_amd.ops.linear_rows: fp32 rows only (got %s)' % x.dtype)
     return _LinearRows.apply(x, weight, bias)
 
 

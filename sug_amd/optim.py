@@ -99,9 +99,14 @@ class Adam(torch.optim.Adam):
                                                  (ctypes.c_void_p * b.T)(*ptrs), lr, b1, b2, eps, wd,
                                                  b.step_dev.data_ptr(), b.scalars.data_ptr(), ctypes.c_void_p(stream)),
                       'sug_adam_step_capturable')
+                torch.autograd.graph.increment_version(b.params)
                 continue
             check(L.sug_adam_step(b.table.data_ptr(), b.first_dev.data_ptr(), b.first_host, b.T,
                                   (ctypes.c_void_p * b.T)(*ptrs), lr, b1, b2, eps, wd,
                                   1.0 - math.pow(b1, b.step_val), 1.0 - math.pow(b2, b.step_val),
                                   ctypes.c_void_p(stream)), 'sug_adam_step')
+            # the kernel wrote through raw pointers: bump the version counters so that anything keyed
+            # on p._version (conv_2d's [W1;W2-W1] cache, DGCNN's prefix cache, autograd's
+            # saved-tensor checks) sees the update, as after an in-place torch op
+            torch.autograd.graph.increment_version(b.params)
         return None
