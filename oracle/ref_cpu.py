@@ -459,6 +459,19 @@ def pointnet_cls(p, x, training=True, drop_p=0.0):
 # --------------------------------------------------------------------------
 # MMD alignment loss (model/mmd.py)
 # --------------------------------------------------------------------------
+def focal_loss(preds, labels, alpha, gamma=2, size_average=True):
+    """model/model_utils.py:152-176, FIRST call of a fresh module: -alpha_y (1 - p_y)^gamma log p_y.
+    (The reference overwrites self.alpha with the gathered per-sample vector (:168), so later calls of
+    the same module index that vector by label -- a defect the build does not reproduce.)"""
+    preds = preds.view(-1, preds.size(-1))
+    logp = F.log_softmax(preds, dim=1)
+    p = torch.exp(logp).gather(1, labels.view(-1, 1))
+    logp = logp.gather(1, labels.view(-1, 1))
+    a = torch.as_tensor(alpha, dtype=torch.float32).gather(0, labels.view(-1))
+    loss = torch.mul(a, (-torch.mul(torch.pow(1 - p, gamma), logp)).t())
+    return loss.mean() if size_average else loss.sum()
+
+
 def one_hot(labels, num_class=10):
     """create_one_hot_labels, utils/common_utils.py:161-164."""
     oh = torch.zeros(labels.shape[0], num_class, device=labels.device)

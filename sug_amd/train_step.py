@@ -229,6 +229,7 @@ class SUGStep:
     def __init__(self, model, lr=1e-3, weight_decay=5e-5, lr_scaler=1.0, methods=None, criterion=None,
                  global_mmd=True, fused_adam=None, share_prefix=True, use_graph=False, pair_domains=True):
         self.model = model
+        self.base_lr, self.lr_scaler = float(lr), float(lr_scaler)
         # source and target batch go through the encoder as one 2B-cloud batch with per-domain
         # BatchNorm statistics (Net_MDA.forward_pair): same results, half the launches
         self.pair_domains = bool(pair_domains) and hasattr(model, 'forward_pair')
@@ -285,6 +286,25 @@ class SUGStep:
                                                {'params': model.attention_s.parameters()},
                                                {'params': model.attention_t.parameters()}],
                                               lr=lr * lr_scaler, weight_decay=weight_decay, **kw)
+
+    # ------------------------------------------------------------------ learning-rate schedules
+    def set_epoch(self, epoch, max_epoch_num):
+        """Learning rates of the three optimizers at the start of `epoch`, as the reference sets them
+        (train_dg_single_gpu.py:194-203, :210-212): CosineAnnealingLR(T_max=max_epoch_num, eta_min=0)
+        stepped with an explicit epoch (= its closed form) for optimizer_g / optimizer_c, and
+        utils/train_utils.py:39-48 `adjust_learning_rate` for optimizer_dis (halved every 5 epochs up
+        to epoch 30, every 10 afterwards; untouched at epoch 0).  Returns (lr_g, lr_c, lr_dis)."""
+        import math
+        cos = (1.0 + math.cos(math.pi * epoch / max_epoch_num)) / 2.0
+        for opt in (self.optimizer_g, self.optimizer_c):
+            for g in opt.param_groups:
+                g['lr'] = self.base_lr * cos
+        if epoch > 0:
+            lr = self.base_lr * self.lr_scaler * (0.5 ** (epoch // 5 if epoch <= 30 else epoch // 10))
+            for g in self.optimizer_dis.param_groups:
+                g['lr'] = lr
+        return (self.optimizer_g.param_groups[0]['lr'], self.optimizer_c.param_groups[0]['lr'],
+                self.optimizer_dis.param_groups[0]['lr'])
 
     # ------------------------------------------------------------------ losses
     def _mmd(self, label, feat_s, label_t, feat_t, cfg, data_s, data_t):

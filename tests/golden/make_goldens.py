@@ -337,6 +337,26 @@ def gen_pointnet_cls():
     save('pointnet_cls.npz', x=x, label=lab, y=y, loss=loss, seed=seed)
 
 
+def gen_focal():
+    """focal_loss (model/model_utils.py:131-176, the CLS_LOSS: FocalLoss criterion of
+    train_dg_single_gpu.py:167,176): first call of a fresh module, uniform and per-class alpha."""
+    g = torch.Generator().manual_seed(41)
+    out = {}
+    for tag, B, alpha, gamma, avg in (('uni', 16, None, 2, True), ('cls', 32, [0.05 * (i + 1) for i in range(10)], 1.5, True),
+                                      ('sum', 8, [0.1] * 10, 2, False)):
+        pr = (torch.randn(B, 10, generator=g) * 2).requires_grad_(True)
+        lab = torch.randint(0, 10, (B,), generator=g)
+        crit = r_mu.focal_loss(alpha=alpha, gamma=gamma, num_classes=10, size_average=avg)
+        a0 = crit.alpha.clone()
+        v = crit(pr, lab)
+        (gp,) = torch.autograd.grad(v, pr)
+        out[tag + '_pred'], out[tag + '_label'], out[tag + '_alpha'] = pr, lab, a0
+        out[tag + '_gamma'] = np.float64(gamma)
+        out[tag + '_loss'], out[tag + '_grad'] = v, gp
+        same(O.focal_loss(pr, lab, a0, gamma, avg), v, 'focal ' + tag, 1e-6)
+    save('focal.npz', **out)
+
+
 # ------------------------------------------------------------------ MMD
 def gen_mmd():
     g = torch.Generator().manual_seed(99)
@@ -436,7 +456,8 @@ def gen_step():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['ops', 'mmd', 'pointnet_cls', 'dgcnn', 'pointnet', 'pointnet2', 'ptran', 'step']
+    which = sys.argv[1:] or ['ops', 'mmd', 'pointnet_cls', 'dgcnn', 'pointnet', 'pointnet2', 'ptran', 'step', 'focal', 'ptran2048',
+                             'pointnet2_b4']
     if 'ops' in which:
         gen_ops()
     if 'mmd' in which:
@@ -451,5 +472,11 @@ if __name__ == '__main__':
         gen_model('Pointnet2', 2, 2048, 13, 'model_pointnet2.npz')
     if 'ptran' in which:
         gen_model('PTran', 2, 1024, 14, 'model_ptran.npz')
+    if 'focal' in which:
+        gen_focal()
+    if 'ptran2048' in which:            # BASELINE config 5's cloud size (the FPS schedule stays 256/64/16/4)
+        gen_model('PTran', 2, 2048, 15, 'model_ptran_n2048.npz')
+    if 'pointnet2_b4' in which:         # config 3 shape at a batch that exercises the 8-cloud XCD grouping with pairs
+        gen_model('Pointnet2', 4, 2048, 16, 'model_pointnet2_b4.npz')
     if 'step' in which:
         gen_step()

@@ -80,7 +80,9 @@ def run_passes(name, fname, knn_forced):
 
 
 @pytest.mark.parametrize('name,fname', [('Pointnet', 'model_pointnet.npz'), ('Pointnet2', 'model_pointnet2.npz'),
-                                        ('PTran', 'model_ptran.npz')])
+                                        ('PTran', 'model_ptran.npz'),
+                                        ('PTran', 'model_ptran_n2048.npz'),         # BASELINE config 5 cloud size
+                                        ('Pointnet2', 'model_pointnet2_b4.npz')])   # config 3 shape, B=4
 def test_encoder_parity(name, fname):
     G, net, (y1, y2, s1, s2), loss = run_passes(name, fname, False)
     seed = G['seed']

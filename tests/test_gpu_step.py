@@ -171,3 +171,40 @@ def test_pair_domains_match_separate_passes(model_name):
             torch.testing.assert_close(b, a, rtol=2e-3, atol=2e-4 * gmax)
     for k in res[0][2]:
         torch.testing.assert_close(res[1][2][k].float(), res[0][2][k].float(), rtol=1e-5, atol=1e-6)
+
+
+def test_step_with_tuned_library_gemms_matches_default():
+    """bench.py's default switches on the recorded TunableOp choices (sug_amd/tuning) and sends the
+    weight gradients of the listed shapes to the library: same losses as the untuned step (first
+    step 1e-4; the second only loosely -- see test_two_training_steps_match_reference)."""
+    import torch.cuda.tunable as tn
+    from sug_amd import ops
+    from sug_amd.model.Model import Net_MDA
+    from sug_amd.train_step import SUGStep
+    from sug_amd.tuning import enable_tuned_gemms
+    G = load_golden('step_dgcnn.npz')
+    seed = G['seed']
+    data, data_t = G['data'].cuda(), G['data_t'].cuda()
+    lab, lab_t = G['label'].cuda(), G['label_t'].cuda()
+    res = []
+    try:
+        for tuned in (False, True):
+            if tuned:
+                enable_tuned_gemms()        # the table may be ignored on another ROCm stack; the step must still be right
+                ops.DW_FORCE_LIBRARY = True  # every weight gradient through the library (the golden batch is not a tuned shape)
+            net = Net_MDA('DGCNN')
+            net.load_state_dict(O.fill_params({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed))
+            for m in net.modules():
+                if isinstance(m, torch.nn.Dropout2d):
+                    m.p = 0.0
+            tr = SUGStep(net.cuda().train())
+            torch.manual_seed(seed)
+            res.append([[float(v) for v in tr.step(data, lab, data_t, lab_t)] for _ in range(2)])
+    finally:
+        tn.enable(False)
+        ops.DW_FORCE_LIBRARY = False
+        ops.DW_LIBRARY_SHAPES = set()
+    for a, b in zip(res[0][0], res[1][0]):
+        assert abs(a - b) <= 1e-4 * max(1.0, abs(a)), res
+    for a, b in zip(res[0][1], res[1][1]):
+        assert abs(a - b) <= 5e-3 * max(1.0, abs(a)), res

@@ -69,7 +69,8 @@ def test_pointnet_forward_oracle_vs_golden():
 
 
 @pytest.mark.parametrize('name,fname', [('DGCNN', 'model_dgcnn.npz'), ('Pointnet', 'model_pointnet.npz'),
-                                        ('Pointnet2', 'model_pointnet2.npz'), ('PTran', 'model_ptran.npz')])
+                                        ('Pointnet2', 'model_pointnet2.npz'), ('PTran', 'model_ptran.npz'),
+                                        ('PTran', 'model_ptran_n2048.npz'), ('Pointnet2', 'model_pointnet2_b4.npz')])
 def test_mirror_has_reference_parameters(name, fname):
     """Same parameter / buffer names as the reference (so its checkpoints load): every name the
     reference produced a gradient or BN buffer for exists here, and the FPS start draws
@@ -105,3 +106,49 @@ def test_host_helpers():
     for meth in ('mean2one', 'none', 'naive_inverse', 'exp_inverse'):
         torch.testing.assert_close(mmd.distance2weights(d, meth), O.distance2weights(d, meth))
     assert float(mmd.distance2weights(torch.tensor([2.0, 4.0]), 'mean2one').abs().sum()) == 0.0   # int(1/3) == 0
+
+
+@pytest.mark.parametrize('tag,avg', [('uni', True), ('cls', True), ('sum', False)])
+def test_focal_loss_oracle_and_mirror_vs_golden(tag, avg):
+    """focal_loss (model/model_utils.py:131-176): the oracle restatement and the host mirror (pure
+    torch, device-agnostic) reproduce the reference's value and gradient."""
+    from sug_amd.model.model_utils import focal_loss
+    G = load_golden('focal.npz')
+    pr, lab, alpha, gamma = G[tag + '_pred'], G[tag + '_label'], G[tag + '_alpha'], float(G[tag + '_gamma'])
+    tol = dict(rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(O.focal_loss(pr, lab, alpha, gamma, avg), G[tag + '_loss'], **tol)
+    crit = focal_loss(alpha=alpha.tolist(), gamma=gamma, num_classes=10, size_average=avg)
+    x = pr.clone().requires_grad_(True)
+    v = crit(x, lab)
+    torch.testing.assert_close(v, G[tag + '_loss'], **tol)
+    (g,) = torch.autograd.grad(v, x)
+    torch.testing.assert_close(g, G[tag + '_grad'], **tol)
+    # unlike the reference module (which overwrites self.alpha, model_utils.py:168), a second call
+    # of the same module gives the same value
+    torch.testing.assert_close(crit(pr, lab), G[tag + '_loss'], **tol)
+
+
+def test_step_driver_lr_schedules():
+    """SUGStep.set_epoch reproduces the reference's three schedules (train_dg_single_gpu.py:194-203,
+    :210-212; utils/train_utils.py:39-48): CosineAnnealingLR stepped with an explicit epoch for
+    optimizer_g / optimizer_c, the 5/10-epoch halving for optimizer_dis."""
+    import math
+    from sug_amd.model.Model import Net_MDA
+    from sug_amd.train_step import SUGStep
+    LR, scaler, T = 1e-3, 2.0, 40
+    tr = SUGStep(Net_MDA('Pointnet'), lr=LR, lr_scaler=scaler)
+    w = torch.nn.Parameter(torch.zeros(1))
+    ref_opt = torch.optim.Adam([w], lr=LR)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(ref_opt, T_max=T)
+    import warnings
+    for epoch in (0, 1, 2, 5, 6, 30, 31, 39):
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            sched.step(epoch=epoch)             # the reference's call (closed form of the cosine)
+        want_cos = ref_opt.param_groups[0]['lr']
+        want_dis = LR * scaler if epoch == 0 else LR * scaler * (0.5 ** (epoch // 5 if epoch <= 30 else epoch // 10))
+        lr_g, lr_c, lr_dis = tr.set_epoch(epoch, T)
+        assert math.isclose(lr_g, want_cos, rel_tol=1e-12, abs_tol=1e-18) and lr_c == lr_g
+        assert math.isclose(lr_dis, want_dis, rel_tol=1e-12)
+        assert all(g['lr'] == lr_dis for g in tr.optimizer_dis.param_groups)
+        assert all(g['lr'] == lr_g for g in tr.optimizer_g.param_groups)
