@@ -306,6 +306,40 @@ int sug_bn_act_pool_layer_bwd(const float* y, int64_t ldy, const float* coef, co
                               float slope, int training, double* red, float* ws, float* dy, int64_t lddy,
                               void* stream);
 
+/* ---- per-point MLP layer fused with the max over a group of rows ------------------------------
+ * replaces `conv_2d(K, Co)` (1x1 Conv2d + bias -> BatchNorm2d -> ReLU) followed by the max over the
+ * points of a cloud: Pointnet_g.conv5 + torch.max (model/Model.py:274-279), transform_net.conv2d3 +
+ * maxpool (model/model_utils.py:72-79), Pointnet_cls (model/model_pointnet.py:36-48); and the last
+ * layer of a set-abstraction MLP + max over nsample (model/pointnet2_utils.py:193-207).
+ * y = x . w^T + bias ([rows,K] x [Co,K]^T, an ascending-k fp32 fma chain on the matrix pipe) is never
+ * stored.  Rows form segments of `seg` consecutive rows (a cloud's N points, or a group's nsample
+ * points); per (segment, channel) the kernel keeps zext = max_rows y (gamma >= 0) or min_rows y
+ * (gamma < 0) -- the element BN + (Leaky)ReLU maps to the max -- and arg = its row inside the segment
+ * (lowest row on ties), and it accumulates the BatchNorm sums of y as per-row-block partial rows in
+ * ws ([*nblk][2*Co]: sum | sum of squares; *nblk <= SUG_STATS_BLOCKS).
+ * K in {64, 128}; Co % 128 == 0; seg % 32 == 0; rows % seg == 0; x, w 16-byte aligned, ldx % 4 == 0. */
+int sug_pointmlp_max_fwd(const float* x, int64_t ldx, int64_t rows, int K, const float* w, const float* bias,
+                         const float* gamma, int Co, int seg, float* zext, int32_t* arg, float* ws, int* nblk,
+                         void* stream);
+/* Layer entry point: the above per domain group, then the BatchNorm coefficients (training: batch
+ * statistics + running-buffer update; eval: coef read, caller fills it) and
+ * out[s,c] = LeakyReLU_slope(scale[c]*zext[s,c] + shift[c]), out [rows/seg, Co] (row stride ldo).
+ * coef [groups,5,Co]; ws SUG_STATS_BLOCKS*2*Co floats. */
+int sug_pointmlp_max_layer_fwd(const float* x, int64_t ldx, int64_t rows, int K, const float* w, const float* bias,
+                               const float* gamma, const float* beta, int Co, int seg, int groups, int training,
+                               float eps, float momentum, float slope, float* running_mean, float* running_var,
+                               float* zext, int32_t* arg, float* coef, float* out, int64_t ldo, float* ws,
+                               void* stream);
+/* Backward, the terms that follow the winning rows n*(s,c) = s*seg + arg[s,c], with
+ * a[s,c] = scale[c] * gout[s,c] * act' (sug_edgeconv_bwd_reduce on the [rows/seg, Co] tensors):
+ *   dx[n*(s,c), :] += a[s,c] * w[c,:]   (dx holds the dense BatchNorm-statistics term -(x.A + v) or zeros)
+ *   dw[c,:]         = sum_s a[s,c] * x[n*(s,c), :]
+ * both in a fixed summation order (bit-reproducible).  ws: sug_pointmlp_max_bwd_workspace floats. */
+int64_t sug_pointmlp_max_bwd_workspace(int64_t rows, int K, int Co, int seg);
+int sug_pointmlp_max_bwd_sparse(const float* a, const int32_t* arg, const float* x, int64_t ldx, const float* w,
+                                int64_t rows, int K, int Co, int seg, float* dx, int64_t lddx, float* dw,
+                                float* ws, void* stream);
+
 /* ---- Gaussian multi-kernel MMD --------------------------------------------------
  * replaces _mix_rbf_kernel + _mmd2(biased=True), model/mmd.py:239-254, :274-312.
  * Z = [X;Y] : [2m, D] rows (ld = ldz).  e_ij = n_i - 2<z_i,z_j> + n_j with n the

@@ -63,6 +63,10 @@ SIGNATURES = {
     'sug_bn_bwd_apply': [_vp, _vp, _i64, _vp, _vp, _i64, _i32, _vp, _i64, _vp],
     'sug_bn_act_pool_fwd': [_vp, _i64, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp],
     'sug_bn_act_pool_bwd': [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp, _i64, _vp],
+    'sug_pointmlp_max_fwd': [_vp, _i64, _i64, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
+    'sug_pointmlp_max_layer_fwd': [_vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _vp,
+                                   _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
+    'sug_pointmlp_max_bwd_sparse': [_vp, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp],
     'sug_mmd_rbf': [_vp, _i64, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp],
     'sug_chamfer': [_vp, _vp, _i32, _i32, _i32, _vp, _vp],
 }
@@ -88,6 +92,8 @@ def lib():
             fn.restype = ctypes.c_int
         L.sug_linear_dw_workspace.restype = ctypes.c_int64
         L.sug_linear_dw_workspace.argtypes = [_i64, _i32, _i32]
+        L.sug_pointmlp_max_bwd_workspace.restype = ctypes.c_int64
+        L.sug_pointmlp_max_bwd_workspace.argtypes = [_i64, _i32, _i32, _i32]
         L.sug_adam_chunk.restype = ctypes.c_int
         L.sug_adam_chunk.argtypes = []
         L.sug_last_error.restype = ctypes.c_char_p

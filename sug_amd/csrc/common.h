@@ -28,6 +28,11 @@ void sug_set_error(const char* fmt, ...);
 int sug_knn_mfma_supported(const float* x, int64_t ldx, int C, int k);
 int sug_knn_mfma(const float* x, int64_t ldx, int B, int N, int C, int k, int32_t* idx, hipStream_t st);
 
+// edgeconv.hip: fold `nblk` per-workgroup partial rows ws[nblk][2C] (sum | sum of squares, fixed
+// order, fp64) into the BatchNorm coefficients coef[5][C] and update the running buffers
+int sug_stats_finalize(const float* ws, int nblk, int C, const float* gamma, const float* beta, double count, float eps,
+                       float momentum, float* running_mean, float* running_var, float* coef, hipStream_t st);
+
 #define WAVE 64
 
 // Opt-in to more than 64 KB of dynamic LDS for one kernel.  The attribute is per DEVICE, so the

@@ -570,6 +570,15 @@ inline int col_width(int C) {
 
 }  // namespace
 
+int sug_stats_finalize(const float* ws, int nblk, int C, const float* gamma, const float* beta, double count, float eps,
+                       float momentum, float* running_mean, float* running_var, float* coef, hipStream_t st) {
+  SUG_REQUIRE(ws && gamma && beta && coef && nblk > 0 && C > 0 && count > 0, "sug_stats_finalize: bad argument");
+  hipLaunchKernelGGL(stats_finalize_kernel, dim3(sug_divup(C, 8)), dim3(256), 0, st, ws, nblk, C, gamma, beta, count, eps,
+                     momentum, running_mean, running_var, coef);
+  SUG_LAUNCH_CHECK("sug_stats_finalize");
+  return SUG_OK;
+}
+
 // producer only: per-workgroup partial rows in ws, their number in *nblk
 static int edgeconv_fwd_partials(const float* pq, int64_t ldpq, const int32_t* idx, const float* gamma, int B, int N,
                                  int k, int Co, float* z, uint8_t* arg, float* s1, float* ws, int* nblk,

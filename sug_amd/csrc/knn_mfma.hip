@@ -19,6 +19,7 @@
 //
 // Algorithmic bytes 4*C*N + 4*N*k per cloud; FLOPs N^2*(2C+3): compute bound.
 #include "common.h"
+#include "mfma_tile.h"
 #include <type_traits>
 
 #ifdef SUG_KNN_STAMP      // diagnostic build only (tools/bench_knn.py): per-phase cycle stamps of block 0
@@ -37,9 +38,7 @@ extern "C" int sug_debug_read_stamps(unsigned long long* host) {
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int TJ = 32;   // candidate rows per tile = MFMA M
+using namespace sug_tile;      // f32x16, TJ, TileRegs, tile_load, tile_store (mfma_tile.h)
 
 template <int K>
 __device__ __forceinline__ void insert_desc(float (&v)[K], int (&id)[K], float s, int j) {
@@ -73,78 +72,6 @@ __device__ __forceinline__ void insert_desc_tie(float (&v)[K], int (&id)[K], flo
   if (better(s, j, v[0], id[0])) {
     v[0] = s;
     id[0] = j;
-  }
-}
-
-// Global -> register half of the staging (so the loads fly under the previous tile's MFMAs).
-template <int CP>
-struct TileRegs {
-  static constexpr int NV = (CP == 4) ? 1 : (CP / 64);   // (row, 8-feature chunk) items per thread
-  float4 lo[NV], hi[NV];
-};
-
-template <int CP>
-__device__ __forceinline__ void tile_load(TileRegs<CP>& t, const float* __restrict__ xb, int64_t ldx,
-                                          int N, int row0) {
-  if constexpr (CP == 4) {
-    const int r = row0 + (int)threadIdx.x;
-    float x = 0.f, y = 0.f, z = 0.f;
-    if (threadIdx.x < TJ && r < N) {
-      const float* p = xb + (int64_t)r * ldx;
-      x = p[0]; y = p[1]; z = p[2];
-    }
-    t.lo[0] = make_float4(x, y, z, 0.f);
-  } else {
-    constexpr int CH = CP / 8;                 // chunks per row
-#pragma unroll
-    for (int u = 0; u < TileRegs<CP>::NV; ++u) {
-      const int item = (int)threadIdx.x + u * 256;
-      const int r = row0 + item / CH, c8 = item % CH;
-      if (r < N) {
-        const float4* p = reinterpret_cast<const float4*>(xb + (int64_t)r * ldx + c8 * 8);
-        t.lo[u] = p[0];
-        t.hi[u] = p[1];
-      } else {
-        t.lo[u] = make_float4(0, 0, 0, 0);
-        t.hi[u] = make_float4(0, 0, 0, 0);
-      }
-    }
-  }
-}
-
-// Register -> LDS half: de-interleave, and the row norms |x_j|^2.
-template <int CP>
-__device__ __forceinline__ void tile_store(const TileRegs<CP>& t, float* __restrict__ s_tile,
-                                           float* __restrict__ s_norm, int N, int row0) {
-  constexpr int RS = CP + 4;
-  if constexpr (CP == 4) {
-    if (threadIdx.x < TJ) {
-      const int r = threadIdx.x;
-      const float4 p = t.lo[0];
-      float* d = s_tile + r * RS;
-      d[0] = p.x; d[1] = p.z;        // even features 0,2
-      d[2] = p.y; d[3] = 0.f;        // odd features 1,(3 = pad)
-      s_norm[r] = (row0 + r < N) ? sq3(p.x, p.y, p.z) : INFINITY;
-    }
-  } else {
-    constexpr int CH = CP / 8;
-    constexpr int HALF = CP / 2;
-#pragma unroll
-    for (int u = 0; u < TileRegs<CP>::NV; ++u) {
-      const int item = (int)threadIdx.x + u * 256;
-      const int r = item / CH, c8 = item % CH;
-      const float4 a = t.lo[u], b = t.hi[u];
-      float* d = s_tile + r * RS;
-      *reinterpret_cast<float4*>(d + 4 * c8) = make_float4(a.x, a.z, b.x, b.z);
-      *reinterpret_cast<float4*>(d + HALF + 4 * c8) = make_float4(a.y, a.w, b.y, b.w);
-      float p = __fmul_rn(a.x, a.x);
-      p = fmaf(a.y, a.y, p); p = fmaf(a.z, a.z, p); p = fmaf(a.w, a.w, p);
-      p = fmaf(b.x, b.x, p); p = fmaf(b.y, b.y, p); p = fmaf(b.z, b.z, p); p = fmaf(b.w, b.w, p);
-      // fixed-order tree over the CH lanes of this row (consecutive lanes)
-#pragma unroll
-      for (int o = 1; o < CH; o <<= 1) p += __shfl_xor(p, o);
-      if (c8 == 0) s_norm[r] = (row0 + r < N) ? p : INFINITY;
-    }
   }
 }
 

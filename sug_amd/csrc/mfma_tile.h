@@ -1,0 +1,93 @@
+// Row-tile staging for the fp32 MFMA kernels (knn_mfma.hip, pointmlp.hip): 32 rows of a
+// [rows, CP] fp32 matrix travel global -> registers -> LDS, de-interleaved so that one
+// ds_read_b128 feeds the A operand of four consecutive v_mfma_f32_32x32x2_f32 k-steps.
+//
+// LDS image of a tile: row r at s_tile + r*(CP+4); inside a row [even features | odd features]
+// (CP/2 floats each).  Lane l of a wave (row i = l&31, half h = l>>5) reads its operands for
+// k-steps s = 0..CP/2-1 from  s_tile + i*RS + h*CP/2 + s : the value is feature 2s+h, which is
+// A[i][k = l>>5] of step s.  Row stride CP+4 floats keeps the b128 reads conflict-free.
+#pragma once
+#include "common.h"
+
+namespace sug_tile {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int TJ = 32;   // rows per tile = MFMA M
+
+// Global -> register half of the staging (so the loads fly under the previous tile's MFMAs).
+template <int CP>
+struct TileRegs {
+  static constexpr int NV = (CP == 4) ? 1 : (CP / 64);   // (row, 8-feature chunk) items per thread
+  float4 lo[NV], hi[NV];
+};
+
+// rows [row0, row0+32) of xb (row stride ldx); rows >= N read as zero.  256 threads.
+template <int CP>
+__device__ __forceinline__ void tile_load(TileRegs<CP>& t, const float* __restrict__ xb, int64_t ldx,
+                                          int N, int row0) {
+  if constexpr (CP == 4) {
+    const int r = row0 + (int)threadIdx.x;
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (threadIdx.x < TJ && r < N) {
+      const float* p = xb + (int64_t)r * ldx;
+      x = p[0]; y = p[1]; z = p[2];
+    }
+    t.lo[0] = make_float4(x, y, z, 0.f);
+  } else {
+    constexpr int CH = CP / 8;                 // chunks per row
+#pragma unroll
+    for (int u = 0; u < TileRegs<CP>::NV; ++u) {
+      const int item = (int)threadIdx.x + u * 256;
+      const int r = row0 + item / CH, c8 = item % CH;
+      if (r < N) {
+        const float4* p = reinterpret_cast<const float4*>(xb + (int64_t)r * ldx + c8 * 8);
+        t.lo[u] = p[0];
+        t.hi[u] = p[1];
+      } else {
+        t.lo[u] = make_float4(0, 0, 0, 0);
+        t.hi[u] = make_float4(0, 0, 0, 0);
+      }
+    }
+  }
+}
+
+// Register -> LDS half: de-interleave; with NORM also the row norms |x_j|^2 (rows >= N: +inf).
+template <int CP, bool NORM = true>
+__device__ __forceinline__ void tile_store(const TileRegs<CP>& t, float* __restrict__ s_tile,
+                                           float* __restrict__ s_norm, int N, int row0) {
+  constexpr int RS = CP + 4;
+  if constexpr (CP == 4) {
+    if (threadIdx.x < TJ) {
+      const int r = threadIdx.x;
+      const float4 p = t.lo[0];
+      float* d = s_tile + r * RS;
+      d[0] = p.x; d[1] = p.z;        // even features 0,2
+      d[2] = p.y; d[3] = 0.f;        // odd features 1,(3 = pad)
+      if constexpr (NORM) s_norm[r] = (row0 + r < N) ? sq3(p.x, p.y, p.z) : INFINITY;
+    }
+  } else {
+    constexpr int CH = CP / 8;
+    constexpr int HALF = CP / 2;
+#pragma unroll
+    for (int u = 0; u < TileRegs<CP>::NV; ++u) {
+      const int item = (int)threadIdx.x + u * 256;
+      const int r = item / CH, c8 = item % CH;
+      const float4 a = t.lo[u], b = t.hi[u];
+      float* d = s_tile + r * RS;
+      *reinterpret_cast<float4*>(d + 4 * c8) = make_float4(a.x, a.z, b.x, b.z);
+      *reinterpret_cast<float4*>(d + HALF + 4 * c8) = make_float4(a.y, a.w, b.y, b.w);
+      if constexpr (NORM) {
+        float p = __fmul_rn(a.x, a.x);
+        p = fmaf(a.y, a.y, p); p = fmaf(a.z, a.z, p); p = fmaf(a.w, a.w, p);
+        p = fmaf(b.x, b.x, p); p = fmaf(b.y, b.y, p); p = fmaf(b.z, b.z, p); p = fmaf(b.w, b.w, p);
+        // fixed-order tree over the CH lanes of this row (consecutive lanes)
+#pragma unroll
+        for (int o = 1; o < CH; o <<= 1) p += __shfl_xor(p, o);
+        if (c8 == 0) s_norm[r] = (row0 + r < N) ? p : INFINITY;
+      }
+    }
+  }
+}
+
+}  // namespace sug_tile

@@ -1,0 +1,394 @@
+// Per-point MLP layer fused with the max over a group of rows: the last 1x1 conv of PointNet's
+// trunk and of its T-Nets followed by the global max over the N points (model/Model.py:274-279,
+// model/model_utils.py:72-79, model/model_pointnet.py:36-48) and the last layer of a PointNet++
+// set-abstraction MLP followed by the max over the nsample grouped points
+// (model/pointnet2_utils.py:193-207).  The reference writes y = conv(x) ([B,1024,N] resp.
+// [B,C,nsample,npoint]), normalises it (train-mode BatchNorm), applies ReLU and only then reduces;
+// here y exists only as fp32 MFMA accumulator tiles.
+//
+// BatchNorm followed by (Leaky)ReLU is monotone per channel, so max_rows act(bn(y)) = act(bn(ext(y)))
+// with ext = max for gamma >= 0 and min for gamma < 0: per (segment, channel) the kernel keeps the
+// extreme pre-BN value and its row, and accumulates the BatchNorm sums of y on the way.
+//
+// Geometry: workgroup = 4 waves = (row block, 128 output channels); a wave owns 32 channels, whose
+// weight rows stay in registers as the B operand (lane l: channel l&31, k = 2s + (l>>5));
+// 32-row tiles of x stream global -> registers -> LDS (mfma_tile.h) and feed the A operand;
+// y tile (rows x channels) = 16 accumulator registers per lane: channel l&31, rows
+// (r&3) + 8*(r>>2) + 4*(l>>5).  The epilogue of tile t (bias, BN sums, running extreme) is VALU work
+// issued between the MFMAs of tile t+1.
+//
+// FLOPs 2*R*K*Co on the fp32 matrix pipe (157 TFLOP/s peak); algorithmic bytes
+// 4*R*K (x, once per 128-channel block through L2) + 4*Co*K + 8*(R/L)*Co.
+#include "common.h"
+#include "mfma_tile.h"
+
+namespace {
+using namespace sug_tile;
+
+template <int CP>
+__global__ __launch_bounds__(256, 2) void pointmlp_max_kernel(
+    const float* __restrict__ x, int64_t ldx, int R, const float* __restrict__ W,
+    const float* __restrict__ bias, const float* __restrict__ gamma, int Co, int L, int rows_per_wg, int nrb,
+    float* __restrict__ zext, int32_t* __restrict__ arg, float* __restrict__ ws) {
+  constexpr int RS = CP + 4;
+  constexpr int HALF = CP / 2;
+  constexpr int P = HALF / 16;                       // MFMAs per accumulator slot (2 or 4)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* s_tile = reinterpret_cast<float*>(smem);    // [3][TJ][RS]
+
+  // (row block, channel block): the channel blocks of a row block re-read the same x rows, so they
+  // get the same blockIdx % 8 (one XCD, one L2) when the row blocks split evenly over the XCDs
+  const int ncb = Co >> 7;
+  int rb, cb;
+  if ((nrb & 7) == 0) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    rb = (j / ncb) * 8 + xcd;
+    cb = j % ncb;
+  } else {
+    rb = blockIdx.x / ncb;
+    cb = blockIdx.x % ncb;
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int cj = lane & 31, h = lane >> 5;
+  const int col = cb * 128 + wv * 32 + cj;
+  const int row_begin = rb * rows_per_wg;
+  const int nrows = (R - row_begin < rows_per_wg) ? R - row_begin : rows_per_wg;
+  const float* xb = x + (int64_t)row_begin * ldx;
+
+  // B operand: this lane's channel, k = 2s + h
+  float bq[HALF];
+  {
+    const float* wr = W + (int64_t)col * CP;
+#pragma unroll
+    for (int g = 0; g < CP / 8; ++g) {
+      const float4 lo = *reinterpret_cast<const float4*>(wr + 8 * g);
+      const float4 hi = *reinterpret_cast<const float4*>(wr + 8 * g + 4);
+      bq[4 * g + 0] = h ? lo.y : lo.x;
+      bq[4 * g + 1] = h ? lo.w : lo.z;
+      bq[4 * g + 2] = h ? hi.y : hi.x;
+      bq[4 * g + 3] = h ? hi.w : hi.z;
+    }
+  }
+  const float bj = bias ? bias[col] : 0.f;
+  const float sgn = gamma[col] >= 0.f ? 1.f : -1.f;
+
+  float s1 = 0.f, s2 = 0.f;                          // BN sums of this lane's rows of this channel
+  float best = -INFINITY;
+  int barg = 0;
+  const int ntile = (nrows + TJ - 1) / TJ;
+  auto tbuf = [&](int t) { return s_tile + (t % 3) * TJ * RS; };
+
+#define SUG_SB() __builtin_amdgcn_sched_barrier(0)
+  // MFMA chain of the NEXT tile, issued in pieces between the epilogue steps of the CURRENT one
+  auto step = [&](const f32x16& acc_cur, f32x16& acc_next, const float* __restrict__ arow, int t) {
+    float av[HALF];
+#pragma unroll
+    for (int g = 0; g < HALF / 4; ++g) {
+      const float4 a4 = *reinterpret_cast<const float4*>(arow + 4 * g);
+      av[4 * g + 0] = a4.x; av[4 * g + 1] = a4.y; av[4 * g + 2] = a4.z; av[4 * g + 3] = a4.w;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_next[r] = 0.f;
+    const int lim = nrows - t * TJ - 4 * h;          // rows of this tile that exist, seen from this lane half
+    const int segrow = (t * TJ) % L + 4 * h;         // row of the tile's first row inside its segment (L % 32 == 0)
+    SUG_SB();
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      acc_next = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c * P + 0], bq[c * P + 0], acc_next, 0, 0, 0);
+      SUG_SB();
+      {
+        const int rt = (c & 3) + 8 * (c >> 2);       // row inside the tile (+ 4h)
+        const bool valid = rt < lim;
+        const float y = __fadd_rn(acc_cur[c], bj);
+        const float yv = valid ? y : 0.f;
+        s1 += yv;
+        s2 = fmaf(yv, yv, s2);
+        const float tt = valid ? sgn * y : -INFINITY;
+        const bool up = tt > best;                   // strict: the first extreme of a lane's ascending rows wins
+        best = up ? tt : best;
+        barg = up ? segrow + rt : barg;
+      }
+      SUG_SB();
+#pragma unroll
+      for (int p = 1; p < P; ++p)
+        acc_next = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c * P + p], bq[c * P + p], acc_next, 0, 0, 0);
+      SUG_SB();
+    }
+  };
+
+  // a segment ends with this tile: merge the two lane halves (other rows, same channel) and emit
+  auto flush = [&](int t) {
+    const float pb = __shfl_xor(best, 32);
+    const int pa = __shfl_xor(barg, 32);
+    const bool take = pb > best || (pb == best && pa < barg);
+    const float fb = take ? pb : best;
+    const int fa = take ? pa : barg;
+    if (h == 0) {
+      const int64_t o = (int64_t)((row_begin + t * TJ) / L) * Co + col;
+      zext[o] = sgn * fb;
+      arg[o] = fa;
+    }
+    best = -INFINITY;
+    barg = 0;
+  };
+
+  {
+    TileRegs<CP> tra, trb;
+    tile_load<CP>(tra, xb, ldx, nrows, 0);
+    tile_store<CP, false>(tra, tbuf(0), nullptr, nrows, 0);
+    __syncthreads();
+    if (ntile > 1) tile_load<CP>(trb, xb, ldx, nrows, TJ);
+    if (ntile > 2) tile_load<CP>(tra, xb, ldx, nrows, 2 * TJ);
+    f32x16 acc_cur;
+    {
+      const float* arow = tbuf(0) + cj * RS + h * HALF;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc_cur[r] = 0.f;
+#pragma unroll
+      for (int g = 0; g < HALF / 4; ++g) {
+        const float4 a4 = *reinterpret_cast<const float4*>(arow + 4 * g);
+        acc_cur = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, bq[4 * g + 0], acc_cur, 0, 0, 0);
+        acc_cur = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, bq[4 * g + 1], acc_cur, 0, 0, 0);
+        acc_cur = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, bq[4 * g + 2], acc_cur, 0, 0, 0);
+        acc_cur = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, bq[4 * g + 3], acc_cur, 0, 0, 0);
+      }
+    }
+    if (ntile > 1) tile_store<CP, false>(trb, tbuf(1), nullptr, nrows, TJ);
+    __syncthreads();
+    if (ntile > 3) tile_load<CP>(trb, xb, ldx, nrows, 3 * TJ);
+    // iteration t: MFMA chain of tile t+1 || epilogue of tile t; registers of tile t+2 -> LDS; global
+    // loads of tiles t+3, t+4 in flight (the last iteration's chain runs on a stale buffer, unused)
+#define SUG_PM_BODY(T, TR) do { \
+      f32x16 acc_next; \
+      step(acc_cur, acc_next, tbuf((T) + 1) + cj * RS + h * HALF, (T)); \
+      if ((((T) + 1) * TJ) % L == 0 || (T) + 1 == ntile) flush((T)); \
+      if ((T) + 2 < ntile) tile_store<CP, false>(TR, tbuf((T) + 2), nullptr, nrows, ((T) + 2) * TJ); \
+      __syncthreads(); \
+      if ((T) + 4 < ntile) tile_load<CP>(TR, xb, ldx, nrows, ((T) + 4) * TJ); \
+      acc_cur = acc_next; \
+    } while (0)
+    for (int t = 0; t < ntile; t += 2) {
+      SUG_PM_BODY(t, tra);
+      if (t + 1 < ntile) SUG_PM_BODY(t + 1, trb);
+    }
+#undef SUG_PM_BODY
+  }
+#undef SUG_SB
+  // BN partial sums of this (row block, channel): fixed order (lane half 0 + lane half 1)
+  s1 += __shfl_xor(s1, 32);
+  s2 += __shfl_xor(s2, 32);
+  if (h == 0) {
+    ws[(size_t)rb * 2 * Co + col] = s1;
+    ws[(size_t)rb * 2 * Co + Co + col] = s2;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward, the part that follows the arg-extreme rows.  With a[s,c] = scale_c * gout * act'
+// (sug_edgeconv_bwd_reduce on the [S,Co] tensors) and n*(s,c) = s*L + arg[s,c]:
+//     dx[n*(s,c), :] += a[s,c] * W[c, :]            (rows of x that won a channel)
+//     dW[c, :]       += a[s,c] * x[n*(s,c), :]
+// The BatchNorm-statistics terms of the gradient are dense in the rows but of rank K: the caller adds
+// them as -(x.A + v) and a [Co,K] matrix built from X^T X (see ops.PointMLPMax).
+//
+// dx: one workgroup per (segment, chunk of 128 rows); a wave owns rows, walks the channels that
+// picked each row in ascending channel order (ballot), so the sum order is fixed.
+template <int KV>     // K / 64 floats per lane
+__global__ __launch_bounds__(256) void pointmlp_bwd_dx_kernel(const float* __restrict__ a, const int32_t* __restrict__ arg,
+                                                              const float* __restrict__ W, int Co, int L, int S,
+                                                              int chunks, float* __restrict__ dx, int64_t lddx) {
+  extern __shared__ __attribute__((aligned(16))) float s_mem[];
+  float* s_a = s_mem;                                        // [Co]
+  int* s_arg = reinterpret_cast<int*>(s_mem + Co);           // [Co]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  constexpr int K = KV * 64;
+  const int rows_per_chunk = (L + chunks - 1) / chunks;
+  for (int item = blockIdx.x; item < S * chunks; item += gridDim.x) {
+    const int s = item / chunks, ch = item % chunks;
+    __syncthreads();
+    for (int c = threadIdx.x; c < Co; c += 256) {
+      s_a[c] = a[(int64_t)s * Co + c];
+      s_arg[c] = arg[(int64_t)s * Co + c];
+    }
+    __syncthreads();
+    const int r0 = ch * rows_per_chunk;
+    const int r1 = (r0 + rows_per_chunk < L) ? r0 + rows_per_chunk : L;
+    for (int r = r0 + wv; r < r1; r += 4) {
+      float acc[KV];
+#pragma unroll
+      for (int u = 0; u < KV; ++u) acc[u] = 0.f;
+      bool any = false;
+      for (int c0 = 0; c0 < Co; c0 += 64) {
+        unsigned long long m = __ballot(c0 + lane < Co && s_arg[c0 + lane] == r);
+        while (m) {
+          const int c = c0 + __builtin_ctzll(m);
+          m &= m - 1;
+          const float av = s_a[c];
+          const float* wr = W + (int64_t)c * K + lane * KV;
+#pragma unroll
+          for (int u = 0; u < KV; ++u) acc[u] = fmaf(av, wr[u], acc[u]);
+          any = true;
+        }
+      }
+      if (any) {
+        float* d = dx + ((int64_t)s * L + r) * lddx + lane * KV;
+#pragma unroll
+        for (int u = 0; u < KV; ++u) d[u] += acc[u];
+      }
+    }
+  }
+}
+
+// dW partials: grid (channel blocks of 64, segment chunks); a wave owns 16 channels and sums
+// a[s,c] * x[n*(s,c),:] over the segments of its chunk in ascending s; one partial row per chunk
+// (dwp [nsc][Co][K]), folded in order by pointmlp_bwd_dw_fold_kernel.
+template <int KV>
+__global__ __launch_bounds__(256) void pointmlp_bwd_dw_kernel(const float* __restrict__ a, const int32_t* __restrict__ arg,
+                                                              const float* __restrict__ x, int64_t ldx, int Co, int L,
+                                                              int S, int nsc, float* __restrict__ dwp) {
+  constexpr int K = KV * 64;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int c0 = blockIdx.x * 64 + wv * 16;
+  const int sc = blockIdx.y;
+  const int per = (S + nsc - 1) / nsc;
+  const int sa = sc * per, sb = (sa + per < S) ? sa + per : S;
+  float acc[16][KV];
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+#pragma unroll
+    for (int u = 0; u < KV; ++u) acc[i][u] = 0.f;
+  for (int s = sa; s < sb; ++s) {
+    float av = 0.f;
+    int rw = 0;
+    if (lane < 16 && c0 + lane < Co) {
+      av = a[(int64_t)s * Co + c0 + lane];
+      rw = arg[(int64_t)s * Co + c0 + lane];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float ai = __shfl(av, i);
+      const int ri = __shfl(rw, i);
+      const float* xr = x + ((int64_t)s * L + ri) * ldx + lane * KV;
+#pragma unroll
+      for (int u = 0; u < KV; ++u) acc[i][u] = fmaf(ai, xr[u], acc[i][u]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    if (c0 + i < Co) {
+      float* d = dwp + ((int64_t)sc * Co + c0 + i) * K + lane * KV;
+#pragma unroll
+      for (int u = 0; u < KV; ++u) d[u] = acc[i][u];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void pointmlp_bwd_dw_fold_kernel(const float* __restrict__ dwp, int nsc, int64_t n,
+                                                                   float* __restrict__ dw) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  double t = 0.0;
+  for (int i = 0; i < nsc; ++i) t += (double)dwp[(int64_t)i * n + e];
+  dw[e] = (float)t;
+}
+
+}  // namespace
+
+static int pointmlp_rows_per_wg(int64_t rows, int L) {
+  // whole segments per workgroup, ~1024 rows, at most SUG_STATS_BLOCKS row blocks
+  int64_t rpw = L >= 1024 ? L : (1024 / L) * L;
+  while ((rows + rpw - 1) / rpw > SUG_STATS_BLOCKS) rpw *= 2;
+  return (int)rpw;
+}
+
+extern "C" int sug_pointmlp_max_fwd(const float* x, int64_t ldx, int64_t rows, int K, const float* w, const float* bias,
+                                    const float* gamma, int Co, int seg, float* zext, int32_t* arg, float* ws,
+                                    int* nblk, void* stream) {
+  SUG_REQUIRE(x && w && gamma && zext && arg && ws && nblk, "sug_pointmlp_max_fwd: null pointer");
+  SUG_REQUIRE(K == 64 || K == 128, "sug_pointmlp_max_fwd: K=%d (64 or 128 input channels)", K);
+  SUG_REQUIRE(Co > 0 && Co % 128 == 0, "sug_pointmlp_max_fwd: Co=%d must be a multiple of 128", Co);
+  SUG_REQUIRE(seg >= 32 && seg % 32 == 0, "sug_pointmlp_max_fwd: segment length %d must be a multiple of 32", seg);
+  SUG_REQUIRE(rows > 0 && rows % seg == 0 && rows < (1ll << 31), "sug_pointmlp_max_fwd: %lld rows are not whole segments of %d",
+              (long long)rows, seg);
+  SUG_REQUIRE(ldx >= K && ldx % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0,
+              "sug_pointmlp_max_fwd: x / w must be 16-byte aligned with row strides in multiples of 4");
+  const int rpw = pointmlp_rows_per_wg(rows, seg);
+  const int nrb = sug_divup(rows, rpw);
+  const int grid = nrb * (Co / 128);
+  hipStream_t st = (hipStream_t)stream;
+  if (K == 128) {
+    const size_t sh = (size_t)3 * TJ * (128 + 4) * sizeof(float);
+    hipLaunchKernelGGL((pointmlp_max_kernel<128>), dim3(grid), dim3(256), sh, st, x, ldx, (int)rows, w, bias, gamma, Co,
+                       seg, rpw, nrb, zext, arg, ws);
+  } else {
+    const size_t sh = (size_t)3 * TJ * (64 + 4) * sizeof(float);
+    hipLaunchKernelGGL((pointmlp_max_kernel<64>), dim3(grid), dim3(256), sh, st, x, ldx, (int)rows, w, bias, gamma, Co,
+                       seg, rpw, nrb, zext, arg, ws);
+  }
+  SUG_LAUNCH_CHECK("sug_pointmlp_max_fwd");
+  *nblk = nrb;
+  return SUG_OK;
+}
+
+extern "C" int sug_pointmlp_max_layer_fwd(const float* x, int64_t ldx, int64_t rows, int K, const float* w,
+                                          const float* bias, const float* gamma, const float* beta, int Co, int seg,
+                                          int groups, int training, float eps, float momentum, float slope,
+                                          float* running_mean, float* running_var, float* zext, int32_t* arg,
+                                          float* coef, float* out, int64_t ldo, float* ws, void* stream) {
+  SUG_REQUIRE(groups >= 1 && rows > 0 && rows % ((int64_t)groups * seg) == 0,
+              "sug_pointmlp_max_layer_fwd: %lld rows do not split into %d groups of whole segments", (long long)rows, groups);
+  SUG_REQUIRE(beta && coef && out && ldo >= Co, "sug_pointmlp_max_layer_fwd: null pointer / bad ldo");
+  const int64_t rg = rows / groups, sg = rg / seg;
+  for (int g = 0; g < groups; ++g) {
+    float* cg = coef + (int64_t)g * 5 * Co;
+    int nblk = 0;
+    int rc = sug_pointmlp_max_fwd(x + g * rg * ldx, ldx, rg, K, w, bias, gamma, Co, seg, zext + g * sg * Co,
+                                  arg + g * sg * Co, ws, &nblk, stream);
+    if (rc != SUG_OK) return rc;
+    if (training) {
+      rc = sug_stats_finalize(ws, nblk, Co, gamma, beta, (double)rg, eps, momentum, running_mean, running_var, cg,
+                              (hipStream_t)stream);
+      if (rc != SUG_OK) return rc;
+    }
+    rc = sug_affine_act(zext + g * sg * Co, Co, cg, sg, Co, slope, out + g * sg * ldo, ldo, stream);
+    if (rc != SUG_OK) return rc;
+  }
+  return SUG_OK;
+}
+
+extern "C" int64_t sug_pointmlp_max_bwd_workspace(int64_t rows, int K, int Co, int seg) {
+  const int64_t S = rows / (seg > 0 ? seg : 1);
+  int64_t nsc = S < 256 ? S : 256;
+  if (nsc < 1) nsc = 1;
+  return nsc * (int64_t)Co * K;
+}
+
+extern "C" int sug_pointmlp_max_bwd_sparse(const float* a, const int32_t* arg, const float* x, int64_t ldx,
+                                           const float* w, int64_t rows, int K, int Co, int seg, float* dx,
+                                           int64_t lddx, float* dw, float* ws, void* stream) {
+  SUG_REQUIRE(a && arg && x && w && dx && dw && ws, "sug_pointmlp_max_bwd_sparse: null pointer");
+  SUG_REQUIRE(K == 64 || K == 128, "sug_pointmlp_max_bwd_sparse: K=%d (64 or 128)", K);
+  SUG_REQUIRE(Co > 0 && Co <= 4096 && seg > 0 && rows > 0 && rows % seg == 0 && ldx >= K && lddx >= K,
+              "sug_pointmlp_max_bwd_sparse: bad shape");
+  const int64_t S = rows / seg;
+  SUG_REQUIRE(S < (1ll << 30), "sug_pointmlp_max_bwd_sparse: too many segments");
+  hipStream_t st = (hipStream_t)stream;
+  const int chunks = sug_divup(seg, 128);
+  int64_t g64 = S * chunks;
+  const int grid = (int)(g64 < 4096 ? g64 : 4096);
+  const size_t sh = (size_t)Co * 8;
+  int nsc = (int)(S < 256 ? S : 256);
+  dim3 g2(sug_divup(Co, 64), nsc);
+  if (K == 128) {
+    hipLaunchKernelGGL((pointmlp_bwd_dx_kernel<2>), dim3(grid), dim3(256), sh, st, a, arg, w, Co, seg, (int)S, chunks, dx, lddx);
+    hipLaunchKernelGGL((pointmlp_bwd_dw_kernel<2>), g2, dim3(256), 0, st, a, arg, x, ldx, Co, seg, (int)S, nsc, ws);
+  } else {
+    hipLaunchKernelGGL((pointmlp_bwd_dx_kernel<1>), dim3(grid), dim3(256), sh, st, a, arg, w, Co, seg, (int)S, chunks, dx, lddx);
+    hipLaunchKernelGGL((pointmlp_bwd_dw_kernel<1>), g2, dim3(256), 0, st, a, arg, x, ldx, Co, seg, (int)S, nsc, ws);
+  }
+  SUG_LAUNCH_CHECK("sug_pointmlp_max_bwd_sparse");
+  const int64_t n = (int64_t)Co * K;
+  hipLaunchKernelGGL(pointmlp_bwd_dw_fold_kernel, dim3(sug_divup(n, 256)), dim3(256), 0, st, ws, nsc, n, dw);
+  SUG_LAUNCH_CHECK("sug_pointmlp_max_bwd_sparse(fold)");
+  return SUG_OK;
+}

@@ -195,8 +195,7 @@ class Pointnet_g(nn.Module):
         y = self.conv2.rows(self.conv1.rows(y))
         y = torch.bmm(y, self.trans_net2.rows(y))
         y, node_fea, node_off = self.conv3.rows(y, loc)
-        y = self.conv5.rows(self.conv4.rows(y))
-        y = bn_module(self.bn1, torch.max(y, dim=1)[0])
+        y = bn_module(self.bn1, self.conv5.rows_max(self.conv4.rows(y)))
         node_fea = node_fea.transpose(1, 2).unsqueeze(-1)
         node_off = node_off.transpose(1, 2)
         if node:

@@ -87,6 +87,16 @@ class conv_2d(nn.Module):
     def forward(self, x):
         return self.rows(x.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
 
+    def rows_max(self, x):
+        """x [B,N,Cin] -> [B,Cout] = max over the N points of act(bn(conv(x))): the layer and the
+        reduction in one kernel, the [B,N,Cout] tensor is never written (sug_pointmlp_max_*;
+        Model.py:274-279, model_utils.py:72-79)."""
+        B, N, C = x.shape
+        W = self.weight2d()
+        if self.activation in _ACT_SLOPE and OWN_BN(self.conv[1]) and ops.pointmlp_max_supported(C, W.shape[0], N):
+            return ops.pointmlp_max(x, W, self.conv[0].bias, self.conv[1], _ACT_SLOPE[self.activation], N)
+        return torch.max(self.rows(x), dim=1)[0]
+
     def edge_rows(self, x, idx, return_stats=False, out=None):
         """Fused EdgeConv layer: max_k act(bn(W.[x_j - x_i ; x_i])) for x [B,N,C] rows and
         idx [B,N,k] (get_graph_feature + conv + max, model_utils.py:188-210, Model.py:88-94).
@@ -152,8 +162,7 @@ class transform_net(nn.Module):
 
     def rows(self, x):
         """x [B,N,C] -> [B,K,K]."""
-        y = self.conv2d3.rows(self.conv2d2.rows(self.conv2d1.rows(x)))
-        y = torch.max(y, dim=1)[0]
+        y = self.conv2d3.rows_max(self.conv2d2.rows(self.conv2d1.rows(x)))
         y = self.fc3(self.fc2(self.fc1(y)))
         y = y + torch.eye(self.K, device=y.device, dtype=y.dtype).view(1, self.K * self.K)
         return y.view(-1, self.K, self.K)
@@ -165,7 +174,7 @@ class transform_net(nn.Module):
         return self.rows(x.squeeze(-1).transpose(1, 2))
 
     def rows_tail(self, y):
-        y = torch.max(self.conv2d3.rows(y), dim=1)[0]
+        y = self.conv2d3.rows_max(y)
         y = self.fc3(self.fc2(self.fc1(y)))
         y = y + torch.eye(self.K, device=y.device, dtype=y.dtype).view(1, self.K * self.K)
         return y.view(-1, self.K, self.K)

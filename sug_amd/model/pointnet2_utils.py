@@ -85,12 +85,19 @@ class PointNetSetAbstraction(nn.Module):
         else:
             new_xyz, g = sample_and_group(self.npoint, self.radius, self.nsample, xyz, points)
         node = None
+        last = len(self.mlp_convs) - 1
+        out = None
         for i, conv in enumerate(self.mlp_convs):                      # g: [B,S,ns,C] rows
             w = conv.weight.view(conv.weight.shape[0], -1)
+            if i == last and ops.pointmlp_max_supported(g.shape[-1], w.shape[0], g.shape[2]):
+                # last layer + max over the group in one kernel: [B,S,ns,C'] is never written
+                out = ops.pointmlp_max(g, w, conv.bias, self.mlp_bns[i], 0.0, g.shape[2]).view(g.shape[0], g.shape[1], -1)
+                break
             g = ops.bn_act_rows(ops.linear_rows(g, w, conv.bias), self.mlp_bns[i], 0.0)
             if adapt and i == 1:
                 node = g
-        out = torch.max(g, dim=2)[0]
+        if out is None:
+            out = torch.max(g, dim=2)[0]
         if adapt:
             return new_xyz, out, torch.max(node, dim=2)[0]
         return new_xyz, out

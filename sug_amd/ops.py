@@ -707,6 +707,114 @@ def edgeconv_bn_act_max(pq, idx, gamma, beta, running_mean, running_var, trainin
                            None if out is None else [out])
 
 
+# ----------------------------------------------------------------------------- per-point MLP + max
+def pointmlp_max_supported(K, Co, seg):
+    return K in (64, 128) and Co % 128 == 0 and seg >= 32 and seg % 32 == 0
+
+
+class _PointMLPMax(torch.autograd.Function):
+    """max over `seg` consecutive rows of act(BN(x . W^T + b)) without ever storing the [rows, Co]
+    product (sug_pointmlp_max_*).  Backward: the rows that won a channel get a[s,c]*W[c,:]
+    (sug_pointmlp_max_bwd_sparse); the train-mode BatchNorm statistics terms, which are dense over the
+    rows but of rank K, are -(x.A + v) with A = W^T diag(k2) W -- one [rows,K]x[K,K] GEMM instead of
+    the [rows,Co]x[Co,K] one -- and the matching weight-gradient term comes from X^T X."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, training, slope, eps, momentum, seg, G):
+        _need_gpu(x, weight, gamma)
+        K = x.shape[-1]
+        x2 = x.reshape(-1, K)
+        if x2.stride(1) != 1 or x2.stride(0) % 4 or x2.data_ptr() % 16:
+            x2 = x2.contiguous()
+        rows, Co = x2.shape[0], weight.shape[0]
+        if rows % (G * seg):
+            raise RuntimeError('pointmlp_max: %d rows do not split into %d groups of %d-row segments' % (rows, G, seg))
+        S = rows // seg
+        dev = x.device
+        w2 = weight.detach().reshape(Co, K).contiguous()
+        b1 = None if bias is None else bias.detach().contiguous()
+        g, b = gamma.detach().contiguous(), beta.detach().contiguous()
+        zext = torch.empty(S, Co, dtype=torch.float32, device=dev)
+        arg = torch.empty(S, Co, dtype=torch.int32, device=dev)
+        out = torch.empty(S, Co, dtype=torch.float32, device=dev)
+        ws = torch.empty(STATS_BLOCKS * 2 * Co, dtype=torch.float32, device=dev)
+        if training:
+            coef = torch.empty(G, 5, Co, dtype=torch.float32, device=dev)
+        else:
+            coef = eval_coef(g, b, running_mean, running_var, eps).unsqueeze(0).repeat(G, 1, 1)
+        check(_timed('pointmlp_max_K%d_Co%d' % (K, Co), {'B': rows, 'N': seg, 'k': K, 'Co': Co},
+                     lambda: lib().sug_pointmlp_max_layer_fwd(_p(x2), x2.stride(0), rows, K, _p(w2), _p(b1), _p(g), _p(b),
+                                                              Co, seg, G, 1 if training else 0, eps, momentum,
+                                                              float(slope), _p(running_mean), _p(running_var), _p(zext),
+                                                              _p(arg), _p(coef), _p(out), Co, _p(ws), _st())),
+              'sug_pointmlp_max_layer_fwd')
+        if any(ctx.needs_input_grad[i] for i in (0, 1, 2, 3, 4)):
+            ctx.save_for_backward(x2, w2, b1, zext, arg, coef)
+            ctx.meta = (rows, K, Co, seg, G, float(slope), bool(training), tuple(x.shape), tuple(weight.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x2, w2, b1, zext, arg, coef = ctx.saved_tensors
+        rows, K, Co, seg, G, slope, training, xshape, wshape = ctx.meta
+        dev = gout.device
+        S = rows // seg
+        rg, sg = rows // G, S // G
+        gout = gout.reshape(S, Co)
+        if gout.stride(1) != 1:
+            gout = gout.contiguous()
+        a = torch.empty(S, Co, dtype=torch.float32, device=dev)
+        red = torch.empty(G, 2 * Co, dtype=torch.float64, device=dev)
+        ws = torch.empty(STATS_BLOCKS * 2 * Co, dtype=torch.float32, device=dev)
+        dx = torch.empty(rows, K, dtype=torch.float32, device=dev) if training else \
+            torch.zeros(rows, K, dtype=torch.float32, device=dev)
+        dw = torch.zeros(Co, K, dtype=torch.float32, device=dev)
+        dws = torch.empty(Co, K, dtype=torch.float32, device=dev)
+        wsp = torch.empty(int(lib().sug_pointmlp_max_bwd_workspace(rg, K, Co, seg)), dtype=torch.float32, device=dev)
+        L = lib()
+        for gi in range(G):
+            xg = x2[gi * rg:(gi + 1) * rg]
+            zg, ag, cg = zext[gi * sg:(gi + 1) * sg], a[gi * sg:(gi + 1) * sg], coef[gi]
+            gg = gout[gi * sg:(gi + 1) * sg]
+            check(L.sug_edgeconv_bwd_reduce(_p(gg), gg.stride(0), _p(zg), _p(cg), sg, Co, slope, _p(ag), _p(red[gi]), _p(ws),
+                                            _st()), 'sug_edgeconv_bwd_reduce')
+            dxg = dx[gi * rg:(gi + 1) * rg]
+            if training:
+                # dy = a_full - (scale/M)(dbeta + xhat*dgamma) = a_full - k1 - k2*y over ALL rows, y = x.W^T + b
+                scale, mean, rstd = cg[0].double(), cg[2].double(), cg[3].double()
+                dbeta, dgamma = red[gi, :Co], red[gi, Co:]
+                k2d = scale / rg * rstd * dgamma
+                k1d = scale / rg * (dbeta - mean * rstd * dgamma)
+                kb = (k1d + (k2d * b1.double() if b1 is not None else 0.0)).float()
+                k2 = k2d.float()
+                wk = w2 * k2.unsqueeze(1)                                   # diag(k2) W
+                xtx = torch.empty(K, K, dtype=torch.float32, device=dev)
+                wsx = torch.empty(int(L.sug_linear_dw_workspace(rg, K, K)), dtype=torch.float32, device=dev)
+                check(L.sug_linear_dw(_p(xg), xg.stride(0), _p(xg), xg.stride(0), rg, K, K, _p(xtx), _p(wsx), _st()),
+                      'sug_linear_dw')
+                sx = xg.sum(dim=0, dtype=torch.float64).float()
+                torch.addmm((kb @ w2).neg(), xg, wk.t() @ w2, alpha=-1.0, out=dxg)     # -(x.A + v)
+                dw.sub_(kb.unsqueeze(1) * sx.unsqueeze(0)).sub_(wk @ xtx)
+            check(L.sug_pointmlp_max_bwd_sparse(_p(ag), _p(arg[gi * sg:(gi + 1) * sg]), _p(xg), xg.stride(0), _p(w2), rg, K,
+                                                Co, seg, _p(dxg), K, _p(dws), _p(wsp), _st()),
+                  'sug_pointmlp_max_bwd_sparse')
+            dw.add_(dws)
+        rf = red[0].float() if G == 1 else red.sum(0, dtype=torch.float32)
+        db = None
+        if b1 is not None:
+            # a bias in front of train-mode BatchNorm has zero gradient identically
+            db = torch.zeros_like(b1) if training else a.sum(dim=0)
+        return dx.view(xshape), dw.view(wshape), db, rf[Co:], rf[:Co], None, None, None, None, None, None, None, None
+
+
+def pointmlp_max(x, weight, bias, bn, slope, seg):
+    """x [..., K] rows (segments of `seg` consecutive rows), weight [Co, K(,1,1)], bn an nn.BatchNorm
+    module -> [rows/seg, Co] = max over each segment of LeakyReLU_slope(bn(x.W^T + b))."""
+    _count_bn_call(bn)
+    return _PointMLPMax.apply(x, weight, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training,
+                              slope, bn.eps, bn.momentum, seg, BN_GROUPS)
+
+
 # ----------------------------------------------------------------------------- concat without copies
 class _AssembleRows(torch.autograd.Function):
     """torch.cat(parts, dim=-1) for parts that (mostly) already live in column slices of `buf`

@@ -1,0 +1,109 @@
+"""GPU parity of the fused per-point MLP + max kernel (sug_pointmlp_max_*) against the operator the
+reference composes (model/Model.py:274-279, model/model_utils.py:72-79, model/pointnet2_utils.py:193-207):
+1x1 conv (+bias) -> train-mode BatchNorm -> ReLU -> max over the points of a segment, written in
+plain fp32 torch with the full [rows, Co] tensor.  Tolerance 1e-4 forward (north star)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _reference(x, W, b, bn, seg, slope, groups):
+    outs = []
+    for xg in x.chunk(groups, dim=0):
+        y = xg @ W.t()
+        if b is not None:
+            y = y + b
+        z = torch.nn.functional.leaky_relu(bn(y), slope)
+        outs.append(z.view(-1, seg, z.shape[1]).max(dim=1)[0])
+    return torch.cat(outs)
+
+
+@pytest.mark.parametrize('B,seg,K,Co,groups,bias,train', [
+    (4, 1024, 128, 1024, 1, True, True),      # PointNet conv5 / T-Net conv2d3 + global max
+    (4, 1024, 128, 1024, 2, True, True),      # paired domains: BatchNorm per half
+    (96, 32, 64, 128, 1, True, True),         # PointNet++ sa1 last layer, nsample = 32
+    (40, 64, 128, 256, 2, True, True),        # sa2 last layer, nsample = 64
+    (3, 96, 64, 128, 1, False, True),         # segment of 3 tiles, no bias, odd segment count
+    (4, 1024, 128, 1024, 1, True, False),     # eval mode (running statistics)
+])
+def test_pointmlp_max_vs_torch(B, seg, K, Co, groups, bias, train):
+    from sug_amd import ops
+    g = torch.Generator().manual_seed(B + seg + Co)
+    x = torch.randn(B * seg, K, generator=g).cuda()
+    W = (torch.randn(Co, K, generator=g) / K ** 0.5).cuda()
+    b = (torch.randn(Co, generator=g) * 0.1).cuda() if bias else None
+    gam = torch.randn(Co, generator=g).cuda()              # mixed signs: max and min channels
+    bet = (torch.randn(Co, generator=g) * 0.2).cuda()
+    probe = torch.randn(B, Co, generator=g).cuda()
+
+    def make_bn():
+        bn = torch.nn.BatchNorm1d(Co).cuda().train(train)
+        with torch.no_grad():
+            bn.weight.copy_(gam)
+            bn.bias.copy_(bet)
+            bn.running_mean.copy_(torch.linspace(-0.2, 0.2, Co))
+            bn.running_var.copy_(torch.linspace(0.5, 1.5, Co))
+        return bn
+
+    bn_r, bn_k = make_bn(), make_bn()
+    xr, Wr = x.clone().requires_grad_(True), W.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if bias else None
+    ref = _reference(xr, Wr, br, bn_r, seg, 0.0, groups)
+    (ref * probe).sum().backward()
+
+    xk, Wk = x.clone().requires_grad_(True), W.clone().requires_grad_(True)
+    bk = b.clone().requires_grad_(True) if bias else None
+    with ops.bn_groups(groups):
+        out = ops.pointmlp_max(xk, Wk, bk, bn_k, 0.0, seg)
+    (out * probe).sum().backward()
+
+    torch.testing.assert_close(out, ref, rtol=1e-4, atol=1e-4)
+
+    def rel(a, b_):
+        return float((a - b_).norm() / b_.norm().clamp_min(1e-12))
+
+    assert rel(xk.grad, xr.grad) < 1e-3, 'dx %.3e' % rel(xk.grad, xr.grad)
+    assert rel(Wk.grad, Wr.grad) < 1e-3, 'dW %.3e' % rel(Wk.grad, Wr.grad)
+    assert rel(bn_k.weight.grad, bn_r.weight.grad) < 1e-3
+    assert rel(bn_k.bias.grad, bn_r.bias.grad) < 1e-3
+    if bias:
+        if train:       # zero in exact arithmetic; the reference's value is rounding noise
+            assert float(bk.grad.abs().max()) <= 1e-3 * float(probe.abs().sum() / Co) + 1e-6
+            assert float(br.grad.abs().max()) <= 1e-3 * float(probe.abs().sum() / Co) + 1e-4
+        else:
+            assert rel(bk.grad, br.grad) < 1e-3
+    if train:
+        torch.testing.assert_close(bn_k.running_mean, bn_r.running_mean, rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(bn_k.running_var, bn_r.running_var, rtol=1e-4, atol=1e-5)
+        assert int(bn_k.num_batches_tracked) == groups
+
+
+def test_pointmlp_max_is_deterministic_and_full_size():
+    """Config-3 sa1 shape (64 clouds x 512 groups x 32 samples = 1M rows, 64 -> 128 channels) and the
+    PointNet conv5 shape at 64 clouds: bit-reproducible forward and backward, finite, and equal to the
+    unfused composition within 1e-4."""
+    from sug_amd import ops
+    for B, seg, K, Co in ((64 * 512, 32, 64, 128), (64, 1024, 128, 1024)):
+        g = torch.Generator().manual_seed(seg)
+        x = torch.randn(B * seg, K, generator=g).cuda()
+        W = (torch.randn(Co, K, generator=g) / K ** 0.5).cuda()
+        b = (torch.randn(Co, generator=g) * 0.1).cuda()
+        probe = torch.randn(B, Co, generator=g).cuda()
+        res = []
+        for _ in range(2):
+            bn = torch.nn.BatchNorm1d(Co).cuda().train()
+            with torch.no_grad():
+                bn.weight.copy_(torch.linspace(-1, 1, Co))
+            xi, Wi = x.clone().requires_grad_(True), W.clone().requires_grad_(True)
+            out = ops.pointmlp_max(xi, Wi, b, bn, 0.0, seg)
+            (out * probe).sum().backward()
+            res.append((out.detach(), xi.grad, Wi.grad, bn.weight.grad, bn.running_var.clone()))
+        for u, v in zip(res[0], res[1]):
+            assert torch.equal(u, v)
+        assert all(bool(torch.isfinite(t).all()) for t in res[0])
+        bn = torch.nn.BatchNorm1d(Co).cuda().train()
+        with torch.no_grad():
+            bn.weight.copy_(torch.linspace(-1, 1, Co))
+        ref = _reference(x, W, b, bn, seg, 0.0, 1)
+        torch.testing.assert_close(res[0][0], ref, rtol=1e-4, atol=1e-4)
