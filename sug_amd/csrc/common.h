@@ -33,6 +33,9 @@ int sug_knn_mfma(const float* x, int64_t ldx, int B, int N, int C, int k, int32_
 int sug_stats_finalize(const float* ws, int nblk, int C, const float* gamma, const float* beta, double count, float eps,
                        float momentum, float* running_mean, float* running_var, float* coef, hipStream_t st);
 
+// knn_pc.hip: producer / consumer MFMA kNN (C in {3, 64, 128}, k <= 20)
+int sug_knn_pc(const float* x, int64_t ldx, int B, int N, int C, int k, int32_t* idx, hipStream_t st);
+
 #define WAVE 64
 
 // Opt-in to more than 64 KB of dynamic LDS for one kernel.  The attribute is per DEVICE, so the

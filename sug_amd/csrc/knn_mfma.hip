@@ -21,6 +21,7 @@
 #include "common.h"
 #include "mfma_tile.h"
 #include <type_traits>
+#include <stdlib.h>
 
 #ifdef SUG_KNN_STAMP      // diagnostic build only (tools/bench_knn.py): per-phase cycle stamps of block 0
 __device__ unsigned long long g_knn_stamp[16];
@@ -702,6 +703,10 @@ int sug_knn_mfma_supported(const float* x, int64_t ldx, int C, int k) {
 }
 
 int sug_knn_mfma(const float* x, int64_t ldx, int B, int N, int C, int k, int32_t* idx, hipStream_t st) {
+  // default: the producer / consumer kernel (knn_pc.hip).  SUG_KNN_LEGACY=1 selects the single-wave
+  // kernels of this file (kept for A/B timing, tools/bench_knn.py).
+  static const bool legacy = [] { const char* e = getenv("SUG_KNN_LEGACY"); return e && e[0] == '1'; }();
+  if (!legacy) return sug_knn_pc(x, ldx, B, N, C, k, idx, st);
   if (k <= 16) return dispatch<16>(x, ldx, B, N, C, k, idx, st);
   return dispatch<20>(x, ldx, B, N, C, k, idx, st);
 }
