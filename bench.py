@@ -60,7 +60,17 @@ def kernel_model(name, shape):
     if name.startswith(('edgeconv_bwd', 'edgeconv_layer_bwd')):     # layer call: + reverse lists + BN sums
         Co = shape['Co']            # read a, arg, s1, PQ, rev lists; write dPQ (8Co)
         return {'bytes': B * N * (4 * Co + Co + 4 * Co + 8 * Co + 8 * Co + 4 * k + 4), 'flops': B * N * k * Co * 4}
+    if name.startswith('pointmlp_max'):             # shape: B = rows, N = segment length, k = input channels
+        R, L, K, Co = shape['B'], shape['N'], shape['k'], shape['Co']
+        return {'bytes': 4 * R * K + 4 * Co * K + 8 * (R // L) * Co, 'flops': 2 * R * K * Co}
     return {'bytes': 0, 'flops': 0}
+
+
+# The shipped METHODS block (tools/cfgs/cfgs_local/DG_unified_loss.yaml:13-30): soft MMD on both levels,
+# SDA weights on both ('mean2one'); TARGET_LOSS / class weighting are data-loader-side options left off.
+BENCH_METHODS = {'GEO_MMD': [{'NAME': 'SOFT_MMD', 'LABEL_SCALE': 50, 'GEO_WEIGHTS': 'mean2one', 'GEO_SCALE': 1}],
+                 'SEM_MMD': [{'NAME': 'SOFT_MMD', 'LABEL_SCALE': 5, 'SEM_WEIGHTS': 'mean2one', 'LABEL_WEIGHT': 0.5,
+                              'SEM_SCALE': 1}]}
 
 
 def cpu_baseline(B, N, steps=1):
@@ -81,12 +91,12 @@ def cpu_baseline(B, N, steps=1):
     opt = [torch.optim.Adam([v for k, v in p.items() if k.startswith('g.') and v.requires_grad and 'pred_offset' not in k], lr=1e-3, weight_decay=5e-5),
            torch.optim.Adam([v for k, v in p.items() if k.startswith(('c1.', 'c2.')) and v.requires_grad], lr=1e-3, weight_decay=5e-5),
            torch.optim.Adam(g + [v for k, v in p.items() if k.startswith('attention') and v.requires_grad], lr=1e-3, weight_decay=5e-5)]
-    sem = dict(O.SEM_CFG)
+    geo, sem = dict(BENCH_METHODS['GEO_MMD'][0]), dict(BENCH_METHODS['SEM_MMD'][0])
 
     def run(batch, n):
         data, lab, data_t, lab_t = synth(batch, N, 666, 'cpu')
         for _ in range(n):
-            lc, lg, ls = O.sug_losses(p, 'DGCNN', data, lab, data_t, lab_t, O.GEO_CFG, sem, drop_p=0.4)
+            lc, lg, ls = O.sug_losses(p, 'DGCNN', data, lab, data_t, lab_t, geo, sem, drop_p=0.4)
             (lc + lg + ls).backward()
             opt[2].step(); opt[0].step(); opt[1].step()
             for o in opt:
@@ -126,8 +136,10 @@ def main():
     ap.add_argument('--batch', type=int, default=32, help='clouds per domain per GPU')
     ap.add_argument('--npoints', type=int, default=1024)
     ap.add_argument('--model', default='DGCNN')
-    ap.add_argument('--cpu-batch', type=int, default=16, help='per-domain batch of the CPU baseline sample')
-    ap.add_argument('--cpu-steps', type=int, default=2)
+    ap.add_argument('--cpu-batch', type=int, default=32, help='per-domain batch of the CPU baseline sample (default: the GPU workload)')
+    ap.add_argument('--cpu-steps', type=int, default=3)
+    ap.add_argument('--caller-steps', type=int, default=10,
+                    help='extra timed steps in the unchanged-caller form (four separate model(...) calls, no sharing); 0 = skip')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--graph', action='store_true',
                     help='replay the step from a hipGraph (opt-in; same speed as eager when the step is GPU-bound)')
@@ -175,7 +187,7 @@ def main():
         for t in list(model.parameters()) + list(model.buffers()):
             dist.broadcast(t.data, 0)
     trainer = SUGStep(model, lr=1e-3, weight_decay=5e-5, share_prefix=not args.no_share_prefix,
-                      use_graph=args.graph, pair_domains=not args.no_pair)
+                      use_graph=args.graph, pair_domains=not args.no_pair, methods=BENCH_METHODS)
     B, N = args.batch, args.npoints
     data, lab, data_t, lab_t = synth(B, N, 666 + rank, dev)
     torch.manual_seed(666 + rank)                       # FPS start draws, per rank (train_dg.py:78)
@@ -209,6 +221,36 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     prof, ops.PROFILE = (graph_prof if trainer.use_graph else ops.PROFILE), None
+    # the other hand-written layer kernels (EdgeConv forward / backward layer calls, per-point MLP + max):
+    # a few extra steps outside the timed region, for the `kernels` table only
+    if not trainer.use_graph:
+        ops.PROFILE_ONLY, ops.PROFILE = {'edgeconv', 'pointmlp'}, {}
+        for _ in range(5):
+            trainer.step(data, lab, data_t, lab_t)
+        sync()
+        extra_prof, ops.PROFILE, ops.PROFILE_ONLY = ops.PROFILE, None, {'knn'}
+    else:
+        extra_prof = {}
+    # The same workload the way train_dg_single_gpu.py:260-310 calls the API: four separate model(...)
+    # calls per step, nothing shared between them (the headline uses the exact restructurings of
+    # paired domains + shared prefix).
+    caller_ms = None
+    if args.caller_steps > 0 and not trainer.use_graph and (trainer.pair_domains or trainer.share_prefix):
+        keep = (trainer.pair_domains, trainer.share_prefix)
+        trainer.pair_domains = trainer.share_prefix = False
+        if hasattr(model.g, 'share_prefix'):
+            model.g.share_prefix = False
+        for m_ in trainer._split_layers:
+            m_.cache_weight_split = False
+        for _ in range(3):
+            trainer.step(data, lab, data_t, lab_t)
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(args.caller_steps):
+            trainer.step(data, lab, data_t, lab_t)
+        sync()
+        caller_ms = 1e3 * (time.perf_counter() - t1) / args.caller_steps
+        trainer.pair_domains, trainer.share_prefix = keep
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -220,17 +262,21 @@ def main():
         value = clouds / dt
         # ---- per-kernel live timings (events on the launch stream) -> roofline of the dominant one
         kern = {}
-        for name, recs in prof.items():
+        timed_names = set(prof)
+        for name, recs in list(prof.items()) + list(extra_prof.items()):
             ms = [a.elapsed_time(b) for a, b, _ in recs]
             shape = recs[0][2]
             mdl = kernel_model(name, shape)
             avg = sum(ms) / len(ms)
-            kern[name] = {'launches': len(ms), 'avg_ms': avg, 'total_ms': sum(ms),
-                          'GBps': mdl['bytes'] / avg / 1e6 if avg > 0 else 0.0,
-                          'TFLOPs': mdl['flops'] / avg / 1e9 if avg > 0 else 0.0, 'bytes': mdl['bytes']}
+            gbps = mdl['bytes'] / avg / 1e6 if avg > 0 else 0.0
+            tfl = mdl['flops'] / avg / 1e9 if avg > 0 else 0.0
+            cb = mdl['flops'] / max(mdl['bytes'], 1) > FP32_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS
+            kern[name] = {'launches': len(ms), 'avg_ms': avg, 'total_ms': sum(ms), 'GBps': gbps, 'TFLOPs': tfl,
+                          'bytes': mdl['bytes'], 'bound': 'mfma' if cb else 'hbm',
+                          'frac': tfl / FP32_PEAK_TFLOPS if cb else gbps / HBM_PEAK_GBS}
         roofline = None
         if kern:
-            dom = max(kern, key=lambda n: kern[n]['total_ms'])
+            dom = max(timed_names, key=lambda n: kern[n]['total_ms'])
             kd = kern[dom]
             ai = kernel_model(dom, prof[dom][0][2])
             compute_bound = ai['flops'] / max(ai['bytes'], 1) > FP32_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS
@@ -246,7 +292,7 @@ def main():
             # process): only for the shape they were taken on
             try:
                 pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles',
-                                                  'r01_pmc_traffic.json'))).get(dom)
+                                                  'r02_pmc_traffic.json'))).get(dom)
                 shp = prof[dom][0][2]
                 if pmc and all(pmc[k] == shp[k] for k in ('B', 'N', 'k')):
                     roofline['traffic'] = pmc['traffic_bytes']
@@ -270,7 +316,8 @@ def main():
                           'global_batch': world * B, 'parallelism': 'dp%d' % world,
                           'launch': 'hipGraph replay of the whole step' if trainer.use_graph else 'eager',
                           'share_prefix': trainer.share_prefix, 'pair_domains': trainer.pair_domains,
-                          'tuned_gemms': tuned},
+                          'tuned_gemms': tuned, 'geo_weights': 'mean2one', 'sem_weights': 'mean2one',
+                          'unchanged_caller_ms_per_step': caller_ms},
                'roofline': roofline, 'cpu_baseline': cpu, 'losses': loss_vals,
                'kernels': {k: {kk: (round(vv, 5) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in kern.items()}}
         print(json.dumps(out))

@@ -353,10 +353,23 @@ int sug_pointmlp_max_bwd_sparse(const float* a, const int32_t* arg, const float*
 int sug_mmd_rbf(const float* z, int64_t ldz, int m, int D, const float* w,
                 const float* neg_gamma, int nsigma, double* sums, float* wt, void* stream);
 
-/* Backward of sug_mmd_rbf for 2m <= 128: dz[i,:] = gscale[0] * 2 * (rowsum(wt)[i]*z[i,:] - (wt.z)[i,:])
+/* Backward of sug_mmd_rbf: dz[i,:] = gscale[0] * 2 * (rowsum(wt)[i]*z[i,:] - (wt.z)[i,:])
  * (the autograd of model/mmd.py:239-312 w.r.t. the features); gscale: device scalar = dL/dmmd2. */
 int sug_mmd_rbf_bwd(const float* z, int64_t ldz, const float* wt, int m, int D, const float* gscale,
                     float* dz, int64_t lddz, void* stream);
+
+/* Row-block forms for the batch-sharded global MMD (no reference counterpart: the WIP DDP
+ * trainer uses per-rank MMD, train_dg.py:357-368).  z is the gathered [2m, D] matrix (all ranks' X rows,
+ * then all ranks' Y rows); this rank owns X rows [row0, row0+mloc) and Y rows m + [row0, row0+mloc).
+ * sug_mmd_rbf_rows adds the contributions of the pairs (i in own rows, j in all columns) to sums[0..2]
+ * (the ranks' partial sums are then added: an all-reduce of 3 doubles) and writes wt for the own rows
+ * only, [2*mloc, 2m]; sug_mmd_rbf_rows_bwd turns that into the gradient of the OWN rows,
+ * dz [2*mloc, D] = gmul * gscale[0] * 2 * (rowsum(wt) z_i - wt.z): no collective in the backward.
+ * row0 = 0, mloc = m are sug_mmd_rbf / sug_mmd_rbf_bwd. */
+int sug_mmd_rbf_rows(const float* z, int64_t ldz, int m, int D, const float* w, const float* neg_gamma,
+                     int nsigma, int row0, int mloc, double* sums, float* wt, void* stream);
+int sug_mmd_rbf_rows_bwd(const float* z, int64_t ldz, const float* wt, int m, int D, int row0, int mloc,
+                         const float* gscale, float gmul, float* dz, int64_t lddz, void* stream);
 
 /* SDA sample weights from class probabilities: prob_weights_soft + distance2weights,
  * model/mmd.py:134-148 and :178-202 (the reference computes them on the CPU with scipy's kl_div).

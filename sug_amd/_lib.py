@@ -51,6 +51,8 @@ SIGNATURES = {
                             _vp, _vp],
     'sug_col_stats_bn': [_vp, _i64, _i64, _i32, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp],
     'sug_bn_replay': [_vp, _i32, _i32, _f32, _vp, _vp, _vp],
+    'sug_mmd_rbf_rows': [_vp, _i64, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
+    'sug_mmd_rbf_rows_bwd': [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _f32, _vp, _i64, _vp],
     'sug_mmd_rbf_bwd': [_vp, _i64, _vp, _i32, _i32, _vp, _vp, _i64, _vp],
     'sug_sda_prob_weights': [_vp, _i64, _vp, _i64, _vp, _vp, _i32, _i32, _f32, _i32, _vp, _vp],
     'sug_adam_step': [_vp, _vp, _vp, _i32, _vp, _f64, _f64, _f64, _f64, _f64, _f64, _f64, _vp],

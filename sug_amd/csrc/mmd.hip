@@ -15,7 +15,15 @@ constexpr int TI = 16;
 constexpr int DK = 64;
 
 // Kernel value, its derivative coefficient and the contribution of pair (i,j) to the three sums.
-__device__ __forceinline__ void pair_epilogue(int i, int j, int m, float g, float ni, float nj,
+// Row blocks (batch-sharded global MMD): a rank evaluates only the rows of Z = [X;Y] that
+// belong to its own samples -- local row li in [0, 2*mloc) is global row row0 + li (li < mloc: its
+// X rows) or m + row0 + li - mloc (its Y rows) -- against all 2m columns.  row0 = 0, mloc = m is the
+// whole matrix.  wt is stored by LOCAL row: [2*mloc, 2m].
+__device__ __forceinline__ int global_row(int li, int m, int row0, int mloc) {
+  return li < mloc ? row0 + li : m + row0 + (li - mloc);
+}
+
+__device__ __forceinline__ void pair_epilogue(int li, int i, int j, int m, float g, float ni, float nj,
                                               const float* __restrict__ w, const float* __restrict__ neg_gamma,
                                               int ns, float* __restrict__ wt, float& kxx, float& kyy, float& kxy) {
   const int M2 = 2 * m;
@@ -47,13 +55,13 @@ __device__ __forceinline__ void pair_epilogue(int i, int j, int m, float g, floa
     }
     // e_ii is identically 0: no gradient, and keeping cf*Kp_ii (huge) on the diagonal would
     // cancel catastrophically in dZ = 2*(diag(rowsum(wt)) - wt).Z
-    if (wt) wt[(int64_t)i * M2 + j] = (i == j) ? 0.f : cf * Kp;
+    if (wt) wt[(int64_t)li * M2 + j] = (i == j) ? 0.f : cf * Kp;
   }
 }
 
 __global__ __launch_bounds__(256) void mmd_rbf_kernel(const float* __restrict__ z, int64_t ldz, int m,
                                                       int D, const float* __restrict__ w,
-                                                      const float* __restrict__ neg_gamma, int ns,
+                                                      const float* __restrict__ neg_gamma, int ns, int row0, int mloc,
                                                       double* __restrict__ sums,
                                                       float* __restrict__ wt) {
   __shared__ float s_a[TI][DK + 1];
@@ -61,8 +69,10 @@ __global__ __launch_bounds__(256) void mmd_rbf_kernel(const float* __restrict__ 
   __shared__ double s_sum[3];
   const int M2 = 2 * m;
   const int ti = threadIdx.x / TI, tj = threadIdx.x % TI;
-  const int i0 = blockIdx.y * TI, j0 = blockIdx.x * TI;
-  const int i = i0 + ti, j = j0 + tj;
+  const int i0 = blockIdx.y * TI, j0 = blockIdx.x * TI;        // i0: LOCAL row of the tile
+  const int li = i0 + ti, j = j0 + tj;
+  const int ML = 2 * mloc;
+  const int i = li < ML ? global_row(li, m, row0, mloc) : M2;
   if (threadIdx.x < 3) s_sum[threadIdx.x] = 0.0;
   float g = 0.f, ni = 0.f, nj = 0.f;
   for (int d0 = 0; d0 < D; d0 += DK) {
@@ -70,7 +80,7 @@ __global__ __launch_bounds__(256) void mmd_rbf_kernel(const float* __restrict__ 
     for (int e = threadIdx.x; e < TI * DK; e += 256) {
       const int r = e / DK, c = e % DK;
       const int d = d0 + c;
-      const int ra = i0 + r, rb = j0 + r;
+      const int ra = (i0 + r) < ML ? global_row(i0 + r, m, row0, mloc) : M2, rb = j0 + r;
       s_a[r][c] = (ra < M2 && d < D) ? z[(int64_t)ra * ldz + d] : 0.f;
       s_b[r][c] = (rb < M2 && d < D) ? z[(int64_t)rb * ldz + d] : 0.f;
     }
@@ -84,7 +94,7 @@ __global__ __launch_bounds__(256) void mmd_rbf_kernel(const float* __restrict__ 
     }
   }
   float kxx = 0.f, kyy = 0.f, kxy = 0.f;
-  if (i < M2 && j < M2) pair_epilogue(i, j, m, g, ni, nj, w, neg_gamma, ns, wt, kxx, kyy, kxy);
+  if (i < M2 && j < M2) pair_epilogue(li, i, j, m, g, ni, nj, w, neg_gamma, ns, wt, kxx, kyy, kxy);
   double dxx = wave_sum_d((double)kxx), dyy = wave_sum_d((double)kyy), dxy = wave_sum_d((double)kxy);
   if ((threadIdx.x & (WAVE - 1)) == 0) {
     atomicAdd(&s_sum[0], dxx);
@@ -102,13 +112,14 @@ __global__ __launch_bounds__(256) void mmd_rbf_kernel(const float* __restrict__ 
 // so e_ii is still exactly 0.  (2m/4)^2 workgroups instead of (2m/16)^2.
 __global__ __launch_bounds__(256) void mmd_rbf_small_kernel(const float* __restrict__ z, int64_t ldz, int m,
                                                             int D, const float* __restrict__ w,
-                                                            const float* __restrict__ neg_gamma, int ns,
-                                                            double* __restrict__ sums,
+                                                            const float* __restrict__ neg_gamma, int ns, int row0,
+                                                            int mloc, double* __restrict__ sums,
                                                             float* __restrict__ wt) {
   __shared__ double s_sum[3];
   const int M2 = 2 * m;
   const int l16 = threadIdx.x & 15, pr = threadIdx.x >> 4;
-  const int i = blockIdx.y * 4 + (pr >> 2), j = blockIdx.x * 4 + (pr & 3);
+  const int li = blockIdx.y * 4 + (pr >> 2), j = blockIdx.x * 4 + (pr & 3);
+  const int i = li < 2 * mloc ? global_row(li, m, row0, mloc) : M2;
   if (threadIdx.x < 3) s_sum[threadIdx.x] = 0.0;
   __syncthreads();
   float g = 0.f, ni = 0.f, nj = 0.f;
@@ -130,7 +141,7 @@ __global__ __launch_bounds__(256) void mmd_rbf_small_kernel(const float* __restr
     nj += __shfl_xor(nj, o);
   }
   float kxx = 0.f, kyy = 0.f, kxy = 0.f;
-  if (l16 == 0 && i < M2 && j < M2) pair_epilogue(i, j, m, g, ni, nj, w, neg_gamma, ns, wt, kxx, kyy, kxy);
+  if (l16 == 0 && i < M2 && j < M2) pair_epilogue(li, i, j, m, g, ni, nj, w, neg_gamma, ns, wt, kxx, kyy, kxy);
   double dxx = wave_sum_d((double)kxx), dyy = wave_sum_d((double)kyy), dxy = wave_sum_d((double)kxy);
   if ((threadIdx.x & (WAVE - 1)) == 0) {
     atomicAdd(&s_sum[0], dxx);
@@ -167,28 +178,50 @@ __global__ __launch_bounds__(256) void chamfer_dir_kernel(const float* __restric
 }
 
 
-// dZ[i,:] = scale * 2 * (rowsum(wt)[i] * Z[i,:] - sum_j wt[i,j] Z[j,:]) for small 2m (<= 128 rows):
-// workgroup = (64 columns of D) x 4 row groups; Z columns through LDS, wt rows broadcast.
+// dZ[li,:] = scale * 2 * (rowsum(wt)[li] * Z[i,:] - sum_j wt[li,j] Z[j,:]) for the local rows li (global
+// row i, see global_row) over all 2m columns j: workgroup = (64 columns of D) x 4 row groups; the Z
+// column panel goes through LDS in chunks of JT rows, wt rows are broadcast reads.
+constexpr int JT = 128;
 __global__ __launch_bounds__(256) void mmd_bwd_kernel(const float* __restrict__ z, int64_t ldz,
-                                                      const float* __restrict__ wt, int M2, int D,
-                                                      const float* __restrict__ gscale,
+                                                      const float* __restrict__ wt, int m, int D, int row0, int mloc,
+                                                      const float* __restrict__ gscale, float gmul,
                                                       float* __restrict__ dz, int64_t lddz) {
-  extern __shared__ float s_z[];                 // [M2][64]
+  __shared__ float s_z[JT * 64];
+  const int M2 = 2 * m, ML = 2 * mloc;
   const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const int d = blockIdx.x * 64 + c;
-  for (int j = rg; j < M2; j += 4) s_z[j * 64 + c] = d < D ? z[(int64_t)j * ldz + d] : 0.f;
-  __syncthreads();
-  if (d >= D) return;
-  const float g2 = 2.f * gscale[0];
-  for (int i = rg; i < M2; i += 4) {
-    const float* w = wt + (int64_t)i * M2;
-    float rs = 0.f, acc = 0.f;
-    for (int j = 0; j < M2; ++j) {
-      const float wij = w[j];
-      rs += wij;
-      acc = fmaf(wij, s_z[j * 64 + c], acc);
+  const int li0 = blockIdx.y * 32;                          // 32 local rows per workgroup, 8 per row group
+  float rs[8], acc[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) { rs[u] = 0.f; acc[u] = 0.f; }
+  for (int j0 = 0; j0 < M2; j0 += JT) {
+    __syncthreads();
+    for (int j = rg; j < JT; j += 4) s_z[j * 64 + c] = (d < D && j0 + j < M2) ? z[(int64_t)(j0 + j) * ldz + d] : 0.f;
+    __syncthreads();
+    const int jn = (M2 - j0) < JT ? (M2 - j0) : JT;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int li = li0 + rg * 8 + u;
+      if (li >= ML) continue;
+      const float* wr = wt + (int64_t)li * M2 + j0;
+      float r = rs[u], a = acc[u];
+      for (int j = 0; j < jn; ++j) {
+        const float wij = wr[j];
+        r += wij;
+        a = fmaf(wij, s_z[j * 64 + c], a);
+      }
+      rs[u] = r;
+      acc[u] = a;
     }
-    dz[(int64_t)i * lddz + d] = g2 * (rs * s_z[i * 64 + c] - acc);
+  }
+  if (d >= D) return;
+  const float g2 = 2.f * gscale[0] * gmul;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int li = li0 + rg * 8 + u;
+    if (li >= ML) continue;
+    const int i = global_row(li, m, row0, mloc);
+    dz[(int64_t)li * lddz + d] = g2 * (rs[u] * z[(int64_t)i * ldz + d] - acc[u]);
   }
 }
 
@@ -264,22 +297,26 @@ __global__ __launch_bounds__(256) void sda_prob_weights_kernel(const float* __re
 
 }  // namespace
 
-extern "C" int sug_mmd_rbf(const float* z, int64_t ldz, int m, int D, const float* w,
-                           const float* neg_gamma, int nsigma, double* sums, float* wt, void* stream) {
+extern "C" int sug_mmd_rbf_rows(const float* z, int64_t ldz, int m, int D, const float* w, const float* neg_gamma,
+                                int nsigma, int row0, int mloc, double* sums, float* wt, void* stream) {
   SUG_REQUIRE(z && neg_gamma && sums, "sug_mmd_rbf: null pointer");
   SUG_REQUIRE(m > 0 && D > 0 && ldz >= D, "sug_mmd_rbf: bad shape m=%d D=%d", m, D);
   SUG_REQUIRE(nsigma >= 1 && nsigma <= 8, "sug_mmd_rbf: nsigma=%d", nsigma);
+  SUG_REQUIRE(row0 >= 0 && mloc > 0 && row0 + mloc <= m, "sug_mmd_rbf: row block [%d, %d) outside 0..%d", row0, row0 + mloc, m);
   if (2 * m <= 128 && D >= 256) {      // few rows, long rows: split D across lanes for parallelism
-    const int T4 = sug_divup(2 * m, 4);
-    hipLaunchKernelGGL(mmd_rbf_small_kernel, dim3(T4, T4), dim3(256), 0, (hipStream_t)stream, z, ldz, m, D, w,
-                       neg_gamma, nsigma, sums, wt);
+    hipLaunchKernelGGL(mmd_rbf_small_kernel, dim3(sug_divup(2 * m, 4), sug_divup(2 * mloc, 4)), dim3(256), 0,
+                       (hipStream_t)stream, z, ldz, m, D, w, neg_gamma, nsigma, row0, mloc, sums, wt);
   } else {
-    const int T = sug_divup(2 * m, TI);
-    hipLaunchKernelGGL(mmd_rbf_kernel, dim3(T, T), dim3(256), 0, (hipStream_t)stream, z, ldz, m, D, w,
-                       neg_gamma, nsigma, sums, wt);
+    hipLaunchKernelGGL(mmd_rbf_kernel, dim3(sug_divup(2 * m, TI), sug_divup(2 * mloc, TI)), dim3(256), 0,
+                       (hipStream_t)stream, z, ldz, m, D, w, neg_gamma, nsigma, row0, mloc, sums, wt);
   }
   SUG_LAUNCH_CHECK("sug_mmd_rbf");
   return SUG_OK;
+}
+
+extern "C" int sug_mmd_rbf(const float* z, int64_t ldz, int m, int D, const float* w,
+                           const float* neg_gamma, int nsigma, double* sums, float* wt, void* stream) {
+  return sug_mmd_rbf_rows(z, ldz, m, D, w, neg_gamma, nsigma, 0, m, sums, wt, stream);
 }
 
 extern "C" int sug_chamfer(const float* a, const float* b, int B, int N, int M, float* out,
@@ -293,15 +330,20 @@ extern "C" int sug_chamfer(const float* a, const float* b, int B, int N, int M, 
   return SUG_OK;
 }
 
-extern "C" int sug_mmd_rbf_bwd(const float* z, int64_t ldz, const float* wt, int m, int D, const float* gscale,
-                               float* dz, int64_t lddz, void* stream) {
+extern "C" int sug_mmd_rbf_rows_bwd(const float* z, int64_t ldz, const float* wt, int m, int D, int row0, int mloc,
+                                    const float* gscale, float gmul, float* dz, int64_t lddz, void* stream) {
   SUG_REQUIRE(z && wt && gscale && dz, "sug_mmd_rbf_bwd: null pointer");
-  SUG_REQUIRE(m > 0 && 2 * m <= 128 && D > 0 && ldz >= D && lddz >= D, "sug_mmd_rbf_bwd: bad shape (2m <= 128)");
-  const int M2 = 2 * m;
-  hipLaunchKernelGGL(mmd_bwd_kernel, dim3(sug_divup(D, 64)), dim3(256), (size_t)M2 * 64 * sizeof(float),
-                     (hipStream_t)stream, z, ldz, wt, M2, D, gscale, dz, lddz);
+  SUG_REQUIRE(m > 0 && D > 0 && ldz >= D && lddz >= D, "sug_mmd_rbf_bwd: bad shape");
+  SUG_REQUIRE(row0 >= 0 && mloc > 0 && row0 + mloc <= m, "sug_mmd_rbf_bwd: row block outside 0..%d", m);
+  hipLaunchKernelGGL(mmd_bwd_kernel, dim3(sug_divup(D, 64), sug_divup(2 * mloc, 32)), dim3(256), 0, (hipStream_t)stream, z,
+                     ldz, wt, m, D, row0, mloc, gscale, gmul, dz, lddz);
   SUG_LAUNCH_CHECK("sug_mmd_rbf_bwd");
   return SUG_OK;
+}
+
+extern "C" int sug_mmd_rbf_bwd(const float* z, int64_t ldz, const float* wt, int m, int D, const float* gscale,
+                               float* dz, int64_t lddz, void* stream) {
+  return sug_mmd_rbf_rows_bwd(z, ldz, wt, m, D, 0, m, gscale, 1.0f, dz, lddz, stream);
 }
 
 extern "C" int sug_sda_prob_weights(const float* pred_s, int64_t lds, const float* pred_t, int64_t ldt,

@@ -15,11 +15,11 @@ min_var_est = 1e-8
 sigma_list = [0.01, 0.1, 1, 10, 100]
 
 
-def mmd_cal(label_s, feat_s, label_t, feat_t, args: dict, data_s=None, data_t=None, KPC=False):
-    """model/mmd.py:25-41."""
-    sample_weights = None
+def mmd_cal(label_s, feat_s, label_t, feat_t, args: dict, data_s=None, data_t=None, KPC=False, sample_weights=None):
+    """model/mmd.py:25-41.  `sample_weights` (not in the reference signature): SDA weights the caller
+    already has (the batch-sharded step computes them once from the gathered batch)."""
     sample_weights_flag = args.get("GEO_WEIGHTS", None) or args.get("SEM_WEIGHTS", None)
-    if data_s is not None and sample_weights_flag:
+    if sample_weights is None and data_s is not None and sample_weights_flag:
         sample_weights = cal_sample_weights(data_s, data_t, args, label_s=label_s, label_t=label_t)
     if args["NAME"] == "SOFT_MMD":
         return soft_mmd(label_s, feat_s, label_t, feat_t, float(args["LABEL_SCALE"]), sample_weights=sample_weights)
@@ -49,6 +49,19 @@ def soft_mmd(label_s, feat_s, label_t, feat_t, label_weight, sample_weights=None
     return ops.mix_rbf_mmd2_rows(Z, m, sample_weights, sigma_list)
 
 
+def soft_mmd_sharded(label_s, feat_s, label_t, feat_t, label_g, feat_g_s, label_tg, feat_g_t, label_weight, row0,
+                     sample_weights=None, world=1):
+    """soft_mmd of the GLOBAL batch from a rank's shard: feat_s / feat_t [mloc, D] are this
+    rank's (differentiable) features, feat_g_s / feat_g_t [M, D] the gathered values of all ranks (this
+    rank's rows at row0); equals soft_mmd(label_g, feat_g_s, label_tg, feat_g_t, ...) on every rank."""
+    mloc, M = feat_s.shape[0], feat_g_s.shape[0]
+    oh = torch.cat((create_one_hot_labels(label_s), create_one_hot_labels(label_t)), 0) * label_weight
+    Zloc = torch.cat((torch.cat((feat_s, feat_t), 0), oh), dim=1)
+    ohg = torch.cat((create_one_hot_labels(label_g), create_one_hot_labels(label_tg)), 0) * label_weight
+    Zall = torch.cat((torch.cat((feat_g_s.detach(), feat_g_t.detach()), 0), ohg), dim=1)
+    return ops.mix_rbf_mmd2_rows_sharded(Zloc, Zall, mloc, M, row0, sample_weights, sigma_list, world)
+
+
 def hard_mmd(label_s, feat_s, label_t, feat_t):
     """model/mmd.py:69-77."""
     same = torch.eq(label_s, label_t)
@@ -62,19 +75,25 @@ def max_hard_mmd(label_s, feat_s, label_t, feat_t):
     return mix_rbf_mmd2(feat_s[ind_s], feat_t[ind_t], sigma_list)
 
 
-def geometric_weights(pc_s, pc_t, metric="chamfer_distance", weighting="none", KPC=False):
-    """model/mmd.py:107-131: Chamfer distance between paired clouds -> weights [1,m].
-    The reference calls a third-party ChamferDistance op; sug_chamfer follows its call-site
-    contract (parity unpinned, see oracle/ref_cpu.py:chamfer_weights)."""
+def chamfer_distances(pc_s, pc_t):
+    """Per-pair Chamfer distance [m] of paired clouds ([m,3,N(,1)] or [m,N,3]): cd_distance,
+    model/mmd.py:169-175 (mean of dist1 + mean of dist2)."""
     assert pc_s.shape[0] == pc_t.shape[0]
-    if metric != "chamfer_distance":
-        raise RuntimeError("Currently Only Support CD distance")
     if pc_s.shape[1] == 3:
         a = pc_s.reshape(pc_s.shape[0], 3, -1).transpose(1, 2)
         b = pc_t.reshape(pc_t.shape[0], 3, -1).transpose(1, 2)
     else:
         a, b = pc_s, pc_t
-    distance = ops.chamfer(a, b)
+    return ops.chamfer(a, b)
+
+
+def geometric_weights(pc_s, pc_t, metric="chamfer_distance", weighting="none", KPC=False):
+    """model/mmd.py:107-131: Chamfer distance between paired clouds -> weights [1,m].
+    The reference calls a third-party ChamferDistance op; sug_chamfer follows its call-site
+    contract (parity unpinned, see oracle/ref_cpu.py:chamfer_weights)."""
+    if metric != "chamfer_distance":
+        raise RuntimeError("Currently Only Support CD distance")
+    distance = chamfer_distances(pc_s, pc_t)
     return distance2weights(distances=distance, method=weighting).reshape(1, -1)
 
 

@@ -890,19 +890,64 @@ class _MixRbfMMD2(torch.autograd.Function):
     def backward(ctx, g):
         Z, wt = ctx.saved_tensors
         M2, D = Z.shape
-        if M2 <= 128:
-            gs = g.detach().to(device=Z.device, dtype=torch.float32).reshape(1)
-            dZ = torch.empty(M2, D, dtype=torch.float32, device=Z.device)
-            check(lib().sug_mmd_rbf_bwd(_p(Z), Z.stride(0), _p(wt), M2 // 2, D, _p(gs), _p(dZ), D, _st()),
-                  'sug_mmd_rbf_bwd')
-            return dZ, None, None, None
-        dZ = 2.0 * (wt.sum(dim=1, keepdim=True) * Z - wt @ Z)
-        return g * dZ, None, None, None
+        gs = g.detach().to(device=Z.device, dtype=torch.float32).reshape(1)
+        dZ = torch.empty(M2, D, dtype=torch.float32, device=Z.device)
+        check(lib().sug_mmd_rbf_bwd(_p(Z), Z.stride(0), _p(wt), M2 // 2, D, _p(gs), _p(dZ), D, _st()),
+              'sug_mmd_rbf_bwd')
+        return dZ, None, None, None
 
 
 def mix_rbf_mmd2_rows(Z, m, sample_weights=None, sigmas=SIGMA_LIST):
     """Z = cat(X, Y) [2m, D] -> biased MMD^2 (0-d tensor)."""
     return _MixRbfMMD2.apply(Z, m, sample_weights, tuple(sigmas))
+
+
+class _MixRbfMMD2Sharded(torch.autograd.Function):
+    """The global-batch MMD^2 of a batch-sharded step: every rank holds the gathered
+    Zall = [X of all ranks ; Y of all ranks] (values only) and evaluates the row block of the kernel
+    matrix that belongs to its own samples, rows [row0, row0+mloc) of each domain, against all 2M
+    columns (sug_mmd_rbf_rows); the three partial sums cross the ranks as one 3-double all-reduce.
+    Backward: the gradient of the own rows comes from the own row block alone
+    (sug_mmd_rbf_rows_bwd) -- no collective -- scaled by the world size because the data-parallel
+    gradient averaging divides by it again (every rank's loss contains the same global term)."""
+
+    @staticmethod
+    def forward(ctx, Zloc, Zall, mloc, M, row0, w, sigmas, world, group):
+        import torch.distributed as dist
+        _need_gpu(Zloc, Zall)
+        Za = Zall if (Zall.stride(1) == 1 and Zall.stride(0) >= Zall.shape[1]) else Zall.contiguous()
+        D = Za.shape[1]
+        dev = Za.device
+        ng = _neg_gammas(sigmas, dev)
+        sums = torch.zeros(3, dtype=torch.float64, device=dev)
+        need = ctx.needs_input_grad[0]
+        wt = torch.empty(2 * mloc, 2 * M, dtype=torch.float32, device=dev) if need else None
+        wc = w.detach().reshape(-1).to(device=dev, dtype=torch.float32).contiguous() if w is not None else None
+        check(lib().sug_mmd_rbf_rows(_p(Za), Za.stride(0), M, D, _p(wc), _p(ng), len(sigmas), row0, mloc, _p(sums),
+                                     _p(wt), _st()), 'sug_mmd_rbf_rows')
+        if world > 1:
+            dist.all_reduce(sums, group=group)
+        if need:
+            ctx.save_for_backward(Za, wt)
+            ctx.meta = (mloc, M, row0, world)
+        mm = float(M) * float(M)
+        return ((sums[0] + sums[1] - 2.0 * sums[2]) / mm).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        Za, wt = ctx.saved_tensors
+        mloc, M, row0, world = ctx.meta
+        D = Za.shape[1]
+        gs = g.detach().to(device=Za.device, dtype=torch.float32).reshape(1)
+        dZ = torch.empty(2 * mloc, D, dtype=torch.float32, device=Za.device)
+        check(lib().sug_mmd_rbf_rows_bwd(_p(Za), Za.stride(0), _p(wt), M, D, row0, mloc, _p(gs), float(world), _p(dZ), D,
+                                         _st()), 'sug_mmd_rbf_rows_bwd')
+        return dZ, None, None, None, None, None, None, None, None
+
+
+def mix_rbf_mmd2_rows_sharded(Zloc, Zall, mloc, M, row0, sample_weights=None, sigmas=SIGMA_LIST, world=1, group=None):
+    """Zloc = cat(X_own, Y_own) [2*mloc, D] (differentiable), Zall = cat(X_all, Y_all) [2M, D] (values)."""
+    return _MixRbfMMD2Sharded.apply(Zloc, Zall, mloc, M, row0, sample_weights, tuple(sigmas), world, group)
 
 
 _SDA_METHODS = {'none': 0, 'naive_inverse': 1, 'exp_inverse': 2, 'mean2one': 3}

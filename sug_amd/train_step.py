@@ -315,6 +315,39 @@ class SUGStep:
                 data_s, data_t = gather_rows_ddp(data_s.detach()), gather_rows_ddp(data_t.detach())
         return mmd.mmd_cal(label, feat_s, label_t, feat_t, cfg, data_s=data_s, data_t=data_t)
 
+    def _global_soft_mmd(self, data, label, data_t, label_t, node_s, node_t, head1, head2):
+        """The three soft-MMD terms of the GLOBAL batch on a batch-sharded step.  Everything
+        the terms need from the other ranks -- node features, semantic features, logits, labels and the
+        per-pair Chamfer distances behind GEO_WEIGHTS -- crosses the ranks as VALUES in ONE packed
+        all-gather; each rank then evaluates its own row block of every kernel matrix
+        (mmd.soft_mmd_sharded: one 3-double all-reduce per term, no collective in the backward).
+        The SDA weights are computed from the gathered batch, identically on every rank."""
+        M_, geo, sem = self.methods, self.methods['GEO_MMD'][0], self.methods['SEM_MMD'][0]
+        rank = dist.get_rank()
+        mloc = label.shape[0]
+        (s1, t1, p1s, p1t), (s2, t2, p2s, p2t) = head1, head2
+        vals = [label, label_t, node_s.detach(), node_t.detach(), s1.detach(), t1.detach(), s2.detach(), t2.detach(),
+                p1s.detach(), p1t.detach(), p2s.detach(), p2t.detach()]
+        if geo.get('GEO_WEIGHTS'):
+            vals.append(mmd.chamfer_distances(data, data_t).reshape(-1, 1))
+        g = gather_rows_packed(vals)
+        label_g, label_tg, fn_s, fn_t, g_s1, g_t1, g_s2, g_t2, g_p1s, g_p1t, g_p2s, g_p2t = g[:12]
+        row0 = rank * mloc
+        w_geo = None
+        if geo.get('GEO_WEIGHTS'):
+            w_geo = mmd.distance2weights(g[12].reshape(-1), geo['GEO_WEIGHTS']).reshape(1, -1)
+        loss_geo = M_['MMD_WEIGHT'] * geo['GEO_SCALE'] * mmd.soft_mmd_sharded(
+            label, node_s, label_t, node_t, label_g, fn_s, label_tg, fn_t, float(geo['LABEL_SCALE']), row0, w_geo,
+            self.world)
+        terms = []
+        for (fs, ft, gs, gt, gps, gpt) in ((s1, t1, g_s1, g_t1, g_p1s, g_p1t), (s2, t2, g_s2, g_t2, g_p2s, g_p2t)):
+            w = None
+            if sem.get('SEM_WEIGHTS'):
+                w = mmd.prob_weights_soft(gps, gpt, label_g, label_tg, sem['LABEL_WEIGHT'], sem['SEM_WEIGHTS'])
+            terms.append(sem['SEM_SCALE'] * mmd.soft_mmd_sharded(label, fs, label_t, ft, label_g, gs, label_tg, gt,
+                                                                 float(sem['LABEL_SCALE']), row0, w, self.world))
+        return loss_geo, M_['MMD_WEIGHT'] * (0.5 * terms[0] + 0.5 * terms[1])
+
     def losses(self, data, label, data_t, label_t, mmd_on=True):
         M = self.methods
         model = self.model
@@ -342,15 +375,11 @@ class SUGStep:
             feat_node_s = model(data, node_adaptation_s=True)
             feat_node_t = model(data_t, node_adaptation_t=True)
         geo, sem = M['GEO_MMD'][0], M['SEM_MMD'][0]
-        if self.global_mmd and sem['SEM_SCALE'] > 0 and not geo.get('GEO_WEIGHTS') and pred_s1.dim() == 2:
-            # everything the three MMD terms need crosses the ranks in one packed collective
-            (label_g, label_tg, fn_s, fn_t, s1, t1, s2, t2, p1s, p1t, p2s, p2t) = gather_rows_packed(
-                [label, label_t, feat_node_s, feat_node_t, sem_s1, sem_t1, sem_s2, sem_t2,
-                 pred_s1.detach(), pred_t1.detach(), pred_s2.detach(), pred_t2.detach()])
-            loss_geo = M['MMD_WEIGHT'] * geo['GEO_SCALE'] * mmd.mmd_cal(label_g, fn_s, label_tg, fn_t, geo)
-            l1 = sem['SEM_SCALE'] * mmd.mmd_cal(label_g, s1, label_tg, t1, sem, data_s=p1s, data_t=p1t)
-            l2 = sem['SEM_SCALE'] * mmd.mmd_cal(label_g, s2, label_tg, t2, sem, data_s=p2s, data_t=p2t)
-            return loss_cls, loss_geo, M['MMD_WEIGHT'] * (0.5 * l1 + 0.5 * l2)
+        if self.global_mmd and geo['NAME'] == 'SOFT_MMD' and sem['NAME'] == 'SOFT_MMD' and sem['SEM_SCALE'] > 0 \
+                and pred_s1.dim() == 2:
+            return (loss_cls,) + self._global_soft_mmd(data, label, data_t, label_t, feat_node_s, feat_node_t,
+                                                        (sem_s1, sem_t1, pred_s1, pred_t1),
+                                                        (sem_s2, sem_t2, pred_s2, pred_t2))
         loss_geo = M['MMD_WEIGHT'] * geo['GEO_SCALE'] * self._mmd(label, feat_node_s, label_t, feat_node_t, geo, data, data_t)
         loss_sem = None
         if sem['SEM_SCALE'] > 0:

@@ -1,0 +1,139 @@
+"""GPU twin of tests/test_dist_gloo.py: a 2-rank SUGStep on HIP tensors (one process per rank, batch
+sharded, bucketed gradient all-reduce overlapped with backward, packed differentiable all-gather for
+the global-batch MMD) against single-process runs of the same shards.
+
+  * backend 'nccl' (= RCCL over xGMI): needs >= 2 devices, skipped otherwise (the driver's 8-GPU node);
+  * backend 'gloo' with both ranks on cuda:0: the same code path minus RCCL, runs on the 1-GPU box.
+
+Checked per rank: loss_cls equals a single-process step on that rank's shard (local BatchNorm, as the
+reference's DDP, train_dg.py:216-217); the MMD terms are identical on all ranks and equal the MMD of
+the gathered features; after the optimizer step every rank holds the same parameters."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make(seed):
+    from oracle import ref_cpu as O
+    from sug_amd.model.Model import Net_MDA
+    net = Net_MDA('DGCNN')
+    net.load_state_dict(O.fill_params({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed))
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout2d):
+            m.p = 0.0
+    return net
+
+
+def _data(B, N, seed):
+    from oracle import ref_cpu as O
+    g = torch.Generator().manual_seed(seed)
+    data, data_t = O.synth_clouds(B, N, g), O.synth_clouds(B, N, g)
+    lab, lab_t = torch.randint(0, 10, (B,), generator=g), torch.randint(0, 10, (B,), generator=g)
+    return data, lab, data_t, lab_t
+
+
+def _worker(rank, world, port, backend, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY='0')
+    import torch.distributed as dist
+    dev = torch.device('cuda', rank if backend == 'nccl' else 0)
+    torch.cuda.set_device(dev)
+    if backend == 'nccl':
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    from sug_amd.train_step import SUGStep
+    B, N = 4, 1024                              # global batch per domain; each rank owns B / world clouds
+    data, lab, data_t, lab_t = _data(B, N, 5)
+    lo, hi = rank * B // world, (rank + 1) * B // world
+    shard = [t[lo:hi].to(dev) for t in (data, lab, data_t, lab_t)]
+    net = _make(3).to(dev).train()
+    tr = SUGStep(net, global_mmd=True)
+    torch.manual_seed(100 + rank)                  # FPS start draws, per rank (train_dg.py:78)
+    out = []
+    for _ in range(2):
+        out.append([float(v) for v in tr.step(*shard)])
+    chk = torch.stack([p.detach().double().sum() for p in net.parameters()]).cpu()
+    q.put((rank, out, chk.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(backend):
+    import torch.multiprocessing as mp
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, backend, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return res
+
+
+def _check(res):
+    from sug_amd.train_step import SUGStep
+    (r0, out0, chk0), (r1, out1, chk1) = res
+    # the MMD terms are computed on the gathered global batch: identical on both ranks
+    for s in range(2):
+        assert abs(out0[s][1] - out1[s][1]) <= 1e-6 * max(1.0, abs(out0[s][1])), (out0, out1)
+        assert abs(out0[s][2] - out1[s][2]) <= 1e-6 * max(1.0, abs(out0[s][2])), (out0, out1)
+    # averaged gradients + identical optimizers: the replicas stay in step
+    assert abs(chk0 - chk1).max() <= 1e-6 * max(1.0, abs(chk0).max()), 'parameters diverged between ranks'
+    # per-rank classification loss = a single-process step on that shard (first step: same weights)
+    B, N = 4, 1024
+    data, lab, data_t, lab_t = _data(B, N, 5)
+    for rank, out in ((0, out0), (1, out1)):
+        lo, hi = rank * B // 2, (rank + 1) * B // 2
+        net = _make(3).cuda().train()
+        tr = SUGStep(net, global_mmd=False)
+        torch.manual_seed(100 + rank)
+        lc, _, _ = tr.losses(*[t[lo:hi].cuda() for t in (data, lab, data_t, lab_t)])
+        assert abs(float(lc) - out[0][0]) <= 1e-4 * max(1.0, abs(out[0][0])), (rank, float(lc), out)
+    # and the first step's global MMD = MMD of the two shards' features put together
+    feats = []
+    for rank in range(2):
+        lo, hi = rank * B // 2, (rank + 1) * B // 2
+        net = _make(3).cuda().train()
+        torch.manual_seed(100 + rank)
+        d, l, dt, lt = [t[lo:hi].cuda() for t in (data, lab, data_t, lab_t)]
+        pair = torch.cat((d, dt))
+        with torch.no_grad():
+            (ps1, ps2, ss1, ss2), (pt1, pt2, st1, st2) = net.forward_pair(pair)
+            fs, ft = net.forward_pair(pair, node_adaptation=True)
+        feats.append((l, lt, fs, ft))
+    from sug_amd.model import mmd
+    from sug_amd.train_step import GEO_MMD
+    cat = lambda i: torch.cat([f[i] for f in feats])
+    geo = float(mmd.mmd_cal(cat(0), cat(2), cat(1), cat(3), GEO_MMD))
+    assert abs(geo - out0[0][1]) <= 1e-4 * max(1.0, abs(geo)), (geo, out0)
+
+
+def test_two_rank_step_gloo_on_one_gpu():
+    _check(_run('gloo'))
+
+
+def test_two_rank_step_rccl():
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs 2 HIP devices (RCCL over xGMI)')
+    _check(_run('nccl'))
