@@ -141,6 +141,9 @@ def main():
     ap.add_argument('--caller-steps', type=int, default=10,
                     help='extra timed steps in the unchanged-caller form (four separate model(...) calls, no sharing); 0 = skip')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--fp16', action='store_true',
+                    help='Point Transformer only (BASELINE config 5): k-expanded attention tensors and their 512x512 linears in '
+                         'fp16 (MFMA, fp32 accumulation); default fp32 = the reference arithmetic')
     ap.add_argument('--graph', action='store_true',
                     help='replay the step from a hipGraph (opt-in; same speed as eager when the step is GPU-bound)')
     ap.add_argument('--no-share-prefix', action='store_true',
@@ -181,6 +184,9 @@ def main():
         from sug_amd.tuning import enable_tuned_gemms
         tuned = enable_tuned_gemms()
 
+    if args.fp16:
+        from sug_amd.model import Ptran_transformer as PT
+        PT.GEMM_DTYPE = torch.float16
     torch.manual_seed(666)                              # train_dg_single_gpu.py:65
     model = Net_MDA(args.model).to(dev).train()
     if world > 1:                                       # same initial weights on every rank
@@ -309,7 +315,8 @@ def main():
                                                             torch.get_num_threads())}
         out = {'metric': 'point-clouds/sec (train step, N=%d)' % N, 'value': value, 'unit': 'point-clouds/sec',
                'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
-               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+               'dtype': 'f16' if (args.fp16 and args.model == 'PTran') else 'f32',
                'data': 'synthetic',
                'config': {'workload': '%s, N=%d, batch=%d per domain per GPU, MSA+SDA losses on '
                                       '(2 sem + 2 node forwards, 3 soft-MMD, backward, 3 Adam)' % (BACKBONE.get(args.model, args.model), N, B),

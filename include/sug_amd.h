@@ -340,6 +340,34 @@ int sug_pointmlp_max_bwd_sparse(const float* a, const int32_t* arg, const float*
                                 int64_t rows, int K, int Co, int seg, float* dx, int64_t lddx, float* dw,
                                 float* ws, void* stream);
 
+/* ---- Point Transformer vector attention (BASELINE config 5) --------------------------------------
+ * The memory-bound parts of TransformerBlock.forward (model/Ptran_transformer.py:32-45) around the three
+ * 512 x 512 linears of the k-expanded rows (library GEMMs: fp32, or fp16 MFMA with fp32 accumulation):
+ * rows r = (b*n + i)*k + j, d = 512 channels contiguous, nbr [B,n,k] = neighbour index inside the cloud
+ * (sug_knn_query_direct).  dtype: 0 = fp32, 1 = fp16 for the k-expanded tensors T0 / delta / U / L and their
+ * gradients (void*); q, K, V [B,n,512], xyz [B,n,3], weights and all reductions are fp32.  k <= 16.
+ *   pos1: T0[r,:] = relu(w1 . (xyz_i - xyz_nbr) + b1), w1 [512,3]                    (fc_delta[0] + ReLU, :39)
+ *   qk:   U[r,:]  = q[i,:] - K[nbr,:] + delta[r,:]                                    (input of fc_gamma, :41)
+ *   attn: mixed[i,:] = sum_j softmax_j(L[r,:]*scale) * (V[nbr,:] + delta[r,:]); mx / sm [B,n,512] = the
+ *         per-channel max and sum of exponentials, kept for the backward               (:42-44)
+ * Backward: rev_off / rev_ent = sug_knn_reverse(nbr) (dK and dV are gathered over reverse neighbour lists:
+ * no atomics).  sug_ptran_attn_bwd: g = d mixed -> dlogits, da = the gradient of delta through (v + delta),
+ * dv [B,n,512].  sug_ptran_qk_bwd: du = dU; da is read and overwritten with d delta = du + da; dq, dk
+ * [B,n,512].  sug_ptran_pos1_bwd: g = dT0 -> dw1 [512,3], db1 [512]; ws: 512*4*512 floats. */
+int sug_ptran_pos1_fwd(const float* xyz, const int32_t* nbr, const float* w1, const float* b1, int B, int n, int k,
+                       int d, int dtype, void* out, void* stream);
+int sug_ptran_pos1_bwd(const void* g, const float* xyz, const int32_t* nbr, const float* w1, const float* b1, int B,
+                       int n, int k, int d, int dtype, float* dw1, float* db1, float* ws, void* stream);
+int sug_ptran_qk_fwd(const float* q, const float* kf, const void* delta, const int32_t* nbr, int B, int n, int k, int d,
+                     int dtype, void* out, void* stream);
+int sug_ptran_qk_bwd(const void* du, void* da, const int32_t* rev_off, const int32_t* rev_ent, int B, int n, int k, int d,
+                     int dtype, float* dq, float* dk, void* stream);
+int sug_ptran_attn_fwd(const void* logits, const void* delta, const float* vf, const int32_t* nbr, int B, int n, int k,
+                       int d, int dtype, float scale, float* mixed, float* mx, float* sm, void* stream);
+int sug_ptran_attn_bwd(const float* g, const void* logits, const void* delta, const float* vf, const int32_t* nbr,
+                       const float* mx, const float* sm, const int32_t* rev_off, const int32_t* rev_ent, int B, int n,
+                       int k, int d, int dtype, float scale, void* dlogits, void* da, float* dv, void* stream);
+
 /* ---- Gaussian multi-kernel MMD --------------------------------------------------
  * replaces _mix_rbf_kernel + _mmd2(biased=True), model/mmd.py:239-254, :274-312.
  * Z = [X;Y] : [2m, D] rows (ld = ldz).  e_ij = n_i - 2<z_i,z_j> + n_j with n the

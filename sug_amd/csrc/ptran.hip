@@ -1,0 +1,417 @@
+// Point Transformer vector attention (d_model = 512, k <= 16 neighbours): the memory-bound parts of
+// TransformerBlock.forward, model/Ptran_transformer.py:32-45, around the three 512 x 512 linears of the
+// k-expanded rows (which stay library GEMMs on the matrix pipe, fp32 in the parity mode, fp16 MFMA with
+// fp32 accumulation in the 16-bit mode of BASELINE config 5):
+//
+//   pos1   T0[b,i,j,:] = relu(W1 . (xyz_i - xyz_nbr(i,j)) + b1)              fc_delta[0] + ReLU    (:39)
+//   qk     U [b,i,j,:] = q[b,i,:] - K[b,nbr(i,j),:] + delta[b,i,j,:]         input of fc_gamma      (:41)
+//   attn   mixed[b,i,:] = sum_j softmax_j(L[b,i,j,:] / sqrt(d)) * (V[b,nbr(i,j),:] + delta[b,i,j,:])   (:42-44)
+//
+// and their gradients.  The reference materialises, per block, the gathered keys / values, q - k,
+// q - k + delta, attn / sqrt(d), the softmax, v + delta and their product: 9 tensors of [B,n,k,512];
+// here the k-expanded tensors that exist are the GEMM operands / results T0, delta, U, T1, L.
+// Layout: rows r = (b*n + i)*k + j, 512 channels contiguous; one wave per row (or per point), a lane
+// owns 8 consecutive channels (16-byte fp16 / 2 x 16-byte fp32 accesses).  T = float or __half for the
+// k-expanded tensors; q, K, V, xyz, the weights of pos1 and every reduction stay fp32.
+// All kernels are HBM-bound: algorithmic bytes = each k-expanded operand once.
+#include "common.h"
+#include <hip/hip_fp16.h>
+
+namespace {
+
+constexpr int D = 512;
+
+template <typename T>
+__device__ __forceinline__ void ld8(const T* __restrict__ p, float (&v)[8]);
+template <>
+__device__ __forceinline__ void ld8<float>(const float* __restrict__ p, float (&v)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+template <>
+__device__ __forceinline__ void ld8<__half>(const __half* __restrict__ p, float (&v)[8]) {
+  const uint4 u = *reinterpret_cast<const uint4*>(p);
+  const __half2* h = reinterpret_cast<const __half2*>(&u);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float2 f = __half22float2(h[i]);
+    v[2 * i] = f.x;
+    v[2 * i + 1] = f.y;
+  }
+}
+template <typename T>
+__device__ __forceinline__ void st8(T* __restrict__ p, const float (&v)[8]);
+template <>
+__device__ __forceinline__ void st8<float>(float* __restrict__ p, const float (&v)[8]) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+template <>
+__device__ __forceinline__ void st8<__half>(__half* __restrict__ p, const float (&v)[8]) {
+  uint4 u;
+  __half2* h = reinterpret_cast<__half2*>(&u);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) h[i] = __floats2half2_rn(v[2 * i], v[2 * i + 1]);
+  *reinterpret_cast<uint4*>(p) = u;
+}
+
+// ---- pos1: T0 = relu(W1 . rel + b1), rel = xyz_i - xyz_nbr
+template <typename T>
+__global__ __launch_bounds__(256) void ptran_pos1_kernel(const float* __restrict__ xyz, const int32_t* __restrict__ nbr,
+                                                         const float* __restrict__ W1, const float* __restrict__ b1,
+                                                         int64_t R, int n, int k, T* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t w0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * 256) >> 6;
+  float wx[8], wy[8], wz[8], bb[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int c = lane * 8 + u;
+    wx[u] = W1[c * 3 + 0]; wy[u] = W1[c * 3 + 1]; wz[u] = W1[c * 3 + 2]; bb[u] = b1[c];
+  }
+  for (int64_t r = w0; r < R; r += nw) {
+    const int64_t p = r / k, b = p / n;
+    const int m = nbr[r];
+    const float* xi = xyz + p * 3;
+    const float* xj = xyz + (b * n + m) * 3;
+    const float dx = xi[0] - xj[0], dy = xi[1] - xj[1], dz = xi[2] - xj[2];
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float t = fmaf(wz[u], dz, fmaf(wy[u], dy, wx[u] * dx)) + bb[u];
+      v[u] = t > 0.f ? t : 0.f;
+    }
+    st8<T>(out + r * D + lane * 8, v);
+  }
+}
+
+// dW1[c,0..2] = sum_r g[r,c] * [pre(r,c) > 0] * rel(r), db1[c] likewise: per-workgroup partials [nb][4][512]
+template <typename T>
+__global__ __launch_bounds__(256) void ptran_pos1_bwd_kernel(const T* __restrict__ g, const float* __restrict__ xyz,
+                                                             const int32_t* __restrict__ nbr, const float* __restrict__ W1,
+                                                             const float* __restrict__ b1, int64_t R, int n, int k,
+                                                             float* __restrict__ part) {
+  __shared__ float s_red[4][4][D];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t w0 = (int64_t)blockIdx.x * 4 + wv, nw = (int64_t)gridDim.x * 4;
+  float wx[8], wy[8], wz[8], bb[8], ax[8], ay[8], az[8], ab[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int c = lane * 8 + u;
+    wx[u] = W1[c * 3 + 0]; wy[u] = W1[c * 3 + 1]; wz[u] = W1[c * 3 + 2]; bb[u] = b1[c];
+    ax[u] = ay[u] = az[u] = ab[u] = 0.f;
+  }
+  for (int64_t r = w0; r < R; r += nw) {
+    const int64_t p = r / k, b = p / n;
+    const int m = nbr[r];
+    const float* xi = xyz + p * 3;
+    const float* xj = xyz + (b * n + m) * 3;
+    const float dx = xi[0] - xj[0], dy = xi[1] - xj[1], dz = xi[2] - xj[2];
+    float gv[8];
+    ld8<T>(g + r * D + lane * 8, gv);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float t = fmaf(wz[u], dz, fmaf(wy[u], dy, wx[u] * dx)) + bb[u];
+      const float gg = t > 0.f ? gv[u] : 0.f;
+      ax[u] = fmaf(gg, dx, ax[u]); ay[u] = fmaf(gg, dy, ay[u]); az[u] = fmaf(gg, dz, az[u]); ab[u] += gg;
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int c = lane * 8 + u;
+    s_red[wv][0][c] = ax[u]; s_red[wv][1][c] = ay[u]; s_red[wv][2][c] = az[u]; s_red[wv][3][c] = ab[u];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 4 * D; e += 256) {
+    const int q = e / D, c = e % D;
+    part[(int64_t)blockIdx.x * 4 * D + e] = ((s_red[0][q][c] + s_red[1][q][c]) + s_red[2][q][c]) + s_red[3][q][c];
+  }
+}
+
+// fold the partials in a fixed order (fp64): out[0..3*512) = dW1 [512][3], out[3*512..) = db1
+__global__ __launch_bounds__(256) void ptran_pos1_fold_kernel(const float* __restrict__ part, int nb, float* __restrict__ dW1,
+                                                              float* __restrict__ db1) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= 4 * D) return;
+  double t = 0.0;
+  for (int i = 0; i < nb; ++i) t += (double)part[(int64_t)i * 4 * D + e];
+  const int q = e / D, c = e % D;
+  if (q < 3) dW1[c * 3 + q] = (float)t;
+  else db1[c] = (float)t;
+}
+
+// ---- qk: U = q_i - K_nbr + delta
+template <typename T>
+__global__ __launch_bounds__(256) void ptran_qk_kernel(const float* __restrict__ q, const float* __restrict__ kf,
+                                                       const T* __restrict__ delta, const int32_t* __restrict__ nbr,
+                                                       int64_t P, int n, int k, T* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t w0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * 256) >> 6;
+  for (int64_t p = w0; p < P; p += nw) {
+    const int64_t b = p / n;
+    float qv[8];
+    ld8<float>(q + p * D + lane * 8, qv);
+    for (int j = 0; j < k; ++j) {
+      const int64_t r = p * k + j;
+      const int m = nbr[r];
+      float kv[8], dv[8], o[8];
+      ld8<float>(kf + (b * n + m) * D + lane * 8, kv);
+      ld8<T>(delta + r * D + lane * 8, dv);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) o[u] = (qv[u] - kv[u]) + dv[u];
+      st8<T>(out + r * D + lane * 8, o);
+    }
+  }
+}
+
+// backward of qk, fused with the sum of delta's two gradients: da (in: the attention's gradient of
+// delta, out: d delta = dU + da); dq[p] = sum_j dU[p,j]; dK[m] = - sum over the reverse list of m
+template <typename T>
+__global__ __launch_bounds__(256) void ptran_qk_bwd_kernel(const T* __restrict__ dU, T* __restrict__ da,
+                                                           const int32_t* __restrict__ rev_off,
+                                                           const int32_t* __restrict__ rev_ent, int64_t P, int n, int k,
+                                                           float* __restrict__ dq, float* __restrict__ dk) {
+  const int lane = threadIdx.x & 63;
+  const int64_t w0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * 256) >> 6;
+  for (int64_t p = w0; p < P; p += nw) {
+    const int64_t b = p / n;
+    const int i = (int)(p - b * n);
+    float aq[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) aq[u] = 0.f;
+    for (int j = 0; j < k; ++j) {
+      const int64_t r = p * k + j;
+      float uv[8], av[8];
+      ld8<T>(dU + r * D + lane * 8, uv);
+      ld8<T>(da + r * D + lane * 8, av);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { aq[u] += uv[u]; av[u] += uv[u]; }
+      st8<T>(da + r * D + lane * 8, av);
+    }
+    st8<float>(dq + p * D + lane * 8, aq);
+    const int32_t* off = rev_off + b * (n + 1) + i;
+    const int e0 = off[0], e1 = off[1];
+    const int32_t* ent = rev_ent + b * (int64_t)n * k;
+    float ak[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) ak[u] = 0.f;
+    for (int t = e0; t < e1; ++t) {
+      const int64_t r = b * (int64_t)n * k + ent[t];
+      float uv[8];
+      ld8<T>(dU + r * D + lane * 8, uv);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) ak[u] -= uv[u];
+    }
+    st8<float>(dk + p * D + lane * 8, ak);
+  }
+}
+
+// ---- attn: softmax over the k neighbours (per channel) of L * scale, applied to V_nbr + delta
+template <typename T, int KK>
+__global__ __launch_bounds__(256) void ptran_attn_kernel(const T* __restrict__ L, const T* __restrict__ delta,
+                                                         const float* __restrict__ vf, const int32_t* __restrict__ nbr,
+                                                         int64_t P, int n, int k, float scale, float* __restrict__ mixed,
+                                                         float* __restrict__ mx, float* __restrict__ sm) {
+  const int lane = threadIdx.x & 63;
+  const int64_t w0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * 256) >> 6;
+  for (int64_t p = w0; p < P; p += nw) {
+    const int64_t b = p / n;
+    float z[KK][8], zmax[8], zsum[8], acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { zmax[u] = -INFINITY; zsum[u] = 0.f; acc[u] = 0.f; }
+#pragma unroll
+    for (int j = 0; j < KK; ++j) {
+      if (j < k) {
+        ld8<T>(L + (p * k + j) * D + lane * 8, z[j]);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { z[j][u] *= scale; zmax[u] = fmaxf(zmax[u], z[j][u]); }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < KK; ++j) {
+      if (j < k) {
+        const int64_t r = p * k + j;
+        const int m = nbr[r];
+        float vv[8], dv[8];
+        ld8<float>(vf + (b * n + m) * D + lane * 8, vv);
+        ld8<T>(delta + r * D + lane * 8, dv);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const float e = expf(z[j][u] - zmax[u]);
+          zsum[u] += e;
+          acc[u] = fmaf(e, vv[u] + dv[u], acc[u]);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] /= zsum[u];
+    st8<float>(mixed + p * D + lane * 8, acc);
+    st8<float>(mx + p * D + lane * 8, zmax);
+    st8<float>(sm + p * D + lane * 8, zsum);
+  }
+}
+
+// backward: dL, da (the gradient of delta through v + delta) per row; dV[m] over the reverse list of m
+template <typename T, int KK>
+__global__ __launch_bounds__(256) void ptran_attn_bwd_kernel(const float* __restrict__ g, const T* __restrict__ L,
+                                                             const T* __restrict__ delta, const float* __restrict__ vf,
+                                                             const int32_t* __restrict__ nbr, const float* __restrict__ mx,
+                                                             const float* __restrict__ sm, const int32_t* __restrict__ rev_off,
+                                                             const int32_t* __restrict__ rev_ent, int64_t P, int n, int k,
+                                                             float scale, T* __restrict__ dL, T* __restrict__ da,
+                                                             float* __restrict__ dv) {
+  const int lane = threadIdx.x & 63;
+  const int64_t w0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * 256) >> 6;
+  for (int64_t p = w0; p < P; p += nw) {
+    const int64_t b = p / n;
+    const int i = (int)(p - b * n);
+    float gv[8], zmax[8], rs[8];
+    ld8<float>(g + p * D + lane * 8, gv);
+    ld8<float>(mx + p * D + lane * 8, zmax);
+    ld8<float>(sm + p * D + lane * 8, rs);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) rs[u] = 1.0f / rs[u];
+    float pr[KK][8], dp[KK][8], dot[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) dot[u] = 0.f;
+#pragma unroll
+    for (int j = 0; j < KK; ++j) {
+      if (j < k) {
+        const int64_t r = p * k + j;
+        const int m = nbr[r];
+        float lv[8], vv[8], dlt[8], av[8];
+        ld8<T>(L + r * D + lane * 8, lv);
+        ld8<float>(vf + (b * n + m) * D + lane * 8, vv);
+        ld8<T>(delta + r * D + lane * 8, dlt);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          pr[j][u] = expf(lv[u] * scale - zmax[u]) * rs[u];
+          dp[j][u] = gv[u] * (vv[u] + dlt[u]);
+          dot[u] = fmaf(pr[j][u], dp[j][u], dot[u]);
+          av[u] = gv[u] * pr[j][u];
+        }
+        st8<T>(da + r * D + lane * 8, av);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < KK; ++j) {
+      if (j < k) {
+        float o[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) o[u] = pr[j][u] * (dp[j][u] - dot[u]) * scale;
+        st8<T>(dL + (p * k + j) * D + lane * 8, o);
+      }
+    }
+    // dV of this point as a neighbour of others
+    const int32_t* off = rev_off + b * (n + 1) + i;
+    const int e0 = off[0], e1 = off[1];
+    const int32_t* ent = rev_ent + b * (int64_t)n * k;
+    float acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+    for (int t = e0; t < e1; ++t) {
+      const int e = ent[t];
+      const int64_t r = b * (int64_t)n * k + e;
+      const int64_t ps = b * n + e / k;
+      float lv[8], g2[8], m2[8], s2[8];
+      ld8<T>(L + r * D + lane * 8, lv);
+      ld8<float>(g + ps * D + lane * 8, g2);
+      ld8<float>(mx + ps * D + lane * 8, m2);
+      ld8<float>(sm + ps * D + lane * 8, s2);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[u] = fmaf(expf(lv[u] * scale - m2[u]) / s2[u], g2[u], acc[u]);
+    }
+    st8<float>(dv + p * D + lane * 8, acc);
+  }
+}
+
+inline int grid_for(int64_t waves) {
+  int64_t g = (waves + 3) / 4;
+  if (g > 8192) g = 8192;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+#define PT_REQ_COMMON(name)                                                                                          \
+  SUG_REQUIRE(B > 0 && n > 0 && k > 0 && k <= 16 && d == D, name ": bad shape (d_model must be 512, k <= 16)");     \
+  SUG_REQUIRE(dtype == 0 || dtype == 1, name ": dtype 0 (fp32) or 1 (fp16)")
+
+extern "C" int sug_ptran_pos1_fwd(const float* xyz, const int32_t* nbr, const float* w1, const float* b1, int B, int n,
+                                  int k, int d, int dtype, void* out, void* stream) {
+  SUG_REQUIRE(xyz && nbr && w1 && b1 && out, "sug_ptran_pos1_fwd: null pointer");
+  PT_REQ_COMMON("sug_ptran_pos1_fwd");
+  const int64_t R = (int64_t)B * n * k;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == 0) hipLaunchKernelGGL(ptran_pos1_kernel<float>, dim3(grid_for(R)), dim3(256), 0, st, xyz, nbr, w1, b1, R, n, k, (float*)out);
+  else hipLaunchKernelGGL(ptran_pos1_kernel<__half>, dim3(grid_for(R)), dim3(256), 0, st, xyz, nbr, w1, b1, R, n, k, (__half*)out);
+  SUG_LAUNCH_CHECK("sug_ptran_pos1_fwd");
+  return SUG_OK;
+}
+
+extern "C" int sug_ptran_pos1_bwd(const void* g, const float* xyz, const int32_t* nbr, const float* w1, const float* b1,
+                                  int B, int n, int k, int d, int dtype, float* dw1, float* db1, float* ws, void* stream) {
+  SUG_REQUIRE(g && xyz && nbr && w1 && b1 && dw1 && db1 && ws, "sug_ptran_pos1_bwd: null pointer");
+  PT_REQ_COMMON("sug_ptran_pos1_bwd");
+  const int64_t R = (int64_t)B * n * k;
+  int nb = (int)((R + 63) / 64);
+  if (nb > 512) nb = 512;                                   // ws: 512 * 4 * 512 floats
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == 0) hipLaunchKernelGGL(ptran_pos1_bwd_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)g, xyz, nbr, w1, b1, R, n, k, ws);
+  else hipLaunchKernelGGL(ptran_pos1_bwd_kernel<__half>, dim3(nb), dim3(256), 0, st, (const __half*)g, xyz, nbr, w1, b1, R, n, k, ws);
+  SUG_LAUNCH_CHECK("sug_ptran_pos1_bwd");
+  hipLaunchKernelGGL(ptran_pos1_fold_kernel, dim3(sug_divup(4 * D, 256)), dim3(256), 0, st, ws, nb, dw1, db1);
+  SUG_LAUNCH_CHECK("sug_ptran_pos1_bwd(fold)");
+  return SUG_OK;
+}
+
+extern "C" int sug_ptran_qk_fwd(const float* q, const float* kf, const void* delta, const int32_t* nbr, int B, int n, int k,
+                                int d, int dtype, void* out, void* stream) {
+  SUG_REQUIRE(q && kf && delta && nbr && out, "sug_ptran_qk_fwd: null pointer");
+  PT_REQ_COMMON("sug_ptran_qk_fwd");
+  const int64_t P = (int64_t)B * n;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == 0) hipLaunchKernelGGL(ptran_qk_kernel<float>, dim3(grid_for(P)), dim3(256), 0, st, q, kf, (const float*)delta, nbr, P, n, k, (float*)out);
+  else hipLaunchKernelGGL(ptran_qk_kernel<__half>, dim3(grid_for(P)), dim3(256), 0, st, q, kf, (const __half*)delta, nbr, P, n, k, (__half*)out);
+  SUG_LAUNCH_CHECK("sug_ptran_qk_fwd");
+  return SUG_OK;
+}
+
+extern "C" int sug_ptran_qk_bwd(const void* du, void* da, const int32_t* rev_off, const int32_t* rev_ent, int B, int n,
+                                int k, int d, int dtype, float* dq, float* dk, void* stream) {
+  SUG_REQUIRE(du && da && rev_off && rev_ent && dq && dk, "sug_ptran_qk_bwd: null pointer");
+  PT_REQ_COMMON("sug_ptran_qk_bwd");
+  const int64_t P = (int64_t)B * n;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == 0) hipLaunchKernelGGL(ptran_qk_bwd_kernel<float>, dim3(grid_for(P)), dim3(256), 0, st, (const float*)du, (float*)da, rev_off, rev_ent, P, n, k, dq, dk);
+  else hipLaunchKernelGGL(ptran_qk_bwd_kernel<__half>, dim3(grid_for(P)), dim3(256), 0, st, (const __half*)du, (__half*)da, rev_off, rev_ent, P, n, k, dq, dk);
+  SUG_LAUNCH_CHECK("sug_ptran_qk_bwd");
+  return SUG_OK;
+}
+
+extern "C" int sug_ptran_attn_fwd(const void* logits, const void* delta, const float* vf, const int32_t* nbr, int B, int n,
+                                  int k, int d, int dtype, float scale, float* mixed, float* mx, float* sm, void* stream) {
+  SUG_REQUIRE(logits && delta && vf && nbr && mixed && mx && sm, "sug_ptran_attn_fwd: null pointer");
+  PT_REQ_COMMON("sug_ptran_attn_fwd");
+  const int64_t P = (int64_t)B * n;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == 0) hipLaunchKernelGGL((ptran_attn_kernel<float, 16>), dim3(grid_for(P)), dim3(256), 0, st, (const float*)logits, (const float*)delta, vf, nbr, P, n, k, scale, mixed, mx, sm);
+  else hipLaunchKernelGGL((ptran_attn_kernel<__half, 16>), dim3(grid_for(P)), dim3(256), 0, st, (const __half*)logits, (const __half*)delta, vf, nbr, P, n, k, scale, mixed, mx, sm);
+  SUG_LAUNCH_CHECK("sug_ptran_attn_fwd");
+  return SUG_OK;
+}
+
+extern "C" int sug_ptran_attn_bwd(const float* g, const void* logits, const void* delta, const float* vf, const int32_t* nbr,
+                                  const float* mx, const float* sm, const int32_t* rev_off, const int32_t* rev_ent, int B,
+                                  int n, int k, int d, int dtype, float scale, void* dlogits, void* da, float* dv,
+                                  void* stream) {
+  SUG_REQUIRE(g && logits && delta && vf && nbr && mx && sm && rev_off && rev_ent && dlogits && da && dv,
+              "sug_ptran_attn_bwd: null pointer");
+  PT_REQ_COMMON("sug_ptran_attn_bwd");
+  const int64_t P = (int64_t)B * n;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == 0) hipLaunchKernelGGL((ptran_attn_bwd_kernel<float, 16>), dim3(grid_for(P)), dim3(256), 0, st, g, (const float*)logits, (const float*)delta, vf, nbr, mx, sm, rev_off, rev_ent, P, n, k, scale, (float*)dlogits, (float*)da, dv);
+  else hipLaunchKernelGGL((ptran_attn_bwd_kernel<__half, 16>), dim3(grid_for(P)), dim3(256), 0, st, g, (const __half*)logits, (const __half*)delta, vf, nbr, mx, sm, rev_off, rev_ent, P, n, k, scale, (__half*)dlogits, (__half*)da, dv);
+  SUG_LAUNCH_CHECK("sug_ptran_attn_bwd");
+  return SUG_OK;
+}

@@ -66,16 +66,22 @@ class TransformerBlock(nn.Module):
         """[B,n,3] -> int32 [B,n,min(k,n)]: an argsort over n < k columns has only n entries."""
         return ops.knn_query(xyz, xyz, min(self.k, xyz.shape[1]), direct=True)
 
-    def forward(self, xyz, features):
-        """xyz [B,n,3], features [B,n,f] -> (features' [B,n,f], attention [B,n,k,d])."""
+    def forward(self, xyz, features, need_attn=False):
+        """xyz [B,n,3], features [B,n,f] -> (features' [B,n,f], attention [B,n,k,d] or None).
+        The attention tensor (second return value of the reference, unused by PTran_g) is only
+        materialised on request: the fused path never builds it."""
         xyz = xyz.contiguous()
         nbr = self.neighbours(xyz)
         lifted = _apply(self.fc1, features)
-        query = _apply(self.w_qs, lifted).unsqueeze(2)                         # [B,n,1,d]
-        key = ops.gather_rows(_apply(self.w_ks, lifted), nbr)                  # [B,n,k,d]
-        value = ops.gather_rows(_apply(self.w_vs, lifted), nbr)
+        q, kf, vf = _apply(self.w_qs, lifted), _apply(self.w_ks, lifted), _apply(self.w_vs, lifted)
+        if self.fc1.out_features == 512 and not need_attn and GEMM_DTYPE in (None, torch.float16):
+            mixed = ops.ptran_attention(xyz, nbr, q, kf, vf, self.fc_delta, self.fc_gamma, GEMM_DTYPE)
+            return _apply(self.fc2, mixed) + features, None
+        # composition out of separate ops (other widths, bf16 experiments, or when the attention is wanted)
+        key = ops.gather_rows(kf, nbr)                                         # [B,n,k,d]
+        value = ops.gather_rows(vf, nbr)
         delta = _apply2(self.fc_delta, xyz.unsqueeze(2) - ops.gather_rows(xyz, nbr))
-        logits = _apply2(self.fc_gamma, query - key + delta)
+        logits = _apply2(self.fc_gamma, q.unsqueeze(2) - key + delta)
         attn = torch.softmax(logits / self.temperature, dim=2)                 # over the neighbours
         mixed = (attn * (value + delta)).sum(dim=2)
         return _apply(self.fc2, mixed) + features, attn

@@ -815,6 +815,90 @@ def pointmlp_max(x, weight, bias, bn, slope, seg):
                               slope, bn.eps, bn.momentum, seg, BN_GROUPS)
 
 
+# ----------------------------------------------------------------------------- Point Transformer attention
+class _PTranAttention(torch.autograd.Function):
+    """Vector attention of one TransformerBlock (model/Ptran_transformer.py:39-44) from the projected
+    q / K / V rows: pos-encoding MLP on the neighbour offsets, attention MLP on q - k + delta, softmax
+    over the k neighbours per channel, weighted sum of v + delta.  The three 512 x 512 linears on the
+    k-expanded rows are library GEMMs in `dtype` (fp32 = the reference's arithmetic; fp16 = MFMA with
+    fp32 accumulation, BASELINE config 5); everything between them is sug_ptran_* (one pass each).
+    The backward is written out by hand: nothing but the GEMM operands T0, delta, U, T1, L is saved, the
+    two gradients of delta are summed inside sug_ptran_qk_bwd, dK / dV are gathered over reverse
+    neighbour lists (deterministic, no atomics)."""
+
+    @staticmethod
+    def forward(ctx, xyz, nbr, q, kf, vf, w1, b1, w2, b2, wg1, bg1, wg2, bg2, dtype):
+        _need_gpu(xyz, nbr, q, kf, vf)
+        B, n, k = nbr.shape
+        d = q.shape[-1]
+        dev = q.device
+        lo = torch.float32 if dtype is None else dtype
+        code = 0 if lo == torch.float32 else 1
+        if lo not in (torch.float32, torch.float16):
+            raise RuntimeError('ptran_attention: fp32 or fp16 (got %s)' % lo)
+        R = B * n * k
+        xyz, nbr = xyz.detach().contiguous(), _i32(nbr).contiguous()
+        q, kf, vf = q.contiguous(), kf.contiguous(), vf.contiguous()
+        w1c, b1c = w1.detach().contiguous(), b1.detach().contiguous()
+        wl = [t.detach().to(lo) for t in (w2, b2, wg1, bg1, wg2, bg2)]
+        L_ = lib()
+        T0 = torch.empty(R, d, dtype=lo, device=dev)
+        check(L_.sug_ptran_pos1_fwd(_p(xyz), _p(nbr), _p(w1c), _p(b1c), B, n, k, d, code, _p(T0), _st()), 'sug_ptran_pos1_fwd')
+        delta = torch.addmm(wl[1], T0, wl[0].t())
+        U = torch.empty(R, d, dtype=lo, device=dev)
+        check(L_.sug_ptran_qk_fwd(_p(q), _p(kf), _p(delta), _p(nbr), B, n, k, d, code, _p(U), _st()), 'sug_ptran_qk_fwd')
+        T1 = torch.addmm(wl[3], U, wl[2].t()).relu_()
+        Lg = torch.addmm(wl[5], T1, wl[4].t())
+        mixed = torch.empty(B, n, d, dtype=torch.float32, device=dev)
+        mx, sm = torch.empty_like(mixed), torch.empty_like(mixed)
+        scale = 1.0 / (d ** 0.5)
+        check(L_.sug_ptran_attn_fwd(_p(Lg), _p(delta), _p(vf), _p(nbr), B, n, k, d, code, scale, _p(mixed), _p(mx), _p(sm),
+                                    _st()), 'sug_ptran_attn_fwd')
+        ctx.save_for_backward(xyz, nbr, vf, w1c, b1c, wl[0], wl[2], wl[4], T0, delta, U, T1, Lg, mx, sm)
+        ctx.meta = (B, n, k, d, code, scale)
+        return mixed
+
+    @staticmethod
+    def backward(ctx, g):
+        xyz, nbr, vf, w1c, b1c, w2l, wg1l, wg2l, T0, delta, U, T1, Lg, mx, sm = ctx.saved_tensors
+        B, n, k, d, code, scale = ctx.meta
+        dev, lo = g.device, T0.dtype
+        L_ = lib()
+        g = g.contiguous().float()
+        off, ent = knn_reverse(nbr)
+        dL, da = torch.empty_like(Lg), torch.empty_like(Lg)
+        dv = torch.empty(B, n, d, dtype=torch.float32, device=dev)
+        check(L_.sug_ptran_attn_bwd(_p(g), _p(Lg), _p(delta), _p(vf), _p(nbr), _p(mx), _p(sm), _p(off), _p(ent), B, n, k, d,
+                                    code, scale, _p(dL), _p(da), _p(dv), _st()), 'sug_ptran_attn_bwd')
+        f32 = torch.float32
+        dwg2 = (dL.t() @ T1).to(f32)
+        dbg2 = dL.sum(dim=0, dtype=f32)
+        dT1 = torch.ops.aten.threshold_backward(dL @ wg2l, T1, 0)
+        dwg1 = (dT1.t() @ U).to(f32)
+        dbg1 = dT1.sum(dim=0, dtype=f32)
+        dU = dT1 @ wg1l
+        dq, dk = torch.empty_like(dv), torch.empty_like(dv)
+        check(L_.sug_ptran_qk_bwd(_p(dU), _p(da), _p(off), _p(ent), B, n, k, d, code, _p(dq), _p(dk), _st()), 'sug_ptran_qk_bwd')
+        ddelta = da                                            # = dU + da
+        dw2 = (ddelta.t() @ T0).to(f32)
+        db2 = ddelta.sum(dim=0, dtype=f32)
+        dT0 = ddelta @ w2l
+        dw1 = torch.empty(d, 3, dtype=f32, device=dev)
+        db1 = torch.empty(d, dtype=f32, device=dev)
+        ws = torch.empty(512 * 4 * d, dtype=f32, device=dev)
+        check(L_.sug_ptran_pos1_bwd(_p(dT0), _p(xyz), _p(nbr), _p(w1c), _p(b1c), B, n, k, d, code, _p(dw1), _p(db1), _p(ws),
+                                    _st()), 'sug_ptran_pos1_bwd')
+        return None, None, dq, dk, dv, dw1, db1, dw2, db2, dwg1, dbg1, dwg2, dbg2, None
+
+
+def ptran_attention(xyz, nbr, q, kf, vf, fc_delta, fc_gamma, dtype=None):
+    """xyz [B,n,3], nbr [B,n,k], q / kf / vf [B,n,512] (w_qs / w_ks / w_vs of the lifted features),
+    fc_delta = Sequential(Linear(3,512), ReLU, Linear(512,512)), fc_gamma likewise (512,512) -> [B,n,512]."""
+    return _PTranAttention.apply(xyz, nbr, q, kf, vf, fc_delta[0].weight, fc_delta[0].bias, fc_delta[2].weight,
+                                 fc_delta[2].bias, fc_gamma[0].weight, fc_gamma[0].bias, fc_gamma[2].weight,
+                                 fc_gamma[2].bias, dtype)
+
+
 # ----------------------------------------------------------------------------- concat without copies
 class _AssembleRows(torch.autograd.Function):
     """torch.cat(parts, dim=-1) for parts that (mostly) already live in column slices of `buf`

@@ -29,6 +29,21 @@ class Adam(torch.optim.Adam):
         super().load_state_dict(state_dict)
         self._plan = None
 
+    def _sync_steps_from_device(self):
+        """graph_capturable mode keeps the step count on the device (replays advance it without the
+        host): copy it back into state['step'] -- before the plan is rebuilt, and for state_dict()."""
+        if not (self._graph_capturable and self._plan):
+            return
+        for b in self._plan:
+            n = float(int(b.step_dev.item()))
+            b.step_val = int(n)
+            for p in b.params:
+                self.state[p]['step'] = torch.tensor(n, dtype=torch.float32)
+
+    def state_dict(self):
+        self._sync_steps_from_device()
+        return super().state_dict()
+
     def _hyper(self, g):
         if g.get('amsgrad') or g.get('maximize') or g.get('capturable') or g.get('differentiable'):
             raise RuntimeError('sug_amd.optim.Adam: amsgrad / maximize / capturable / differentiable are not supported')
@@ -36,6 +51,10 @@ class Adam(torch.optim.Adam):
         return (float(lr), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']), float(g['weight_decay']))
 
     def _build(self, key):
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('sug_amd.optim.Adam: the update plan changed (other hyper-parameters or another set of '
+                               'parameters with gradients) while a hipGraph is being captured; run one eager step first')
+        self._sync_steps_from_device()              # a rebuilt plan continues the old step counts
         chunk = lib().sug_adam_chunk()
         buckets = {}
         for g in self.param_groups:

@@ -208,15 +208,26 @@ class _StartFeeder:
 
     def build(self):
         total = sum(b for b, _ in self.plan)
-        self.host = torch.empty(total, dtype=torch.int32).pin_memory()
+        # two pinned staging buffers, used alternately: the host must not overwrite one while its
+        # asynchronous copy to the device may still be pending (replays are not synchronised)
+        self.host = [torch.empty(total, dtype=torch.int32).pin_memory() for _ in range(2)]
+        self.done = [None, None]
+        self.turn = 0
         self.dev = torch.zeros(total, dtype=torch.int32, device=self.device)
 
     def refill(self):           # before every replay
+        h = self.host[self.turn]
+        if self.done[self.turn] is not None:
+            self.done[self.turn].synchronize()
         off = 0
         for B, N in self.plan:
-            self.host[off:off + B] = torch.randint(0, N, (B,), dtype=torch.long).to(torch.int32)
+            h[off:off + B] = torch.randint(0, N, (B,), dtype=torch.long).to(torch.int32)
             off += B
-        self.dev.copy_(self.host, non_blocking=True)
+        self.dev.copy_(h, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.done[self.turn] = ev
+        self.turn ^= 1
 
     def provide(self, B, N):    # provider during capture
         off = sum(b for b, _ in self.plan[:self.cursor])
@@ -263,12 +274,8 @@ class SUGStep:
         # its second replay; not reproduced since the pooling tail moved into bn_act_pool (3000 clean
         # replays, tools/graph_soak.py).  Single-GPU only.
         self.use_graph = bool(use_graph) and self.world == 1 and next(model.parameters()).is_cuda
-        self._graph = None
+        self._graphs = None
         self._tick = torch.zeros(1, device=next(model.parameters()).device) if self.use_graph else None
-        self._feeder = None
-        self._static_in = None
-        self._static_out = None
-        self._graph_epoch = None
         from .optim import Adam as _SugAdam
         AdamCls = _SugAdam if own_adam else torch.optim.Adam
         if self.use_graph:
@@ -397,46 +404,55 @@ class SUGStep:
         return self._eager_step(data, label, data_t, label_t, epoch)
 
     def _graph_step(self, data, label, data_t, label_t, epoch):
+        """hipGraph mode (experimental, opt-in; not used for the reported numbers).  One captured graph
+        per configuration key = (MMD on/off, input shapes, the learning rates of the three optimizers):
+        the kernels take lr by value, so a schedule step simply selects / captures another graph.  The
+        first step of a key runs eagerly (it records the FPS start-draw plan and builds the Adam update
+        plans OUTSIDE any capture), the second captures, later ones replay."""
         mmd_on = epoch >= self.methods['PURE_CLS_EPOCH']
-        if self._feeder is None:
-            # step 1: eager, recording the (B, N) sequence of FPS start draws
-            self._feeder = _StartFeeder(data.device)
-            ops.START_PROVIDER = self._feeder.record
+        lrs = tuple(g['lr'] for o in (self.optimizer_g, self.optimizer_c, self.optimizer_dis) for g in o.param_groups[:1])
+        key = (mmd_on, tuple(tuple(t.shape) for t in (data, label, data_t, label_t)), lrs)
+        if self._graphs is None:
+            self._graphs = {}
+        st = self._graphs.get(key)
+        if st is None:
+            st = {'feeder': _StartFeeder(data.device), 'graph': None}
+            self._graphs[key] = st
+            ops.START_PROVIDER = st['feeder'].record
             try:
                 out = self._eager_step(data, label, data_t, label_t, epoch)
             finally:
                 ops.START_PROVIDER = None
-            self._feeder.build()
+            st['feeder'].build()
             return out
-        if self._graph is None or self._graph_epoch != mmd_on or any(
-                a.shape != b.shape for a, b in zip(self._static_in, (data, label, data_t, label_t))):
-            self._static_in = [t.clone() for t in (data, label, data_t, label_t)]
-            self._graph_epoch = mmd_on
+        if st['graph'] is None:
+            st['in'] = [t.clone() for t in (data, label, data_t, label_t)]
             for o in (self.optimizer_g, self.optimizer_c, self.optimizer_dis):
                 o.zero_grad(set_to_none=True)
-            self._feeder.cursor = 0
-            self._graph = torch.cuda.CUDAGraph()
+            st['feeder'].cursor = 0
+            st['graph'] = torch.cuda.CUDAGraph()
             if os.environ.get('SUG_GRAPH_DUMP'):
-                self._graph.enable_debug_mode()
-            ops.START_PROVIDER = self._feeder.provide
+                st['graph'].enable_debug_mode()
+            ops.START_PROVIDER = st['feeder'].provide
             try:
-                with torch.cuda.graph(self._graph):
-                    self._static_out = self._eager_step(*self._static_in, epoch)
+                with torch.cuda.graph(st['graph']):
+                    st['out'] = self._eager_step(*st['in'], epoch)
             finally:
                 ops.START_PROVIDER = None
             if os.environ.get('SUG_GRAPH_DUMP'):
-                self._graph.debug_dump(os.environ['SUG_GRAPH_DUMP'])
-        for dst, src in zip(self._static_in, (data, label, data_t, label_t)):
+                st['graph'].debug_dump(os.environ['SUG_GRAPH_DUMP'])
+        for dst, src in zip(st['in'], (data, label, data_t, label_t)):
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
-        self._feeder.refill()
-        # One eager op on ordinary (non-graph-pool) memory between two replays.  Without it,
-        # back-to-back hipGraphLaunch of this graph faults in its second replay on ROCm 7.0 /
-        # gfx950 (a torch scatter reads out-of-range indices; any eager kernel or copy touching
-        # normal-pool memory in between avoids it, a sleep or a device sync does not).
+        st['feeder'].refill()
+        # One eager op on ordinary (non-graph-pool) memory between two replays: an early version of the
+        # step faulted in its second back-to-back replay on ROCm 7.0 / gfx950 (a torch scatter read
+        # out-of-range indices; any eager kernel in between avoided it, a sleep or a device sync did not).
+        # Not root-caused and not reproduced since the pooling tail became one kernel (3000 clean replays,
+        # tools/graph_soak.py); the op stays as a guard, and the mode stays experimental for that reason.
         self._tick.add_(1)
-        self._graph.replay()
-        return self._static_out
+        st['graph'].replay()
+        return st['out']
 
     def _eager_step(self, data, label, data_t, label_t, epoch=0):
         mmd_on = epoch >= self.methods['PURE_CLS_EPOCH']

@@ -208,3 +208,39 @@ def test_step_with_tuned_library_gemms_matches_default():
         assert abs(a - b) <= 1e-4 * max(1.0, abs(a)), res
     for a, b in zip(res[0][1], res[1][1]):
         assert abs(a - b) <= 5e-3 * max(1.0, abs(a)), res
+
+
+def test_graph_mode_follows_eager_through_an_lr_change():
+    """hipGraph mode (experimental): eager planning step, capture, replays -- and a learning-rate
+    change selects a new graph (the kernels take lr by value) -- follow the eager trajectory; the
+    Adam step count kept on the device comes back through state_dict()."""
+    from sug_amd.model.Model import Net_MDA
+    from sug_amd.train_step import SUGStep
+    G = load_golden('step_dgcnn.npz')
+    seed = G['seed']
+    data, data_t = G['data'].cuda(), G['data_t'].cuda()
+    lab, lab_t = G['label'].cuda(), G['label_t'].cuda()
+    res, steps = [], None
+    for use_graph in (False, True):
+        net = Net_MDA('DGCNN')
+        net.load_state_dict(O.fill_params({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed))
+        for m in net.modules():
+            if isinstance(m, torch.nn.Dropout2d):
+                m.p = 0.0
+        tr = SUGStep(net.cuda().train(), use_graph=use_graph)
+        torch.manual_seed(seed)
+        out = []
+        for i in range(7):
+            if i == 4:
+                tr.set_epoch(3, 10)              # cosine for g / c, unchanged for dis (< 5 epochs)
+            out.append([float(v) for v in tr.step(data, lab, data_t, lab_t)])
+        res.append(out)
+        if use_graph:
+            sd = tr.optimizer_c.state_dict()
+            steps = {float(v['step']) for v in sd['state'].values()}
+    assert steps == {7.0}, steps
+    for a, b in zip(res[0], res[1]):
+        for x, y in zip(a, b):
+            assert abs(x - y) <= 2e-2 * max(1.0, abs(x)), res        # trajectories: same noise bound as two eager runs
+    for x, y in zip(res[0][0], res[1][0]):
+        assert abs(x - y) <= 1e-5 * max(1.0, abs(x)), res
