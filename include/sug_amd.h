@@ -353,7 +353,7 @@ int sug_pointmlp_max_bwd_sparse(const float* a, const int32_t* arg, const float*
  * Backward: rev_off / rev_ent = sug_knn_reverse(nbr) (dK and dV are gathered over reverse neighbour lists:
  * no atomics).  sug_ptran_attn_bwd: g = d mixed -> dlogits, da = the gradient of delta through (v + delta),
  * dv [B,n,512].  sug_ptran_qk_bwd: du = dU; da is read and overwritten with d delta = du + da; dq, dk
- * [B,n,512].  sug_ptran_pos1_bwd: g = dT0 -> dw1 [512,3], db1 [512]; ws: 512*4*512 floats. */
+ * [B,n,512].  sug_ptran_pos1_bwd: g = dT0 -> dw1 [512,3], db1 [512]; ws: 1024*4*512 floats. */
 int sug_ptran_pos1_fwd(const float* xyz, const int32_t* nbr, const float* w1, const float* b1, int B, int n, int k,
                        int d, int dtype, void* out, void* stream);
 int sug_ptran_pos1_bwd(const void* g, const float* xyz, const int32_t* nbr, const float* w1, const float* b1, int B,

@@ -127,16 +127,24 @@ __global__ __launch_bounds__(256) void ptran_pos1_bwd_kernel(const T* __restrict
   }
 }
 
-// fold the partials in a fixed order (fp64): out[0..3*512) = dW1 [512][3], out[3*512..) = db1
+// fold the partials in a fixed order (fp64): 32 outputs per workgroup, 8 row groups each, combined in order
 __global__ __launch_bounds__(256) void ptran_pos1_fold_kernel(const float* __restrict__ part, int nb, float* __restrict__ dW1,
                                                               float* __restrict__ db1) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= 4 * D) return;
+  __shared__ double s_p[8][33];
+  const int o = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int e = blockIdx.x * 32 + o;
   double t = 0.0;
-  for (int i = 0; i < nb; ++i) t += (double)part[(int64_t)i * 4 * D + e];
-  const int q = e / D, c = e % D;
-  if (q < 3) dW1[c * 3 + q] = (float)t;
-  else db1[c] = (float)t;
+  for (int i = grp; i < nb; i += 8) t += (double)part[(int64_t)i * 4 * D + e];
+  s_p[grp][o] = t;
+  __syncthreads();
+  if (grp == 0) {
+    double a = 0.0;
+#pragma unroll
+    for (int g8 = 0; g8 < 8; ++g8) a += s_p[g8][o];
+    const int q = e / D, c = e % D;
+    if (q < 3) dW1[c * 3 + q] = (float)a;
+    else db1[c] = (float)a;
+  }
 }
 
 // ---- qk: U = q_i - K_nbr + delta
@@ -164,17 +172,13 @@ __global__ __launch_bounds__(256) void ptran_qk_kernel(const float* __restrict__
 }
 
 // backward of qk, fused with the sum of delta's two gradients: da (in: the attention's gradient of
-// delta, out: d delta = dU + da); dq[p] = sum_j dU[p,j]; dK[m] = - sum over the reverse list of m
+// delta, out: d delta = dU + da); dq[p] = sum_j dU[p,j]  (dK: ptran_rev_sum_kernel on dU)
 template <typename T>
-__global__ __launch_bounds__(256) void ptran_qk_bwd_kernel(const T* __restrict__ dU, T* __restrict__ da,
-                                                           const int32_t* __restrict__ rev_off,
-                                                           const int32_t* __restrict__ rev_ent, int64_t P, int n, int k,
-                                                           float* __restrict__ dq, float* __restrict__ dk) {
+__global__ __launch_bounds__(256) void ptran_qk_bwd_kernel(const T* __restrict__ dU, T* __restrict__ da, int64_t P, int n,
+                                                           int k, float* __restrict__ dq) {
   const int lane = threadIdx.x & 63;
   const int64_t w0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * 256) >> 6;
   for (int64_t p = w0; p < P; p += nw) {
-    const int64_t b = p / n;
-    const int i = (int)(p - b * n);
     float aq[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) aq[u] = 0.f;
@@ -188,20 +192,6 @@ __global__ __launch_bounds__(256) void ptran_qk_bwd_kernel(const T* __restrict__
       st8<T>(da + r * D + lane * 8, av);
     }
     st8<float>(dq + p * D + lane * 8, aq);
-    const int32_t* off = rev_off + b * (n + 1) + i;
-    const int e0 = off[0], e1 = off[1];
-    const int32_t* ent = rev_ent + b * (int64_t)n * k;
-    float ak[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) ak[u] = 0.f;
-    for (int t = e0; t < e1; ++t) {
-      const int64_t r = b * (int64_t)n * k + ent[t];
-      float uv[8];
-      ld8<T>(dU + r * D + lane * 8, uv);
-#pragma unroll
-      for (int u = 0; u < 8; ++u) ak[u] -= uv[u];
-    }
-    st8<float>(dk + p * D + lane * 8, ak);
   }
 }
 
@@ -255,15 +245,12 @@ template <typename T, int KK>
 __global__ __launch_bounds__(256) void ptran_attn_bwd_kernel(const float* __restrict__ g, const T* __restrict__ L,
                                                              const T* __restrict__ delta, const float* __restrict__ vf,
                                                              const int32_t* __restrict__ nbr, const float* __restrict__ mx,
-                                                             const float* __restrict__ sm, const int32_t* __restrict__ rev_off,
-                                                             const int32_t* __restrict__ rev_ent, int64_t P, int n, int k,
-                                                             float scale, T* __restrict__ dL, T* __restrict__ da,
-                                                             float* __restrict__ dv) {
+                                                             const float* __restrict__ sm, int64_t P, int n, int k,
+                                                             float scale, T* __restrict__ dL, T* __restrict__ da) {
   const int lane = threadIdx.x & 63;
   const int64_t w0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * 256) >> 6;
   for (int64_t p = w0; p < P; p += nw) {
     const int64_t b = p / n;
-    const int i = (int)(p - b * n);
     float gv[8], zmax[8], rs[8];
     ld8<float>(g + p * D + lane * 8, gv);
     ld8<float>(mx + p * D + lane * 8, zmax);
@@ -301,7 +288,20 @@ __global__ __launch_bounds__(256) void ptran_attn_bwd_kernel(const float* __rest
         st8<T>(dL + (p * k + j) * D + lane * 8, o);
       }
     }
-    // dV of this point as a neighbour of others
+  }
+}
+
+// out[m,:] = sign * sum over the reverse neighbour list of m of src[e,:] (entries ascending: fixed order).
+// dV = + sum of da (= g * attn, the attention's gradient of v + delta), dK = - sum of dU.
+template <typename T>
+__global__ __launch_bounds__(256) void ptran_rev_sum_kernel(const T* __restrict__ src, const int32_t* __restrict__ rev_off,
+                                                            const int32_t* __restrict__ rev_ent, int64_t P, int n, int k,
+                                                            float sign, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t w0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * 256) >> 6;
+  for (int64_t p = w0; p < P; p += nw) {
+    const int64_t b = p / n;
+    const int i = (int)(p - b * n);
     const int32_t* off = rev_off + b * (n + 1) + i;
     const int e0 = off[0], e1 = off[1];
     const int32_t* ent = rev_ent + b * (int64_t)n * k;
@@ -309,18 +309,14 @@ __global__ __launch_bounds__(256) void ptran_attn_bwd_kernel(const float* __rest
 #pragma unroll
     for (int u = 0; u < 8; ++u) acc[u] = 0.f;
     for (int t = e0; t < e1; ++t) {
-      const int e = ent[t];
-      const int64_t r = b * (int64_t)n * k + e;
-      const int64_t ps = b * n + e / k;
-      float lv[8], g2[8], m2[8], s2[8];
-      ld8<T>(L + r * D + lane * 8, lv);
-      ld8<float>(g + ps * D + lane * 8, g2);
-      ld8<float>(mx + ps * D + lane * 8, m2);
-      ld8<float>(sm + ps * D + lane * 8, s2);
+      float v[8];
+      ld8<T>(src + (b * (int64_t)n * k + ent[t]) * D + lane * 8, v);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) acc[u] = fmaf(expf(lv[u] * scale - m2[u]) / s2[u], g2[u], acc[u]);
+      for (int u = 0; u < 8; ++u) acc[u] += v[u];
     }
-    st8<float>(dv + p * D + lane * 8, acc);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] *= sign;
+    st8<float>(out + p * D + lane * 8, acc);
   }
 }
 
@@ -355,12 +351,12 @@ extern "C" int sug_ptran_pos1_bwd(const void* g, const float* xyz, const int32_t
   PT_REQ_COMMON("sug_ptran_pos1_bwd");
   const int64_t R = (int64_t)B * n * k;
   int nb = (int)((R + 63) / 64);
-  if (nb > 512) nb = 512;                                   // ws: 512 * 4 * 512 floats
+  if (nb > 1024) nb = 1024;                                 // ws: 1024 * 4 * 512 floats
   hipStream_t st = (hipStream_t)stream;
   if (dtype == 0) hipLaunchKernelGGL(ptran_pos1_bwd_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)g, xyz, nbr, w1, b1, R, n, k, ws);
   else hipLaunchKernelGGL(ptran_pos1_bwd_kernel<__half>, dim3(nb), dim3(256), 0, st, (const __half*)g, xyz, nbr, w1, b1, R, n, k, ws);
   SUG_LAUNCH_CHECK("sug_ptran_pos1_bwd");
-  hipLaunchKernelGGL(ptran_pos1_fold_kernel, dim3(sug_divup(4 * D, 256)), dim3(256), 0, st, ws, nb, dw1, db1);
+  hipLaunchKernelGGL(ptran_pos1_fold_kernel, dim3(4 * D / 32), dim3(256), 0, st, ws, nb, dw1, db1);
   SUG_LAUNCH_CHECK("sug_ptran_pos1_bwd(fold)");
   return SUG_OK;
 }
@@ -383,8 +379,13 @@ extern "C" int sug_ptran_qk_bwd(const void* du, void* da, const int32_t* rev_off
   PT_REQ_COMMON("sug_ptran_qk_bwd");
   const int64_t P = (int64_t)B * n;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == 0) hipLaunchKernelGGL(ptran_qk_bwd_kernel<float>, dim3(grid_for(P)), dim3(256), 0, st, (const float*)du, (float*)da, rev_off, rev_ent, P, n, k, dq, dk);
-  else hipLaunchKernelGGL(ptran_qk_bwd_kernel<__half>, dim3(grid_for(P)), dim3(256), 0, st, (const __half*)du, (__half*)da, rev_off, rev_ent, P, n, k, dq, dk);
+  if (dtype == 0) {
+    hipLaunchKernelGGL(ptran_rev_sum_kernel<float>, dim3(grid_for(P)), dim3(256), 0, st, (const float*)du, rev_off, rev_ent, P, n, k, -1.0f, dk);
+    hipLaunchKernelGGL(ptran_qk_bwd_kernel<float>, dim3(grid_for(P)), dim3(256), 0, st, (const float*)du, (float*)da, P, n, k, dq);
+  } else {
+    hipLaunchKernelGGL(ptran_rev_sum_kernel<__half>, dim3(grid_for(P)), dim3(256), 0, st, (const __half*)du, rev_off, rev_ent, P, n, k, -1.0f, dk);
+    hipLaunchKernelGGL(ptran_qk_bwd_kernel<__half>, dim3(grid_for(P)), dim3(256), 0, st, (const __half*)du, (__half*)da, P, n, k, dq);
+  }
   SUG_LAUNCH_CHECK("sug_ptran_qk_bwd");
   return SUG_OK;
 }
@@ -410,8 +411,13 @@ extern "C" int sug_ptran_attn_bwd(const float* g, const void* logits, const void
   PT_REQ_COMMON("sug_ptran_attn_bwd");
   const int64_t P = (int64_t)B * n;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == 0) hipLaunchKernelGGL((ptran_attn_bwd_kernel<float, 16>), dim3(grid_for(P)), dim3(256), 0, st, g, (const float*)logits, (const float*)delta, vf, nbr, mx, sm, rev_off, rev_ent, P, n, k, scale, (float*)dlogits, (float*)da, dv);
-  else hipLaunchKernelGGL((ptran_attn_bwd_kernel<__half, 16>), dim3(grid_for(P)), dim3(256), 0, st, g, (const __half*)logits, (const __half*)delta, vf, nbr, mx, sm, rev_off, rev_ent, P, n, k, scale, (__half*)dlogits, (__half*)da, dv);
+  if (dtype == 0) {
+    hipLaunchKernelGGL((ptran_attn_bwd_kernel<float, 16>), dim3(grid_for(P)), dim3(256), 0, st, g, (const float*)logits, (const float*)delta, vf, nbr, mx, sm, P, n, k, scale, (float*)dlogits, (float*)da);
+    hipLaunchKernelGGL(ptran_rev_sum_kernel<float>, dim3(grid_for(P)), dim3(256), 0, st, (const float*)da, rev_off, rev_ent, P, n, k, 1.0f, dv);
+  } else {
+    hipLaunchKernelGGL((ptran_attn_bwd_kernel<__half, 16>), dim3(grid_for(P)), dim3(256), 0, st, g, (const __half*)logits, (const __half*)delta, vf, nbr, mx, sm, P, n, k, scale, (__half*)dlogits, (__half*)da);
+    hipLaunchKernelGGL(ptran_rev_sum_kernel<__half>, dim3(grid_for(P)), dim3(256), 0, st, (const __half*)da, rev_off, rev_ent, P, n, k, 1.0f, dv);
+  }
   SUG_LAUNCH_CHECK("sug_ptran_attn_bwd");
   return SUG_OK;
 }

@@ -236,6 +236,27 @@ class PTran_g(nn.Module):
         self.nblocks = nblocks
         self.npoints = npoints
         self.conv1d = nn.Conv1d(64, 64, 1, stride=2)
+        # Opt-in common-subexpression sharing (set by SUGStep), as for DGCNN: fc1 + transformer1 run at full
+        # resolution, before any farthest-point sampling, have no BatchNorm and no dropout -- the semantic
+        # and the node pass of one step compute them on identical inputs with identical weights, so the
+        # second pass reuses the first one's result (one backward over both passes).
+        self.share_prefix = False
+        self._prefix_cache = {}
+
+    def clear_prefix_cache(self):
+        self._prefix_cache = {}
+
+    def _prefix(self, x, x_, xyz):
+        if not (self.share_prefix and self.training):
+            return self.transformer1(xyz, self.fc1(x_))[0]
+        ver = sum(p._version for m in (self.fc1, self.transformer1) for p in m.parameters())
+        key = (x.data_ptr(), x._version, tuple(x.shape), torch.is_grad_enabled(), ver)
+        hit = self._prefix_cache.get(key)
+        if hit is None:
+            if len(self._prefix_cache) >= 4:
+                self._prefix_cache.clear()
+            hit = self._prefix_cache[key] = self.transformer1(xyz, self.fc1(x_))[0]
+        return hit
 
     def fps_plan(self, N):
         """Point counts of the farthest_point_sample calls of one forward, in call order."""
@@ -245,8 +266,7 @@ class PTran_g(nn.Module):
         """x [B,3,N,1] -> (feat [B,512], node_fea [B,64,64](, None))."""
         x_ = x.squeeze(-1).permute(0, 2, 1).contiguous()              # [B,N,3]
         xyz = x_[..., :3]
-        x1 = self.fc1(x_)
-        points = self.transformer1(xyz, x1)[0]
+        points = self._prefix(x, x_, xyz)
         xyz_and_feats = [(xyz, points)]
         for i in range(self.nblocks):
             xyz, points = self.transition_downs[i](xyz, points)

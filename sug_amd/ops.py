@@ -871,21 +871,33 @@ class _PTranAttention(torch.autograd.Function):
         check(L_.sug_ptran_attn_bwd(_p(g), _p(Lg), _p(delta), _p(vf), _p(nbr), _p(mx), _p(sm), _p(off), _p(ent), B, n, k, d,
                                     code, scale, _p(dL), _p(da), _p(dv), _st()), 'sug_ptran_attn_bwd')
         f32 = torch.float32
-        dwg2 = (dL.t() @ T1).to(f32)
+
+        def dweight(gy, x):
+            """gy^T . x over the R rows in row chunks (batched GEMM = split-K: one [512,512] product alone
+            fills 32 workgroups), chunk results summed in fp32."""
+            R = gy.shape[0]
+            S = 1
+            while R % (2 * S) == 0 and R // (2 * S) >= 16384:
+                S *= 2
+            if S == 1:
+                return (gy.t() @ x).to(f32)
+            return torch.bmm(gy.view(S, R // S, d).transpose(1, 2), x.view(S, R // S, d)).sum(dim=0, dtype=f32)
+
+        dwg2 = dweight(dL, T1)
         dbg2 = dL.sum(dim=0, dtype=f32)
         dT1 = torch.ops.aten.threshold_backward(dL @ wg2l, T1, 0)
-        dwg1 = (dT1.t() @ U).to(f32)
+        dwg1 = dweight(dT1, U)
         dbg1 = dT1.sum(dim=0, dtype=f32)
         dU = dT1 @ wg1l
         dq, dk = torch.empty_like(dv), torch.empty_like(dv)
         check(L_.sug_ptran_qk_bwd(_p(dU), _p(da), _p(off), _p(ent), B, n, k, d, code, _p(dq), _p(dk), _st()), 'sug_ptran_qk_bwd')
         ddelta = da                                            # = dU + da
-        dw2 = (ddelta.t() @ T0).to(f32)
+        dw2 = dweight(ddelta, T0)
         db2 = ddelta.sum(dim=0, dtype=f32)
         dT0 = ddelta @ w2l
         dw1 = torch.empty(d, 3, dtype=f32, device=dev)
         db1 = torch.empty(d, dtype=f32, device=dev)
-        ws = torch.empty(512 * 4 * d, dtype=f32, device=dev)
+        ws = torch.empty(1024 * 4 * d, dtype=f32, device=dev)
         check(L_.sug_ptran_pos1_bwd(_p(dT0), _p(xyz), _p(nbr), _p(w1c), _p(b1c), B, n, k, d, code, _p(dw1), _p(db1), _p(ws),
                                     _st()), 'sug_ptran_pos1_bwd')
         return None, None, dq, dk, dv, dw1, db1, dw2, db2, dwg1, dbg1, dwg2, dbg2, None

@@ -87,16 +87,18 @@ def test_two_training_steps_match_reference():
     print('worst checksum deviation / allowance vs oracle = %.3f' % worst)
 
 
-def test_prefix_sharing_is_exact():
-    """SUGStep(share_prefix=True) (the semantic and node pass of a batch share kNN+conv1/conv2)
-    gives bit-identical losses, gradients and BN buffers to four independent passes."""
+@pytest.mark.parametrize('model_name', ['DGCNN', 'PTran'])
+def test_prefix_sharing_is_exact(model_name):
+    """SUGStep(share_prefix=True) (the semantic and node pass of a batch share the stage in front of the
+    first random sampling: kNN+conv1/conv2 for DGCNN, fc1 + transformer1 for the Point Transformer)
+    gives bit-identical losses and BN buffers, and the same gradients, as four independent passes."""
     from sug_amd.model.Model import Net_MDA
     from sug_amd.train_step import SUGStep
     G = load_golden('step_dgcnn.npz')
     seed = G['seed']
     res = []
     for share in (False, True):
-        net = Net_MDA('DGCNN')
+        net = Net_MDA(model_name)
         net.load_state_dict(O.fill_params({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed))
         for m in net.modules():
             if isinstance(m, torch.nn.Dropout2d):
