@@ -321,6 +321,11 @@ int sug_bn_act_pool_layer_bwd(const float* y, int64_t ldy, const float* coef, co
 int sug_pointmlp_max_fwd(const float* x, int64_t ldx, int64_t rows, int K, const float* w, const float* bias,
                          const float* gamma, int Co, int seg, float* zext, int32_t* arg, float* ws, int* nblk,
                          void* stream);
+/* y[r,:] = x[r,:] . w^T (+ bias) on the same fp32 MFMA pipeline, y stored ([rows, Co], row stride ldy): the
+ * per-point 1x1 convolution itself (conv_2d, model/model_utils.py:8-32) where no reduction follows, e.g. the
+ * EdgeConv operand PQ = x . [W1 ; W2-W1]^T.  Same shape limits as sug_pointmlp_max_fwd (rows arbitrary). */
+int sug_rows_gemm(const float* x, int64_t ldx, int64_t rows, int K, const float* w, const float* bias, int Co,
+                  float* y, int64_t ldy, void* stream);
 /* Layer entry point: the above per domain group, then the BatchNorm coefficients (training: batch
  * statistics + running-buffer update; eval: coef read, caller fills it) and
  * out[s,c] = LeakyReLU_slope(scale[c]*zext[s,c] + shift[c]), out [rows/seg, Co] (row stride ldo).

@@ -71,6 +71,7 @@ SIGNATURES = {
     'sug_bn_bwd_apply': [_vp, _vp, _i64, _vp, _vp, _i64, _i32, _vp, _i64, _vp],
     'sug_bn_act_pool_fwd': [_vp, _i64, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp],
     'sug_bn_act_pool_bwd': [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp, _i64, _vp],
+    'sug_rows_gemm': [_vp, _i64, _i64, _i32, _vp, _vp, _i32, _vp, _i64, _vp],
     'sug_pointmlp_max_fwd': [_vp, _i64, _i64, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
     'sug_pointmlp_max_layer_fwd': [_vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _vp,
                                    _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp],

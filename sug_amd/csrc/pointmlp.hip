@@ -184,6 +184,102 @@ __global__ __launch_bounds__(256, 2) void pointmlp_max_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// Plain per-point linear layer on the same pipeline: y[r, :] = x[r, :] . w^T (+ bias), y stored.
+// Used for the EdgeConv operand PQ = x . [W1 ; W2-W1]^T (model_utils.py:188-210 after the algebra of
+// edgeconv.hip) at K = 64 / 128, where the library's fp32 GEMM selection runs at 30-60 TFLOP/s.
+// Same geometry as pointmlp_max_kernel; the y tile of iteration t is stored while the MFMA chain of
+// tile t+1 runs: register r of a lane = row (r&3) + 8*(r>>2) + 4*(l>>5), 32 consecutive channels per
+// half-wave = one 128-byte segment per row.
+template <int CP>
+__global__ __launch_bounds__(256, 2) void rows_gemm_kernel(const float* __restrict__ x, int64_t ldx, int R,
+                                                           const float* __restrict__ W, const float* __restrict__ bias,
+                                                           int Co, int rows_per_wg, int nrb, float* __restrict__ y,
+                                                           int64_t ldy) {
+  constexpr int RS = CP + 4;
+  constexpr int HALF = CP / 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* s_tile = reinterpret_cast<float*>(smem);    // [3][TJ][RS]
+  const int ncb = Co >> 7;
+  int rb, cb;
+  if ((nrb & 7) == 0) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    rb = (j / ncb) * 8 + xcd;
+    cb = j % ncb;
+  } else {
+    rb = blockIdx.x / ncb;
+    cb = blockIdx.x % ncb;
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int cj = lane & 31, h = lane >> 5;
+  const int col = cb * 128 + wv * 32 + cj;
+  const int row_begin = rb * rows_per_wg;
+  const int nrows = (R - row_begin < rows_per_wg) ? R - row_begin : rows_per_wg;
+  const float* xb = x + (int64_t)row_begin * ldx;
+  float bq[HALF];
+  {
+    const float* wr = W + (int64_t)col * CP;
+#pragma unroll
+    for (int g = 0; g < CP / 8; ++g) {
+      const float4 lo = *reinterpret_cast<const float4*>(wr + 8 * g);
+      const float4 hi = *reinterpret_cast<const float4*>(wr + 8 * g + 4);
+      bq[4 * g + 0] = h ? lo.y : lo.x;
+      bq[4 * g + 1] = h ? lo.w : lo.z;
+      bq[4 * g + 2] = h ? hi.y : hi.x;
+      bq[4 * g + 3] = h ? hi.w : hi.z;
+    }
+  }
+  const float bj = bias ? bias[col] : 0.f;
+  const int ntile = (nrows + TJ - 1) / TJ;
+  auto tbuf = [&](int t) { return s_tile + (t % 3) * TJ * RS; };
+  auto chain = [&](const float* __restrict__ arow) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int g = 0; g < HALF / 4; ++g) {
+      const float4 a4 = *reinterpret_cast<const float4*>(arow + 4 * g);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, bq[4 * g + 0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, bq[4 * g + 1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, bq[4 * g + 2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, bq[4 * g + 3], acc, 0, 0, 0);
+    }
+    return acc;
+  };
+  auto store = [&](const f32x16& acc, int t) {
+    float* yb = y + (int64_t)(row_begin + t * TJ + 4 * h) * ldy + col;
+    const int lim = nrows - t * TJ - 4 * h;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const int rt = (c & 3) + 8 * (c >> 2);
+      if (rt < lim) yb[(int64_t)rt * ldy] = __fadd_rn(acc[c], bj);
+    }
+  };
+  TileRegs<CP> tra, trb;
+  tile_load<CP>(tra, xb, ldx, nrows, 0);
+  tile_store<CP, false>(tra, tbuf(0), nullptr, nrows, 0);
+  __syncthreads();
+  if (ntile > 1) tile_load<CP>(trb, xb, ldx, nrows, TJ);
+  if (ntile > 2) tile_load<CP>(tra, xb, ldx, nrows, 2 * TJ);
+  f32x16 acc_cur = chain(tbuf(0) + cj * RS + h * HALF);
+  if (ntile > 1) tile_store<CP, false>(trb, tbuf(1), nullptr, nrows, TJ);
+  __syncthreads();
+  if (ntile > 3) tile_load<CP>(trb, xb, ldx, nrows, 3 * TJ);
+#define SUG_RG_BODY(T, TR) do { \
+    f32x16 acc_next = chain(tbuf((T) + 1) + cj * RS + h * HALF); \
+    store(acc_cur, (T)); \
+    if ((T) + 2 < ntile) tile_store<CP, false>(TR, tbuf((T) + 2), nullptr, nrows, ((T) + 2) * TJ); \
+    __syncthreads(); \
+    if ((T) + 4 < ntile) tile_load<CP>(TR, xb, ldx, nrows, ((T) + 4) * TJ); \
+    acc_cur = acc_next; \
+  } while (0)
+  for (int t = 0; t < ntile; t += 2) {
+    SUG_RG_BODY(t, tra);
+    if (t + 1 < ntile) SUG_RG_BODY(t + 1, trb);
+  }
+#undef SUG_RG_BODY
+}
+
+// ---------------------------------------------------------------------------------------------
 // Backward, the part that follows the arg-extreme rows.  With a[s,c] = scale_c * gout * act'
 // (sug_edgeconv_bwd_reduce on the [S,Co] tensors) and n*(s,c) = s*L + arg[s,c]:
 //     dx[n*(s,c), :] += a[s,c] * W[c, :]            (rows of x that won a channel)
@@ -327,6 +423,28 @@ extern "C" int sug_pointmlp_max_fwd(const float* x, int64_t ldx, int64_t rows, i
   }
   SUG_LAUNCH_CHECK("sug_pointmlp_max_fwd");
   *nblk = nrb;
+  return SUG_OK;
+}
+
+extern "C" int sug_rows_gemm(const float* x, int64_t ldx, int64_t rows, int K, const float* w, const float* bias, int Co,
+                             float* y, int64_t ldy, void* stream) {
+  SUG_REQUIRE(x && w && y, "sug_rows_gemm: null pointer");
+  SUG_REQUIRE(K == 64 || K == 128, "sug_rows_gemm: K=%d (64 or 128 input channels)", K);
+  SUG_REQUIRE(Co > 0 && Co % 128 == 0 && ldy >= Co, "sug_rows_gemm: Co=%d must be a multiple of 128 (ldy >= Co)", Co);
+  SUG_REQUIRE(rows > 0 && rows < (1ll << 31), "sug_rows_gemm: bad row count");
+  SUG_REQUIRE(ldx >= K && ldx % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0,
+              "sug_rows_gemm: x / w must be 16-byte aligned with row strides in multiples of 4");
+  const int rpw = 1024;
+  const int nrb = sug_divup(rows, rpw);
+  const int grid = nrb * (Co / 128);
+  hipStream_t st = (hipStream_t)stream;
+  if (K == 128)
+    hipLaunchKernelGGL((rows_gemm_kernel<128>), dim3(grid), dim3(256), (size_t)3 * TJ * (128 + 4) * sizeof(float), st, x, ldx,
+                       (int)rows, w, bias, Co, rpw, nrb, y, ldy);
+  else
+    hipLaunchKernelGGL((rows_gemm_kernel<64>), dim3(grid), dim3(256), (size_t)3 * TJ * (64 + 4) * sizeof(float), st, x, ldx,
+                       (int)rows, w, bias, Co, rpw, nrb, y, ldy);
+  SUG_LAUNCH_CHECK("sug_rows_gemm");
   return SUG_OK;
 }
 

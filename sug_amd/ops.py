@@ -284,6 +284,10 @@ def group_max(feat, idx):
 DW_LIBRARY_SHAPES = set()
 DW_FORCE_LIBRARY = False        # tuning runs: every weight gradient through the library
 DW_SHAPE_LOG = None             # tuning runs: list collecting the (rows, M, N) seen
+import os as _os
+# measured on MI355X (graph mode, C2 step): the library's selection is 0.1-0.2 ms per step faster for these
+# forward GEMMs, tuned table or not -- the own kernel stays opt-in (SUG_OWN_ROWS_GEMM=1)
+OWN_ROWS_GEMM = _os.environ.get('SUG_OWN_ROWS_GEMM', '0') == '1'            # forward y = x.W^T of skinny layers (K in {64,128}, Co % 128 == 0) by sug_rows_gemm
 
 
 class _LinearRows(torch.autograd.Function):
@@ -292,7 +296,19 @@ class _LinearRows(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias):
-        y = torch.nn.functional.linear(x, weight, bias)
+        M, N = weight.shape
+        x2 = x.reshape(-1, N)
+        if OWN_ROWS_GEMM and N in (64, 128) and M % 128 == 0 and x2.shape[0] >= 4096 and x2.stride(1) == 1 \
+                and x2.stride(0) % 4 == 0 and x2.data_ptr() % 16 == 0 and weight.is_contiguous():
+            # fp32 MFMA kernel of the library (the rocBLAS selection for these skinny shapes is 2-3x slower)
+            y = torch.empty(x2.shape[0], M, dtype=torch.float32, device=x.device)
+            check(_timed('rows_gemm_K%d_Co%d' % (N, M), {'B': x2.shape[0], 'N': 1, 'k': N, 'Co': M},
+                         lambda: lib().sug_rows_gemm(_p(x2), x2.stride(0), x2.shape[0], N, _p(weight.detach()),
+                                                     _p(None if bias is None else bias.detach()), M, _p(y), M, _st())),
+                  'sug_rows_gemm')
+            y = y.view(*x.shape[:-1], M)
+        else:
+            y = torch.nn.functional.linear(x, weight, bias)
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         return y

@@ -107,3 +107,36 @@ def test_pointmlp_max_is_deterministic_and_full_size():
             bn.weight.copy_(torch.linspace(-1, 1, Co))
         ref = _reference(x, W, b, bn, seg, 0.0, 1)
         torch.testing.assert_close(res[0][0], ref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize('R,K,Co', [(65536, 128, 512), (65536, 64, 256), (5000, 64, 128), (4100, 128, 1024)])
+def test_rows_gemm_vs_torch(R, K, Co):
+    """sug_rows_gemm (the per-point linear layer without a following reduction, e.g. EdgeConv's PQ operand):
+    an fp32 fma chain over k, compared with torch's fp32 GEMM and with an fp64 product."""
+    from sug_amd import ops
+    g = torch.Generator().manual_seed(R + Co)
+    x = torch.randn(R, K, generator=g).cuda()
+    W = (torch.randn(Co, K, generator=g) / K ** 0.5).cuda()
+    b = torch.randn(Co, generator=g).cuda()
+    keep, ops.OWN_ROWS_GEMM = ops.OWN_ROWS_GEMM, True           # opt-in path (the library GEMM is the default)
+    try:
+        _rows_gemm_checks(ops, x, W, b, R, K)
+    finally:
+        ops.OWN_ROWS_GEMM = keep
+
+
+def _rows_gemm_checks(ops, x, W, b, R, K):
+    y = ops.linear_rows(x, W, b)
+    ref64 = (x.double() @ W.double().t() + b.double())
+    assert float((y.double() - ref64).abs().max()) < 2e-5
+    wide = torch.zeros(R, K + 8, device='cuda')
+    wide[:, 4:4 + K] = x                           # a column slice of a wider buffer (row stride K + 8)
+    y2 = ops.linear_rows(wide[:, 4:4 + K], W, None)
+    assert torch.equal(y2 + b, y) or float((y2 + b - y).abs().max()) < 1e-6
+    # gradients still flow through the library / sug_linear_dw backward
+    xr, Wr = x.clone().requires_grad_(True), W.clone().requires_grad_(True)
+    ops.linear_rows(xr, Wr, b).square().sum().backward()
+    xt, Wt = x.clone().requires_grad_(True), W.clone().requires_grad_(True)
+    torch.nn.functional.linear(xt, Wt, b).square().sum().backward()
+    assert float((xr.grad - xt.grad).norm() / xt.grad.norm()) < 1e-5
+    assert float((Wr.grad - Wt.grad).norm() / Wt.grad.norm()) < 1e-5
