@@ -207,7 +207,8 @@ def main():
     # Kernel events: only the kNN kernels (the dominant hand-written kernel) are instrumented,
     # because every event pair costs host time in a host-bound step.  Eager mode times them over
     # the timed region; graph mode (events cannot be captured on ROCm) over its eager warm-up step.
-    ops.PROFILE_ONLY = {'knn'}
+    timed_family = {'DGCNN': {'knn'}, 'Pointnet': {'pointmlp'}, 'Pointnet2': {'pointmlp'}}.get(args.model, {'knn'})
+    ops.PROFILE_ONLY = set(timed_family)
     for i in range(max(args.warmup, 3 if trainer.use_graph else 1)):
         ops.PROFILE = {} if (trainer.use_graph and i == 0) else ops.PROFILE
         trainer.step(data, lab, data_t, lab_t)
@@ -230,11 +231,11 @@ def main():
     # the other hand-written layer kernels (EdgeConv forward / backward layer calls, per-point MLP + max):
     # a few extra steps outside the timed region, for the `kernels` table only
     if not trainer.use_graph:
-        ops.PROFILE_ONLY, ops.PROFILE = {'edgeconv', 'pointmlp'}, {}
+        ops.PROFILE_ONLY, ops.PROFILE = {'edgeconv', 'pointmlp', 'knn'} - timed_family, {}
         for _ in range(5):
             trainer.step(data, lab, data_t, lab_t)
         sync()
-        extra_prof, ops.PROFILE, ops.PROFILE_ONLY = ops.PROFILE, None, {'knn'}
+        extra_prof, ops.PROFILE, ops.PROFILE_ONLY = ops.PROFILE, None, set(timed_family)
     else:
         extra_prof = {}
     # The same workload the way train_dg_single_gpu.py:260-310 calls the API: four separate model(...)
@@ -269,6 +270,8 @@ def main():
         # ---- per-kernel live timings (events on the launch stream) -> roofline of the dominant one
         kern = {}
         timed_names = set(prof)
+        allprof = dict(extra_prof)
+        allprof.update(prof)
         for name, recs in list(prof.items()) + list(extra_prof.items()):
             ms = [a.elapsed_time(b) for a, b, _ in recs]
             shape = recs[0][2]
@@ -282,9 +285,9 @@ def main():
                           'frac': tfl / FP32_PEAK_TFLOPS if cb else gbps / HBM_PEAK_GBS}
         roofline = None
         if kern:
-            dom = max(timed_names, key=lambda n: kern[n]['total_ms'])
+            dom = max(timed_names or set(kern), key=lambda n: kern[n]['total_ms'])
             kd = kern[dom]
-            ai = kernel_model(dom, prof[dom][0][2])
+            ai = kernel_model(dom, allprof[dom][0][2])
             compute_bound = ai['flops'] / max(ai['bytes'], 1) > FP32_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS
             if compute_bound:
                 roofline = {'kernel': dom, 'bound': 'mfma', 'achieved': kd['TFLOPs'], 'peak': FP32_PEAK_TFLOPS,
@@ -299,7 +302,7 @@ def main():
             try:
                 pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles',
                                                   'r02_pmc_traffic.json'))).get(dom)
-                shp = prof[dom][0][2]
+                shp = allprof[dom][0][2]
                 if pmc and all(pmc[k] == shp[k] for k in ('B', 'N', 'k')):
                     roofline['traffic'] = pmc['traffic_bytes']
                     roofline['traffic_note'] = 'bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE; ' \

@@ -160,14 +160,18 @@ class Pointnet2_g(nn.Module):
         """Point counts of the farthest_point_sample calls of one forward, in call order."""
         return [N, self.sa1.npoint]
 
-    def forward(self, xyz, node=False):
+    def forward(self, xyz, node=False, feat_grad=True):
+        """feat_grad=False: the caller discards `feat` (node-adaptation pass): everything behind the layer
+        the node features are taken from still runs -- it updates BatchNorm running statistics and draws
+        its FPS start -- but without autograd."""
         rows = xyz.squeeze(-1).transpose(1, 2).contiguous()           # [B,N,3(+3)]
         B = rows.shape[0]
         norm = rows[:, :, 3:].contiguous() if self.normal_channel else None
         loc = rows[:, :, :3].contiguous()
-        l1_xyz, l1_pts, node_fea = self.sa1.rows(loc, norm, adapt=True)     # [B,512,3], [B,512,128], [B,512,64]
-        l2_xyz, l2_pts = self.sa2.rows(l1_xyz, l1_pts)
-        _, l3_pts = self.sa3.rows(l2_xyz, l2_pts)
+        l1_xyz, l1_pts, node_fea = self.sa1.rows(loc, norm, adapt=True, tail_grad=feat_grad)   # [B,512,3], [B,512,128], [B,512,64]
+        with torch.set_grad_enabled(torch.is_grad_enabled() and feat_grad):
+            l2_xyz, l2_pts = self.sa2.rows(l1_xyz, l1_pts)
+            _, l3_pts = self.sa3.rows(l2_xyz, l2_pts)
         feat = l3_pts.reshape(B, 1024)
         node_fea = self.dim_redu(node_fea.transpose(1, 2)).reshape(B, 64, 64, 1)
         if node:
@@ -189,13 +193,15 @@ class Pointnet_g(nn.Module):
         self.conv5 = conv_2d(128, 1024, 1)
         self.bn1 = nn.BatchNorm1d(1024)
 
-    def forward(self, x, node=False):
+    def forward(self, x, node=False, feat_grad=True):
+        """feat_grad=False: node-adaptation pass, the stage behind the SA-node module runs without autograd."""
         loc = x.squeeze(-1).transpose(1, 2).contiguous()              # [B,N,3]
         y = torch.bmm(loc, self.trans_net1.rows(loc))
         y = self.conv2.rows(self.conv1.rows(y))
         y = torch.bmm(y, self.trans_net2.rows(y))
         y, node_fea, node_off = self.conv3.rows(y, loc)
-        y = bn_module(self.bn1, self.conv5.rows_max(self.conv4.rows(y)))
+        with torch.set_grad_enabled(torch.is_grad_enabled() and feat_grad):
+            y = bn_module(self.bn1, self.conv5.rows_max(self.conv4.rows(y)))
         node_fea = node_fea.transpose(1, 2).unsqueeze(-1)
         node_off = node_off.transpose(1, 2)
         if node:
@@ -262,15 +268,18 @@ class PTran_g(nn.Module):
         """Point counts of the farthest_point_sample calls of one forward, in call order."""
         return [N] + [self.npoints // 4 ** (i + 1) for i in range(self.nblocks - 1)]
 
-    def forward(self, x, node=False):
-        """x [B,3,N,1] -> (feat [B,512], node_fea [B,64,64](, None))."""
+    def forward(self, x, node=False, feat_grad=True):
+        """x [B,3,N,1] -> (feat [B,512], node_fea [B,64,64](, None)).
+        feat_grad=False: node-adaptation pass, the stages behind the one the node features come from run
+        without autograd (they still draw their FPS starts and update BatchNorm buffers)."""
         x_ = x.squeeze(-1).permute(0, 2, 1).contiguous()              # [B,N,3]
         xyz = x_[..., :3]
         points = self._prefix(x, x_, xyz)
         xyz_and_feats = [(xyz, points)]
         for i in range(self.nblocks):
-            xyz, points = self.transition_downs[i](xyz, points)
-            points = self.transformers[i](xyz, points)[0]
+            with torch.set_grad_enabled(torch.is_grad_enabled() and (feat_grad or i < 2)):
+                xyz, points = self.transition_downs[i](xyz, points)
+                points = self.transformers[i](xyz, points)[0]
             xyz_and_feats.append((xyz, points))
         node_features = self.conv1d(xyz_and_feats[2][1])              # [B,64 points,128] -> [B,64,64]
         points = points.mean(1)
@@ -330,7 +339,7 @@ class Net_MDA(nn.Module):
     def forward(self, x, constant=1, adaptation=False, node_vis=False, mid_feat=False, node_adaptation_s=False,
                 node_adaptation_t=False, semantic_adaption=False):
         only_node = (node_adaptation_s or node_adaptation_t) and not (node_vis or mid_feat)
-        if only_node and isinstance(self.g, DGCNN):
+        if only_node:
             x, feat_ori, node_idx = self.g(x, node=True, feat_grad=False)       # the pooled feature is not used
         else:
             x, feat_ori, node_idx = self.g(x, node=True)
@@ -370,7 +379,7 @@ class Net_MDA(nn.Module):
             draws = [[torch.randint(0, n, (B,), dtype=torch.long) for n in plan] for _ in range(2)]
             queue = [torch.cat((draws[0][c], draws[1][c])) for c in range(len(plan))]
         with ops.bn_groups(2), ops.start_queue(queue), ops.deferred_bn_counts():
-            if node_adaptation and isinstance(self.g, DGCNN):
+            if node_adaptation:
                 x, feat_ori, _ = self.g(x_pair, node=True, feat_grad=False)     # only the node features are used
             else:
                 x, feat_ori, _ = self.g(x_pair, node=True)

@@ -78,8 +78,10 @@ class PointNetSetAbstraction(nn.Module):
             last = out_channel
         self.group_all = group_all
 
-    def rows(self, xyz, points, adapt=False):
-        """xyz [B,N,3], points [B,N,D] or None -> new_xyz [B,S,3], feats [B,S,D'](, node [B,S,D1])."""
+    def rows(self, xyz, points, adapt=False, tail_grad=True):
+        """xyz [B,N,3], points [B,N,D] or None -> new_xyz [B,S,3], feats [B,S,D'](, node [B,S,D1]).
+        tail_grad=False (with adapt): the layers behind the one the node features come from run without
+        autograd (their output is discarded by the caller; BatchNorm buffers are still updated)."""
         if self.group_all:
             new_xyz, g = sample_and_group_all(xyz, points)
         else:
@@ -89,11 +91,12 @@ class PointNetSetAbstraction(nn.Module):
         out = None
         for i, conv in enumerate(self.mlp_convs):                      # g: [B,S,ns,C] rows
             w = conv.weight.view(conv.weight.shape[0], -1)
-            if i == last and ops.pointmlp_max_supported(g.shape[-1], w.shape[0], g.shape[2]):
-                # last layer + max over the group in one kernel: [B,S,ns,C'] is never written
-                out = ops.pointmlp_max(g, w, conv.bias, self.mlp_bns[i], 0.0, g.shape[2]).view(g.shape[0], g.shape[1], -1)
-                break
-            g = ops.bn_act_rows(ops.linear_rows(g, w, conv.bias), self.mlp_bns[i], 0.0)
+            with torch.set_grad_enabled(torch.is_grad_enabled() and (tail_grad or not adapt or i <= 1)):
+                if i == last and ops.pointmlp_max_supported(g.shape[-1], w.shape[0], g.shape[2]):
+                    # last layer + max over the group in one kernel: [B,S,ns,C'] is never written
+                    out = ops.pointmlp_max(g, w, conv.bias, self.mlp_bns[i], 0.0, g.shape[2]).view(g.shape[0], g.shape[1], -1)
+                    break
+                g = ops.bn_act_rows(ops.linear_rows(g, w, conv.bias), self.mlp_bns[i], 0.0)
             if adapt and i == 1:
                 node = g
         if out is None:
