@@ -144,8 +144,13 @@ def main():
     ap.add_argument('--fp16', action='store_true',
                     help='Point Transformer only (BASELINE config 5): k-expanded attention tensors and their 512x512 linears in '
                          'fp16 (MFMA, fp32 accumulation); default fp32 = the reference arithmetic')
-    ap.add_argument('--graph', action='store_true',
-                    help='replay the step from a hipGraph (opt-in; same speed as eager when the step is GPU-bound)')
+    ap.add_argument('--graph', action='store_true', help='(default on one GPU) replay the whole step from a hipGraph')
+    ap.add_argument('--eager', action='store_true',
+                    help='launch every kernel of the timed steps from Python instead of replaying a captured hipGraph '
+                         '(the default on one GPU: an eager step is host-bound on this path -- ~450 launches in ~6.5 ms -- '
+                         'and a single host hiccup inside a 20-step window moves the result by several per cent)')
+    ap.add_argument('--eager-steps', type=int, default=10,
+                    help='graph mode: extra eager steps after the timed region (per-kernel HIP-event timings, eager ms/step)')
     ap.add_argument('--no-share-prefix', action='store_true',
                     help='recompute the kNN+conv1/conv2 stage in the node passes instead of sharing it (identical results)')
     ap.add_argument('--no-tuned-gemms', action='store_true',
@@ -192,8 +197,13 @@ def main():
     if world > 1:                                       # same initial weights on every rank
         for t in list(model.parameters()) + list(model.buffers()):
             dist.broadcast(t.data, 0)
-    trainer = SUGStep(model, lr=1e-3, weight_decay=5e-5, share_prefix=not args.no_share_prefix,
-                      use_graph=args.graph, pair_domains=not args.no_pair, methods=BENCH_METHODS)
+    want_graph = world == 1 and not args.eager
+
+    def make_trainer(use_graph):
+        return SUGStep(model, lr=1e-3, weight_decay=5e-5, share_prefix=not args.no_share_prefix, use_graph=use_graph,
+                       pair_domains=not args.no_pair, methods=BENCH_METHODS)
+
+    trainer = make_trainer(want_graph)
     B, N = args.batch, args.npoints
     data, lab, data_t, lab_t = synth(B, N, 666 + rank, dev)
     torch.manual_seed(666 + rank)                       # FPS start draws, per rank (train_dg.py:78)
@@ -204,45 +214,68 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # Kernel events: only the kNN kernels (the dominant hand-written kernel) are instrumented,
-    # because every event pair costs host time in a host-bound step.  Eager mode times them over
-    # the timed region; graph mode (events cannot be captured on ROCm) over its eager warm-up step.
+    # Launch mode.  Default on one GPU: the step (4 encoder passes, losses, backward, 3 Adam updates) is captured
+    # once into a hipGraph and the timed steps replay it -- same kernels, same arithmetic, one host call per step.
+    # Kernel events cannot be captured on ROCm, so the per-kernel HIP-event timings (roofline, `kernels`) come from
+    # eager steps of the same trainer right after the timed region.  --eager: everything launched from Python; the
+    # kernels of the dominant family are then timed inside the timed region itself.
     timed_family = {'DGCNN': {'knn'}, 'Pointnet': {'pointmlp'}, 'Pointnet2': {'pointmlp'}}.get(args.model, {'knn'})
+    all_families = {'edgeconv', 'pointmlp', 'knn'}
     ops.PROFILE_ONLY = set(timed_family)
-    for i in range(max(args.warmup, 3 if trainer.use_graph else 1)):
-        ops.PROFILE = {} if (trainer.use_graph and i == 0) else ops.PROFILE
-        trainer.step(data, lab, data_t, lab_t)
-        if trainer.use_graph and i == 0:
-            graph_prof, ops.PROFILE = ops.PROFILE, None
-    sync()
+    try:
+        for i in range(max(args.warmup, 3 if trainer.use_graph else 1)):
+            trainer.step(data, lab, data_t, lab_t)
+        sync()
+    except RuntimeError as e:                              # capture refused on this stack: fall back to eager launches
+        if not trainer.use_graph:
+            raise
+        print('bench.py: hipGraph capture failed (%s); falling back to eager launches' % str(e).splitlines()[0], file=sys.stderr)
+        trainer = make_trainer(False)
+        for i in range(max(args.warmup, 1)):
+            trainer.step(data, lab, data_t, lab_t)
+        sync()
+    graph_mode = trainer.use_graph
     # The interpreter's full (generation-2) collection walks every object torch has created so
     # far: a ~70 ms pause that otherwise lands somewhere in the first 20 steps.  Collect now and
     # freeze the survivors (what a long-running training loop reaches after its first minutes).
     gc.collect()
     gc.freeze()
-    if not trainer.use_graph:
+    if not graph_mode:
         ops.PROFILE = {}
     t0 = time.perf_counter()
     for _ in range(args.steps):
         losses = trainer.step(data, lab, data_t, lab_t)
     sync()
     dt = time.perf_counter() - t0
-    prof, ops.PROFILE = (graph_prof if trainer.use_graph else ops.PROFILE), None
-    # the other hand-written layer kernels (EdgeConv forward / backward layer calls, per-point MLP + max):
-    # a few extra steps outside the timed region, for the `kernels` table only
-    if not trainer.use_graph:
-        ops.PROFILE_ONLY, ops.PROFILE = {'edgeconv', 'pointmlp', 'knn'} - timed_family, {}
+    loss_vals = [None if l is None else float(l) for l in losses]
+    prof, ops.PROFILE = ({} if graph_mode else ops.PROFILE), None
+    eager_ms = None
+    if graph_mode:
+        # eager steps of the same trainer: per-kernel event timings of every hand-written family + eager ms/step
+        trainer.use_graph = False
+        for _ in range(2):
+            trainer.step(data, lab, data_t, lab_t)
+        sync()
+        ops.PROFILE_ONLY, ops.PROFILE = set(all_families), {}
+        t1 = time.perf_counter()
+        for _ in range(max(args.eager_steps, 1)):
+            trainer.step(data, lab, data_t, lab_t)
+        sync()
+        eager_ms = 1e3 * (time.perf_counter() - t1) / max(args.eager_steps, 1)
+        extra_prof, ops.PROFILE, ops.PROFILE_ONLY = ops.PROFILE, None, set(timed_family)
+    else:
+        # the other hand-written layer kernels (EdgeConv layer calls, per-point MLP + max): a few extra steps
+        # outside the timed region, for the `kernels` table only
+        ops.PROFILE_ONLY, ops.PROFILE = all_families - timed_family, {}
         for _ in range(5):
             trainer.step(data, lab, data_t, lab_t)
         sync()
         extra_prof, ops.PROFILE, ops.PROFILE_ONLY = ops.PROFILE, None, set(timed_family)
-    else:
-        extra_prof = {}
     # The same workload the way train_dg_single_gpu.py:260-310 calls the API: four separate model(...)
     # calls per step, nothing shared between them (the headline uses the exact restructurings of
     # paired domains + shared prefix).
     caller_ms = None
-    if args.caller_steps > 0 and not trainer.use_graph and (trainer.pair_domains or trainer.share_prefix):
+    if args.caller_steps > 0 and (trainer.pair_domains or trainer.share_prefix):
         keep = (trainer.pair_domains, trainer.share_prefix)
         trainer.pair_domains = trainer.share_prefix = False
         if hasattr(model.g, 'share_prefix'):
@@ -262,8 +295,6 @@ def main():
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    loss_vals = [None if l is None else float(l) for l in losses]
-
     if rank == 0:
         clouds = world * 2 * B * args.steps
         value = clouds / dt
@@ -285,7 +316,8 @@ def main():
                           'frac': tfl / FP32_PEAK_TFLOPS if cb else gbps / HBM_PEAK_GBS}
         roofline = None
         if kern:
-            dom = max(timed_names or set(kern), key=lambda n: kern[n]['total_ms'])
+            fam = [n for n in kern if n.startswith(tuple(timed_family))]
+            dom = max(timed_names or fam or set(kern), key=lambda n: kern[n]['total_ms'])
             kd = kern[dom]
             ai = kernel_model(dom, allprof[dom][0][2])
             compute_bound = ai['flops'] / max(ai['bytes'], 1) > FP32_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS
@@ -324,7 +356,8 @@ def main():
                'config': {'workload': '%s, N=%d, batch=%d per domain per GPU, MSA+SDA losses on '
                                       '(2 sem + 2 node forwards, 3 soft-MMD, backward, 3 Adam)' % (BACKBONE.get(args.model, args.model), N, B),
                           'global_batch': world * B, 'parallelism': 'dp%d' % world,
-                          'launch': 'hipGraph replay of the whole step' if trainer.use_graph else 'eager',
+                          'launch': 'hipGraph replay of the whole step' if graph_mode else 'eager',
+                          'eager_ms_per_step': eager_ms,
                           'share_prefix': trainer.share_prefix, 'pair_domains': trainer.pair_domains,
                           'tuned_gemms': tuned, 'geo_weights': 'mean2one', 'sem_weights': 'mean2one',
                           'unchanged_caller_ms_per_step': caller_ms},

@@ -277,14 +277,16 @@ int sug_edgeconv_layer_fwd(const float* pq, int64_t ldpq, const int32_t* idx, co
                            float eps, float momentum, float slope, float* running_mean,
                            float* running_var, float* z, uint8_t* arg, float* s1, float* coef,
                            float* out, int64_t ldo, double* stats, float* ws, void* stream);
-/* Its backward: reverse neighbour lists (rev_off [B,N+1], rev_ent [B,N*k], scratch), per-group BN
+/* (All three layer backward entry points take `dgb`: NULL, or fp32 [2C] receiving the BatchNorm parameter
+ * gradients dbeta | dgamma summed over the groups -- sug_fold_groups on `red`.)
+ * Its backward: reverse neighbour lists (rev_off [B,N+1], rev_ent [B,N*k], scratch), per-group BN
  * sums red [groups+1, 2Co] (row g: dbeta | dgamma; the spare last row must be zero when
  * training = 0), a [B,N,Co] scratch, dpq [B,N,2Co] (row stride lddpq). */
 int sug_edgeconv_layer_bwd(const float* gout, int64_t ldg, const float* z, const uint8_t* arg,
                            const float* s1, const float* pq, int64_t ldpq, const int32_t* idx,
                            const float* coef, int B, int N, int k, int Co, int groups, int training,
                            float slope, float* a, double* red, int32_t* rev_off, int32_t* rev_ent,
-                           float* dpq, int64_t lddpq, float* ws, void* stream);
+                           float* dpq, int64_t lddpq, float* ws, float* dgb, void* stream);
 /* conv_2d / Conv1d + BatchNorm + (Leaky)ReLU on rows (model_utils.py:8-32, pointnet2_utils.py:195-198):
  * out = act(BN(y)), y [rows,C]. */
 int sug_bn_act_rows_fwd(const float* y, int64_t ldy, int64_t rows, int C, int groups, const float* gamma,
@@ -294,7 +296,7 @@ int sug_bn_act_rows_fwd(const float* y, int64_t ldy, int64_t rows, int C, int gr
 /* Backward: a [rows,C] scratch (= dy when training = 0), red [groups,2C], dy [rows,C]; y dense. */
 int sug_bn_act_rows_bwd(const float* gout, int64_t ldg, const float* y, int64_t ldy, const float* coef,
                         int64_t rows, int C, int groups, int training, float slope, float* a, double* red,
-                        float* dy, float* ws, void* stream);
+                        float* dy, float* ws, float* dgb, void* stream);
 /* bn5 -> LeakyReLU -> max | mean over the points (Model.py:112-116) per group; ws_pool: 12*(B/groups)*C floats. */
 int sug_bn_act_pool_layer_fwd(const float* y, int64_t ldy, int B, int N, int C, int groups,
                               const float* gamma, const float* beta, int training, float eps, float momentum,
@@ -304,7 +306,7 @@ int sug_bn_act_pool_layer_fwd(const float* y, int64_t ldy, int B, int N, int C, 
 int sug_bn_act_pool_layer_bwd(const float* y, int64_t ldy, const float* coef, const float* gmax,
                               const float* gmean, const int32_t* arg, int B, int N, int C, int groups,
                               float slope, int training, double* red, float* ws, float* dy, int64_t lddy,
-                              void* stream);
+                              float* dgb, void* stream);
 
 /* ---- per-point MLP layer fused with the max over a group of rows ------------------------------
  * replaces `conv_2d(K, Co)` (1x1 Conv2d + bias -> BatchNorm2d -> ReLU) followed by the max over the
@@ -373,6 +375,9 @@ int sug_ptran_attn_bwd(const float* g, const void* logits, const void* delta, co
                        const float* mx, const float* sm, const int32_t* rev_off, const int32_t* rev_ent, int B, int n,
                        int k, int d, int dtype, float scale, void* dlogits, void* da, float* dv, void* stream);
 
+/* out[i] = (float) sum over g of red[g][i], i < n (fp64 partial rows of `groups` domain groups, in order). */
+int sug_fold_groups(const double* red, int groups, int n, float* out, void* stream);
+
 /* ---- Gaussian multi-kernel MMD --------------------------------------------------
  * replaces _mix_rbf_kernel + _mmd2(biased=True), model/mmd.py:239-254, :274-312.
  * Z = [X;Y] : [2m, D] rows (ld = ldz).  e_ij = n_i - 2<z_i,z_j> + n_j with n the
@@ -385,6 +390,11 @@ int sug_ptran_attn_bwd(const float* g, const void* logits, const void* delta, co
  * model/mmd.py:251-252); nsigma <= 8. */
 int sug_mmd_rbf(const float* z, int64_t ldz, int m, int D, const float* w,
                 const float* neg_gamma, int nsigma, double* sums, float* wt, void* stream);
+
+/* sug_mmd_rbf with the scalar formed on the device: zeroes sums (3 doubles of scratch), runs the kernel and
+ * writes value[0] = (S_XX + S_YY - 2 S_wXY) / m^2 as fp32 (model/mmd.py:300-312, biased estimator). */
+int sug_mmd_rbf_value(const float* z, int64_t ldz, int m, int D, const float* w, const float* neg_gamma,
+                      int nsigma, double* sums, float* wt, float* value, void* stream);
 
 /* Backward of sug_mmd_rbf: dz[i,:] = gscale[0] * 2 * (rowsum(wt)[i]*z[i,:] - (wt.z)[i,:])
  * (the autograd of model/mmd.py:239-312 w.r.t. the features); gscale: device scalar = dL/dmmd2. */

@@ -39,14 +39,15 @@ SIGNATURES = {
     'sug_edgeconv_layer_fwd': [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _vp, _vp,
                                _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp],
     'sug_edgeconv_layer_bwd': [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32,
-                               _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
+                               _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp],
     'sug_bn_act_rows_fwd': [_vp, _i64, _i64, _i32, _i32, _vp, _vp, _i32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _i64,
                             _vp, _vp, _vp],
-    'sug_bn_act_rows_bwd': [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp],
+    'sug_bn_act_rows_bwd': [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp],
     'sug_bn_act_pool_layer_fwd': [_vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _f32, _f32, _f32, _vp, _vp, _vp,
                                   _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     'sug_bn_act_pool_layer_bwd': [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp,
-                                  _i64, _vp],
+                                  _i64, _vp, _vp],
+    'sug_fold_groups': [_vp, _i32, _i32, _vp, _vp],
     'sug_edgeconv_fwd_bn': [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp,
                             _vp, _vp],
     'sug_col_stats_bn': [_vp, _i64, _i64, _i32, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp],
@@ -57,6 +58,7 @@ SIGNATURES = {
     'sug_ptran_qk_bwd': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
     'sug_ptran_attn_fwd': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp],
     'sug_ptran_attn_bwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp],
+    'sug_mmd_rbf_value': [_vp, _i64, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp],
     'sug_mmd_rbf_rows': [_vp, _i64, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
     'sug_mmd_rbf_rows_bwd': [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _f32, _vp, _i64, _vp],
     'sug_mmd_rbf_bwd': [_vp, _i64, _vp, _i32, _i32, _vp, _vp, _i64, _vp],
@@ -109,7 +111,7 @@ def lib():
         L.sug_last_error.argtypes = []
         L.sug_abi_version.restype = ctypes.c_int
         L.sug_abi_version.argtypes = []
-        if L.sug_abi_version() != 1:
+        if L.sug_abi_version() != 2:
             raise RuntimeError('sug_amd: ABI version mismatch, rebuild libsug_amd.so')
         _lib = L
     return _lib

@@ -398,3 +398,24 @@ extern "C" int sug_bn_act_pool_bwd(const float* y, int64_t ldy, const float* coe
   SUG_LAUNCH_CHECK("sug_bn_act_pool_bwd(apply)");
   return SUG_OK;
 }
+
+
+// out[i] = (float) sum_g red[g][i]: the per-domain-group BatchNorm gradient sums (dbeta | dgamma, fp64) of a
+// layer folded into the fp32 parameter gradients, in group order.
+namespace {
+__global__ __launch_bounds__(256) void fold_groups_kernel(const double* __restrict__ red, int groups, int n,
+                                                          float* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double t = 0.0;
+  for (int g = 0; g < groups; ++g) t += red[(int64_t)g * n + i];
+  out[i] = (float)t;
+}
+}  // namespace
+
+extern "C" int sug_fold_groups(const double* red, int groups, int n, float* out, void* stream) {
+  SUG_REQUIRE(red && out && groups >= 1 && n > 0, "sug_fold_groups: bad argument");
+  hipLaunchKernelGGL(fold_groups_kernel, dim3(sug_divup(n, 256)), dim3(256), 0, (hipStream_t)stream, red, groups, n, out);
+  SUG_LAUNCH_CHECK("sug_fold_groups");
+  return SUG_OK;
+}

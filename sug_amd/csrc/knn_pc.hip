@@ -266,10 +266,19 @@ __global__ __launch_bounds__(512, 2) void knn_pc_kernel(const float* __restrict_
       // per slot; strict compares keep the earlier (lower) index ahead among equal scores.
       // (loads are unconditional -- an unmarked lane re-reads slot 0 -- so that no branch wraps them;
       //  the entry of the next iteration is fetched while the current one is inserted)
-      int nit = __popc(mask);
+      // iterations = the largest number of marked candidates of any lane: a wave-wide maximum built bit by
+      // bit from ballots (scalar unit only; a shuffle tree would cost six LDS-latency round trips per tile)
+      const int pc = __popc(mask);
+      unsigned long long cand = ~0ull;
+      int nit = 0;
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) nit = max(nit, __shfl_xor(nit, o));
-      nit = __builtin_amdgcn_readfirstlane(nit);
+      for (int bit = 5; bit >= 0; --bit) {
+        const unsigned long long m = __ballot((pc >> bit) & 1) & cand;
+        if (m) {
+          nit |= 1 << bit;
+          cand = m;
+        }
+      }
       // The LDS reads are issued by hand and waited for only after the insertion of the previous entry
       // (hipcc waits right at the load, or wraps the loads in a branch and then copies all 40 list
       // registers every iteration).

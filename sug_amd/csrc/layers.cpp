@@ -38,7 +38,7 @@ extern "C" int sug_edgeconv_layer_bwd(const float* gout, int64_t ldg, const floa
                                       const float* s1, const float* pq, int64_t ldpq, const int32_t* idx,
                                       const float* coef, int B, int N, int k, int Co, int groups, int training,
                                       float slope, float* a, double* red, int32_t* rev_off, int32_t* rev_ent,
-                                      float* dpq, int64_t lddpq, float* ws, void* stream) {
+                                      float* dpq, int64_t lddpq, float* ws, float* dgb, void* stream) {
   LAYER_REQUIRE(groups >= 1 && B > 0 && B % groups == 0, "sug_edgeconv_layer_bwd: B=%d does not split into %d groups", B, groups);
   LAYER_REQUIRE(red && a && rev_off && rev_ent, "sug_edgeconv_layer_bwd: null pointer");
   const int Bg = B / groups;
@@ -56,6 +56,7 @@ extern "C" int sug_edgeconv_layer_bwd(const float* gout, int64_t ldg, const floa
                                        rev_off + (int64_t)g * Bg * (N + 1), rev_ent + (int64_t)g * Bg * N * k, cg, ru,
                                        Bg, N, k, Co, dpq + r0 * lddpq, lddpq, stream));
   }
+  if (dgb) LAYER_TRY(sug_fold_groups(red, groups, 2 * Co, dgb, stream));
   return SUG_OK;
 }
 
@@ -79,7 +80,7 @@ extern "C" int sug_bn_act_rows_fwd(const float* y, int64_t ldy, int64_t rows, in
 
 extern "C" int sug_bn_act_rows_bwd(const float* gout, int64_t ldg, const float* y, int64_t ldy, const float* coef,
                                    int64_t rows, int C, int groups, int training, float slope, float* a,
-                                   double* red, float* dy, float* ws, void* stream) {
+                                   double* red, float* dy, float* ws, float* dgb, void* stream) {
   LAYER_REQUIRE(groups >= 1 && rows > 0 && rows % groups == 0, "sug_bn_act_rows_bwd: %lld rows do not split into %d groups",
                 (long long)rows, groups);
   LAYER_REQUIRE(ldy == C, "sug_bn_act_rows_bwd: y must be dense");
@@ -92,6 +93,7 @@ extern "C" int sug_bn_act_rows_bwd(const float* gout, int64_t ldg, const float* 
     if (training)
       LAYER_TRY(sug_bn_bwd_apply(a + g * rg * C, y + g * rg * C, C, cg, rd, rg, C, dy + g * rg * C, C, stream));
   }
+  if (dgb) LAYER_TRY(sug_fold_groups(red, groups, 2 * C, dgb, stream));
   return SUG_OK;
 }
 
@@ -118,7 +120,7 @@ extern "C" int sug_bn_act_pool_layer_fwd(const float* y, int64_t ldy, int B, int
 extern "C" int sug_bn_act_pool_layer_bwd(const float* y, int64_t ldy, const float* coef, const float* gmax,
                                          const float* gmean, const int32_t* arg, int B, int N, int C, int groups,
                                          float slope, int training, double* red, float* ws, float* dy, int64_t lddy,
-                                         void* stream) {
+                                         float* dgb, void* stream) {
   LAYER_REQUIRE(groups >= 1 && B > 0 && B % groups == 0, "sug_bn_act_pool_layer_bwd: B=%d does not split into %d groups", B, groups);
   const int Bg = B / groups;
   const int64_t rg = (int64_t)Bg * N;
@@ -126,5 +128,6 @@ extern "C" int sug_bn_act_pool_layer_bwd(const float* y, int64_t ldy, const floa
     LAYER_TRY(sug_bn_act_pool_bwd(y + g * rg * ldy, ldy, coef + (int64_t)g * 5 * C, gmax + (int64_t)g * Bg * C,
                                   gmean + (int64_t)g * Bg * C, arg + (int64_t)g * Bg * C, Bg, N, C, slope, training,
                                   red + (int64_t)g * 2 * C, ws, dy + g * rg * lddy, lddy, stream));
+  if (dgb) LAYER_TRY(sug_fold_groups(red, groups, 2 * C, dgb, stream));
   return SUG_OK;
 }

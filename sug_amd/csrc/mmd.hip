@@ -319,6 +319,27 @@ extern "C" int sug_mmd_rbf(const float* z, int64_t ldz, int m, int D, const floa
   return sug_mmd_rbf_rows(z, ldz, m, D, w, neg_gamma, nsigma, 0, m, sums, wt, stream);
 }
 
+namespace {
+__global__ void mmd_value_kernel(const double* __restrict__ sums, double mm, float* __restrict__ out) {
+  if (threadIdx.x == 0) out[0] = (float)((sums[0] + sums[1] - 2.0 * sums[2]) / mm);
+}
+}  // namespace
+
+extern "C" int sug_mmd_rbf_value(const float* z, int64_t ldz, int m, int D, const float* w, const float* neg_gamma,
+                                 int nsigma, double* sums, float* wt, float* value, void* stream) {
+  SUG_REQUIRE(sums && value, "sug_mmd_rbf_value: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(sums, 0, 3 * sizeof(double), st) != hipSuccess) {
+    sug_set_error("sug_mmd_rbf_value: memset failed");
+    return SUG_ERR_LAUNCH;
+  }
+  const int rc = sug_mmd_rbf_rows(z, ldz, m, D, w, neg_gamma, nsigma, 0, m, sums, wt, stream);
+  if (rc != SUG_OK) return rc;
+  hipLaunchKernelGGL(mmd_value_kernel, dim3(1), dim3(64), 0, st, sums, (double)m * (double)m, value);
+  SUG_LAUNCH_CHECK("sug_mmd_rbf_value");
+  return SUG_OK;
+}
+
 extern "C" int sug_chamfer(const float* a, const float* b, int B, int N, int M, float* out,
                            void* stream) {
   SUG_REQUIRE(a && b && out, "sug_chamfer: null pointer");

@@ -301,12 +301,21 @@ class Pointnet_c(nn.Module):
         self.mlp3 = nn.Linear(256, num_class)
         self.PTran = PTran_flag
 
+    @staticmethod
+    def _drop(layer, x):
+        """nn.Dropout2d on a 2-D [B,C] input (what the reference feeds it, Model.py:428-431) draws one
+        Bernoulli per (sample, channel) element, i.e. it IS element-wise dropout; F.dropout does that in one
+        fused launch instead of three (bernoulli_, div_, mul) and one instead of two in the backward."""
+        if x.dim() == 2:
+            return F.dropout(x, layer.p, layer.training)
+        return layer(x)
+
     def forward(self, x, adapt=False):
         if not self.PTran:
-            x = self.dropout1(self.mlp1(x))
+            x = self._drop(self.dropout1, self.mlp1(x))
         x = self.mlp2(x)
         mid_feature = x
-        x = self.mlp3(self.dropout2(x))
+        x = self.mlp3(self._drop(self.dropout2, x))
         if adapt:
             return x, mid_feature
         return x

@@ -505,9 +505,9 @@ class _BNActRows(torch.autograd.Function):
         red = torch.empty(G, 2 * C, dtype=torch.float64, device=dev)
         ws = torch.empty(STATS_BLOCKS * 2 * C, dtype=torch.float32, device=dev)
         dy = torch.empty(rows, C, dtype=torch.float32, device=dev) if training else a
+        rf = torch.empty(2 * C, dtype=torch.float32, device=dev)
         check(lib().sug_bn_act_rows_bwd(_p(g2), g2.stride(0), _p(y2), C, _p(coef), rows, C, G, 1 if training else 0,
-                                        slope, _p(a), _p(red), _p(dy), _p(ws), _st()), 'sug_bn_act_rows_bwd')
-        rf = red[0].float() if G == 1 else red.sum(0, dtype=torch.float32)
+                                        slope, _p(a), _p(red), _p(dy), _p(ws), _p(rf), _st()), 'sug_bn_act_rows_bwd')
         return dy.view(shape), rf[C:], rf[:C], None, None, None, None, None, None, None
 
 
@@ -603,10 +603,10 @@ class _BNActPool(torch.autograd.Function):
         red = torch.empty(G, 2 * C, dtype=torch.float64, device=dev)
         ws = torch.empty(STATS_BLOCKS * 2 * C, dtype=torch.float32, device=dev)
         dy = torch.empty(B, N, C, dtype=torch.float32, device=dev)
+        rf = torch.empty(2 * C, dtype=torch.float32, device=dev)
         check(lib().sug_bn_act_pool_layer_bwd(_p(y), ld, _p(coef), _p(gmax), _p(gmean), _p(arg), B, N, C, G, slope,
-                                              1 if training else 0, _p(red), _p(ws), _p(dy), C, _st()),
+                                              1 if training else 0, _p(red), _p(ws), _p(dy), C, _p(rf), _st()),
               'sug_bn_act_pool_layer_bwd')
-        rf = red[0].float() if G == 1 else red.sum(0, dtype=torch.float32)
         return dy, rf[C:], rf[:C], None, None, None, None, None, None, None
 
 
@@ -706,12 +706,12 @@ class _EdgeConv(torch.autograd.Function):
         off = torch.empty(B, N + 1, dtype=torch.int32, device=dev)
         ent = torch.empty(B, N * k, dtype=torch.int32, device=dev)
         dpq = torch.empty(B, N, 2 * Co, dtype=torch.float32, device=dev)
+        rf = torch.empty(2 * Co, dtype=torch.float32, device=dev)
         check(_timed('edgeconv_layer_bwd_Co%d' % Co, {'B': B, 'N': N, 'k': k, 'Co': Co},
                      lambda: lib().sug_edgeconv_layer_bwd(_p(gout), ldg, _p(z), _p(arg), _p(s1), _p(pq), ld, _p(idx),
                                                           _p(coef), B, N, k, Co, G, 1 if training else 0, slope, _p(a),
-                                                          _p(red), _p(off), _p(ent), _p(dpq), 2 * Co, _p(ws), _st())),
+                                                          _p(red), _p(off), _p(ent), _p(dpq), 2 * Co, _p(ws), _p(rf), _st())),
               'sug_edgeconv_layer_bwd')
-        rf = red[0].float() if G == 1 else red[:G].sum(0, dtype=torch.float32)
         return dpq, None, rf[Co:], rf[:Co], None, None, None, None, None, None, None, None
 
 
@@ -987,16 +987,16 @@ class _MixRbfMMD2(torch.autograd.Function):
         D = Zc.shape[1]
         dev = Z.device
         ng = _neg_gammas(sigmas, dev)
-        sums = torch.zeros(3, dtype=torch.float64, device=dev)
+        sums = torch.empty(3, dtype=torch.float64, device=dev)
+        val = torch.empty((), dtype=torch.float32, device=dev)
         need = ctx.needs_input_grad[0]
         wt = torch.empty(2 * m, 2 * m, dtype=torch.float32, device=dev) if need else None
         wc = w.detach().reshape(-1).to(device=dev, dtype=torch.float32).contiguous() if w is not None else None
-        check(lib().sug_mmd_rbf(_p(Zc), Zc.stride(0), m, D, _p(wc), _p(ng), len(sigmas), _p(sums), _p(wt), _st()),
-              'sug_mmd_rbf')
+        check(lib().sug_mmd_rbf_value(_p(Zc), Zc.stride(0), m, D, _p(wc), _p(ng), len(sigmas), _p(sums), _p(wt), _p(val),
+                                      _st()), 'sug_mmd_rbf_value')
         if need:
             ctx.save_for_backward(Zc, wt)
-        mm = float(m) * float(m)
-        return ((sums[0] + sums[1] - 2.0 * sums[2]) / mm).float()
+        return val
 
     @staticmethod
     def backward(ctx, g):
