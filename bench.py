@@ -149,6 +149,7 @@ def main():
                     help='launch every kernel of the timed steps from Python instead of replaying a captured hipGraph '
                          '(the default on one GPU: an eager step is host-bound on this path -- ~450 launches in ~6.5 ms -- '
                          'and a single host hiccup inside a 20-step window moves the result by several per cent)')
+    ap.add_argument('--plain', action='store_true', help='only warm-up + timed steps (for rocprofv3 kernel traces): no extra passes')
     ap.add_argument('--eager-steps', type=int, default=10,
                     help='graph mode: extra eager steps after the timed region (per-kernel HIP-event timings, eager ms/step)')
     ap.add_argument('--no-share-prefix', action='store_true',
@@ -250,7 +251,9 @@ def main():
     loss_vals = [None if l is None else float(l) for l in losses]
     prof, ops.PROFILE = ({} if graph_mode else ops.PROFILE), None
     eager_ms = None
-    if graph_mode:
+    if args.plain:
+        extra_prof = {}
+    elif graph_mode:
         # eager steps of the same trainer: per-kernel event timings of every hand-written family + eager ms/step
         trainer.use_graph = False
         for _ in range(2):
@@ -275,7 +278,7 @@ def main():
     # calls per step, nothing shared between them (the headline uses the exact restructurings of
     # paired domains + shared prefix).
     caller_ms = None
-    if args.caller_steps > 0 and (trainer.pair_domains or trainer.share_prefix):
+    if args.caller_steps > 0 and not args.plain and (trainer.pair_domains or trainer.share_prefix):
         keep = (trainer.pair_domains, trainer.share_prefix)
         trainer.pair_domains = trainer.share_prefix = False
         if hasattr(model.g, 'share_prefix'):

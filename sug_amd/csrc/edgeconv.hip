@@ -556,6 +556,132 @@ __global__ __launch_bounds__(256) void edgeconv_bwd_scatter_kernel(
   }
 }
 
+// LDS-resident backward (the transposed twin of edgeconv_fwd_lds_kernel).  The scatter above pulls, per reverse
+// entry, the a / arg / Q rows of another point through L2 (9*Co bytes per entry, 20x the matrices: it runs at the
+// L2's rate, not HBM's).  Here a workgroup = (cloud, 16-channel slice, part of the destination points) stages the
+// slice of a, Q and the packed arg bytes of the whole cloud in LDS (N x 144 B = 144 KB at N = 1024) and every entry
+// is served from there.  4 lanes per destination point, 16 points per wave; the points are visited in descending
+// order of their reverse-list length (counting sort in LDS, over the part's own points) so that the 16 points a wave walks in lock-step have
+// lists of similar length.  Which lane computes a point does not influence its value: the sums run over the
+// point's own (sorted) reverse list, a-term and Q-sum in separate accumulators.
+template <int SW, int KK>
+__global__ __launch_bounds__(1024) void edgeconv_bwd_lds_kernel(
+    const float* __restrict__ a, const uint8_t* __restrict__ arg, const float* __restrict__ s1,
+    const float* __restrict__ pq, int64_t ldpq, const int32_t* __restrict__ rev_off,
+    const int32_t* __restrict__ rev_ent, const float* __restrict__ coef, const double* __restrict__ red,
+    int B, int N, int Co, int psplit, float invM, float* __restrict__ dpq, int64_t lddpq) {
+  extern __shared__ __attribute__((aligned(16))) float s_lds[];
+  constexpr int LP = SW / 4;                   // lanes per point
+  constexpr int PPP = 1024 / LP;               // points per pass
+  float* s_a = s_lds;                                                  // [N][SW]
+  float* s_q = s_lds + (size_t)N * SW;                                 // [N][SW]
+  uint32_t* s_g = reinterpret_cast<uint32_t*>(s_q + (size_t)N * SW);   // [N][LP] packed arg bytes
+  int* s_hist = reinterpret_cast<int*>(s_g + (size_t)N * LP);          // [256] (+ scan scratch [256])
+  uint16_t* s_perm = reinterpret_cast<uint16_t*>(s_hist + 512);        // [N]
+  const int nslice = Co / SW;
+  const int per_cloud = nslice * psplit;
+  int b, r;
+  if ((B & 7) == 0) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    b = (j / per_cloud) * 8 + xcd;
+    r = j % per_cloud;
+  } else {
+    b = blockIdx.x / per_cloud;
+    r = blockIdx.x % per_cloud;
+  }
+  const int sl = r % nslice, part = r / nslice;
+  const int c0 = sl * SW;
+  const int64_t rowb = (int64_t)b * N;
+  for (int e = threadIdx.x; e < N * LP; e += 1024) {
+    const int n = e / LP, c4 = e % LP;
+    const int64_t o = (rowb + n) * Co + c0 + c4 * 4;
+    st4(s_a + n * SW + c4 * 4, ld4(a + o));
+    st4(s_q + n * SW + c4 * 4, ld4(pq + (rowb + n) * ldpq + Co + c0 + c4 * 4));
+    s_g[n * LP + c4] = *reinterpret_cast<const uint32_t*>(arg + o);
+  }
+  // visiting order: descending reverse-list length (bins 0..255, longer lists share bin 0)
+  const int32_t* offb = rev_off + (int64_t)b * (N + 1);
+  if (threadIdx.x < 256) s_hist[threadIdx.x] = 0;
+  __syncthreads();
+  // a part owns the points m = part (mod psplit); the order inside a bin (set by the atomics) is free
+  for (int m = part + psplit * (int)threadIdx.x; m < N; m += psplit * 1024) {
+    const int c = offb[m + 1] - offb[m];
+    atomicAdd(&s_hist[255 - (c < 255 ? c : 255)], 1);
+  }
+  __syncthreads();
+  {
+    int* scr = s_hist + 256;
+    const int mine = threadIdx.x < 256 ? s_hist[threadIdx.x] : 0;
+    if (threadIdx.x < 256) scr[threadIdx.x] = mine;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+      int t = 0;
+      if (threadIdx.x < 256 && threadIdx.x >= o) t = scr[threadIdx.x - o];
+      __syncthreads();
+      if (threadIdx.x < 256) scr[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (threadIdx.x < 256) s_hist[threadIdx.x] = scr[threadIdx.x] - mine;      // exclusive start of the bin
+    __syncthreads();
+  }
+  for (int m = part + psplit * (int)threadIdx.x; m < N; m += psplit * 1024) {
+    const int c = offb[m + 1] - offb[m];
+    s_perm[atomicAdd(&s_hist[255 - (c < 255 ? c : 255)], 1)] = (uint16_t)m;
+  }
+  const int n_own = (N - part + psplit - 1) / psplit;
+  const int lp = threadIdx.x % LP, slot = threadIdx.x / LP;
+  const int c = c0 + lp * 4;
+  const float4 sc = ld4(coef + c), mean = ld4(coef + 2 * Co + c), rstd = ld4(coef + 3 * Co + c);
+  const float dbx = (float)red[c + 0], dby = (float)red[c + 1], dbz = (float)red[c + 2], dbw = (float)red[c + 3];
+  const float dgx = (float)red[Co + c + 0], dgy = (float)red[Co + c + 1];
+  const float dgz = (float)red[Co + c + 2], dgw = (float)red[Co + c + 3];
+  const float fx = sc.x * invM, fy = sc.y * invM, fz = sc.z * invM, fw = sc.w * invM;
+  const float hx = fx * rstd.x * dgx, hy = fy * rstd.y * dgy, hz = fz * rstd.z * dgz, hw = fw * rstd.w * dgw;
+  const float kf = (float)KK;
+  const int32_t* entb = rev_ent + (int64_t)b * N * KK;
+  __syncthreads();
+  for (int pos = slot; pos < n_own; pos += PPP) {
+    const int m = s_perm[pos];
+    const int off = offb[m], cnt = offb[m + 1] - off;
+    const int32_t* ent = entb + off;
+    float ax = 0, ay = 0, az = 0, aw = 0, qx = 0, qy = 0, qz = 0, qw = 0;
+    constexpr int GB = 8;
+    for (int t0 = 0; t0 < cnt; t0 += GB) {
+      int en[GB];
+#pragma unroll
+      for (int t = 0; t < GB; ++t) en[t] = (t0 + t < cnt) ? ent[t0 + t] : -1;
+#pragma unroll
+      for (int t = 0; t < GB; ++t) {
+        if (en[t] >= 0) {
+          const int n = en[t] / KK, j = en[t] - n * KK;
+          const float4 av = ld4(s_a + n * SW + lp * 4), qv = ld4(s_q + n * SW + lp * 4);
+          const uint32_t g = s_g[n * LP + lp];
+          ax += (int)(g & 255u) == j ? av.x : 0.f;
+          ay += (int)((g >> 8) & 255u) == j ? av.y : 0.f;
+          az += (int)((g >> 16) & 255u) == j ? av.z : 0.f;
+          aw += (int)(g >> 24) == j ? av.w : 0.f;
+          qx += qv.x; qy += qv.y; qz += qv.z; qw += qv.w;
+        }
+      }
+    }
+    const int64_t p = rowb + m;
+    const float4 pm = ld4(pq + p * ldpq + c);
+    const float cf = (float)cnt;
+    float4 dP, dQ;
+    dP.x = ax - (hx * qx + cf * (fx * dbx + hx * (pm.x - mean.x)));
+    dP.y = ay - (hy * qy + cf * (fy * dby + hy * (pm.y - mean.y)));
+    dP.z = az - (hz * qz + cf * (fz * dbz + hz * (pm.z - mean.z)));
+    dP.w = aw - (hw * qw + cf * (fw * dbw + hw * (pm.w - mean.w)));
+    const float4 ap = ld4(s_a + m * SW + lp * 4), sp = ld4(s1 + p * Co + c);
+    dQ.x = ap.x - (kf * fx * dbx + hx * (sp.x - kf * mean.x));
+    dQ.y = ap.y - (kf * fy * dby + hy * (sp.y - kf * mean.y));
+    dQ.z = ap.z - (kf * fz * dbz + hz * (sp.z - kf * mean.z));
+    dQ.w = ap.w - (kf * fw * dbw + hw * (sp.w - kf * mean.w));
+    st4(dpq + p * lddpq + c, dP);
+    st4(dpq + p * lddpq + Co + c, dQ);
+  }
+}
+
 inline int lanes_per_point(int Co) {
   int lpp = 1;
   while (lpp < (Co >> 2) && lpp < 64) lpp <<= 1;
@@ -787,16 +913,33 @@ extern "C" int sug_edgeconv_bwd_scatter(const float* a, const uint8_t* arg, cons
   SUG_REQUIRE(Co > 0 && Co % 4 == 0 && Co <= 1024, "sug_edgeconv_bwd_scatter: Co=%d", Co);
   SUG_REQUIRE(ldpq >= 2 * Co && ldpq % 4 == 0 && lddpq >= 2 * Co && lddpq % 4 == 0,
               "sug_edgeconv_bwd_scatter: bad row strides");
+  const int64_t BN = (int64_t)B * N;
+  const float invM = (float)(1.0 / ((double)BN * k));
+  hipStream_t st = (hipStream_t)stream;
+#ifndef SUG_EDGECONV_NO_LDS
+  // LDS-resident gathers when a 16-channel slice of one cloud's a, Q and arg fits (N <= 1024)
+  const size_t sh_lds = (size_t)N * 16 * 9 + 512 * sizeof(int) + (size_t)N * sizeof(uint16_t);
+  if (k == 20 && Co % 16 == 0 && N <= 65535 && sh_lds <= 158 * 1024 && !getenv("SUG_EDGECONV_BWD_LEGACY") &&
+      ((uintptr_t)a % 16) == 0 && ((uintptr_t)pq % 16) == 0 && ((uintptr_t)arg % 4) == 0 && ((uintptr_t)dpq % 16) == 0 &&
+      ((uintptr_t)s1 % 16) == 0 && ((uintptr_t)coef % 16) == 0) {
+    const int nslice = Co / 16;
+    int psplit = 256 / (B * nslice);             // one workgroup per CU (144 KB of LDS each): fill the chip once
+    psplit = psplit < 1 ? 1 : (psplit > 4 ? 4 : psplit);
+    static SugLdsOptIn note;
+    if (int rc = sug_allow_dynamic_lds(note, &edgeconv_bwd_lds_kernel<16, 20>, 158 * 1024, "sug_edgeconv_bwd_scatter(lds)")) return rc;
+    hipLaunchKernelGGL((edgeconv_bwd_lds_kernel<16, 20>), dim3(B * nslice * psplit), dim3(1024), sh_lds, st, a, arg, s1, pq,
+                       ldpq, rev_off, rev_ent, coef, red, B, N, Co, psplit, invM, dpq, lddpq);
+    SUG_LAUNCH_CHECK("sug_edgeconv_bwd_scatter(lds)");
+    return SUG_OK;
+  }
+#endif
   const int lpp = lanes_per_point(Co);
   const int nch = sug_divup(Co >> 2, lpp);
-  const int64_t BN = (int64_t)B * N;
   const int ppb = 256 / lpp;
   const int cpx = sug_divup(B, 8);
   int bpc = sug_divup(N, ppb);
   while (bpc > 1 && (int64_t)8 * cpx * bpc > 8192) bpc = (bpc + 1) / 2;
   const int grid = 8 * cpx * bpc;
-  const float invM = (float)(1.0 / ((double)BN * k));
-  hipStream_t st = (hipStream_t)stream;
 #define LAUNCH_SCATTER(NC) do { \
     if (k == 20) hipLaunchKernelGGL((edgeconv_bwd_scatter_kernel<NC, 20>), dim3(grid), dim3(256), 0, st, a, arg, s1, pq, ldpq, rev_off, rev_ent, coef, red, BN, N, k, Co, lpp, bpc, invM, dpq, lddpq); \
     else hipLaunchKernelGGL((edgeconv_bwd_scatter_kernel<NC, 0>), dim3(grid), dim3(256), 0, st, a, arg, s1, pq, ldpq, rev_off, rev_ent, coef, red, BN, N, k, Co, lpp, bpc, invM, dpq, lddpq); \
