@@ -568,8 +568,9 @@ template <int SW, int KK>
 __global__ __launch_bounds__(1024) void edgeconv_bwd_lds_kernel(
     const float* __restrict__ a, const uint8_t* __restrict__ arg, const float* __restrict__ s1,
     const float* __restrict__ pq, int64_t ldpq, const int32_t* __restrict__ rev_off,
-    const int32_t* __restrict__ rev_ent, const float* __restrict__ coef, const double* __restrict__ red,
-    int B, int N, int Co, int psplit, float invM, float* __restrict__ dpq, int64_t lddpq) {
+    const int32_t* __restrict__ rev_ent, const float* __restrict__ coef_all, const double* __restrict__ red_all,
+    int B, int N, int Co, int psplit, float invM, int Bg, int64_t coef_stride, int64_t red_stride,
+    float* __restrict__ dpq, int64_t lddpq) {
   extern __shared__ __attribute__((aligned(16))) float s_lds[];
   constexpr int LP = SW / 4;                   // lanes per point
   constexpr int PPP = 1024 / LP;               // points per pass
@@ -592,6 +593,9 @@ __global__ __launch_bounds__(1024) void edgeconv_bwd_lds_kernel(
   const int sl = r % nslice, part = r / nslice;
   const int c0 = sl * SW;
   const int64_t rowb = (int64_t)b * N;
+  // BatchNorm group of this cloud (clouds [g*Bg, (g+1)*Bg) share statistics)
+  const float* coef = coef_all + (int64_t)(b / Bg) * coef_stride;
+  const double* red = red_all + (int64_t)(b / Bg) * red_stride;
   for (int e = threadIdx.x; e < N * LP; e += 1024) {
     const int n = e / LP, c4 = e % LP;
     const int64_t o = (rowb + n) * Co + c0 + c4 * 4;
@@ -902,18 +906,43 @@ extern "C" int sug_edgeconv_bwd_reduce(const float* gout, int64_t ldg, const flo
   return SUG_OK;
 }
 
+// groups > 1: the B clouds are `groups` BatchNorm groups of B/groups clouds; group g reads coef + g*coef_stride and
+// red + g*red_stride (strides in elements; a zero red_stride shares one row, e.g. the zero row of eval mode)
+static int edgeconv_bwd_scatter_groups(const float* a, const uint8_t* arg, const float* s1, const float* pq,
+                                       int64_t ldpq, const int32_t* rev_off, const int32_t* rev_ent, const float* coef,
+                                       const double* red, int B, int N, int k, int Co, int groups, int64_t coef_stride,
+                                       int64_t red_stride, float* dpq, int64_t lddpq, void* stream);
+
 extern "C" int sug_edgeconv_bwd_scatter(const float* a, const uint8_t* arg, const float* s1,
                                         const float* pq, int64_t ldpq, const int32_t* rev_off,
                                         const int32_t* rev_ent, const float* coef, const double* red,
                                         int B, int N, int k, int Co, float* dpq, int64_t lddpq,
                                         void* stream) {
+  return edgeconv_bwd_scatter_groups(a, arg, s1, pq, ldpq, rev_off, rev_ent, coef, red, B, N, k, Co, 1, 0, 0, dpq, lddpq,
+                                     stream);
+}
+
+int sug_edgeconv_bwd_scatter_groups(const float* a, const uint8_t* arg, const float* s1, const float* pq, int64_t ldpq,
+                                    const int32_t* rev_off, const int32_t* rev_ent, const float* coef, const double* red,
+                                    int B, int N, int k, int Co, int groups, int64_t coef_stride, int64_t red_stride,
+                                    float* dpq, int64_t lddpq, void* stream) {
+  return edgeconv_bwd_scatter_groups(a, arg, s1, pq, ldpq, rev_off, rev_ent, coef, red, B, N, k, Co, groups, coef_stride,
+                                     red_stride, dpq, lddpq, stream);
+}
+
+static int edgeconv_bwd_scatter_groups(const float* a, const uint8_t* arg, const float* s1, const float* pq,
+                                       int64_t ldpq, const int32_t* rev_off, const int32_t* rev_ent, const float* coef,
+                                       const double* red, int B, int N, int k, int Co, int groups, int64_t coef_stride,
+                                       int64_t red_stride, float* dpq, int64_t lddpq, void* stream) {
   SUG_REQUIRE(a && arg && s1 && pq && rev_off && rev_ent && coef && red && dpq,
               "sug_edgeconv_bwd_scatter: null pointer");
   SUG_REQUIRE(B > 0 && N > 0 && k > 0 && k <= 255, "sug_edgeconv_bwd_scatter: bad shape");
+  SUG_REQUIRE(groups >= 1 && B % groups == 0, "sug_edgeconv_bwd_scatter: B=%d does not split into %d groups", B, groups);
   SUG_REQUIRE(Co > 0 && Co % 4 == 0 && Co <= 1024, "sug_edgeconv_bwd_scatter: Co=%d", Co);
   SUG_REQUIRE(ldpq >= 2 * Co && ldpq % 4 == 0 && lddpq >= 2 * Co && lddpq % 4 == 0,
               "sug_edgeconv_bwd_scatter: bad row strides");
-  const int64_t BN = (int64_t)B * N;
+  const int Bg = B / groups;
+  const int64_t BN = (int64_t)Bg * N;                 // rows behind one set of BatchNorm statistics
   const float invM = (float)(1.0 / ((double)BN * k));
   hipStream_t st = (hipStream_t)stream;
 #ifndef SUG_EDGECONV_NO_LDS
@@ -928,28 +957,37 @@ extern "C" int sug_edgeconv_bwd_scatter(const float* a, const uint8_t* arg, cons
     static SugLdsOptIn note;
     if (int rc = sug_allow_dynamic_lds(note, &edgeconv_bwd_lds_kernel<16, 20>, 158 * 1024, "sug_edgeconv_bwd_scatter(lds)")) return rc;
     hipLaunchKernelGGL((edgeconv_bwd_lds_kernel<16, 20>), dim3(B * nslice * psplit), dim3(1024), sh_lds, st, a, arg, s1, pq,
-                       ldpq, rev_off, rev_ent, coef, red, B, N, Co, psplit, invM, dpq, lddpq);
+                       ldpq, rev_off, rev_ent, coef, red, B, N, Co, psplit, invM, Bg, coef_stride, red_stride, dpq, lddpq);
     SUG_LAUNCH_CHECK("sug_edgeconv_bwd_scatter(lds)");
     return SUG_OK;
   }
 #endif
+  // generic path: one launch per BatchNorm group
   const int lpp = lanes_per_point(Co);
   const int nch = sug_divup(Co >> 2, lpp);
   const int ppb = 256 / lpp;
-  const int cpx = sug_divup(B, 8);
+  const int cpx = sug_divup(Bg, 8);
   int bpc = sug_divup(N, ppb);
   while (bpc > 1 && (int64_t)8 * cpx * bpc > 8192) bpc = (bpc + 1) / 2;
   const int grid = 8 * cpx * bpc;
 #define LAUNCH_SCATTER(NC) do { \
-    if (k == 20) hipLaunchKernelGGL((edgeconv_bwd_scatter_kernel<NC, 20>), dim3(grid), dim3(256), 0, st, a, arg, s1, pq, ldpq, rev_off, rev_ent, coef, red, BN, N, k, Co, lpp, bpc, invM, dpq, lddpq); \
-    else hipLaunchKernelGGL((edgeconv_bwd_scatter_kernel<NC, 0>), dim3(grid), dim3(256), 0, st, a, arg, s1, pq, ldpq, rev_off, rev_ent, coef, red, BN, N, k, Co, lpp, bpc, invM, dpq, lddpq); \
+    if (k == 20) hipLaunchKernelGGL((edgeconv_bwd_scatter_kernel<NC, 20>), dim3(grid), dim3(256), 0, st, ag, argg, s1g, pqg, ldpq, offg, entg, cg, rg, BN, N, k, Co, lpp, bpc, invM, dpqg, lddpq); \
+    else hipLaunchKernelGGL((edgeconv_bwd_scatter_kernel<NC, 0>), dim3(grid), dim3(256), 0, st, ag, argg, s1g, pqg, ldpq, offg, entg, cg, rg, BN, N, k, Co, lpp, bpc, invM, dpqg, lddpq); \
   } while (0)
-  if (nch == 1)
-    LAUNCH_SCATTER(1);
-  else if (nch == 2)
-    LAUNCH_SCATTER(2);
-  else
-    LAUNCH_SCATTER(4);
+  for (int g = 0; g < groups; ++g) {
+    const int64_t r0 = (int64_t)g * BN;
+    const float *ag = a + r0 * Co, *s1g = s1 + r0 * Co, *pqg = pq + r0 * ldpq, *cg = coef + g * coef_stride;
+    const uint8_t* argg = arg + r0 * Co;
+    const int32_t *offg = rev_off + (int64_t)g * Bg * (N + 1), *entg = rev_ent + r0 * k;
+    const double* rg = red + g * red_stride;
+    float* dpqg = dpq + r0 * lddpq;
+    if (nch == 1)
+      LAUNCH_SCATTER(1);
+    else if (nch == 2)
+      LAUNCH_SCATTER(2);
+    else
+      LAUNCH_SCATTER(4);
+  }
   SUG_LAUNCH_CHECK("sug_edgeconv_bwd_scatter");
   return SUG_OK;
 }

@@ -204,71 +204,139 @@ int dispatch_knn_c(const float* x, int64_t ldx, int B, int N, int C, int k, int3
 }
 
 // ---- reverse lists ---------------------------------------------------------
-// One block per cloud, everything in LDS: counts -> exclusive scan -> fill (atomic cursor)
-// -> each destination sorts its own (short) list so float sums downstream are deterministic
-// -> coalesced write-out.  LDS: 2N ints + N*k ints (N=1024, k=20: 88 KB).
+// A workgroup owns the destinations [lo, hi) of one cloud (RS ranges per cloud, so that 64 clouds fill the chip),
+// everything in LDS: it scans the cloud's N*k neighbour entries, counts those that point into its range (and those
+// that point below it: its base offset in the cloud's entry array), exclusive scan -> fill (atomic cursor, arbitrary
+// order) -> rank sort of every destination's list straight into its final place, so that float sums downstream
+// are deterministic: a half-wave per list (lane u counts the entries smaller than entry u: the reads of one list
+// are LDS broadcasts with no dependence between them), a whole wave for lists longer than 32 (hub points).
+// LDS: 2*Nr + BLOCK/64 ints + the worst case of N*k entries (82 KB).
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void knn_reverse_kernel(const int32_t* __restrict__ idx, int N,
-                                                            int k, int32_t* __restrict__ rev_off,
+                                                            int k, int RS, int32_t* __restrict__ rev_off,
                                                             int32_t* __restrict__ rev_ent) {
-  extern __shared__ int s_i[];  // cnt[N] | cur[N] | scan scratch[BLOCK] | ent[N*k]
+  extern __shared__ int s_i[];  // cnt[Nr] | cur[Nr] | per-wave scratch[2*BLOCK/64] | ent[N*k]
+  constexpr int NW = BLOCK / 64;
+  const int Nr = (N + RS - 1) / RS;
   int* cnt = s_i;
-  int* cur = s_i + N;
-  int* scr = s_i + 2 * N;
-  int* ent = s_i + 2 * N + BLOCK;
-  const int b = blockIdx.x;
+  int* cur = s_i + Nr;
+  int* scr = s_i + 2 * Nr;
+  int* ent = s_i + 2 * Nr + 2 * NW;
+  const int b = blockIdx.x / RS, r = blockIdx.x % RS;
+  const int lo = r * Nr, hi = (lo + Nr < N) ? lo + Nr : N;
+  const int nr = hi > lo ? hi - lo : 0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int32_t* ib = idx + (int64_t)b * N * k;
   int32_t* off = rev_off + (int64_t)b * (N + 1);
   int32_t* gent = rev_ent + (int64_t)b * N * k;
-  for (int i = threadIdx.x; i < N; i += BLOCK) cnt[i] = 0;
+  for (int i = threadIdx.x; i < nr; i += BLOCK) cnt[i] = 0;
   __syncthreads();
   const int total = N * k;
-  for (int e = threadIdx.x; e < total; e += BLOCK) {
-    const int m = ib[e];
-    if (m >= 0 && m < N) atomicAdd(&cnt[m], 1);
+  int below = 0;
+  // the neighbour entries are read U at a time (all loads of a batch in flight before the first use: one load per
+  // iteration, each waiting for the atomic behind it, made this kernel latency-bound)
+  constexpr int U = 5;
+  for (int e0 = threadIdx.x; e0 < total; e0 += BLOCK * U) {
+    int mv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) mv[u] = (e0 + u * BLOCK < total) ? ib[e0 + u * BLOCK] : -1;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int m = mv[u];
+      if (m >= 0 && m < lo) ++below;
+      if (m >= lo && m < hi) atomicAdd(&cnt[m - lo], 1);
+    }
   }
+  // base = number of valid entries that point below this range (integer sums: order-free)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) below += __shfl_xor(below, o);
+  if (lane == 0) scr[wave] = below;
   __syncthreads();
-  const int PER = (N + BLOCK - 1) / BLOCK;
-  const int lo = threadIdx.x * PER;
+  int base = 0;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) base += scr[w];
+  // exclusive scan of the counts: PER consecutive destinations per thread, wave scan, then across waves
+  const int PER = (nr + BLOCK - 1) / BLOCK;
+  const int t0 = threadIdx.x * PER;
   int local = 0;
-  for (int i = lo; i < lo + PER && i < N; ++i) local += cnt[i];
-  scr[threadIdx.x] = local;
-  __syncthreads();
-  for (int o = 1; o < BLOCK; o <<= 1) {
-    int t = threadIdx.x >= o ? scr[threadIdx.x - o] : 0;
-    __syncthreads();
-    scr[threadIdx.x] += t;
-    __syncthreads();
+  for (int i = t0; i < t0 + PER && i < nr; ++i) local += cnt[i];
+  int incl = local;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(incl, o);
+    if (lane >= o) incl += t;
   }
-  int run = scr[threadIdx.x] - local;
-  for (int i = lo; i < lo + PER && i < N; ++i) {
+  if (lane == 63) scr[NW + wave] = incl;
+  __syncthreads();
+  int wbase = 0, filled = 0;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    const int t = scr[NW + w];
+    if (w < wave) wbase += t;
+    filled += t;
+  }
+  int run = wbase + incl - local;
+  for (int i = t0; i < t0 + PER && i < nr; ++i) {
     const int c = cnt[i];
     cur[i] = run;
-    off[i] = run;
+    off[lo + i] = base + run;
     run += c;
   }
-  const int filled = scr[BLOCK - 1];
-  if (threadIdx.x == BLOCK - 1) off[N] = filled;
+  if (r == RS - 1 && threadIdx.x == 0) off[N] = base + filled;
   __syncthreads();
-  for (int e = threadIdx.x; e < total; e += BLOCK) {
-    const int m = ib[e];
-    if (m >= 0 && m < N) ent[atomicAdd(&cur[m], 1)] = e;
-  }
-  __syncthreads();
-  for (int m = threadIdx.x; m < N; m += BLOCK) {
-    const int n = cnt[m], s = cur[m] - n;
-    for (int i = 1; i < n; ++i) {  // insertion sort in LDS, lists average k entries
-      const int key = ent[s + i];
-      int j = i - 1;
-      while (j >= 0 && ent[s + j] > key) {
-        ent[s + j + 1] = ent[s + j];
-        --j;
-      }
-      ent[s + j + 1] = key;
+  for (int e0 = threadIdx.x; e0 < total; e0 += BLOCK * U) {
+    int mv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) mv[u] = (e0 + u * BLOCK < total) ? ib[e0 + u * BLOCK] : -1;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int m = mv[u];
+      if (m >= lo && m < hi) ent[atomicAdd(&cur[m - lo], 1)] = e0 + u * BLOCK;
     }
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < filled; e += BLOCK) gent[e] = ent[e];
+  // lists up to 32 entries: two per wave (one per half-wave); the loop bound is made uniform over the wave
+  const int half = lane >> 5, hl = lane & 31;
+  for (int i0 = wave * 2; i0 < nr; i0 += NW * 2) {
+    const int i = i0 + half;
+    const int n = i < nr ? cnt[i] : 0;
+    const int s = i < nr ? cur[i] - n : 0;
+    const int nn = n <= 32 ? n : 0;
+    const int nmax = max(nn, __shfl_xor(nn, 32));
+    const int nlast = nn > 0 ? nn - 1 : 0;
+    const int key = ent[s + min(hl, nlast)];
+    int rank = 0;
+    for (int j0 = 0; j0 < nmax; j0 += 8) {           // 8 independent LDS reads in flight
+      int v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = ent[s + min(j0 + u, nlast)];   // unconditional (a guarded read is a branch + wait)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) rank += (j0 + u < nn && v[u] < key) ? 1 : 0;      // entries are distinct
+    }
+    // in place: every read of this list (same half-wave, program order) is behind us
+    if (hl < nn) ent[s + rank] = key;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < filled; e += BLOCK) gent[base + e] = ent[e];
+  __syncthreads();            // the long lists below overwrite their (unsorted) copy
+  // longer lists (hub points): a wave per list
+  for (int i = wave; i < nr; i += NW) {
+    const int n = cnt[i];
+    if (n <= 32) continue;                           // uniform over the wave
+    const int s = cur[i] - n;
+    for (int u = lane; u < n; u += 64) {
+      const int key = ent[s + u];
+      int rank = 0;
+      for (int j0 = 0; j0 < n; j0 += 8) {
+        int v[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] = ent[s + min(j0 + t, n - 1)];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) rank += (j0 + t < n && v[t] < key) ? 1 : 0;
+      }
+      gent[base + s + rank] = key;
+    }
+  }
 }
 
 }  // namespace
@@ -292,12 +360,15 @@ extern "C" int sug_knn_reverse(const int32_t* idx, int B, int N, int k, int32_t*
   SUG_REQUIRE(idx && rev_off && rev_ent, "sug_knn_reverse: null pointer");
   SUG_REQUIRE(B > 0 && N > 0 && k > 0, "sug_knn_reverse: bad shape");
   constexpr int BLOCK = 1024;
-  size_t sh = (size_t)(2 * N + BLOCK + (size_t)N * k) * sizeof(int);
+  int RS = 1;                                    // destination ranges per cloud: >= 256 workgroups when B allows
+  while (RS < 8 && B * RS < 256 && N / (RS * 2) >= 64) RS *= 2;
+  const int Nr = (N + RS - 1) / RS;
+  size_t sh = (size_t)(2 * Nr + 2 * (BLOCK / 64) + (size_t)N * k) * sizeof(int);
   SUG_REQUIRE(sh <= 160 * 1024, "sug_knn_reverse: N*k=%d too large for the LDS-resident build", N * k);
   static SugLdsOptIn note;
   if (int rc = sug_allow_dynamic_lds(note, &knn_reverse_kernel<BLOCK>, 160 * 1024, "sug_knn_reverse")) return rc;
-  hipLaunchKernelGGL((knn_reverse_kernel<BLOCK>), dim3(B), dim3(BLOCK), sh, (hipStream_t)stream, idx,
-                     N, k, rev_off, rev_ent);
+  hipLaunchKernelGGL((knn_reverse_kernel<BLOCK>), dim3(B * RS), dim3(BLOCK), sh, (hipStream_t)stream, idx,
+                     N, k, RS, rev_off, rev_ent);
   SUG_LAUNCH_CHECK("sug_knn_reverse");
   return SUG_OK;
 }

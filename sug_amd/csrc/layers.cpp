@@ -7,6 +7,12 @@
 #include "../../include/sug_amd.h"
 
 void sug_set_error(const char* fmt, ...);
+// edgeconv.hip: sug_edgeconv_bwd_scatter over `groups` BatchNorm groups in one launch (group g reads
+// coef + g*coef_stride, red + g*red_stride)
+int sug_edgeconv_bwd_scatter_groups(const float* a, const uint8_t* arg, const float* s1, const float* pq, int64_t ldpq,
+                                    const int32_t* rev_off, const int32_t* rev_ent, const float* coef, const double* red,
+                                    int B, int N, int k, int Co, int groups, int64_t coef_stride, int64_t red_stride,
+                                    float* dpq, int64_t lddpq, void* stream);
 #define LAYER_REQUIRE(cond, ...) do { if (!(cond)) { sug_set_error(__VA_ARGS__); return SUG_ERR_ARG; } } while (0)
 #define LAYER_TRY(call) do { const int rc_ = (call); if (rc_ != SUG_OK) return rc_; } while (0)
 
@@ -49,13 +55,12 @@ extern "C" int sug_edgeconv_layer_bwd(const float* gout, int64_t ldg, const floa
     const float* cg = coef + (int64_t)g * 5 * Co;
     double* rg = red + (int64_t)g * 2 * Co;                  // per group: dbeta | dgamma
     LAYER_TRY(sug_edgeconv_bwd_reduce(gout + r0 * ldg, ldg, z + r0 * Co, cg, rows, Co, slope, a + r0 * Co, rg, ws, stream));
-    // eval mode: the statistics are constants, the scatter must see zero BN sums (red + groups*2Co: a
-    // caller-zeroed spare row)
-    const double* ru = training ? rg : red + (int64_t)groups * 2 * Co;
-    LAYER_TRY(sug_edgeconv_bwd_scatter(a + r0 * Co, arg + r0 * Co, s1 + r0 * Co, pq + r0 * ldpq, ldpq,
-                                       rev_off + (int64_t)g * Bg * (N + 1), rev_ent + (int64_t)g * Bg * N * k, cg, ru,
-                                       Bg, N, k, Co, dpq + r0 * lddpq, lddpq, stream));
   }
+  // eval mode: the statistics are constants, the scatter must see zero BN sums (red + groups*2Co: a
+  // caller-zeroed spare row, shared by all groups)
+  LAYER_TRY(sug_edgeconv_bwd_scatter_groups(a, arg, s1, pq, ldpq, rev_off, rev_ent, coef,
+                                            training ? red : red + (int64_t)groups * 2 * Co, B, N, k, Co, groups,
+                                            (int64_t)5 * Co, training ? (int64_t)2 * Co : 0, dpq, lddpq, stream));
   if (dgb) LAYER_TRY(sug_fold_groups(red, groups, 2 * Co, dgb, stream));
   return SUG_OK;
 }

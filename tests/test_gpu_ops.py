@@ -104,6 +104,27 @@ def test_knn_reverse_lists():
             assert torch.equal(lst, want)
 
 
+@pytest.mark.parametrize('B,N', [(64, 1024), (5, 1000), (40, 512), (2, 96)])
+def test_knn_reverse_lists_full(B, N):
+    """Every destination of every cloud: the reverse lists are the stable sort of the flat neighbour array
+    (entries in ascending order), including hub points with lists far longer than k (wave rank sort) and
+    destinations nobody lists."""
+    from sug_amd import ops
+    g = torch.Generator().manual_seed(B + N)
+    k = 20
+    idx = torch.randint(0, N, (B, N, k), generator=g, dtype=torch.int32)
+    idx[:, :, 0] = torch.randint(0, 3, (B, N), generator=g, dtype=torch.int32)      # three hubs with ~N/3 entries
+    idx[:, : N // 2, 1] = N - 1                                                     # one with N/2
+    off, ent = ops.knn_reverse(idx.cuda())
+    off, ent = off.cpu().long(), ent.cpu().long()
+    flat = idx.reshape(B, -1).long()
+    want_ent = torch.argsort(flat, dim=1, stable=True)
+    assert torch.equal(ent, want_ent)
+    counts = torch.zeros(B, N, dtype=torch.long).scatter_add_(1, flat, torch.ones_like(flat))
+    want_off = torch.cat((torch.zeros(B, 1, dtype=torch.long), counts.cumsum(1)), 1)
+    assert torch.equal(off, want_off)
+
+
 def test_fps_golden(ops_golden):
     from sug_amd import ops
     out = ops.fps(rows(ops_golden['fps_cf_xyz']), 64, ops_golden['fps_cf_start'])
