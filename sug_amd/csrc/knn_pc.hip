@@ -303,7 +303,16 @@ __global__ __launch_bounds__(512, 2) void knn_pc_kernel(const float* __restrict_
       fetch_finish(s_cur, j_cur);
       for (int it = 0; it < nit; ++it) {
         fetch_issue();
+#ifdef SUG_KNN_EXPERIMENT
+        {   // timing experiment only (wrong indices): one v_med3 per slot
+#pragma unroll
+          for (int u = K - 1; u >= 1; --u) asm volatile("v_med3_f32 %0, %1, %0, %2" : "+v"(v[u]) : "v"(v[u - 1]), "v"(s_cur));
+          asm volatile("v_max_f32 %0, %0, %1" : "+v"(v[0]) : "v"(s_cur));
+          id[0] += j_cur;
+        }
+#else
         insert_sorted<K>(v, id, s_cur, j_cur);
+#endif
         fetch_finish(s_cur, j_cur);
       }
       thr = v[K - 1];

@@ -17,8 +17,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 __global__ __launch_bounds__(256) void linear_dw_kernel(const float* __restrict__ g, int64_t ldg,
                                                         const float* __restrict__ x, int64_t ldx,
                                                         int64_t R, int M, int N, int rows_per_block,
-                                                        float* __restrict__ part) {
+                                                        float* __restrict__ part, int with_db) {
   __shared__ float s_acc[3][4][16][64];          // waves 1..3 x (2x2 tiles) x 16 regs x 64 lanes
+  __shared__ float s_db[4][64];                  // column sums of g (bias gradient), per wave
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int col = lane & 31, kh = lane >> 5;
   const int i0 = blockIdx.y * 64, j0 = blockIdx.z * 64;
@@ -37,6 +38,7 @@ __global__ __launch_bounds__(256) void linear_dw_kernel(const float* __restrict_
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  float sa0 = 0.f, sa1 = 0.f;                    // sum of this lane's g elements (rows of its parity)
   for (int64_t r = r0; r < r1; r += 2) {
     const int64_t row = r + kh;
     const bool ok = row < r1;
@@ -44,6 +46,8 @@ __global__ __launch_bounds__(256) void linear_dw_kernel(const float* __restrict_
     const float* xr = x + row * ldx + j0 + col;
     const float a0 = (ok && ia0) ? gr[0] : 0.f, a1 = (ok && ia1) ? gr[32] : 0.f;
     const float b0 = (ok && jb0) ? xr[0] : 0.f, b1 = (ok && jb1) ? xr[32] : 0.f;
+    sa0 += a0;
+    sa1 += a1;
     acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
     acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
     acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
@@ -55,9 +59,19 @@ __global__ __launch_bounds__(256) void linear_dw_kernel(const float* __restrict_
 #pragma unroll
       for (int r = 0; r < 16; ++r) s_acc[wv - 1][t][r][lane] = acc[t >> 1][t & 1][r];
   }
+  const size_t pstride = (size_t)M * N + (with_db ? M : 0);
+  if (with_db && blockIdx.z == 0) {              // even + odd rows, then the four waves in a fixed order
+    sa0 += __shfl_xor(sa0, 32);
+    sa1 += __shfl_xor(sa1, 32);
+    s_db[wv][lane] = kh == 0 ? sa0 : sa1;        // lanes 0-31: columns i0+col, lanes 32-63: columns i0+32+col
+  }
   __syncthreads();
   if (wv == 0) {
-    float* p = part + (size_t)blockIdx.x * M * N;
+    float* p = part + (size_t)blockIdx.x * pstride;
+    if (with_db && blockIdx.z == 0) {
+      const int i = i0 + lane;
+      if (i < M) p[(size_t)M * N + i] = ((s_db[0][lane] + s_db[1][lane]) + s_db[2][lane]) + s_db[3][lane];
+    }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int ti = i0 + (t >> 1) * 32, tj = j0 + (t & 1) * 32;
@@ -78,10 +92,12 @@ __global__ __launch_bounds__(256) void linear_dw_kernel(const float* __restrict_
 __global__ __launch_bounds__(64) void linear_dw_big_kernel(const float* __restrict__ g, int64_t ldg,
                                                            const float* __restrict__ x, int64_t ldx,
                                                            int64_t R, int M, int N, int rows_per_block,
-                                                           float* __restrict__ part) {
+                                                           float* __restrict__ part, int with_db) {
   const int lane = threadIdx.x;
   const int col = lane & 31, kh = lane >> 5;
   const int i0 = blockIdx.y * 128, j0 = blockIdx.z * 128;
+  const bool do_db = with_db && blockIdx.z == 0;
+  float sdb[4] = {0.f, 0.f, 0.f, 0.f};
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   int64_t r1 = r0 + rows_per_block;
   if (r1 > R) r1 = R;
@@ -119,6 +135,10 @@ __global__ __launch_bounds__(64) void linear_dw_big_kernel(const float* __restri
 #pragma unroll
     for (int s = 0; s < ST; ++s) {
       fetch(r + 2 * (s + ST - 1), av[(s + ST - 1) % ST], bv[(s + ST - 1) % ST]);
+      if (do_db) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) sdb[a] += av[s][a];
+      }
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -126,7 +146,15 @@ __global__ __launch_bounds__(64) void linear_dw_big_kernel(const float* __restri
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][a], bv[s][b], acc[a][b], 0, 0, 0);
     }
   }
-  float* p = part + (size_t)blockIdx.x * M * N;
+  float* p = part + (size_t)blockIdx.x * ((size_t)M * N + (with_db ? M : 0));
+  if (do_db) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const float t = sdb[a] + __shfl_xor(sdb[a], 32);
+      const int i = i0 + 32 * a + col;
+      if (kh == 0 && i < M) p[(size_t)M * N + i] = t;
+    }
+  }
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -139,20 +167,25 @@ __global__ __launch_bounds__(64) void linear_dw_big_kernel(const float* __restri
 }
 
 __global__ __launch_bounds__(256) void linear_dw_reduce_kernel(const float* __restrict__ part, int nchunk,
-                                                               int64_t MN, float* __restrict__ dw) {
+                                                               int64_t MN, int64_t P, float* __restrict__ dw,
+                                                               float* __restrict__ db) {
+  // partial rows hold P = MN (+ M bias-gradient columns) elements; e < MN -> dw, the rest -> db
   __shared__ double s_p[16][17];
   const int el = threadIdx.x & 15, cl = threadIdx.x >> 4;
   const int64_t e = (int64_t)blockIdx.x * 16 + el;
   double acc = 0.0;
-  if (e < MN)
-    for (int c = cl; c < nchunk; c += 16) acc += (double)part[(size_t)c * MN + e];
+  if (e < P)
+    for (int c = cl; c < nchunk; c += 16) acc += (double)part[(size_t)c * P + e];
   s_p[cl][el] = acc;
   __syncthreads();
-  if (cl == 0 && e < MN) {
+  if (cl == 0 && e < P) {
     double t = s_p[0][el];
 #pragma unroll
     for (int i = 1; i < 16; ++i) t += s_p[i][el];
-    dw[e] = (float)t;
+    if (e < MN)
+      dw[e] = (float)t;
+    else
+      db[e - MN] = (float)t;
   }
 }
 
@@ -171,26 +204,32 @@ int plan_rows_per_block(int64_t R, int M, int N) {
 
 extern "C" int64_t sug_linear_dw_workspace(int64_t R, int M, int N) {
   if (R <= 0 || M <= 0 || N <= 0) return 0;
-  return (int64_t)sug_divup(R, plan_rows_per_block(R, M, N)) * M * N;
+  return (int64_t)sug_divup(R, plan_rows_per_block(R, M, N)) * ((int64_t)M * N + M);     // room for the db columns
 }
 
-extern "C" int sug_linear_dw(const float* g, int64_t ldg, const float* x, int64_t ldx, int64_t R, int M,
-                             int N, float* dw, float* ws, void* stream) {
+extern "C" int sug_linear_dw_bias(const float* g, int64_t ldg, const float* x, int64_t ldx, int64_t R, int M,
+                                  int N, float* dw, float* db, float* ws, void* stream) {
   SUG_REQUIRE(g && x && dw && ws, "sug_linear_dw: null pointer");
   SUG_REQUIRE(R > 0 && M > 0 && N > 0 && ldg >= M && ldx >= N, "sug_linear_dw: bad shape");
   const int rpb = plan_rows_per_block(R, M, N);
   const int nchunk = sug_divup(R, rpb);
   SUG_REQUIRE(sug_divup(M, 64) <= 65535 && sug_divup(N, 64) <= 65535, "sug_linear_dw: output too large");
   hipStream_t st = (hipStream_t)stream;
+  const int with_db = db ? 1 : 0;
   if (use_big(M, N))
     hipLaunchKernelGGL(linear_dw_big_kernel, dim3(nchunk, sug_divup(M, 128), sug_divup(N, 128)), dim3(64), 0, st, g, ldg,
-                       x, ldx, R, M, N, rpb, ws);
+                       x, ldx, R, M, N, rpb, ws, with_db);
   else
     hipLaunchKernelGGL(linear_dw_kernel, dim3(nchunk, sug_divup(M, 64), sug_divup(N, 64)), dim3(256), 0, st, g, ldg, x,
-                       ldx, R, M, N, rpb, ws);
+                       ldx, R, M, N, rpb, ws, with_db);
   SUG_LAUNCH_CHECK("sug_linear_dw");
-  const int64_t MN = (int64_t)M * N;
-  hipLaunchKernelGGL(linear_dw_reduce_kernel, dim3(sug_divup(MN, 16)), dim3(256), 0, st, ws, nchunk, MN, dw);
+  const int64_t MN = (int64_t)M * N, P = MN + (with_db ? M : 0);
+  hipLaunchKernelGGL(linear_dw_reduce_kernel, dim3(sug_divup(P, 16)), dim3(256), 0, st, ws, nchunk, MN, P, dw, db);
   SUG_LAUNCH_CHECK("sug_linear_dw(reduce)");
   return SUG_OK;
+}
+
+extern "C" int sug_linear_dw(const float* g, int64_t ldg, const float* x, int64_t ldx, int64_t R, int M,
+                             int N, float* dw, float* ws, void* stream) {
+  return sug_linear_dw_bias(g, ldg, x, ldx, R, M, N, dw, nullptr, ws, stream);
 }

@@ -335,9 +335,11 @@ class _LinearRows(torch.autograd.Function):
             else:
                 dw = torch.empty(M, N, dtype=torch.float32, device=g.device)
                 ws = torch.empty(int(lib().sug_linear_dw_workspace(R, M, N)), dtype=torch.float32, device=g.device)
-                check(lib().sug_linear_dw(_p(g2), g2.stride(0), _p(x2), x2.stride(0), R, M, N, _p(dw), _p(ws), _st()),
-                      'sug_linear_dw')
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+                if ctx.has_bias and ctx.needs_input_grad[2]:       # bias gradient from the same pass over g
+                    db = torch.empty(M, dtype=torch.float32, device=g.device)
+                check(lib().sug_linear_dw_bias(_p(g2), g2.stride(0), _p(x2), x2.stride(0), R, M, N, _p(dw), _p(db), _p(ws),
+                                               _st()), 'sug_linear_dw_bias')
+        if ctx.has_bias and ctx.needs_input_grad[2] and db is None:
             db = g2.sum(dim=0)
         return dx, dw, db
 
