@@ -292,6 +292,25 @@ int sug_edgeconv_layer_bwd(const float* gout, int64_t ldg, const float* z, const
                            const float* coef, int B, int N, int k, int Co, int groups, int training,
                            float slope, float* a, double* red, int32_t* rev_off, int32_t* rev_ent,
                            float* dpq, int64_t lddpq, float* ws, float* dgb, void* stream);
+/* ---- first layer of a set-abstraction MLP on the neighbour lists (no grouped tensor) ----------------
+ * Replaces index_points(xyz, idx) - new_xyz, index_points(points, idx), torch.cat, mlp_convs[0],
+ * mlp_bns[0], F.relu of PointNetSetAbstraction.forward (model/pointnet2_utils.py:107-135, 193-198).
+ * W.[x_j - c_s ; f_j] + b = P[j] - Q[s] with P [B,N,C] = W.[x ; f] per point (row stride ldp) and
+ * Q [B,S,C] = Wx.c - b per centroid, both formed by the caller (two small GEMMs); idx [B,S,ns] are the
+ * ball-query lists (values in [0,N)).  Forward: train-mode statistics of y = P[idx] - Q over the B/groups*S*ns
+ * rows of each domain group (coef [groups,5,C] as the other BatchNorm entry points; training = 0: coef is
+ * an input), Z [B,S,ns,C] = relu(BN(y)).  C in {64, 128}.  ws: SUG_STATS_BLOCKS*2*C floats.
+ * Backward: gz [B,S,ns,C] -> dP [B,N,C] (zeroed here, accumulated with float atomics as index_points'
+ * backward accumulates in the reference), dQ [B,S,C]; red [groups+1, 2C] doubles (row g: dbeta | dgamma,
+ * the spare last row zero for training = 0); dgb: NULL or fp32 [2C] = red folded over the groups. */
+int sug_sa_first_fwd(const float* P, int64_t ldp, const float* Q, const int32_t* idx, int B, int N, int S,
+                     int ns, int C, int groups, const float* gamma, const float* beta, int training,
+                     float eps, float momentum, float* running_mean, float* running_var, float* coef,
+                     float* Z, float* ws, void* stream);
+int sug_sa_first_bwd(const float* gz, const float* P, int64_t ldp, const float* Q, const int32_t* idx, int B,
+                     int N, int S, int ns, int C, int groups, int training, const float* coef, double* red,
+                     float* dP, float* dQ, float* ws, float* dgb, void* stream);
+
 /* conv_2d / Conv1d + BatchNorm + (Leaky)ReLU on rows (model_utils.py:8-32, pointnet2_utils.py:195-198):
  * out = act(BN(y)), y [rows,C]. */
 int sug_bn_act_rows_fwd(const float* y, int64_t ldy, int64_t rows, int C, int groups, const float* gamma,

@@ -700,6 +700,13 @@ inline int col_width(int C) {
 
 }  // namespace
 
+int sug_reduce_partials(const float* ws, int nblk, int W, double* out, hipStream_t st) {
+  SUG_REQUIRE(ws && out && nblk > 0 && W > 0, "sug_reduce_partials: bad argument");
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(sug_divup(W, 16)), dim3(256), 0, st, ws, nblk, W, out);
+  SUG_LAUNCH_CHECK("sug_reduce_partials");
+  return SUG_OK;
+}
+
 int sug_stats_finalize(const float* ws, int nblk, int C, const float* gamma, const float* beta, double count, float eps,
                        float momentum, float* running_mean, float* running_var, float* coef, hipStream_t st) {
   SUG_REQUIRE(ws && gamma && beta && coef && nblk > 0 && C > 0 && count > 0, "sug_stats_finalize: bad argument");

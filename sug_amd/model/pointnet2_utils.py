@@ -51,6 +51,16 @@ def sample_and_group(npoint, radius, nsample, xyz, points, returnfps=False):
     return new_xyz, new_points
 
 
+def sample_and_group_idx(npoint, radius, nsample, xyz):
+    """The index half of sample_and_group (model/pointnet2_utils.py:107-124): same FPS start draw and kernels,
+    -> new_xyz [B,S,3], idx [B,S,nsample] int32; the grouped tensor itself is not formed."""
+    B, N, _ = xyz.shape
+    start = ops.draw_start(B, N)
+    fps_idx = ops.fps(xyz, npoint, start)
+    new_xyz = ops.gather_rows(xyz, fps_idx)
+    return new_xyz, ops.ball_query(xyz, new_xyz, radius, nsample)
+
+
 def sample_and_group_all(xyz, points):
     """model/pointnet2_utils.py:138-155."""
     B, N, C = xyz.shape
@@ -82,14 +92,27 @@ class PointNetSetAbstraction(nn.Module):
         """xyz [B,N,3], points [B,N,D] or None -> new_xyz [B,S,3], feats [B,S,D'](, node [B,S,D1]).
         tail_grad=False (with adapt): the layers behind the one the node features come from run without
         autograd (their output is discarded by the caller; BatchNorm buffers are still updated)."""
+        first = 0
         if self.group_all:
             new_xyz, g = sample_and_group_all(xyz, points)
+        elif ops.sa_first_layer_supported(self.mlp_convs[0].out_channels) and len(self.mlp_convs) > 1:
+            # first layer on the neighbour lists: W.[x_j - c_s ; f_j] + b = P[j] - Q[s], P per point, Q per centroid
+            # (the grouped [B,S,ns,3+D] tensor and the pre-activation tensor are never formed)
+            new_xyz, idx = sample_and_group_idx(self.npoint, self.radius, self.nsample, xyz)
+            conv = self.mlp_convs[0]
+            w = conv.weight.view(conv.weight.shape[0], -1)
+            P = ops.linear_rows(xyz if points is None else torch.cat((xyz, points), dim=-1), w)
+            Q = ops.linear_rows(new_xyz, w[:, :3]) - conv.bias
+            g = ops.sa_first_layer(P, Q, idx, self.mlp_bns[0])
+            first = 1
         else:
             new_xyz, g = sample_and_group(self.npoint, self.radius, self.nsample, xyz, points)
         node = None
         last = len(self.mlp_convs) - 1
         out = None
         for i, conv in enumerate(self.mlp_convs):                      # g: [B,S,ns,C] rows
+            if i < first:
+                continue
             w = conv.weight.view(conv.weight.shape[0], -1)
             with torch.set_grad_enabled(torch.is_grad_enabled() and (tail_grad or not adapt or i <= 1)):
                 if i == last and ops.pointmlp_max_supported(g.shape[-1], w.shape[0], g.shape[2]):

@@ -513,6 +513,64 @@ class _BNActRows(torch.autograd.Function):
         return dy.view(shape), rf[C:], rf[:C], None, None, None, None, None, None, None
 
 
+class _SAFirstLayer(torch.autograd.Function):
+    """relu(BN(P[idx] - Q)) over the ball-query lists: the first layer of a set-abstraction MLP without the
+    grouped [B,S,ns,3+D] tensor (sug_sa_first_fwd / bwd)."""
+
+    @staticmethod
+    def forward(ctx, P, Q, idx, gamma, beta, running_mean, running_var, training, eps, momentum, G):
+        _need_gpu(P, Q, idx)
+        P, Q = P.contiguous(), Q.contiguous()
+        idx = _i32(idx).contiguous()
+        B, N, C = P.shape
+        S, ns = idx.shape[1], idx.shape[2]
+        if B % G:
+            raise RuntimeError('sa_first_layer: %d clouds do not split into %d domain groups' % (B, G))
+        dev = P.device
+        g, b = gamma.detach().contiguous(), beta.detach().contiguous()
+        if training:
+            coef = torch.empty(G, 5, C, dtype=torch.float32, device=dev)
+        else:
+            coef = eval_coef(g, b, running_mean, running_var, eps).unsqueeze(0).repeat(G, 1, 1)
+        Z = torch.empty(B, S, ns, C, dtype=torch.float32, device=dev)
+        ws = torch.empty(STATS_BLOCKS * 2 * C, dtype=torch.float32, device=dev)
+        check(lib().sug_sa_first_fwd(_p(P.detach()), C, _p(Q.detach()), _p(idx), B, N, S, ns, C, G, _p(g), _p(b),
+                                     1 if training else 0, eps, momentum, _p(running_mean), _p(running_var), _p(coef),
+                                     _p(Z), _p(ws), _st()), 'sug_sa_first_fwd')
+        ctx.save_for_backward(P, Q, idx, coef)
+        ctx.meta = (bool(training), G)
+        return Z
+
+    @staticmethod
+    def backward(ctx, gz):
+        P, Q, idx, coef = ctx.saved_tensors
+        training, G = ctx.meta
+        B, N, C = P.shape
+        S, ns = idx.shape[1], idx.shape[2]
+        dev = gz.device
+        gz = gz.contiguous()
+        red = torch.zeros(G + 1, 2 * C, dtype=torch.float64, device=dev)
+        dP = torch.empty(B, N, C, dtype=torch.float32, device=dev)
+        dQ = torch.empty(B, S, C, dtype=torch.float32, device=dev)
+        rf = torch.empty(2 * C, dtype=torch.float32, device=dev)
+        ws = torch.empty(STATS_BLOCKS * 2 * C, dtype=torch.float32, device=dev)
+        check(lib().sug_sa_first_bwd(_p(gz), _p(P), C, _p(Q), _p(idx), B, N, S, ns, C, G, 1 if training else 0, _p(coef),
+                                     _p(red), _p(dP), _p(dQ), _p(ws), _p(rf), _st()), 'sug_sa_first_bwd')
+        return dP, dQ, None, rf[C:], rf[:C], None, None, None, None, None, None
+
+
+def sa_first_layer_supported(C):
+    return C in (64, 128)
+
+
+def sa_first_layer(P, Q, idx, bn):
+    """P [B,N,C] = W.[xyz ; feats] per point, Q [B,S,C] = Wxyz.new_xyz - b per centroid, idx [B,S,ns] ball-query
+    lists -> relu(bn(P[idx] - Q)) [B,S,ns,C] (train-mode statistics over each domain group's rows)."""
+    _count_bn_call(bn)
+    return _SAFirstLayer.apply(P, Q, idx, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, bn.eps,
+                               bn.momentum, BN_GROUPS)
+
+
 # num_batches_tracked increments: one tiny launch per BatchNorm call unless deferred; inside a
 # `deferred_bn_counts()` block they are collected and applied with one foreach add at the end.
 _PENDING_COUNTS = None

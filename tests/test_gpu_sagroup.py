@@ -1,0 +1,111 @@
+"""GPU parity of the set-abstraction first layer on the neighbour lists (sug_sa_first_fwd / bwd) against the
+operator chain of the reference (model/pointnet2_utils.py:107-135, 193-198): index_points(xyz, idx) - new_xyz,
+index_points(points, idx), cat, 1x1 conv (+bias), train-mode BatchNorm2d, ReLU -- in plain fp32 torch on the
+grouped [B,S,ns,3+D] tensor.  Tolerance 1e-4 forward (north star), 1e-3 relative on the gradients."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _reference(xyz, points, new_xyz, idx, W, b, bn, groups):
+    B, S, ns = idx.shape
+    bi = torch.arange(B, device=xyz.device).view(B, 1, 1)
+    g = xyz[bi, idx.long()] - new_xyz.view(B, S, 1, 3)
+    if points is not None:
+        g = torch.cat((g, points[bi, idx.long()]), dim=-1)
+    outs = []
+    for gg in g.chunk(groups, dim=0):
+        y = gg @ W.t() + b
+        outs.append(torch.relu(bn(y.reshape(-1, y.shape[-1])).view(y.shape)))
+    return torch.cat(outs)
+
+
+@pytest.mark.parametrize('B,N,S,ns,D,C,groups,train', [
+    (4, 256, 64, 32, 0, 64, 1, True),        # sa1: xyz only
+    (4, 128, 32, 64, 128, 128, 2, True),     # sa2: xyz + 128 features, paired domains
+    (2, 200, 50, 20, 5, 64, 1, True),        # ragged sizes, ns not a multiple of the row batch
+    (4, 128, 32, 64, 128, 128, 1, False),    # eval mode (running statistics)
+])
+def test_sa_first_layer_vs_torch(B, N, S, ns, D, C, groups, train):
+    from sug_amd import ops
+    g = torch.Generator().manual_seed(B + N + C)
+    xyz = torch.rand(B, N, 3, generator=g).cuda()
+    points = torch.randn(B, N, D, generator=g).cuda() if D else None
+    new_xyz = xyz[:, :S].clone()
+    idx = torch.randint(0, N, (B, S, ns), generator=g, dtype=torch.int32).cuda()
+    idx[:, :, ns // 2:] = idx[:, :, :1]                     # ball query pads short lists with the first index
+    W = (torch.randn(C, 3 + D, generator=g) / (3 + D) ** 0.5).cuda()
+    b = (torch.randn(C, generator=g) * 0.1).cuda()
+    probe = torch.randn(B, S, ns, C, generator=g).cuda()
+
+    def make_bn():
+        bn = torch.nn.BatchNorm1d(C).cuda().train(train)
+        with torch.no_grad():
+            bn.weight.copy_(torch.linspace(-1.0, 1.5, C))
+            bn.bias.copy_(torch.linspace(-0.3, 0.3, C))
+            bn.running_mean.copy_(torch.linspace(-0.2, 0.2, C))
+            bn.running_var.copy_(torch.linspace(0.5, 1.5, C))
+        return bn
+
+    bn_r, bn_k = make_bn(), make_bn()
+    Wr, br = W.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    pr = points.clone().requires_grad_(True) if D else None
+    ref = _reference(xyz, pr, new_xyz, idx, Wr, br, bn_r, groups)
+    (ref * probe).sum().backward()
+
+    Wk, bk = W.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    pk = points.clone().requires_grad_(True) if D else None
+    with ops.bn_groups(groups):
+        P = ops.linear_rows(xyz if pk is None else torch.cat((xyz, pk), dim=-1), Wk)
+        Q = ops.linear_rows(new_xyz, Wk[:, :3]) - bk
+        out = ops.sa_first_layer(P, Q, idx, bn_k)
+    (out * probe).sum().backward()
+
+    torch.testing.assert_close(out, ref, rtol=1e-4, atol=1e-4)
+
+    def rel(a, b_):
+        return float((a - b_).norm() / b_.norm().clamp_min(1e-12))
+
+    assert rel(Wk.grad, Wr.grad) < 1e-3, 'dW %.3e' % rel(Wk.grad, Wr.grad)
+    assert rel(bn_k.weight.grad, bn_r.weight.grad) < 1e-3
+    assert rel(bn_k.bias.grad, bn_r.bias.grad) < 1e-3
+    if D:
+        assert rel(pk.grad, pr.grad) < 1e-3, 'dpoints %.3e' % rel(pk.grad, pr.grad)
+    if train:       # the bias in front of a train-mode BatchNorm has zero gradient; both sides hold rounding noise
+        lim = 1e-3 * float(probe.abs().sum() / C) + 1e-4
+        assert float(bk.grad.abs().max()) <= lim and float(br.grad.abs().max()) <= lim
+        torch.testing.assert_close(bn_k.running_mean, bn_r.running_mean, rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(bn_k.running_var, bn_r.running_var, rtol=1e-4, atol=1e-5)
+        assert int(bn_k.num_batches_tracked) == groups
+    else:
+        assert rel(bk.grad, br.grad) < 1e-3
+
+
+def test_sa_first_layer_config3_shape_is_finite():
+    """Config-3 sa2 shape (128 clouds x 128 centroids x 64 samples = 1M rows, 131 -> 128 channels): finite,
+    forward bit-reproducible, statistics identities of the output (every channel's BN input has the batch
+    mean / variance that the coefficients say)."""
+    from sug_amd import ops
+    B, N, S, ns, D, C = 128, 512, 128, 64, 128, 128
+    g = torch.Generator().manual_seed(9)
+    xyz = torch.rand(B, N, 3, generator=g).cuda()
+    points = torch.randn(B, N, D, generator=g).cuda().requires_grad_(True)
+    idx = torch.randint(0, N, (B, S, ns), generator=g, dtype=torch.int32).cuda()
+    W = (torch.randn(C, 3 + D, generator=g) / 11).cuda().requires_grad_(True)
+    b = torch.zeros(C).cuda().requires_grad_(True)
+    bn = torch.nn.BatchNorm1d(C).cuda().train()
+    outs = []
+    for _ in range(2):
+        with ops.bn_groups(2):
+            P = ops.linear_rows(torch.cat((xyz, points), dim=-1), W)
+            Q = ops.linear_rows(xyz[:, :S].contiguous(), W[:, :3]) - b
+            out = ops.sa_first_layer(P, Q, idx, bn)
+        outs.append(out.detach())
+    assert torch.equal(outs[0], outs[1]) and bool(torch.isfinite(outs[0]).all())
+    out.square().sum().backward()
+    assert bool(torch.isfinite(points.grad).all()) and bool(torch.isfinite(W.grad).all())
+    # relu(BN(y)) with gamma = 1, beta = 0: per group and channel, mean of max(xhat, 0) of a unit-variance
+    # variable lies in (0.2, 0.6) whatever its shape
+    m = outs[0].view(2, -1, C).mean(dim=1)
+    assert float(m.min()) > 0.2 and float(m.max()) < 0.6
