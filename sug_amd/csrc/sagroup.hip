@@ -10,8 +10,8 @@
 // (b, s) -> ns neighbour indices, gather P rows (a cloud's P matrix stays in L2) and
 //   forward:  batch statistics of y = P[idx] - Q (pass 1), z = relu(BN(y)) written once (pass 2);
 //   backward: BatchNorm sums from gz and the recomputed y (pass 1), then dy -> dQ[s] = -sum_j dy (registers,
-//             plain store) and dP[idx] += dy (float atomics on the L2-resident dP, like index_points' own
-//             backward in the reference: torch's index_put accumulates with atomics too).
+//             plain store) and dP[idx] += dy (float adds into an LDS-resident channel slice of the cloud's dP;
+//             unordered, like index_points' own backward in the reference: torch's index_put uses atomics too).
 // Lanes: C/4 per segment (float4 of channels), 256/(C/4) segments per workgroup pass; C in {64, 128}.
 #include "common.h"
 
@@ -128,6 +128,70 @@ __global__ __launch_bounds__(256) void sa_first_kernel(
   }
 }
 
+// Backward apply with the dP slice of one cloud in LDS: workgroup = (cloud, SW-channel slice), SW/4 lanes per
+// segment; dy is accumulated into s_dp[point][SW] with LDS float adds (the global-atomic form of MODE 3 above
+// runs at the L2's atomic rate: 0.94 ms per call at the config-3 shapes, 6 ms per step) and the slice is
+// written once with plain stores, so dP needs no zero fill.  dQ as above (registers, one store per segment).
+template <int SW>
+__global__ __launch_bounds__(1024) void sa_first_bwd_lds_kernel(
+    const float* __restrict__ P, int64_t ldp, const float* __restrict__ Q, const int32_t* __restrict__ idx, int N,
+    int S, int ns, int C, int Bg, const float* __restrict__ coef_all, const double* __restrict__ red_all,
+    int64_t red_stride, float invM, const float* __restrict__ gz, float* __restrict__ dP, float* __restrict__ dQ) {
+  extern __shared__ __attribute__((aligned(16))) float s_dp[];      // [N][SW]
+  constexpr int LP = SW / 4;
+  constexpr int SLOTS = 1024 / LP;
+  const int nslice = C / SW;
+  const int b = blockIdx.x / nslice, sl = blockIdx.x % nslice;
+  const int lp = threadIdx.x % LP, slot = threadIdx.x / LP;
+  const int c = sl * SW + lp * 4;
+  const float* coef = coef_all + (int64_t)(b / Bg) * 5 * C;
+  const double* red = red_all + (int64_t)(b / Bg) * red_stride;
+  for (int e = threadIdx.x; e < N * LP; e += 1024) st4(s_dp + (size_t)e * 4, make_float4(0, 0, 0, 0));
+  const float4 scale = ld4(coef + c), shift = ld4(coef + C + c), mean = ld4(coef + 2 * C + c), rstd = ld4(coef + 3 * C + c);
+  const float4 f = make_float4(scale.x * invM, scale.y * invM, scale.z * invM, scale.w * invM);
+  const float4 db = make_float4((float)red[c], (float)red[c + 1], (float)red[c + 2], (float)red[c + 3]);
+  const float4 dg = make_float4((float)red[C + c], (float)red[C + c + 1], (float)red[C + c + 2], (float)red[C + c + 3]);
+  const float* Pb = P + (int64_t)b * N * ldp + c;
+  __syncthreads();
+  for (int sg = slot; sg < S; sg += SLOTS) {
+    const int64_t seg = (int64_t)b * S + sg;
+    const int32_t* ir = idx + seg * ns;
+    const float4 q = ld4(Q + seg * C + c);
+    float4 dq = make_float4(0, 0, 0, 0);
+    for (int j0 = 0; j0 < ns; j0 += JB) {
+      int m[JB];
+      float4 pv[JB], gv[JB];
+#pragma unroll
+      for (int t = 0; t < JB; ++t) m[t] = min(max(ir[j0 + t < ns ? j0 + t : ns - 1], 0), N - 1);
+#pragma unroll
+      for (int t = 0; t < JB; ++t) {
+        pv[t] = ld4(Pb + (int64_t)m[t] * ldp);
+        gv[t] = ld4(gz + (seg * ns + (j0 + t < ns ? j0 + t : ns - 1)) * C + c);
+      }
+#pragma unroll
+      for (int t = 0; t < JB; ++t) {
+        if (j0 + t >= ns) continue;
+        const float yx = pv[t].x - q.x, yy = pv[t].y - q.y, yz = pv[t].z - q.z, yw = pv[t].w - q.w;
+        const float gx = fmaf(scale.x, yx, shift.x) > 0.f ? gv[t].x : 0.f, gy = fmaf(scale.y, yy, shift.y) > 0.f ? gv[t].y : 0.f;
+        const float gz_ = fmaf(scale.z, yz, shift.z) > 0.f ? gv[t].z : 0.f, gw = fmaf(scale.w, yw, shift.w) > 0.f ? gv[t].w : 0.f;
+        const float dx = scale.x * gx - f.x * (db.x + (yx - mean.x) * rstd.x * dg.x);
+        const float dy = scale.y * gy - f.y * (db.y + (yy - mean.y) * rstd.y * dg.y);
+        const float dz = scale.z * gz_ - f.z * (db.z + (yz - mean.z) * rstd.z * dg.z);
+        const float dw = scale.w * gw - f.w * (db.w + (yw - mean.w) * rstd.w * dg.w);
+        dq.x -= dx; dq.y -= dy; dq.z -= dz; dq.w -= dw;
+        float* d = s_dp + (size_t)m[t] * SW + lp * 4;
+        atomicAdd(d + 0, dx); atomicAdd(d + 1, dy); atomicAdd(d + 2, dz); atomicAdd(d + 3, dw);
+      }
+    }
+    st4(dQ + seg * C + c, dq);
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < N * LP; e += 1024) {
+    const int n = e / LP, l = e % LP;
+    st4(dP + ((int64_t)b * N + n) * C + sl * SW + l * 4, ld4(s_dp + (size_t)e * 4));
+  }
+}
+
 struct Plan {
   int segs_per_block, nblk;
 };
@@ -187,7 +251,11 @@ extern "C" int sug_sa_first_bwd(const float* gz, const float* P, int64_t ldp, co
   const Plan pl = plan(segs_g, C);
   const size_t sh = (size_t)(256 / (C >> 2)) * 2 * C * sizeof(float);
   const float invM = (float)(1.0 / ((double)segs_g * ns));
-  if (hipMemsetAsync(dP, 0, (size_t)B * N * C * sizeof(float), st) != hipSuccess) {
+  // slice width of the LDS-resident dP: the widest of 64 / 32 / 16 channels that fits 128 KB
+  int SW = 0;
+  for (int w = 64; w >= 16; w >>= 1)
+    if (C % w == 0 && (size_t)N * w * sizeof(float) <= 128 * 1024) { SW = w; break; }
+  if (!SW && hipMemsetAsync(dP, 0, (size_t)B * N * C * sizeof(float), st) != hipSuccess) {
     sug_set_error("sug_sa_first_bwd: memset failed");
     return SUG_ERR_LAUNCH;
   }
@@ -199,11 +267,29 @@ extern "C" int sug_sa_first_bwd(const float* gz, const float* P, int64_t ldp, co
                        pl.segs_per_block, cg, nullptr, 0.f, gz, nullptr, nullptr, nullptr, ws);
     SUG_LAUNCH_CHECK("sug_sa_first_bwd(reduce)");
     if (int rc = sug_reduce_partials(ws, pl.nblk, 2 * C, rg, st)) return rc;
+    if (SW) continue;
     // eval mode: the statistics are constants (red + groups*2C: a caller-zeroed spare row)
     const double* ru = training ? rg : red + (int64_t)groups * 2 * C;
     hipLaunchKernelGGL((sa_first_kernel<3>), dim3(pl.nblk), dim3(256), 0, st, P, ldp, Q, idx, N, S, ns, C, s0, s1,
                        pl.segs_per_block, cg, ru, invM, gz, nullptr, dP, dQ, nullptr);
     SUG_LAUNCH_CHECK("sug_sa_first_bwd(apply)");
+  }
+  if (SW) {
+    const double* ru = training ? red : red + (int64_t)groups * 2 * C;
+    const int64_t rstride = training ? 2 * C : 0;
+    const size_t shl = (size_t)N * SW * sizeof(float);
+    const dim3 grid(B * (C / SW));
+#define SA_BWD_LDS(W) do { \
+      static SugLdsOptIn note; \
+      if (int rc = sug_allow_dynamic_lds(note, &sa_first_bwd_lds_kernel<W>, 128 * 1024, "sug_sa_first_bwd(lds)")) return rc; \
+      hipLaunchKernelGGL((sa_first_bwd_lds_kernel<W>), grid, dim3(1024), shl, st, P, ldp, Q, idx, N, S, ns, C, B / groups, \
+                         coef, ru, rstride, invM, gz, dP, dQ); \
+    } while (0)
+    if (SW == 64) SA_BWD_LDS(64);
+    else if (SW == 32) SA_BWD_LDS(32);
+    else SA_BWD_LDS(16);
+#undef SA_BWD_LDS
+    SUG_LAUNCH_CHECK("sug_sa_first_bwd(lds)");
   }
   if (dgb) return sug_fold_groups(red, groups, 2 * C, dgb, stream);
   return SUG_OK;
