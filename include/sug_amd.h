@@ -300,16 +300,18 @@ int sug_edgeconv_layer_bwd(const float* gout, int64_t ldg, const float* z, const
  * ball-query lists (values in [0,N)).  Forward: train-mode statistics of y = P[idx] - Q over the B/groups*S*ns
  * rows of each domain group (coef [groups,5,C] as the other BatchNorm entry points; training = 0: coef is
  * an input), Z [B,S,ns,C] = relu(BN(y)).  C in {64, 128}.  ws: SUG_STATS_BLOCKS*2*C floats.
- * Backward: gz [B,S,ns,C] -> dP [B,N,C] (zeroed here, accumulated with float atomics as index_points'
- * backward accumulates in the reference), dQ [B,S,C]; red [groups+1, 2C] doubles (row g: dbeta | dgamma,
- * the spare last row zero for training = 0); dgb: NULL or fp32 [2C] = red folded over the groups. */
+ * Backward: gz [B,S,ns,C] -> dP [B,N,C] (by destination point over the reverse lists of idx: plain stores, no
+ * atomics; the order of a point's sum is as unordered as index_points' backward in the reference), dQ [B,S,C];
+ * red [groups+1, 2C] doubles (row g: dbeta | dgamma, the spare last row zero for training = 0); scratch:
+ * rev_off [B,N+1], rev_ent [B,S*ns] ints, segsum [2,B,S,C] floats; dgb: NULL or fp32 [2C] = red folded over the groups. */
 int sug_sa_first_fwd(const float* P, int64_t ldp, const float* Q, const int32_t* idx, int B, int N, int S,
                      int ns, int C, int groups, const float* gamma, const float* beta, int training,
                      float eps, float momentum, float* running_mean, float* running_var, float* coef,
                      float* Z, float* ws, void* stream);
 int sug_sa_first_bwd(const float* gz, const float* P, int64_t ldp, const float* Q, const int32_t* idx, int B,
                      int N, int S, int ns, int C, int groups, int training, const float* coef, double* red,
-                     float* dP, float* dQ, float* ws, float* dgb, void* stream);
+                     int32_t* rev_off, int32_t* rev_ent, float* segsum, float* dP, float* dQ, float* ws, float* dgb,
+                     void* stream);
 
 /* conv_2d / Conv1d + BatchNorm + (Leaky)ReLU on rows (model_utils.py:8-32, pointnet2_utils.py:195-198):
  * out = act(BN(y)), y [rows,C]. */

@@ -33,6 +33,13 @@ int sug_knn_mfma(const float* x, int64_t ldx, int B, int N, int C, int k, int32_
 int sug_stats_finalize(const float* ws, int nblk, int C, const float* gamma, const float* beta, double count, float eps,
                        float momentum, float* running_mean, float* running_var, float* coef, hipStream_t st);
 
+// knn.hip: reverse lists of B clouds with E index entries each (destinations in [0, N)): rev_off [B, N+1],
+// rev_ent [B, E] (entry positions; ascending per destination when sorted != 0)
+int sug_reverse_lists(const int32_t* idx, int B, int E, int N, int sorted, int32_t* rev_off, int32_t* rev_ent,
+                      hipStream_t st);
+// edgeconv.hip: out[W] (fp64) = ordered sum of nblk partial rows ws[nblk][W]
+int sug_reduce_partials(const float* ws, int nblk, int W, double* out, hipStream_t st);
+
 // knn_pc.hip: producer / consumer MFMA kNN (C in {3, 64, 128}, k <= 20)
 int sug_knn_pc(const float* x, int64_t ldx, int B, int N, int C, int k, int32_t* idx, hipStream_t st);
 

@@ -213,9 +213,10 @@ int dispatch_knn_c(const float* x, int64_t ldx, int B, int N, int C, int k, int3
 // LDS: 2*Nr + BLOCK/64 ints + the worst case of N*k entries (82 KB).
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void knn_reverse_kernel(const int32_t* __restrict__ idx, int N,
-                                                            int k, int RS, int32_t* __restrict__ rev_off,
+                                                            int E, int RS, int sorted, int32_t* __restrict__ rev_off,
                                                             int32_t* __restrict__ rev_ent) {
-  extern __shared__ int s_i[];  // cnt[Nr] | cur[Nr] | per-wave scratch[2*BLOCK/64] | ent[N*k]
+  // E entries per cloud (N*k for a kNN graph, S*nsample for ball-query lists), destinations in [0, N)
+  extern __shared__ int s_i[];  // cnt[Nr] | cur[Nr] | per-wave scratch[2*BLOCK/64] | ent[E]
   constexpr int NW = BLOCK / 64;
   const int Nr = (N + RS - 1) / RS;
   int* cnt = s_i;
@@ -226,12 +227,12 @@ __global__ __launch_bounds__(BLOCK) void knn_reverse_kernel(const int32_t* __res
   const int lo = r * Nr, hi = (lo + Nr < N) ? lo + Nr : N;
   const int nr = hi > lo ? hi - lo : 0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int32_t* ib = idx + (int64_t)b * N * k;
+  const int32_t* ib = idx + (int64_t)b * E;
   int32_t* off = rev_off + (int64_t)b * (N + 1);
-  int32_t* gent = rev_ent + (int64_t)b * N * k;
+  int32_t* gent = rev_ent + (int64_t)b * E;
   for (int i = threadIdx.x; i < nr; i += BLOCK) cnt[i] = 0;
   __syncthreads();
-  const int total = N * k;
+  const int total = E;
   int below = 0;
   // the neighbour entries are read U at a time (all loads of a batch in flight before the first use: one load per
   // iteration, each waiting for the atomic behind it, made this kernel latency-bound)
@@ -296,8 +297,9 @@ __global__ __launch_bounds__(BLOCK) void knn_reverse_kernel(const int32_t* __res
   }
   __syncthreads();
   // lists up to 32 entries: two per wave (one per half-wave); the loop bound is made uniform over the wave
+  // (sorted = 0: the consumer does not need a fixed order -- the lists go out as the atomics left them)
   const int half = lane >> 5, hl = lane & 31;
-  for (int i0 = wave * 2; i0 < nr; i0 += NW * 2) {
+  for (int i0 = wave * 2; sorted && i0 < nr; i0 += NW * 2) {
     const int i = i0 + half;
     const int n = i < nr ? cnt[i] : 0;
     const int s = i < nr ? cur[i] - n : 0;
@@ -320,7 +322,7 @@ __global__ __launch_bounds__(BLOCK) void knn_reverse_kernel(const int32_t* __res
   for (int e = threadIdx.x; e < filled; e += BLOCK) gent[base + e] = ent[e];
   __syncthreads();            // the long lists below overwrite their (unsorted) copy
   // longer lists (hub points): a wave per list
-  for (int i = wave; i < nr; i += NW) {
+  for (int i = wave; sorted && i < nr; i += NW) {
     const int n = cnt[i];
     if (n <= 32) continue;                           // uniform over the wave
     const int s = cur[i] - n;
@@ -355,20 +357,27 @@ extern "C" int sug_knn(const float* x, int64_t ldx, int B, int N, int C, int k, 
   return dispatch_knn_c<32>(x, ldx, B, N, C, k, idx, st);
 }
 
-extern "C" int sug_knn_reverse(const int32_t* idx, int B, int N, int k, int32_t* rev_off,
-                               int32_t* rev_ent, void* stream) {
-  SUG_REQUIRE(idx && rev_off && rev_ent, "sug_knn_reverse: null pointer");
-  SUG_REQUIRE(B > 0 && N > 0 && k > 0, "sug_knn_reverse: bad shape");
+// reverse lists of B clouds with E index entries each, destinations in [0, N)
+int sug_reverse_lists(const int32_t* idx, int B, int E, int N, int sorted, int32_t* rev_off, int32_t* rev_ent,
+                      hipStream_t st) {
+  SUG_REQUIRE(idx && rev_off && rev_ent, "sug_reverse_lists: null pointer");
+  SUG_REQUIRE(B > 0 && N > 0 && E > 0, "sug_reverse_lists: bad shape");
   constexpr int BLOCK = 1024;
   int RS = 1;                                    // destination ranges per cloud: >= 256 workgroups when B allows
   while (RS < 8 && B * RS < 256 && N / (RS * 2) >= 64) RS *= 2;
   const int Nr = (N + RS - 1) / RS;
-  size_t sh = (size_t)(2 * Nr + 2 * (BLOCK / 64) + (size_t)N * k) * sizeof(int);
-  SUG_REQUIRE(sh <= 160 * 1024, "sug_knn_reverse: N*k=%d too large for the LDS-resident build", N * k);
+  size_t sh = (size_t)(2 * Nr + 2 * (BLOCK / 64) + (size_t)E) * sizeof(int);
+  SUG_REQUIRE(sh <= 160 * 1024, "sug_reverse_lists: %d entries per cloud are too many for the LDS-resident build", E);
   static SugLdsOptIn note;
-  if (int rc = sug_allow_dynamic_lds(note, &knn_reverse_kernel<BLOCK>, 160 * 1024, "sug_knn_reverse")) return rc;
-  hipLaunchKernelGGL((knn_reverse_kernel<BLOCK>), dim3(B * RS), dim3(BLOCK), sh, (hipStream_t)stream, idx,
-                     N, k, RS, rev_off, rev_ent);
-  SUG_LAUNCH_CHECK("sug_knn_reverse");
+  if (int rc = sug_allow_dynamic_lds(note, &knn_reverse_kernel<BLOCK>, 160 * 1024, "sug_reverse_lists")) return rc;
+  hipLaunchKernelGGL((knn_reverse_kernel<BLOCK>), dim3(B * RS), dim3(BLOCK), sh, st, idx, N, E, RS, sorted, rev_off,
+                     rev_ent);
+  SUG_LAUNCH_CHECK("sug_reverse_lists");
   return SUG_OK;
+}
+
+extern "C" int sug_knn_reverse(const int32_t* idx, int B, int N, int k, int32_t* rev_off,
+                               int32_t* rev_ent, void* stream) {
+  SUG_REQUIRE(B > 0 && N > 0 && k > 0, "sug_knn_reverse: bad shape");
+  return sug_reverse_lists(idx, B, N * k, N, 1, rev_off, rev_ent, (hipStream_t)stream);
 }

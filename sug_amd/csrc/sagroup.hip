@@ -9,14 +9,14 @@
 // the [B,S,ns,C] pre-activation tensor are never formed.  The kernels here walk the segments
 // (b, s) -> ns neighbour indices, gather P rows (a cloud's P matrix stays in L2) and
 //   forward:  batch statistics of y = P[idx] - Q (pass 1), z = relu(BN(y)) written once (pass 2);
-//   backward: BatchNorm sums from gz and the recomputed y (pass 1), then dy -> dQ[s] = -sum_j dy (registers,
-//             plain store) and dP[idx] += dy (float adds into an LDS-resident channel slice of the cloud's dP;
-//             unordered, like index_points' own backward in the reference: torch's index_put uses atomics too).
+//   backward: BatchNorm sums from gz and the recomputed y, and per segment sum_j g and sum_j y (pass 1); then, by
+//             DESTINATION point over the reverse lists of the ball-query lists (sug_reverse_lists, unsorted),
+//             dP[m] = sum over the rows that gathered m of dy -- plain stores, no atomics (global float atomics
+//             ran this pass at 0.94 ms per call, LDS float adds at 0.45 ms) -- and dQ[s] = -sum_j dy[s,j] in closed
+//             form from the per-segment sums (dy is affine in g and y).  The order of a point's sum follows the
+//             unsorted reverse list: as unordered as index_points' backward in the reference (atomics).
 // Lanes: C/4 per segment (float4 of channels), 256/(C/4) segments per workgroup pass; C in {64, 128}.
 #include "common.h"
-
-// edgeconv.hip
-int sug_reduce_partials(const float* ws, int nblk, int W, double* out, hipStream_t st);
 
 namespace {
 
@@ -26,13 +26,13 @@ __device__ __forceinline__ void st4(float* p, const float4& v) { *reinterpret_ca
 constexpr int JB = 8;      // neighbour rows in flight per lane
 
 // MODE 0: statistics of y;  MODE 1: z = relu(scale*y + shift);
-// MODE 2: backward sums (g = gz * [u > 0]; sum g, sum g*xhat);  MODE 3: backward apply (dQ, dP)
+// MODE 2: backward sums (g = gz * [u > 0]; sum g, sum g*xhat; per segment sum_j g -> segsum[0], sum_j y -> segsum[1])
 template <int MODE>
 __global__ __launch_bounds__(256) void sa_first_kernel(
     const float* __restrict__ P, int64_t ldp, const float* __restrict__ Q, const int32_t* __restrict__ idx,
     int N, int S, int ns, int C, int64_t seg0, int64_t seg1, int segs_per_block, const float* __restrict__ coef,
-    const double* __restrict__ red, float invM, const float* __restrict__ gz, float* __restrict__ Z,
-    float* __restrict__ dP, float* __restrict__ dQ, float* __restrict__ ws) {
+    const float* __restrict__ gz, float* __restrict__ Z, float* __restrict__ segsum, int64_t segsum_stride,
+    float* __restrict__ ws) {
   extern __shared__ float s_red[];                 // [slots][2C] (MODE 0, 2)
   const int LPS = C >> 2;                          // lanes per segment
   const int slots = 256 / LPS;
@@ -41,17 +41,12 @@ __global__ __launch_bounds__(256) void sa_first_kernel(
   int64_t b0 = seg0 + (int64_t)blockIdx.x * segs_per_block;
   int64_t b1 = b0 + segs_per_block;
   if (b1 > seg1) b1 = seg1;
-  float4 scale = make_float4(0, 0, 0, 0), shift = scale, mean = scale, rstd = scale, f = scale, db = scale, dg = scale;
+  float4 scale = make_float4(0, 0, 0, 0), shift = scale, mean = scale, rstd = scale;
   if (MODE != 0) {
     scale = ld4(coef + c); shift = ld4(coef + C + c);
   }
   if (MODE >= 2) {
     mean = ld4(coef + 2 * C + c); rstd = ld4(coef + 3 * C + c);
-  }
-  if (MODE == 3) {
-    f = make_float4(scale.x * invM, scale.y * invM, scale.z * invM, scale.w * invM);
-    db = make_float4((float)red[c], (float)red[c + 1], (float)red[c + 2], (float)red[c + 3]);
-    dg = make_float4((float)red[C + c], (float)red[C + c + 1], (float)red[C + c + 2], (float)red[C + c + 3]);
   }
   float4 a1 = make_float4(0, 0, 0, 0), a2 = a1;
   for (int64_t seg = b0 + slot; seg < b1; seg += slots) {
@@ -59,7 +54,7 @@ __global__ __launch_bounds__(256) void sa_first_kernel(
     const int32_t* ir = idx + seg * ns;
     const float* Pb = P + b * N * ldp + c;
     const float4 q = ld4(Q + seg * C + c);
-    float4 dq = make_float4(0, 0, 0, 0);
+    float4 sgs = make_float4(0, 0, 0, 0), sys = sgs;
     for (int j0 = 0; j0 < ns; j0 += JB) {
       int m[JB];
       float4 pv[JB], gv[JB];
@@ -95,26 +90,19 @@ __global__ __launch_bounds__(256) void sa_first_kernel(
             float4 xh;
             xh.x = (y.x - mean.x) * rstd.x; xh.y = (y.y - mean.y) * rstd.y;
             xh.z = (y.z - mean.z) * rstd.z; xh.w = (y.w - mean.w) * rstd.w;
-            if (MODE == 2) {
-              a1.x += g.x; a1.y += g.y; a1.z += g.z; a1.w += g.w;
-              a2.x = fmaf(g.x, xh.x, a2.x); a2.y = fmaf(g.y, xh.y, a2.y);
-              a2.z = fmaf(g.z, xh.z, a2.z); a2.w = fmaf(g.w, xh.w, a2.w);
-            } else {
-              // dy = scale*g - (scale/M) * (dbeta + xhat * dgamma)   (exact train-mode BN gradient; eval: red = 0)
-              float4 dy;
-              dy.x = scale.x * g.x - f.x * (db.x + xh.x * dg.x);
-              dy.y = scale.y * g.y - f.y * (db.y + xh.y * dg.y);
-              dy.z = scale.z * g.z - f.z * (db.z + xh.z * dg.z);
-              dy.w = scale.w * g.w - f.w * (db.w + xh.w * dg.w);
-              dq.x -= dy.x; dq.y -= dy.y; dq.z -= dy.z; dq.w -= dy.w;
-              float* dp = dP + (b * N + m[t]) * (int64_t)C + c;
-              atomicAdd(dp + 0, dy.x); atomicAdd(dp + 1, dy.y); atomicAdd(dp + 2, dy.z); atomicAdd(dp + 3, dy.w);
-            }
+            a1.x += g.x; a1.y += g.y; a1.z += g.z; a1.w += g.w;
+            a2.x = fmaf(g.x, xh.x, a2.x); a2.y = fmaf(g.y, xh.y, a2.y);
+            a2.z = fmaf(g.z, xh.z, a2.z); a2.w = fmaf(g.w, xh.w, a2.w);
+            sgs.x += g.x; sgs.y += g.y; sgs.z += g.z; sgs.w += g.w;
+            sys.x += y.x; sys.y += y.y; sys.z += y.z; sys.w += y.w;
           }
         }
       }
     }
-    if (MODE == 3) st4(dQ + seg * C + c, dq);
+    if (MODE == 2) {
+      st4(segsum + seg * C + c, sgs);
+      st4(segsum + segsum_stride + seg * C + c, sys);
+    }
   }
   if (MODE == 0 || MODE == 2) {
     st4(s_red + (size_t)slot * 2 * C + c, a1);
@@ -128,67 +116,76 @@ __global__ __launch_bounds__(256) void sa_first_kernel(
   }
 }
 
-// Backward apply with the dP slice of one cloud in LDS: workgroup = (cloud, SW-channel slice), SW/4 lanes per
-// segment; dy is accumulated into s_dp[point][SW] with LDS float adds (the global-atomic form of MODE 3 above
-// runs at the L2's atomic rate: 0.94 ms per call at the config-3 shapes, 6 ms per step) and the slice is
-// written once with plain stores, so dP needs no zero fill.  dQ as above (registers, one store per segment).
-template <int SW>
-__global__ __launch_bounds__(1024) void sa_first_bwd_lds_kernel(
-    const float* __restrict__ P, int64_t ldp, const float* __restrict__ Q, const int32_t* __restrict__ idx, int N,
-    int S, int ns, int C, int Bg, const float* __restrict__ coef_all, const double* __restrict__ red_all,
-    int64_t red_stride, float invM, const float* __restrict__ gz, float* __restrict__ dP, float* __restrict__ dQ) {
-  extern __shared__ __attribute__((aligned(16))) float s_dp[];      // [N][SW]
-  constexpr int LP = SW / 4;
-  constexpr int SLOTS = 1024 / LP;
-  const int nslice = C / SW;
-  const int b = blockIdx.x / nslice, sl = blockIdx.x % nslice;
-  const int lp = threadIdx.x % LP, slot = threadIdx.x / LP;
-  const int c = sl * SW + lp * 4;
+// Backward apply by destination point.  Workgroup = (cloud, chunk of its points and segments); C/4 lanes per
+// point.  dP[m] = sum over the reverse list of m (rows e = s*ns + j of this cloud that gathered m) of
+//   dy[e] = scale*g[e] - (scale/M) * (dbeta + xhat[e] * dgamma),  y[e] = P[m] - Q[s],  g[e] = gz[e] * [scale*y + shift > 0]
+// (gz rows are read whole, once each, in reverse-list order), then dQ[s] = -sum_j dy[s,j] from the segment sums
+// sg = sum_j g, sy = sum_j y:  dQ = -(scale*sg - (scale/M) * (ns*dbeta + dgamma*rstd*(sy - ns*mean))).
+__global__ __launch_bounds__(256) void sa_first_bwd_point_kernel(
+    const float* __restrict__ P, int64_t ldp, const float* __restrict__ Q, int N, int S, int ns, int C, int Bg, int bpc,
+    const float* __restrict__ coef_all, const double* __restrict__ red_all, int64_t red_stride, float invM,
+    const float* __restrict__ gz, const int32_t* __restrict__ rev_off, const int32_t* __restrict__ rev_ent,
+    const float* __restrict__ segsum, int64_t segsum_stride, float* __restrict__ dP, float* __restrict__ dQ) {
+  const int LPS = C >> 2;
+  const int slots = 256 / LPS;
+  const int lp = threadIdx.x % LPS, slot = threadIdx.x / LPS;
+  const int c = lp * 4;
+  const int b = blockIdx.x / bpc, chunk = blockIdx.x % bpc;
   const float* coef = coef_all + (int64_t)(b / Bg) * 5 * C;
   const double* red = red_all + (int64_t)(b / Bg) * red_stride;
-  for (int e = threadIdx.x; e < N * LP; e += 1024) st4(s_dp + (size_t)e * 4, make_float4(0, 0, 0, 0));
   const float4 scale = ld4(coef + c), shift = ld4(coef + C + c), mean = ld4(coef + 2 * C + c), rstd = ld4(coef + 3 * C + c);
   const float4 f = make_float4(scale.x * invM, scale.y * invM, scale.z * invM, scale.w * invM);
   const float4 db = make_float4((float)red[c], (float)red[c + 1], (float)red[c + 2], (float)red[c + 3]);
   const float4 dg = make_float4((float)red[C + c], (float)red[C + c + 1], (float)red[C + c + 2], (float)red[C + c + 3]);
-  const float* Pb = P + (int64_t)b * N * ldp + c;
-  __syncthreads();
-  for (int sg = slot; sg < S; sg += SLOTS) {
-    const int64_t seg = (int64_t)b * S + sg;
-    const int32_t* ir = idx + seg * ns;
-    const float4 q = ld4(Q + seg * C + c);
-    float4 dq = make_float4(0, 0, 0, 0);
-    for (int j0 = 0; j0 < ns; j0 += JB) {
-      int m[JB];
-      float4 pv[JB], gv[JB];
+  // k0 = f*dbeta - f*dgamma*rstd*mean (the part of dy that does not depend on the row), k1 = f*dgamma*rstd
+  const float4 k1 = make_float4(f.x * dg.x * rstd.x, f.y * dg.y * rstd.y, f.z * dg.z * rstd.z, f.w * dg.w * rstd.w);
+  const float4 k0 = make_float4(f.x * db.x - k1.x * mean.x, f.y * db.y - k1.y * mean.y, f.z * db.z - k1.z * mean.z,
+                                f.w * db.w - k1.w * mean.w);
+  const int32_t* offb = rev_off + (int64_t)b * (N + 1);
+  const int32_t* entb = rev_ent + (int64_t)b * S * ns;
+  const float* Qb = Q + (int64_t)b * S * C + c;
+  const float* gzb = gz + (int64_t)b * S * ns * C + c;
+  const bool pow2 = (ns & (ns - 1)) == 0;
+  const int sh = 31 - __clz(ns);
+  for (int m = chunk * slots + slot; m < N; m += bpc * slots) {
+    const int off = offb[m], cnt = offb[m + 1] - off;
+    const float4 p = ld4(P + ((int64_t)b * N + m) * ldp + c);
+    float4 acc = make_float4(0, 0, 0, 0);
+    for (int t0 = 0; t0 < cnt; t0 += JB) {
+      int en[JB];
+      float4 qv[JB], gv[JB];
 #pragma unroll
-      for (int t = 0; t < JB; ++t) m[t] = min(max(ir[j0 + t < ns ? j0 + t : ns - 1], 0), N - 1);
+      for (int t = 0; t < JB; ++t) en[t] = entb[off + (t0 + t < cnt ? t0 + t : cnt - 1)];
 #pragma unroll
       for (int t = 0; t < JB; ++t) {
-        pv[t] = ld4(Pb + (int64_t)m[t] * ldp);
-        gv[t] = ld4(gz + (seg * ns + (j0 + t < ns ? j0 + t : ns - 1)) * C + c);
+        const int sgm = pow2 ? (en[t] >> sh) : en[t] / ns;
+        qv[t] = ld4(Qb + (int64_t)sgm * C);
+        gv[t] = ld4(gzb + (int64_t)en[t] * C);
       }
 #pragma unroll
       for (int t = 0; t < JB; ++t) {
-        if (j0 + t >= ns) continue;
-        const float yx = pv[t].x - q.x, yy = pv[t].y - q.y, yz = pv[t].z - q.z, yw = pv[t].w - q.w;
+        if (t0 + t >= cnt) continue;
+        const float yx = p.x - qv[t].x, yy = p.y - qv[t].y, yz = p.z - qv[t].z, yw = p.w - qv[t].w;
         const float gx = fmaf(scale.x, yx, shift.x) > 0.f ? gv[t].x : 0.f, gy = fmaf(scale.y, yy, shift.y) > 0.f ? gv[t].y : 0.f;
         const float gz_ = fmaf(scale.z, yz, shift.z) > 0.f ? gv[t].z : 0.f, gw = fmaf(scale.w, yw, shift.w) > 0.f ? gv[t].w : 0.f;
-        const float dx = scale.x * gx - f.x * (db.x + (yx - mean.x) * rstd.x * dg.x);
-        const float dy = scale.y * gy - f.y * (db.y + (yy - mean.y) * rstd.y * dg.y);
-        const float dz = scale.z * gz_ - f.z * (db.z + (yz - mean.z) * rstd.z * dg.z);
-        const float dw = scale.w * gw - f.w * (db.w + (yw - mean.w) * rstd.w * dg.w);
-        dq.x -= dx; dq.y -= dy; dq.z -= dz; dq.w -= dw;
-        float* d = s_dp + (size_t)m[t] * SW + lp * 4;
-        atomicAdd(d + 0, dx); atomicAdd(d + 1, dy); atomicAdd(d + 2, dz); atomicAdd(d + 3, dw);
+        acc.x += scale.x * gx - (k0.x + k1.x * yx);
+        acc.y += scale.y * gy - (k0.y + k1.y * yy);
+        acc.z += scale.z * gz_ - (k0.z + k1.z * yz);
+        acc.w += scale.w * gw - (k0.w + k1.w * yw);
       }
     }
-    st4(dQ + seg * C + c, dq);
+    st4(dP + ((int64_t)b * N + m) * C + c, acc);
   }
-  __syncthreads();
-  for (int e = threadIdx.x; e < N * LP; e += 1024) {
-    const int n = e / LP, l = e % LP;
-    st4(dP + ((int64_t)b * N + n) * C + sl * SW + l * 4, ld4(s_dp + (size_t)e * 4));
+  const float nsf = (float)ns;
+  for (int sg = chunk * slots + slot; sg < S; sg += bpc * slots) {
+    const int64_t seg = (int64_t)b * S + sg;
+    const float4 g = ld4(segsum + seg * C + c), y = ld4(segsum + segsum_stride + seg * C + c);
+    float4 dq;
+    dq.x = -(scale.x * g.x - (nsf * k0.x + k1.x * y.x));
+    dq.y = -(scale.y * g.y - (nsf * k0.y + k1.y * y.y));
+    dq.z = -(scale.z * g.z - (nsf * k0.z + k1.z * y.z));
+    dq.w = -(scale.w * g.w - (nsf * k0.w + k1.w * y.w));
+    st4(dQ + seg * C + c, dq);
   }
 }
 
@@ -225,14 +222,14 @@ extern "C" int sug_sa_first_fwd(const float* P, int64_t ldp, const float* Q, con
     const int64_t s0 = g * segs_g, s1 = s0 + segs_g;
     if (training) {
       hipLaunchKernelGGL((sa_first_kernel<0>), dim3(pl.nblk), dim3(256), sh, st, P, ldp, Q, idx, N, S, ns, C, s0, s1,
-                         pl.segs_per_block, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr, nullptr, ws);
+                         pl.segs_per_block, nullptr, nullptr, nullptr, nullptr, 0, ws);
       SUG_LAUNCH_CHECK("sug_sa_first_fwd(stats)");
       if (int rc = sug_stats_finalize(ws, pl.nblk, C, gamma, beta, (double)segs_g * ns, eps, momentum, running_mean,
                                       running_var, cg, st))
         return rc;
     }
     hipLaunchKernelGGL((sa_first_kernel<1>), dim3(pl.nblk), dim3(256), 0, st, P, ldp, Q, idx, N, S, ns, C, s0, s1,
-                       pl.segs_per_block, cg, nullptr, 0.f, nullptr, Z, nullptr, nullptr, nullptr);
+                       pl.segs_per_block, cg, nullptr, Z, nullptr, 0, nullptr);
     SUG_LAUNCH_CHECK("sug_sa_first_fwd(apply)");
   }
   return SUG_OK;
@@ -240,57 +237,41 @@ extern "C" int sug_sa_first_fwd(const float* P, int64_t ldp, const float* Q, con
 
 extern "C" int sug_sa_first_bwd(const float* gz, const float* P, int64_t ldp, const float* Q, const int32_t* idx, int B,
                                 int N, int S, int ns, int C, int groups, int training, const float* coef, double* red,
-                                float* dP, float* dQ, float* ws, float* dgb, void* stream) {
-  SUG_REQUIRE(gz && P && Q && idx && coef && red && dP && dQ && ws, "sug_sa_first_bwd: null pointer");
+                                int32_t* rev_off, int32_t* rev_ent, float* segsum, float* dP, float* dQ, float* ws,
+                                float* dgb, void* stream) {
+  SUG_REQUIRE(gz && P && Q && idx && coef && red && rev_off && rev_ent && segsum && dP && dQ && ws,
+              "sug_sa_first_bwd: null pointer");
   SUG_REQUIRE(B > 0 && N > 0 && S > 0 && ns > 0, "sug_sa_first_bwd: bad shape");
   SUG_REQUIRE(C == 64 || C == 128, "sug_sa_first_bwd: C=%d (64 or 128)", C);
   SUG_REQUIRE(groups >= 1 && B % groups == 0, "sug_sa_first_bwd: B=%d does not split into %d groups", B, groups);
-  SUG_REQUIRE(((uintptr_t)gz % 16) == 0 && ((uintptr_t)dQ % 16) == 0, "sug_sa_first_bwd: rows must be 16-byte aligned");
+  SUG_REQUIRE(((uintptr_t)gz % 16) == 0 && ((uintptr_t)dQ % 16) == 0 && ((uintptr_t)dP % 16) == 0 &&
+                  ((uintptr_t)segsum % 16) == 0 && ((uintptr_t)P % 16) == 0 && ((uintptr_t)Q % 16) == 0 && ldp % 4 == 0,
+              "sug_sa_first_bwd: rows must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   const int64_t segs_g = (int64_t)(B / groups) * S;
   const Plan pl = plan(segs_g, C);
   const size_t sh = (size_t)(256 / (C >> 2)) * 2 * C * sizeof(float);
   const float invM = (float)(1.0 / ((double)segs_g * ns));
-  // slice width of the LDS-resident dP: the widest of 64 / 32 / 16 channels that fits 128 KB
-  int SW = 0;
-  for (int w = 64; w >= 16; w >>= 1)
-    if (C % w == 0 && (size_t)N * w * sizeof(float) <= 128 * 1024) { SW = w; break; }
-  if (!SW && hipMemsetAsync(dP, 0, (size_t)B * N * C * sizeof(float), st) != hipSuccess) {
-    sug_set_error("sug_sa_first_bwd: memset failed");
-    return SUG_ERR_LAUNCH;
-  }
+  const int64_t segsum_stride = (int64_t)B * S * C;
+  // which rows gathered each point (order inside a list: as the atomics of the build left it)
+  if (int rc = sug_reverse_lists(idx, B, S * ns, N, 0, rev_off, rev_ent, st)) return rc;
   for (int g = 0; g < groups; ++g) {
     const float* cg = coef + (int64_t)g * 5 * C;
     double* rg = red + (int64_t)g * 2 * C;
     const int64_t s0 = g * segs_g, s1 = s0 + segs_g;
     hipLaunchKernelGGL((sa_first_kernel<2>), dim3(pl.nblk), dim3(256), sh, st, P, ldp, Q, idx, N, S, ns, C, s0, s1,
-                       pl.segs_per_block, cg, nullptr, 0.f, gz, nullptr, nullptr, nullptr, ws);
+                       pl.segs_per_block, cg, gz, nullptr, segsum, segsum_stride, ws);
     SUG_LAUNCH_CHECK("sug_sa_first_bwd(reduce)");
     if (int rc = sug_reduce_partials(ws, pl.nblk, 2 * C, rg, st)) return rc;
-    if (SW) continue;
-    // eval mode: the statistics are constants (red + groups*2C: a caller-zeroed spare row)
-    const double* ru = training ? rg : red + (int64_t)groups * 2 * C;
-    hipLaunchKernelGGL((sa_first_kernel<3>), dim3(pl.nblk), dim3(256), 0, st, P, ldp, Q, idx, N, S, ns, C, s0, s1,
-                       pl.segs_per_block, cg, ru, invM, gz, nullptr, dP, dQ, nullptr);
-    SUG_LAUNCH_CHECK("sug_sa_first_bwd(apply)");
   }
-  if (SW) {
-    const double* ru = training ? red : red + (int64_t)groups * 2 * C;
-    const int64_t rstride = training ? 2 * C : 0;
-    const size_t shl = (size_t)N * SW * sizeof(float);
-    const dim3 grid(B * (C / SW));
-#define SA_BWD_LDS(W) do { \
-      static SugLdsOptIn note; \
-      if (int rc = sug_allow_dynamic_lds(note, &sa_first_bwd_lds_kernel<W>, 128 * 1024, "sug_sa_first_bwd(lds)")) return rc; \
-      hipLaunchKernelGGL((sa_first_bwd_lds_kernel<W>), grid, dim3(1024), shl, st, P, ldp, Q, idx, N, S, ns, C, B / groups, \
-                         coef, ru, rstride, invM, gz, dP, dQ); \
-    } while (0)
-    if (SW == 64) SA_BWD_LDS(64);
-    else if (SW == 32) SA_BWD_LDS(32);
-    else SA_BWD_LDS(16);
-#undef SA_BWD_LDS
-    SUG_LAUNCH_CHECK("sug_sa_first_bwd(lds)");
-  }
+  // eval mode: the statistics are constants (red + groups*2C: a caller-zeroed spare row, shared by the groups)
+  const double* ru = training ? red : red + (int64_t)groups * 2 * C;
+  const int slots = 256 / (C >> 2);
+  int bpc = sug_divup(N > S ? N : S, slots);
+  while (bpc > 1 && (int64_t)B * bpc > 8192) bpc = (bpc + 1) / 2;
+  hipLaunchKernelGGL(sa_first_bwd_point_kernel, dim3(B * bpc), dim3(256), 0, st, P, ldp, Q, N, S, ns, C, B / groups, bpc,
+                     coef, ru, (int64_t)(training ? 2 * C : 0), invM, gz, rev_off, rev_ent, segsum, segsum_stride, dP, dQ);
+  SUG_LAUNCH_CHECK("sug_sa_first_bwd(apply)");
   if (dgb) return sug_fold_groups(red, groups, 2 * C, dgb, stream);
   return SUG_OK;
 }

@@ -554,8 +554,12 @@ class _SAFirstLayer(torch.autograd.Function):
         dQ = torch.empty(B, S, C, dtype=torch.float32, device=dev)
         rf = torch.empty(2 * C, dtype=torch.float32, device=dev)
         ws = torch.empty(STATS_BLOCKS * 2 * C, dtype=torch.float32, device=dev)
+        off = torch.empty(B, N + 1, dtype=torch.int32, device=dev)
+        ent = torch.empty(B, S * ns, dtype=torch.int32, device=dev)
+        segsum = torch.empty(2, B, S, C, dtype=torch.float32, device=dev)
         check(lib().sug_sa_first_bwd(_p(gz), _p(P), C, _p(Q), _p(idx), B, N, S, ns, C, G, 1 if training else 0, _p(coef),
-                                     _p(red), _p(dP), _p(dQ), _p(ws), _p(rf), _st()), 'sug_sa_first_bwd')
+                                     _p(red), _p(off), _p(ent), _p(segsum), _p(dP), _p(dQ), _p(ws), _p(rf), _st()),
+              'sug_sa_first_bwd')
         return dP, dQ, None, rf[C:], rf[:C], None, None, None, None, None, None
 
 
