@@ -869,11 +869,13 @@ class _PointMLPMax(torch.autograd.Function):
                 k2 = k2d.float()
                 wk = w2 * k2.unsqueeze(1)                                   # diag(k2) W
                 xtx = torch.empty(K, K, dtype=torch.float32, device=dev)
+                sx = torch.empty(K, dtype=torch.float32, device=dev)        # column sums of x, from the same launch
                 wsx = torch.empty(int(L.sug_linear_dw_workspace(rg, K, K)), dtype=torch.float32, device=dev)
-                check(L.sug_linear_dw(_p(xg), xg.stride(0), _p(xg), xg.stride(0), rg, K, K, _p(xtx), _p(wsx), _st()),
-                      'sug_linear_dw')
-                sx = xg.sum(dim=0, dtype=torch.float64).float()
-                torch.addmm((kb @ w2).neg(), xg, wk.t() @ w2, alpha=-1.0, out=dxg)     # -(x.A + v)
+                check(L.sug_linear_dw_bias(_p(xg), xg.stride(0), _p(xg), xg.stride(0), rg, K, K, _p(xtx), _p(sx), _p(wsx),
+                                           _st()), 'sug_linear_dw_bias')
+                # -(x.A + v) with the signs folded into the operands: alpha = beta = 1 keeps the library's
+                # bias epilogue (any other alpha first expands the bias into dx: a full extra pass)
+                torch.addmm((kb @ w2).neg(), xg, (wk.t() @ w2).neg(), out=dxg)
                 dw.sub_(kb.unsqueeze(1) * sx.unsqueeze(0)).sub_(wk @ xtx)
             check(L.sug_pointmlp_max_bwd_sparse(_p(ag), _p(arg[gi * sg:(gi + 1) * sg]), _p(xg), xg.stride(0), _p(w2), rg, K,
                                                 Co, seg, _p(dxg), K, _p(dws), _p(wsp), _st()),
