@@ -320,6 +320,62 @@ __global__ __launch_bounds__(256) void stats_finalize_kernel(const float* __rest
   }
 }
 
+// stats_finalize_kernel for `groups` consecutive blocks of nblk partial rows (one BatchNorm call per domain group,
+// in group order: the running statistics see the groups' updates one after the other, as separate calls would).
+__global__ __launch_bounds__(256) void stats_finalize_groups_kernel(const float* __restrict__ ws, int nblk, int C, int groups,
+                                                                    const float* __restrict__ gamma,
+                                                                    const float* __restrict__ beta, double count,
+                                                                    float eps, float momentum, float* __restrict__ rmean,
+                                                                    float* __restrict__ rvar, float* __restrict__ coef) {
+  __shared__ double s_p[16][17];
+  __shared__ double s_tot[16];
+  const int cl = threadIdx.x & 15, p = threadIdx.x >> 4;
+  const int ch = blockIdx.x * 8 + (cl & 7);                 // cl < 8: sum column, cl >= 8: sum of squares
+  const int col = (cl < 8) ? ch : C + ch;
+  const int W = 2 * C;
+  const bool fin = threadIdx.x < 8 && ch < C;
+  float rm = (fin && rmean) ? rmean[ch] : 0.f, rv = (fin && rvar) ? rvar[ch] : 0.f;
+  for (int g = 0; g < groups; ++g) {
+    const float* wg = ws + (size_t)g * nblk * W;
+    float* cg = coef + (size_t)g * 5 * C;
+    double acc = 0.0;
+    if (ch < C) {
+#pragma unroll 8
+      for (int b = p; b < nblk; b += 16) acc += (double)wg[(size_t)b * W + col];
+    }
+    __syncthreads();
+    s_p[p][cl] = acc;
+    __syncthreads();
+    if (p == 0) {
+      double t = 0.0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) t += s_p[i][cl];
+      s_tot[cl] = t;
+    }
+    __syncthreads();
+    if (fin) {
+      const int c = ch;
+      const double mean = s_tot[threadIdx.x] / count;
+      double var = s_tot[8 + threadIdx.x] / count - mean * mean;
+      if (var < 0) var = 0;
+      const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+      const float scale = gamma[c] * rstd;
+      cg[c] = scale;
+      cg[C + c] = beta[c] - (float)mean * scale;
+      cg[2 * C + c] = (float)mean;
+      cg[3 * C + c] = rstd;
+      const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+      cg[4 * C + c] = (float)unb;
+      rm = (1.f - momentum) * rm + momentum * (float)mean;
+      rv = (1.f - momentum) * rv + momentum * (float)unb;
+    }
+  }
+  if (fin) {
+    if (rmean) rmean[ch] = rm;
+    if (rvar) rvar[ch] = rv;
+  }
+}
+
 // The running-statistics update of G more train-mode forwards on batches whose statistics are
 // already known (coef rows 2 and 4), applied in group order with bn_finalize's arithmetic.
 __global__ __launch_bounds__(256) void bn_replay_kernel(const float* __restrict__ coef, int G, int C,
@@ -360,6 +416,27 @@ __global__ __launch_bounds__(256) void affine_act_vec4_kernel(const float* __res
     const int c = (int)(e % C4) * 4;
     const int64_t r = e / C4;
     const float4 zv = ld4(z + r * ldz + c), sc = ld4(coef + c), sh = ld4(coef + C + c);
+    float4 u;
+    u.x = fmaf(sc.x, zv.x, sh.x); u.y = fmaf(sc.y, zv.y, sh.y);
+    u.z = fmaf(sc.z, zv.z, sh.z); u.w = fmaf(sc.w, zv.w, sh.w);
+    u.x = u.x > 0.f ? u.x : u.x * slope; u.y = u.y > 0.f ? u.y : u.y * slope;
+    u.z = u.z > 0.f ? u.z : u.z * slope; u.w = u.w > 0.f ? u.w : u.w * slope;
+    st4(out + r * ldo + c, u);
+  }
+}
+
+// affine_act_vec4_kernel with one coefficient set per block of rows_g rows (domain groups)
+__global__ __launch_bounds__(256) void affine_act_vec4_groups_kernel(const float* __restrict__ z, int64_t ldz,
+                                                                     const float* __restrict__ coef, int64_t rows,
+                                                                     int64_t rows_g, int C, float slope,
+                                                                     float* __restrict__ out, int64_t ldo) {
+  const int C4 = C >> 2;
+  const int64_t total = rows * C4;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int c = (int)(e % C4) * 4;
+    const int64_t r = e / C4;
+    const float* cg = coef + (r / rows_g) * 5 * C;
+    const float4 zv = ld4(z + r * ldz + c), sc = ld4(cg + c), sh = ld4(cg + C + c);
     float4 u;
     u.x = fmaf(sc.x, zv.x, sh.x); u.y = fmaf(sc.y, zv.y, sh.y);
     u.z = fmaf(sc.z, zv.z, sh.z); u.w = fmaf(sc.w, zv.w, sh.w);
@@ -794,6 +871,51 @@ extern "C" int sug_edgeconv_fwd_bn(const float* pq, int64_t ldpq, const int32_t*
   hipLaunchKernelGGL(stats_finalize_kernel, dim3(sug_divup(Co, 8)), dim3(256), 0, (hipStream_t)stream, ws, grid, Co,
                      gamma, beta, (double)B * N * k, eps, momentum, running_mean, running_var, coef);
   SUG_LAUNCH_CHECK("sug_edgeconv_fwd_bn(finalize)");
+  return SUG_OK;
+}
+
+// EdgeConv forward + BatchNorm coefficients + activation for `groups` domain groups (B/groups clouds each, one
+// BatchNorm call per group) in three launches when the LDS-resident kernel applies to the whole batch: its
+// partial rows are (cloud, part)-major, so each group's rows are contiguous.  Otherwise: group by group.
+int sug_edgeconv_fwd_bn_act_groups(const float* pq, int64_t ldpq, const int32_t* idx, const float* gamma,
+                                   const float* beta, int B, int N, int k, int Co, int groups, float eps, float momentum,
+                                   float slope, float* running_mean, float* running_var, float* z, uint8_t* arg,
+                                   float* s1, float* coef, float* out, int64_t ldo, float* ws, void* stream) {
+  SUG_REQUIRE(beta && coef && out, "sug_edgeconv_layer_fwd: null pointer");
+  SUG_REQUIRE(groups >= 1 && B % groups == 0, "sug_edgeconv_layer_fwd: B=%d does not split into %d groups", B, groups);
+  hipStream_t st = (hipStream_t)stream;
+  const int Bg = B / groups;
+  const int64_t rows = (int64_t)Bg * N;
+  const bool lds = k == 20 && Co % 16 == 0 && (size_t)N * 16 * 4 + 64 * 32 * 4 <= 150 * 1024 && B <= SUG_STATS_BLOCKS / 4 &&
+                   ((uintptr_t)idx % 16) == 0;
+  const bool vec = (ldo % 4 == 0) && ((uintptr_t)out % 16 == 0) && ((uintptr_t)coef % 16 == 0) && ((uintptr_t)z % 16 == 0);
+#ifdef SUG_EDGECONV_NO_LDS
+  const bool one = false;
+#else
+  const bool one = groups > 1 && lds && vec;
+#endif
+  if (one) {
+    int nblk = 0;
+    if (int rc = edgeconv_fwd_partials(pq, ldpq, idx, gamma, B, N, k, Co, z, arg, s1, ws, &nblk, stream)) return rc;
+    hipLaunchKernelGGL(stats_finalize_groups_kernel, dim3(sug_divup(Co, 8)), dim3(256), 0, st, ws, nblk / groups, Co, groups,
+                       gamma, beta, (double)rows * k, eps, momentum, running_mean, running_var, coef);
+    SUG_LAUNCH_CHECK("sug_edgeconv_layer_fwd(finalize)");
+    const int64_t total = (int64_t)B * N * (Co / 4);
+    int64_t g = (total + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(affine_act_vec4_groups_kernel, dim3((int)g), dim3(256), 0, st, z, (int64_t)Co, coef, (int64_t)B * N, rows,
+                       Co, slope, out, ldo);
+    SUG_LAUNCH_CHECK("sug_edgeconv_layer_fwd(act)");
+    return SUG_OK;
+  }
+  for (int g = 0; g < groups; ++g) {
+    const int64_t r0 = (int64_t)g * rows;
+    float* cg = coef + (int64_t)g * 5 * Co;
+    if (int rc = sug_edgeconv_fwd_bn(pq + r0 * ldpq, ldpq, idx + r0 * k, gamma, beta, Bg, N, k, Co, eps, momentum, running_mean,
+                                     running_var, z + r0 * Co, arg + r0 * Co, s1 ? s1 + r0 * Co : nullptr, cg, ws, stream))
+      return rc;
+    if (int rc = sug_affine_act(z + r0 * Co, Co, cg, rows, Co, slope, out + r0 * ldo, ldo, stream)) return rc;
+  }
   return SUG_OK;
 }
 

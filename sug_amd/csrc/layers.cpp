@@ -9,6 +9,10 @@
 void sug_set_error(const char* fmt, ...);
 // edgeconv.hip: sug_edgeconv_bwd_scatter over `groups` BatchNorm groups in one launch (group g reads
 // coef + g*coef_stride, red + g*red_stride)
+int sug_edgeconv_fwd_bn_act_groups(const float* pq, int64_t ldpq, const int32_t* idx, const float* gamma,
+                                   const float* beta, int B, int N, int k, int Co, int groups, float eps, float momentum,
+                                   float slope, float* running_mean, float* running_var, float* z, uint8_t* arg,
+                                   float* s1, float* coef, float* out, int64_t ldo, float* ws, void* stream);
 int sug_edgeconv_bwd_scatter_groups(const float* a, const uint8_t* arg, const float* s1, const float* pq, int64_t ldpq,
                                     const int32_t* rev_off, const int32_t* rev_ent, const float* coef, const double* red,
                                     int B, int N, int k, int Co, int groups, int64_t coef_stride, int64_t red_stride,
@@ -25,16 +29,14 @@ extern "C" int sug_edgeconv_layer_fwd(const float* pq, int64_t ldpq, const int32
   LAYER_REQUIRE(coef && out && z && arg && stats, "sug_edgeconv_layer_fwd: null pointer");
   const int Bg = B / groups;
   const int64_t rows = (int64_t)Bg * N;
+  if (training)      // all groups in three launches when the LDS-resident kernel applies (edgeconv.hip)
+    return sug_edgeconv_fwd_bn_act_groups(pq, ldpq, idx, gamma, beta, B, N, k, Co, groups, eps, momentum, slope, running_mean,
+                                          running_var, z, arg, s1, coef, out, ldo, ws, stream);
   for (int g = 0; g < groups; ++g) {
     const int64_t r0 = (int64_t)g * rows;
     float* cg = coef + (int64_t)g * 5 * Co;
-    if (training)
-      LAYER_TRY(sug_edgeconv_fwd_bn(pq + r0 * ldpq, ldpq, idx + r0 * k, gamma, beta, Bg, N, k, Co, eps, momentum,
-                                    running_mean, running_var, z + r0 * Co, arg + r0 * Co,
-                                    s1 ? s1 + r0 * Co : nullptr, cg, ws, stream));
-    else
-      LAYER_TRY(sug_edgeconv_fwd(pq + r0 * ldpq, ldpq, idx + r0 * k, gamma, Bg, N, k, Co, z + r0 * Co, arg + r0 * Co,
-                                 s1 ? s1 + r0 * Co : nullptr, stats, ws, stream));
+    LAYER_TRY(sug_edgeconv_fwd(pq + r0 * ldpq, ldpq, idx + r0 * k, gamma, Bg, N, k, Co, z + r0 * Co, arg + r0 * Co,
+                               s1 ? s1 + r0 * Co : nullptr, stats, ws, stream));
     LAYER_TRY(sug_affine_act(z + r0 * Co, Co, cg, rows, Co, slope, out + r0 * ldo, ldo, stream));
   }
   return SUG_OK;
