@@ -10,18 +10,27 @@
 //              the MFMA chains of 64 queries each (two 32-query column blocks sharing the A
 //              operand) and write the 64 x 32 score tile to LDS, row = query;
 //   waves 4-7  consumers: lane = ONE query; reads its row of the score tile (candidates in ascending
-//              index order), forms score = (-|x_j|^2 - (-2<x_i,x_j>)) - |x_i|^2 and compares with
-//              thr = its K-th best score as of the previous tile; the few candidates that pass are
-//              marked in a 32-bit mask and then inserted -- all lanes of the wave in lockstep, one
-//              marked candidate per lane per iteration -- into the lane's sorted (score, index) lists
-//              in registers (v_med3 for the scores, two v_cndmask for the indices per slot).
+//              index order), forms score = (-|x_j|^2 - (-2<x_i,x_j>)) - |x_i|^2 and compares with a
+//              threshold derived from its (K+2)-th best key as of the previous tile; the few candidates that
+//              pass are marked in a 32-bit mask and then inserted -- all lanes of the wave in lockstep, one
+//              marked candidate per lane per iteration -- into the lane's sorted list of PACKED KEYS in
+//              registers: key = (fixed-point bucket of d = -score over the query's range of the first tile)
+//              << ceil(log2 N) | candidate index, one v_med3_i32 per slot (the exact (score, index) lists of the first
+//              round-2 kernel cost 4 VALU per slot: the selection, not the MFMA chain, bounds this kernel).
+//              The bucket map is a monotone coarsening of d, so the K+2 smallest keys contain the exact
+//              top K whenever fewer than 3 keys share the boundary bucket; at the end a lane whose first
+//              K+1 keys lie in distinct buckets has the exact answer in key order (the common case), a lane
+//              with equal buckets has its K+2 candidates re-scored exactly (fma chain in the MFMA's k
+//              order, one lane per candidate) and ranked by (score, index), and a lane whose boundary
+//              bucket overflows rescans the cloud exactly (scalar, LDS-resident lists): all three paths
+//              give the lists of the exact consumer bit for bit (tests/golden/knn_pc_hashes.json).
 // One barrier per tile hands tile t's scores to the consumers while the producers work on tile
-// t+1.  No candidate ring, no compaction, no merge: ties keep the lower index because candidates
-// arrive in ascending order and insertion is strict; the lists are the result.
+// t+1.  No candidate ring, no compaction, no merge.
 // LDS: tiles 3 x 32 x (C+4) + score tiles 2 x 4 x 64 x 36 floats = 100 / 125 KB (C = 64 / 128).  Workgroup = 256 queries of one cloud; the 4 workgroups of a 1024-point cloud
 // share an XCD (one L2).
 //
 // FLOPs N^2*(2C+3) per cloud on the matrix pipe (157 TFLOP/s); algorithmic bytes 4*C*N + 4*N*k.
+#include <float.h>
 #include "common.h"
 #include "mfma_tile.h"
 
@@ -35,80 +44,58 @@ __device__ __forceinline__ unsigned lds_addr(const float* p) {
   return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float*)p;
 }
 
-// Sorted insertion of (s, j) into the descending lists v[] / id[], in place, 4 VALU per slot:
-//   up = s > v[u-1];  id[u] = up ? id[u-1] : (here ? j : id[u]);  v[u] = med3(v[u-1], v[u], s);  here = up
-// (hipcc's register allocation of the same loop in C++ copies all 40 list registers every iteration.)
-// The "here" mask alternates between an SGPR pair `m` and VCC; gfx950 needs two wait states between a
-// VALU write of an SGPR / VCC and a VALU read of it as a mask: each v_cndmask reads a mask written
-// at least three instructions earlier.  Strict compares: an equal score stays behind earlier entries.
-__device__ __forceinline__ void ins_first(unsigned long long& m, float s, float vlast) {
-  asm volatile("v_cmp_gt_f32_e64 %[m], %[s], %[v]\n\ts_nop 1" : [m] "=s"(m) : [s] "v"(s), [v] "v"(vlast));
-}
-// slots u, u-1, u-2, u-3 (v4 = v[u] ... v0 = v[u-4], read only); here: in m, out m
-__device__ __forceinline__ void ins_four(unsigned long long& m, float s, int j, float& v4, float& v3, float& v2,
-                                         float& v1, const float& v0, int& i4, int& i3, int& i2, int& i1, const int& i0) {
-  int t;
-  asm volatile(
-      "v_cmp_gt_f32_e32 vcc, %[s], %[v3]\n\t"
-      "v_cndmask_b32_e64 %[t], %[i4], %[j], %[m]\n\t"
-      "v_med3_f32 %[v4], %[v3], %[v4], %[s]\n\t"
-      "v_cndmask_b32_e32 %[i4], %[t], %[i3], vcc\n\t"
-      "v_cmp_gt_f32_e64 %[m], %[s], %[v2]\n\t"
-      "v_cndmask_b32_e32 %[t], %[i3], %[j], vcc\n\t"
-      "v_med3_f32 %[v3], %[v2], %[v3], %[s]\n\t"
-      "v_cndmask_b32_e64 %[i3], %[t], %[i2], %[m]\n\t"
-      "v_cmp_gt_f32_e32 vcc, %[s], %[v1]\n\t"
-      "v_cndmask_b32_e64 %[t], %[i2], %[j], %[m]\n\t"
-      "v_med3_f32 %[v2], %[v1], %[v2], %[s]\n\t"
-      "v_cndmask_b32_e32 %[i2], %[t], %[i1], vcc\n\t"
-      "v_cmp_gt_f32_e64 %[m], %[s], %[v0]\n\t"
-      "v_cndmask_b32_e32 %[t], %[i1], %[j], vcc\n\t"
-      "v_med3_f32 %[v1], %[v0], %[v1], %[s]\n\t"
-      "v_cndmask_b32_e64 %[i1], %[t], %[i0], %[m]"
-      : [m] "+s"(m), [t] "=&v"(t), [v4] "+v"(v4), [v3] "+v"(v3), [v2] "+v"(v2), [v1] "+v"(v1), [i4] "+v"(i4),
-        [i3] "+v"(i3), [i2] "+v"(i2), [i1] "+v"(i1)
-      : [s] "v"(s), [j] "v"(j), [v0] "v"(v0), [i0] "v"(i0)
-      : "vcc");
-}
-// slots 3, 2, 1 and the head slot 0; here: in m
-__device__ __forceinline__ void ins_tail(unsigned long long m, float s, int j, float& v3, float& v2, float& v1, float& v0,
-                                         int& i3, int& i2, int& i1, int& i0) {
-  int t;
-  asm volatile(
-      "v_cmp_gt_f32_e32 vcc, %[s], %[v2]\n\t"
-      "v_cndmask_b32_e64 %[t], %[i3], %[j], %[m]\n\t"
-      "v_med3_f32 %[v3], %[v2], %[v3], %[s]\n\t"
-      "v_cndmask_b32_e32 %[i3], %[t], %[i2], vcc\n\t"
-      "v_cmp_gt_f32_e64 %[m], %[s], %[v1]\n\t"
-      "v_cndmask_b32_e32 %[t], %[i2], %[j], vcc\n\t"
-      "v_med3_f32 %[v2], %[v1], %[v2], %[s]\n\t"
-      "v_cndmask_b32_e64 %[i2], %[t], %[i1], %[m]\n\t"
-      "v_cmp_gt_f32_e32 vcc, %[s], %[v0]\n\t"
-      "v_cndmask_b32_e64 %[t], %[i1], %[j], %[m]\n\t"
-      "v_med3_f32 %[v1], %[v0], %[v1], %[s]\n\t"
-      "v_cndmask_b32_e32 %[i1], %[t], %[i0], vcc\n\t"
-      "v_max_f32_e32 %[v0], %[v0], %[s]\n\t"
-      "v_cndmask_b32_e32 %[i0], %[i0], %[j], vcc"
-      : [m] "+s"(m), [t] "=&v"(t), [v3] "+v"(v3), [v2] "+v"(v2), [v1] "+v"(v1), [v0] "+v"(v0), [i3] "+v"(i3),
-        [i2] "+v"(i2), [i1] "+v"(i1), [i0] "+v"(i0)
-      : [s] "v"(s), [j] "v"(j)
-      : "vcc");
+// Sorted insertion of key x into the ascending list L[0..KP-1], in place, one VALU per slot:
+//   L[u] = med3(x, L[u-1], L[u]) for u = KP-1 .. 1 (L[u-1] is read before it is overwritten), L[0] = min(L[0], x).
+// A key that is not smaller than L[KP-1] leaves the list unchanged.  (asm: hipcc's register allocation of
+// the C++ loop copies the list registers every iteration.)
+template <int KP>
+__device__ __forceinline__ void insert_key(int (&L)[KP], int x) {
+#pragma unroll
+  for (int u = KP - 1; u >= 1; --u) asm volatile("v_med3_i32 %0, %1, %2, %0" : "+v"(L[u]) : "v"(x), "v"(L[u - 1]));
+  asm volatile("v_min_i32 %0, %0, %1" : "+v"(L[0]) : "v"(x));
 }
 
-template <int K>
-__device__ __forceinline__ void insert_sorted(float (&v)[K], int (&id)[K], float s, int j) {
-  static_assert(K % 4 == 0 && K >= 8, "list length: a multiple of 4");
-  unsigned long long m;
-  ins_first(m, s, v[K - 1]);
+// <a, b> over C features in the k order of the MFMA chain (ascending feature index, fma from a zero accumulator)
+template <int CP>
+__device__ __forceinline__ float exact_dot(const float* __restrict__ a, const float* __restrict__ b) {
+  float acc = 0.f;
+  if constexpr (CP == 4) {
+    acc = fmaf(a[0], b[0], acc); acc = fmaf(a[1], b[1], acc); acc = fmaf(a[2], b[2], acc);
+  } else {
+    for (int e = 0; e < CP; e += 4) {
+      const float4 av = *reinterpret_cast<const float4*>(a + e), bv = *reinterpret_cast<const float4*>(b + e);
+      acc = fmaf(av.x, bv.x, acc); acc = fmaf(av.y, bv.y, acc); acc = fmaf(av.z, bv.z, acc); acc = fmaf(av.w, bv.w, acc);
+    }
+  }
+  return acc;
+}
+// |x_j|^2 exactly as tile_store forms it: fma chain inside each 8-feature chunk, xor tree over the chunks
+template <int CP>
+__device__ __forceinline__ float exact_norm(const float* __restrict__ r) {
+  if constexpr (CP == 4) {
+    return sq3(r[0], r[1], r[2]);
+  } else {
+    constexpr int CH = CP / 8;
+    float pc[CH];
 #pragma unroll
-  for (int u = K - 1; u >= 7; u -= 4)
-    ins_four(m, s, j, v[u], v[u - 1], v[u - 2], v[u - 3], v[u - 4], id[u], id[u - 1], id[u - 2], id[u - 3], id[u - 4]);
-  ins_tail(m, s, j, v[3], v[2], v[1], v[0], id[3], id[2], id[1], id[0]);
+    for (int c = 0; c < CH; ++c) {
+      const float4 a = *reinterpret_cast<const float4*>(r + 8 * c), b = *reinterpret_cast<const float4*>(r + 8 * c + 4);
+      float p = __fmul_rn(a.x, a.x);
+      p = fmaf(a.y, a.y, p); p = fmaf(a.z, a.z, p); p = fmaf(a.w, a.w, p);
+      p = fmaf(b.x, b.x, p); p = fmaf(b.y, b.y, p); p = fmaf(b.z, b.z, p); p = fmaf(b.w, b.w, p);
+      pc[c] = p;
+    }
+#pragma unroll
+    for (int o = 1; o < CH; o <<= 1)
+#pragma unroll
+      for (int c = 0; c < CH; c += 2 * o) pc[c] = pc[c] + pc[c + o];
+    return pc[0];
+  }
 }
 
 template <int CP, int K>
 __global__ __launch_bounds__(512, 2) void knn_pc_kernel(const float* __restrict__ x, int64_t ldx, int B, int N,
-                                                        int k, int32_t* __restrict__ idx) {
+                                                        int k, int32_t* __restrict__ idx, int force) {
   constexpr int RS = CP + 4;
   constexpr int HALF = CP / 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -139,7 +126,9 @@ __global__ __launch_bounds__(512, 2) void knn_pc_kernel(const float* __restrict_
   // The two roles are separate code paths (disjoint register sets); both execute the same sequence
   // of workgroup barriers: 17 in the query staging, 2 in the pipeline fill, one per tile.
   if (producer) {
-    // ---- query operands, staged through the tile buffers: 8 tiles of 32 query rows
+    // ---- query operands, staged through the tile buffers: 8 tiles of 32 query rows.  They are scaled by -2 (exact):
+    // the chains then deliver inner = -2<x_i,x_j> itself, bit for bit fl(-2 * dot), and the consumers save the
+    // multiplication per candidate
     float bq0[HALF], bq1[HALF];
     {
       TileRegs<CP> tr;
@@ -153,10 +142,10 @@ __global__ __launch_bounds__(512, 2) void knn_pc_kernel(const float* __restrict_
           const float* qrow = s_tile + qj * RS + h * HALF;
           if (w & 1) {
 #pragma unroll
-            for (int e = 0; e < HALF; ++e) bq1[e] = qrow[e];
+            for (int e = 0; e < HALF; ++e) bq1[e] = -2.f * qrow[e];
           } else {
 #pragma unroll
-            for (int e = 0; e < HALF; ++e) bq0[e] = qrow[e];
+            for (int e = 0; e < HALF; ++e) bq0[e] = -2.f * qrow[e];
           }
         }
       }
@@ -229,45 +218,68 @@ __global__ __launch_bounds__(512, 2) void knn_pc_kernel(const float* __restrict_
     }
     __syncthreads();
 
-    float v[K];
-    int id[K];
-    const int q = q0 + wv * 64 + lane;
+    constexpr int KP = K + 2;
+    constexpr int EMPTY = 0x7fffffff;          // never-filled slot
+    int L[KP];                                 // ascending packed keys
 #pragma unroll
-    for (int t = 0; t < K; ++t) {
-      v[t] = -INFINITY;
-      id[t] = q < N ? q : 0;                   // never-filled slots (NaN features, N < k) point at the query
-    }
-    float thr = -INFINITY;
+    for (int t = 0; t < KP; ++t) L[t] = EMPTY;
+    const int q = q0 + wv * 64 + lane;
+    const int idb = N > 1 ? 32 - __clz(N - 1) : 0;       // index bits
+    const int idm = (1 << idb) - 1, nidm = ~idm;
+    // bucket = min(floor(d * scale), FXMAX), d = -score: fixed point over [0, R], R = the largest d of the query's
+    // first tile (the K+2 smallest d of the cloud cannot exceed it once that tile holds K+2 candidates; larger d
+    // saturate, which keeps the map monotone).  31 - idb bits; FXMAX leaves the EMPTY key a bucket of its own.
+    const unsigned FXMAX = (1u << (31 - idb)) - 2u;
+    float scale = 1.f, inv_scale = 1.f;
+    float thr = -FLT_MAX;                      // candidates with score >= thr may still enter the list
 
     // score of candidate slot c of the current tile: pairwise_distance = -xx - inner - xx^T, inner = -2*dot
     // (model_utils.py:179-181); the same three roundings wherever it is evaluated
-    auto score = [&](float dot, float nj) { return __fsub_rn(__fsub_rn(-nj, __fmul_rn(-2.0f, dot)), ni); };
+    auto score = [&](float inner, float nj) { return __fsub_rn(__fsub_rn(-nj, inner), ni); };
 
     __syncthreads();                            // pipeline fill: tile 0 staged
     __syncthreads();                            // tile 0 scored
     for (int t = 0; t < ntile; ++t) {
       const float* srow = s_score + (((t & 1) * 4 + wv) * 64 + lane) * SROW;
       const float* nrm = nbuf(t);
-      // pass 1: which of the 32 candidates beat thr (the K-th best score as of the previous tile: stale
-      // by at most one tile, never too high).  Candidate c -> bit 31-c.
+      // pass 1: which of the 32 candidates can still enter (thr: from the (K+2)-th key as of the previous tile:
+      // stale by at most one tile, never too high; rows past N score -inf and never pass).  Candidate c -> bit 31-c.
       unsigned int mask = 0u;
+      if (t == 0) {
+        // first tile: every finite score passes; its lowest score sets the range of the fixed-point buckets
+        float smin = INFINITY;
 #pragma unroll
-      for (int g = 0; g < 8; ++g) {
-        const float4 s4 = *reinterpret_cast<const float4*>(srow + 4 * g);
-        const float4 n4 = *reinterpret_cast<const float4*>(nrm + 4 * g);
-        mask = mask + mask + (score(s4.x, n4.x) > thr ? 1u : 0u);
-        mask = mask + mask + (score(s4.y, n4.y) > thr ? 1u : 0u);
-        mask = mask + mask + (score(s4.z, n4.z) > thr ? 1u : 0u);
-        mask = mask + mask + (score(s4.w, n4.w) > thr ? 1u : 0u);
+        for (int g = 0; g < 8; ++g) {
+          const float4 s4 = *reinterpret_cast<const float4*>(srow + 4 * g);
+          const float4 n4 = *reinterpret_cast<const float4*>(nrm + 4 * g);
+          const float sx = score(s4.x, n4.x), sy = score(s4.y, n4.y), sz = score(s4.z, n4.z), sw = score(s4.w, n4.w);
+          mask = mask + mask + (sx >= thr ? 1u : 0u);
+          mask = mask + mask + (sy >= thr ? 1u : 0u);
+          mask = mask + mask + (sz >= thr ? 1u : 0u);
+          mask = mask + mask + (sw >= thr ? 1u : 0u);
+          smin = fminf(smin, sx >= thr ? sx : INFINITY);
+          smin = fminf(smin, sy >= thr ? sy : INFINITY);
+          smin = fminf(smin, sz >= thr ? sz : INFINITY);
+          smin = fminf(smin, sw >= thr ? sw : INFINITY);
+        }
+        const float R = (smin < 0.f && smin > -FLT_MAX) ? -smin : 1.f;      // no finite negative score: any range will do
+        scale = (float)FXMAX / R;
+        inv_scale = R / (float)FXMAX;
+        if (!(scale < FLT_MAX) || !(inv_scale > 0.f)) { scale = 1.f; inv_scale = 1.f; }
+      } else {
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+          const float4 s4 = *reinterpret_cast<const float4*>(srow + 4 * g);
+          const float4 n4 = *reinterpret_cast<const float4*>(nrm + 4 * g);
+          mask = mask + mask + (score(s4.x, n4.x) >= thr ? 1u : 0u);
+          mask = mask + mask + (score(s4.y, n4.y) >= thr ? 1u : 0u);
+          mask = mask + mask + (score(s4.z, n4.z) >= thr ? 1u : 0u);
+          mask = mask + mask + (score(s4.w, n4.w) >= thr ? 1u : 0u);
+        }
       }
       // pass 2: the marked candidates in ascending index order, one per lane per iteration (all lanes in
-      // lockstep); the entry of the NEXT iteration is fetched from the score tile while the current
-      // one is inserted.  Exact sorted insertion: v_med3 on the scores, two v_cndmask on the indices
-      // per slot; strict compares keep the earlier (lower) index ahead among equal scores.
-      // (loads are unconditional -- an unmarked lane re-reads slot 0 -- so that no branch wraps them;
-      //  the entry of the next iteration is fetched while the current one is inserted)
-      // iterations = the largest number of marked candidates of any lane: a wave-wide maximum built bit by
-      // bit from ballots (scalar unit only; a shuffle tree would cost six LDS-latency round trips per tile)
+      // lockstep); iterations = the largest number of marked candidates of any lane: a wave-wide maximum built
+      // bit by bit from ballots (scalar unit only; a shuffle tree would cost six LDS round trips per tile)
       const int pc = __popc(mask);
       unsigned long long cand = ~0ull;
       int nit = 0;
@@ -280,8 +292,7 @@ __global__ __launch_bounds__(512, 2) void knn_pc_kernel(const float* __restrict_
         }
       }
       // The LDS reads are issued by hand and waited for only after the insertion of the previous entry
-      // (hipcc waits right at the load, or wraps the loads in a branch and then copies all 40 list
-      // registers every iteration).
+      // (loads are unconditional -- an unmarked lane re-reads slot 0 -- so that no branch wraps them).
       const unsigned srow_a = lds_addr(srow), nrm_a = lds_addr(nrm);
       float dot, nj;
       bool valid;
@@ -292,37 +303,97 @@ __global__ __launch_bounds__(512, 2) void knn_pc_kernel(const float* __restrict_
         mask &= ~(0x80000000u >> c);
         asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3" : "=&v"(dot), "=&v"(nj) : "v"(srow_a + 4u * c), "v"(nrm_a + 4u * c));
       };
-      auto fetch_finish = [&](float& s_out, int& j_out) {
+      auto fetch_finish = [&](int& key_out) {
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dot), "+v"(nj));
-        s_out = valid ? score(dot, nj) : -INFINITY;
-        j_out = t * TJ + c;
+        // key: bucket of d = -score (v_cvt_u32_f32 truncates, maps negative rounding noise to 0 and saturates),
+        // low bits = candidate index
+        const unsigned fx = min(__float2uint_rz(-score(dot, nj) * scale), FXMAX);
+        key_out = valid ? (int)((fx << idb) | (unsigned)(t * TJ + c)) : EMPTY;
       };
-      float s_cur;
-      int j_cur;
+      int key_cur;
       fetch_issue();
-      fetch_finish(s_cur, j_cur);
+      fetch_finish(key_cur);
       for (int it = 0; it < nit; ++it) {
         fetch_issue();
-#ifdef SUG_KNN_EXPERIMENT
-        {   // timing experiment only (wrong indices): one v_med3 per slot
-#pragma unroll
-          for (int u = K - 1; u >= 1; --u) asm volatile("v_med3_f32 %0, %1, %0, %2" : "+v"(v[u]) : "v"(v[u - 1]), "v"(s_cur));
-          asm volatile("v_max_f32 %0, %0, %1" : "+v"(v[0]) : "v"(s_cur));
-          id[0] += j_cur;
-        }
-#else
-        insert_sorted<K>(v, id, s_cur, j_cur);
-#endif
-        fetch_finish(s_cur, j_cur);
+        insert_key<KP>(L, key_cur);
+        fetch_finish(key_cur);
       }
-      thr = v[K - 1];
+      // a candidate whose key is below L[KP-1] has floor(d*scale) <= its bucket, so d < (bucket + 1) / scale: the
+      // margin (+3, 2e-6 relative) covers the roundings of d*scale, of scale and of this product (buckets < 2^21)
+      const int lk = L[KP - 1];
+      thr = lk == EMPTY ? -FLT_MAX : -((float)((lk >> idb) + 3) * inv_scale * 1.000002f);
       __syncthreads();
     }
-    if (q < N) {
-      int32_t* o = idx + ((int64_t)b * N + q) * k;
+
+    // ---- result.  Buckets (key >> idb) order the candidates as their exact scores do, except inside a bucket.
+    bool amb = false;
+#pragma unroll
+    for (int u = 0; u < K; ++u) amb |= ((L[u] ^ L[u + 1]) & nidm) == 0 && L[u] != EMPTY;
+    bool rescan = amb && ((L[K - 1] ^ L[KP - 1]) & nidm) == 0 && L[KP - 1] != EMPTY;
+    if (force >= 1) amb = true;
+    if (force >= 2) rescan = true;
+    if (q >= N) amb = rescan = false;
+    int32_t* o = idx + ((int64_t)b * N + (q < N ? q : 0)) * k;
+    if (q < N && !amb) {
 #pragma unroll
       for (int t = 0; t < K; ++t)
-        if (t < k) o[t] = id[t];
+        if (t < k) o[t] = L[t] == EMPTY ? q : (L[t] & idm);      // never-filled slots point at the query
+    }
+    if (__ballot(amb) != 0ull) {
+      // scratch: this wave's two score rows blocks (no other wave touches them; the producers are done)
+      int* s_keys = reinterpret_cast<int*>(s_score + ((0 * 4 + wv) * 64) * SROW);       // [64][KP]
+      float* s_fv = s_score + ((1 * 4 + wv) * 64) * SROW;                                // [K][64]
+#pragma unroll
+      for (int t = 0; t < KP; ++t) s_keys[lane * KP + t] = L[t];
+      // (a) exact re-rank of the K+2 candidates of one query at a time: lane u = candidate u
+      unsigned long long todo = __ballot(amb && !rescan);
+      while (todo) {
+        const int ql = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const int qi = q0 + wv * 64 + ql;
+        const float niq = __shfl(ni, ql);
+        const int key = lane < KP ? s_keys[ql * KP + lane] : EMPTY;
+        const bool has = key != EMPTY;
+        const int j = has ? (key & idm) : 0;
+        const float* xq = xb + (int64_t)qi * ldx;
+        const float* xj = xb + (int64_t)j * ldx;
+        const float dj = exact_dot<CP>(xj, xq);
+        const float nj = exact_norm<CP>(xj);
+        const float sc = has ? __fsub_rn(__fsub_rn(-nj, __fmul_rn(-2.0f, dj)), niq) : -INFINITY;
+        int rank = 0;
+#pragma unroll
+        for (int v = 0; v < KP; ++v) {
+          const float sv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sc), v));
+          const int jv = __builtin_amdgcn_readlane(has ? j : 0x7fffffff, v);
+          rank += (sv > sc || (sv == sc && jv < j)) ? 1 : 0;
+        }
+        const int nhas = __popcll(__ballot(has));
+        int32_t* oq = idx + ((int64_t)b * N + qi) * k;
+        if (has && rank < k) oq[rank] = j;
+        if (lane < k && lane >= nhas) oq[lane] = qi;
+      }
+      // (b) exact rescan of the whole cloud, one lane per query, lists in LDS ([slot][lane])
+      if (rescan) {
+        int* s_fid = s_keys;                    // the keys are no longer needed by this wave
+        const float* xq = xb + (int64_t)q * ldx;
+        for (int t = 0; t < K; ++t) { s_fv[t * 64 + lane] = -INFINITY; s_fid[t * 64 + lane] = q; }
+        for (int j = 0; j < N; ++j) {
+          const float* xj = xb + (int64_t)j * ldx;
+          const float sc = __fsub_rn(__fsub_rn(-exact_norm<CP>(xj), __fmul_rn(-2.0f, exact_dot<CP>(xj, xq))), ni);
+          if (sc > s_fv[(K - 1) * 64 + lane]) {           // strict: an equal score stays behind earlier entries
+            int u = K - 1;
+            while (u > 0 && sc > s_fv[(u - 1) * 64 + lane]) {
+              s_fv[u * 64 + lane] = s_fv[(u - 1) * 64 + lane];
+              s_fid[u * 64 + lane] = s_fid[(u - 1) * 64 + lane];
+              --u;
+            }
+            s_fv[u * 64 + lane] = sc;
+            s_fid[u * 64 + lane] = j;
+          }
+        }
+        for (int t = 0; t < K; ++t)
+          if (t < k) o[t] = s_fid[t * 64 + lane];
+      }
     }
   }
 }
@@ -334,7 +405,8 @@ int launch_pc(const float* x, int64_t ldx, int B, int N, int k, int32_t* idx, hi
   static SugLdsOptIn note;
   if (int rc = sug_allow_dynamic_lds(note, &knn_pc_kernel<CP, K>, (int)sh, "sug_knn(mfma, producer/consumer)")) return rc;
   dim3 grid(sug_divup(N, 256) * B);
-  hipLaunchKernelGGL((knn_pc_kernel<CP, K>), grid, dim3(512), sh, st, x, ldx, B, N, k, idx);
+  const char* fe = getenv("SUG_KNN_FORCE");      // test knob: 1 = exact re-rank for every query, 2 = exact rescan
+  hipLaunchKernelGGL((knn_pc_kernel<CP, K>), grid, dim3(512), sh, st, x, ldx, B, N, k, idx, fe ? atoi(fe) : 0);
   SUG_LAUNCH_CHECK("sug_knn(mfma, producer/consumer)");
   return SUG_OK;
 }

@@ -392,3 +392,36 @@ def test_bad_arguments_raise():
     with pytest.raises(RuntimeError):
         with ops.bn_groups(2):
             ops.bn_act_rows(torch.randn(3, 8).cuda(), torch.nn.BatchNorm1d(8).cuda(), 0.0)   # 3 rows, 2 groups
+
+
+@pytest.mark.parametrize('force', ['0', '1', '2'])
+def test_knn_packed_key_paths_match_exact_lists(force):
+    """The packed-key consumer of sug_knn (knn_pc.hip) against the neighbour lists of the exact (score, index)
+    list consumer it replaced (tests/golden/knn_pc_hashes.json, SHA-256 per case; those lists are the ones the
+    oracle tests above pin).  force = 0: as shipped (keys in distinct buckets are final, the others are re-ranked
+    exactly); 1: every query through the exact re-rank; 2: every query through the exact rescan of its cloud.
+    Random and clustered features, exact duplicates, padded clouds, lattices (ties everywhere), N not a multiple
+    of the tile, k = 16 and 20."""
+    import importlib.util, json, os
+    from sug_amd import ops
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    spec = importlib.util.spec_from_file_location('make_knn_hashes', os.path.join(here, 'make_knn_hashes.py'))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    want = json.load(open(os.path.join(here, 'knn_pc_hashes.json')))
+    keep = os.environ.get('SUG_KNN_FORCE')
+    os.environ['SUG_KNN_FORCE'] = force
+    bad = []
+    try:
+        for name, x in mk.cases().items():
+            if force == '2' and x.shape[1] * x.shape[2] > 1024 * 64:
+                continue                      # the scalar rescan of every query: small cases only
+            for k in (20, 16):
+                if mk.digest(ops.knn(x.cuda(), k)) != want['%s_k%d' % (name, k)]:
+                    bad.append('%s_k%d' % (name, k))
+    finally:
+        if keep is None:
+            del os.environ['SUG_KNN_FORCE']
+        else:
+            os.environ['SUG_KNN_FORCE'] = keep
+    assert not bad, bad
