@@ -404,7 +404,7 @@ class SUGStep:
         return self._eager_step(data, label, data_t, label_t, epoch)
 
     def _graph_step(self, data, label, data_t, label_t, epoch):
-        """hipGraph mode (experimental, opt-in; not used for the reported numbers).  One captured graph
+        """hipGraph mode (bench.py's default launch mode on one GPU; opt-in for callers: use_graph=True).  One captured graph
         per configuration key = (MMD on/off, input shapes, the learning rates of the three optimizers):
         the kernels take lr by value, so a schedule step simply selects / captures another graph.  The
         first step of a key runs eagerly (it records the FPS start-draw plan and builds the Adam update
