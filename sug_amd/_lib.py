@@ -69,6 +69,8 @@ SIGNATURES = {
     'sug_sa_first_fwd': [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp],
     'sug_sa_first_bwd': [_vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                          _vp, _vp, _vp],
+    'sug_pointmlp_max_bwd_coef': [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
+    'sug_pointmlp_max_bwd_dwfix': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
     'sug_linear_dw_bias': [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp],
     'sug_node_offset_fwd': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
     'sug_node_offset_bwd': [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp],

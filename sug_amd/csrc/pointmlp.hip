@@ -388,6 +388,63 @@ __global__ __launch_bounds__(256) void pointmlp_bwd_dw_fold_kernel(const float* 
   dw[e] = (float)t;
 }
 
+// The dense BatchNorm-statistics terms of the backward are of rank K: dy = a_full - k1 - k2*y with y = x.W^T + b
+// gives dx = ... - (x.A + v), A = W^T diag(k2) W, v = (k1 + k2*b).W, and dW = ... - kb (x) sum(x) - diag(k2) W.(X^T X).
+// Coefficients from the folded statistics (fp64, as the torch expressions they replace):
+//   k2 = scale/M * rstd * dgamma,  kb = scale/M * (dbeta - mean*rstd*dgamma) + k2*b
+// One launch: block i < K writes row i of -A; block K writes -v, kb, k2.  (A dozen torch launches per group before.)
+__global__ __launch_bounds__(128) void pointmlp_bwd_coef_kernel(const float* __restrict__ coef, const double* __restrict__ red,
+                                                                 const float* __restrict__ bias, const float* __restrict__ w,
+                                                                 double M, int K, int Co, float* __restrict__ kb,
+                                                                 float* __restrict__ k2, float* __restrict__ negA,
+                                                                 float* __restrict__ negv) {
+  extern __shared__ float s_k[];                 // [Co] k2 or kb of this block
+  const bool vrow = (int)blockIdx.x == K;
+  for (int c = threadIdx.x; c < Co; c += 128) {
+    const double scale = coef[c], mean = coef[2 * Co + c], rstd = coef[3 * Co + c];
+    const double dbeta = red[c], dgamma = red[Co + c];
+    const double k2d = scale / M * rstd * dgamma;
+    const double k1d = scale / M * (dbeta - mean * rstd * dgamma);
+    const float k2f = (float)k2d, kbf = (float)(k1d + (bias ? k2d * (double)bias[c] : 0.0));
+    s_k[c] = vrow ? kbf : k2f;
+    if (vrow) {
+      kb[c] = kbf;
+      k2[c] = k2f;
+    }
+  }
+  __syncthreads();
+  const int j = threadIdx.x;
+  if (j >= K) return;
+  float acc = 0.f;
+  if (vrow) {
+    for (int c = 0; c < Co; ++c) acc = fmaf(s_k[c], w[(size_t)c * K + j], acc);
+    negv[j] = -acc;
+  } else {
+    const int i = blockIdx.x;
+    for (int c = 0; c < Co; ++c) acc = fmaf(s_k[c] * w[(size_t)c * K + i], w[(size_t)c * K + j], acc);
+    negA[(size_t)i * K + j] = -acc;
+  }
+}
+
+// dw[c,:] += dws[c,:] - (kb[c]*sx[:] + k2[c] * w[c,:].XtX)   (with_stats = 0: dw += dws)
+__global__ __launch_bounds__(128) void pointmlp_bwd_dwfix_kernel(float* __restrict__ dw, const float* __restrict__ dws,
+                                                                  const float* __restrict__ kb, const float* __restrict__ k2,
+                                                                  const float* __restrict__ w, const float* __restrict__ xtx,
+                                                                  const float* __restrict__ sx, int K, int Co, int with_stats) {
+  __shared__ float s_w[128];
+  const int c = blockIdx.x, j = threadIdx.x;
+  if (j < K) s_w[j] = w[(size_t)c * K + j];
+  __syncthreads();
+  if (j >= K) return;
+  float corr = 0.f;
+  if (with_stats) {
+    float acc = 0.f;
+    for (int i = 0; i < K; ++i) acc = fmaf(s_w[i], xtx[(size_t)i * K + j], acc);
+    corr = kb[c] * sx[j] + k2[c] * acc;
+  }
+  dw[(size_t)c * K + j] += dws[(size_t)c * K + j] - corr;
+}
+
 }  // namespace
 
 static int pointmlp_rows_per_wg(int64_t rows, int L) {
@@ -471,6 +528,28 @@ extern "C" int sug_pointmlp_max_layer_fwd(const float* x, int64_t ldx, int64_t r
     rc = sug_affine_act(zext + g * sg * Co, Co, cg, sg, Co, slope, out + g * sg * ldo, ldo, stream);
     if (rc != SUG_OK) return rc;
   }
+  return SUG_OK;
+}
+
+extern "C" int sug_pointmlp_max_bwd_coef(const float* coef, const double* red, const float* bias, const float* w,
+                                        int64_t rows, int K, int Co, float* kb, float* k2, float* negA, float* negv,
+                                        void* stream) {
+  SUG_REQUIRE(coef && red && w && kb && k2 && negA && negv, "sug_pointmlp_max_bwd_coef: null pointer");
+  SUG_REQUIRE(K > 0 && K <= 128 && Co > 0 && Co <= 8192 && rows > 0, "sug_pointmlp_max_bwd_coef: bad shape");
+  hipLaunchKernelGGL(pointmlp_bwd_coef_kernel, dim3(K + 1), dim3(128), (size_t)Co * sizeof(float), (hipStream_t)stream, coef,
+                     red, bias, w, (double)rows, K, Co, kb, k2, negA, negv);
+  SUG_LAUNCH_CHECK("sug_pointmlp_max_bwd_coef");
+  return SUG_OK;
+}
+
+extern "C" int sug_pointmlp_max_bwd_dwfix(float* dw, const float* dws, const float* kb, const float* k2, const float* w,
+                                         const float* xtx, const float* sx, int K, int Co, int with_stats, void* stream) {
+  SUG_REQUIRE(dw && dws && w, "sug_pointmlp_max_bwd_dwfix: null pointer");
+  SUG_REQUIRE(!with_stats || (kb && k2 && xtx && sx), "sug_pointmlp_max_bwd_dwfix: null pointer");
+  SUG_REQUIRE(K > 0 && K <= 128 && Co > 0, "sug_pointmlp_max_bwd_dwfix: bad shape");
+  hipLaunchKernelGGL(pointmlp_bwd_dwfix_kernel, dim3(Co), dim3(128), 0, (hipStream_t)stream, dw, dws, kb, k2, w, xtx, sx, K,
+                     Co, with_stats);
+  SUG_LAUNCH_CHECK("sug_pointmlp_max_bwd_dwfix");
   return SUG_OK;
 }
 

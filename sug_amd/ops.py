@@ -852,6 +852,10 @@ class _PointMLPMax(torch.autograd.Function):
         dws = torch.empty(Co, K, dtype=torch.float32, device=dev)
         wsp = torch.empty(int(lib().sug_pointmlp_max_bwd_workspace(rg, K, Co, seg)), dtype=torch.float32, device=dev)
         L = lib()
+        f32 = dict(dtype=torch.float32, device=dev)
+        kbk2, negA, negv = torch.empty(2, Co, **f32), torch.empty(K, K, **f32), torch.empty(K, **f32)
+        xtx, sx = torch.empty(K, K, **f32), torch.empty(K, **f32)
+        wsx = torch.empty(int(L.sug_linear_dw_workspace(rg, K, K)), **f32) if training else None
         for gi in range(G):
             xg = x2[gi * rg:(gi + 1) * rg]
             zg, ag, cg = zext[gi * sg:(gi + 1) * sg], a[gi * sg:(gi + 1) * sg], coef[gi]
@@ -860,27 +864,20 @@ class _PointMLPMax(torch.autograd.Function):
                                             _st()), 'sug_edgeconv_bwd_reduce')
             dxg = dx[gi * rg:(gi + 1) * rg]
             if training:
-                # dy = a_full - (scale/M)(dbeta + xhat*dgamma) = a_full - k1 - k2*y over ALL rows, y = x.W^T + b
-                scale, mean, rstd = cg[0].double(), cg[2].double(), cg[3].double()
-                dbeta, dgamma = red[gi, :Co], red[gi, Co:]
-                k2d = scale / rg * rstd * dgamma
-                k1d = scale / rg * (dbeta - mean * rstd * dgamma)
-                kb = (k1d + (k2d * b1.double() if b1 is not None else 0.0)).float()
-                k2 = k2d.float()
-                wk = w2 * k2.unsqueeze(1)                                   # diag(k2) W
-                xtx = torch.empty(K, K, dtype=torch.float32, device=dev)
-                sx = torch.empty(K, dtype=torch.float32, device=dev)        # column sums of x, from the same launch
-                wsx = torch.empty(int(L.sug_linear_dw_workspace(rg, K, K)), dtype=torch.float32, device=dev)
+                # dy = a_full - (scale/M)(dbeta + xhat*dgamma) = a_full - k1 - k2*y over ALL rows, y = x.W^T + b:
+                # the rank-K operands -A, -v and the coefficients kb, k2 from one launch (sug_pointmlp_max_bwd_coef)
+                check(L.sug_pointmlp_max_bwd_coef(_p(cg), _p(red[gi]), _p(b1), _p(w2), rg, K, Co, _p(kbk2[0]), _p(kbk2[1]),
+                                                  _p(negA), _p(negv), _st()), 'sug_pointmlp_max_bwd_coef')
                 check(L.sug_linear_dw_bias(_p(xg), xg.stride(0), _p(xg), xg.stride(0), rg, K, K, _p(xtx), _p(sx), _p(wsx),
-                                           _st()), 'sug_linear_dw_bias')
-                # -(x.A + v) with the signs folded into the operands: alpha = beta = 1 keeps the library's
-                # bias epilogue (any other alpha first expands the bias into dx: a full extra pass)
-                torch.addmm((kb @ w2).neg(), xg, (wk.t() @ w2).neg(), out=dxg)
-                dw.sub_(kb.unsqueeze(1) * sx.unsqueeze(0)).sub_(wk @ xtx)
+                                           _st()), 'sug_linear_dw_bias')        # X^T X and the column sums of x
+                # -(x.A + v): alpha = beta = 1 keeps the library's bias epilogue (any other alpha first expands
+                # the bias into dx: a full extra pass)
+                torch.addmm(negv, xg, negA, out=dxg)
             check(L.sug_pointmlp_max_bwd_sparse(_p(ag), _p(arg[gi * sg:(gi + 1) * sg]), _p(xg), xg.stride(0), _p(w2), rg, K,
                                                 Co, seg, _p(dxg), K, _p(dws), _p(wsp), _st()),
                   'sug_pointmlp_max_bwd_sparse')
-            dw.add_(dws)
+            check(L.sug_pointmlp_max_bwd_dwfix(_p(dw), _p(dws), _p(kbk2[0]), _p(kbk2[1]), _p(w2), _p(xtx), _p(sx), K, Co,
+                                               1 if training else 0, _st()), 'sug_pointmlp_max_bwd_dwfix')
         rf = red[0].float() if G == 1 else red.sum(0, dtype=torch.float32)
         db = None
         if b1 is not None:
