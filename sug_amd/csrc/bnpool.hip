@@ -35,6 +35,35 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_vec4_kernel(const float* __r
   }
 }
 
+// bn_bwd_apply_vec4_kernel over `rows` rows in domain groups of rows_g: coefficient set and sums of each row's group
+__global__ __launch_bounds__(256) void bn_bwd_apply_vec4_groups_kernel(const float* __restrict__ a,
+                                                                       const float* __restrict__ y, int64_t ldy,
+                                                                       const float* __restrict__ coef,
+                                                                       const double* __restrict__ red, int64_t rows,
+                                                                       int64_t rows_g, int C, float invM,
+                                                                       float* __restrict__ dy, int64_t lddy) {
+  const int C4 = C >> 2;
+  const int64_t total = rows * C4;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int c = (int)(e % C4) * 4;
+    const int64_t r = e / C4;
+    const int64_t g = r / rows_g;
+    const float* cg = coef + g * 5 * C;
+    const double* rg = red + g * 2 * C;
+    const float4 av = *reinterpret_cast<const float4*>(a + r * C + c);
+    const float4 yv = *reinterpret_cast<const float4*>(y + r * ldy + c);
+    const float4 sc = *reinterpret_cast<const float4*>(cg + c);
+    const float4 mean = *reinterpret_cast<const float4*>(cg + 2 * C + c);
+    const float4 rstd = *reinterpret_cast<const float4*>(cg + 3 * C + c);
+    float4 o;
+    o.x = av.x - sc.x * invM * ((float)rg[c + 0] + (yv.x - mean.x) * rstd.x * (float)rg[C + c + 0]);
+    o.y = av.y - sc.y * invM * ((float)rg[c + 1] + (yv.y - mean.y) * rstd.y * (float)rg[C + c + 1]);
+    o.z = av.z - sc.z * invM * ((float)rg[c + 2] + (yv.z - mean.z) * rstd.z * (float)rg[C + c + 2]);
+    o.w = av.w - sc.w * invM * ((float)rg[c + 3] + (yv.w - mean.w) * rstd.w * (float)rg[C + c + 3]);
+    *reinterpret_cast<float4*>(dy + r * lddy + c) = o;
+  }
+}
+
 // dy = a - (scale/M) * (dbeta + xhat * dgamma),  a = scale * G  (exact BN gradient)
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ a,
                                                            const float* __restrict__ y, int64_t ldy,
@@ -337,6 +366,19 @@ extern "C" int sug_bn_bwd_apply(const float* a, const float* y, int64_t ldy, con
   else
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(rows * C)), dim3(256), 0, (hipStream_t)stream, a, y,
                        ldy, coef, red, rows, C, (float)(1.0 / (double)rows), dy, lddy);
+  SUG_LAUNCH_CHECK("sug_bn_bwd_apply");
+  return SUG_OK;
+}
+
+// all domain groups (rows_g rows each) in one launch; 1 = layout does not allow it
+int sug_bn_bwd_apply_groups(const float* a, const float* y, int64_t ldy, const float* coef, const double* red,
+                            int64_t rows_g, int groups, int C, float* dy, int64_t lddy, hipStream_t st) {
+  const bool vec = (C % 4 == 0) && (ldy % 4 == 0) && (lddy % 4 == 0) && ((uintptr_t)a % 16 == 0) &&
+                   ((uintptr_t)y % 16 == 0) && ((uintptr_t)dy % 16 == 0) && ((uintptr_t)coef % 16 == 0);
+  if (!vec) return 1;
+  const int64_t rows = rows_g * groups;
+  hipLaunchKernelGGL(bn_bwd_apply_vec4_groups_kernel, dim3(ew_grid(rows * C / 4)), dim3(256), 0, st, a, y, ldy, coef, red,
+                     rows, rows_g, C, (float)(1.0 / (double)rows_g), dy, lddy);
   SUG_LAUNCH_CHECK("sug_bn_bwd_apply");
   return SUG_OK;
 }

@@ -233,6 +233,8 @@ __global__ __launch_bounds__(256) void edgeconv_fwd_lds_kernel(
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ ws, int nblk,
                                                               int W, double* __restrict__ out) {
   __shared__ double s_p[16][17];
+  ws += (size_t)blockIdx.y * nblk * W;           // blockIdx.y = domain group: its nblk partial rows -> out row g
+  out += (size_t)blockIdx.y * W;
   const int cl = threadIdx.x & 15, p = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + cl;
   double acc = 0.0;
@@ -505,6 +507,16 @@ __global__ __launch_bounds__(256) void col_reduce_vec4_kernel(const float* __res
                                                               float* __restrict__ ws, int LX,
                                                               int rows_per_block) {
   extern __shared__ __attribute__((aligned(16))) float s_red[];  // [LY][2*C]
+  // blockIdx.y = domain group: `rows` rows each, consecutive in y / z / a; coefficient set g; partial rows
+  // [g * gridDim.x + blockIdx.x]
+  const int64_t g0 = (int64_t)blockIdx.y * rows;
+  y += g0 * ldy;
+  if (MODE == 1) {
+    z += g0 * C;
+    a += g0 * C;
+    coef += (int64_t)blockIdx.y * 5 * C;
+  }
+  ws += (size_t)blockIdx.y * gridDim.x * 2 * C;
   const int LY = 256 / LX;
   const int lx = threadIdx.x % LX, ly = threadIdx.x / LX;
   const int C4 = C >> 2;
@@ -961,7 +973,7 @@ extern "C" int sug_affine_act(const float* z, int64_t ldz, const float* coef, in
 // Launch the column reduction (vectorised when layout allows); returns the number of partial rows.
 template <int MODE>
 static int launch_col_reduce(const float* y, int64_t ldy, const float* z, const float* coef, int64_t rows,
-                             int C, float slope, float* a, float* ws, hipStream_t st);
+                             int C, float slope, float* a, float* ws, hipStream_t st, int groups = 1);
 
 // rows per block such that the grid stays within SUG_STATS_BLOCKS
 static int col_rows_per_block(int64_t rows, int cw) {
@@ -970,23 +982,27 @@ static int col_rows_per_block(int64_t rows, int cw) {
   return (int)rpb;
 }
 
+// rows = rows per group; groups > 1 (vectorised layout only, else -1): one launch over all groups, partial rows
+// [group][block]; returns the number of partial rows PER GROUP
 template <int MODE>
 static int launch_col_reduce(const float* y, int64_t ldy, const float* z, const float* coef, int64_t rows,
-                             int C, float slope, float* a, float* ws, hipStream_t st) {
+                             int C, float slope, float* a, float* ws, hipStream_t st, int groups) {
   const bool vec = (C % 4 == 0) && (ldy % 4 == 0) && ((uintptr_t)y % 16 == 0) &&
                    (MODE == 0 || (((uintptr_t)z % 16 == 0) && ((uintptr_t)a % 16 == 0) && ((uintptr_t)coef % 16 == 0)));
   if (vec) {
     int lx = 1;
     while (lx < (C >> 2) && lx < 256) lx <<= 1;
     const int ly = 256 / lx;
-    int64_t rpb = (rows + SUG_STATS_BLOCKS - 1) / SUG_STATS_BLOCKS;
+    int64_t rpb = (rows * groups + SUG_STATS_BLOCKS - 1) / SUG_STATS_BLOCKS;
     if (rpb < 4 * ly) rpb = 4 * ly;
     rpb = (rpb + ly - 1) / ly * ly;
     const int grid = sug_divup(rows, rpb);
-    hipLaunchKernelGGL((col_reduce_vec4_kernel<MODE>), dim3(grid), dim3(256), (size_t)ly * 2 * C * sizeof(float),
+    if ((int64_t)grid * groups > SUG_STATS_BLOCKS) return -1;
+    hipLaunchKernelGGL((col_reduce_vec4_kernel<MODE>), dim3(grid, groups), dim3(256), (size_t)ly * 2 * C * sizeof(float),
                        st, y, ldy, z, coef, rows, C, slope, a, ws, lx, (int)rpb);
     return grid;
   }
+  if (groups > 1) return -1;
   const int cw = col_width(C);
   const int rpb = col_rows_per_block(rows, cw);
   const int grid = sug_divup(rows, rpb);
@@ -1019,6 +1035,45 @@ extern "C" int sug_col_stats_bn(const float* y, int64_t ldy, int64_t rows, int C
   hipLaunchKernelGGL(stats_finalize_kernel, dim3(sug_divup(C, 8)), dim3(256), 0, st, ws, grid, C, gamma, beta,
                      (double)rows, eps, momentum, running_mean, running_var, coef);
   SUG_LAUNCH_CHECK("sug_col_stats_bn(finalize)");
+  return SUG_OK;
+}
+
+// Grouped forms (one launch over `groups` domain groups of `rows` rows each; return 1 when the layout does not
+// allow it and the caller must go group by group):
+//   statistics + BatchNorm coefficients of y -> coef [groups,5,C], running buffers updated in group order
+int sug_col_stats_bn_groups(const float* y, int64_t ldy, int64_t rows, int C, int groups, const float* gamma,
+                            const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                            float* coef, float* ws, hipStream_t st) {
+  const int grid = launch_col_reduce<0>(y, ldy, nullptr, nullptr, rows, C, 0.f, nullptr, ws, st, groups);
+  if (grid < 0) return 1;
+  SUG_LAUNCH_CHECK("sug_bn_act_rows_fwd(stats)");
+  hipLaunchKernelGGL(stats_finalize_groups_kernel, dim3(sug_divup(C, 8)), dim3(256), 0, st, ws, grid, C, groups, gamma, beta,
+                     (double)rows, eps, momentum, running_mean, running_var, coef);
+  SUG_LAUNCH_CHECK("sug_bn_act_rows_fwd(finalize)");
+  return SUG_OK;
+}
+//   out = act(coef_g . z) with the coefficient set of each row's group
+int sug_affine_act_groups(const float* z, int64_t ldz, const float* coef, int64_t rows, int groups, int C, float slope,
+                          float* out, int64_t ldo, hipStream_t st) {
+  const bool vec = (C % 4 == 0) && (ldz % 4 == 0) && (ldo % 4 == 0) && ((uintptr_t)z % 16 == 0) &&
+                   ((uintptr_t)out % 16 == 0) && ((uintptr_t)coef % 16 == 0);
+  if (!vec) return 1;
+  const int64_t total = rows * groups * (C / 4);
+  int64_t g = (total + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(affine_act_vec4_groups_kernel, dim3((int)g), dim3(256), 0, st, z, ldz, coef, rows * groups, rows, C,
+                     slope, out, ldo);
+  SUG_LAUNCH_CHECK("sug_bn_act_rows_fwd(act)");
+  return SUG_OK;
+}
+//   a = scale*G and the BatchNorm backward sums red [groups, 2C]
+int sug_bwd_reduce_groups(const float* gout, int64_t ldg, const float* z, const float* coef, int64_t rows, int Co,
+                          int groups, float slope, float* a, double* red, float* ws, hipStream_t st) {
+  const int grid = launch_col_reduce<1>(gout, ldg, z, coef, rows, Co, slope, a, ws, st, groups);
+  if (grid < 0) return 1;
+  SUG_LAUNCH_CHECK("sug_edgeconv_bwd_reduce");
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(sug_divup(2 * Co, 16), groups), dim3(256), 0, st, ws, grid, 2 * Co, red);
+  SUG_LAUNCH_CHECK("sug_edgeconv_bwd_reduce(reduce)");
   return SUG_OK;
 }
 

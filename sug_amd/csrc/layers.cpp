@@ -9,6 +9,18 @@
 void sug_set_error(const char* fmt, ...);
 // edgeconv.hip: sug_edgeconv_bwd_scatter over `groups` BatchNorm groups in one launch (group g reads
 // coef + g*coef_stride, red + g*red_stride)
+// grouped forms of the rows-layer kernels (edgeconv.hip, bnpool.hip): 0 = done, 1 = layout not vectorisable (go group
+// by group), < 0 = error
+struct ihipStream_t;
+int sug_col_stats_bn_groups(const float* y, int64_t ldy, int64_t rows, int C, int groups, const float* gamma,
+                            const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                            float* coef, float* ws, ihipStream_t* st);
+int sug_affine_act_groups(const float* z, int64_t ldz, const float* coef, int64_t rows, int groups, int C, float slope,
+                          float* out, int64_t ldo, ihipStream_t* st);
+int sug_bwd_reduce_groups(const float* gout, int64_t ldg, const float* z, const float* coef, int64_t rows, int Co,
+                          int groups, float slope, float* a, double* red, float* ws, ihipStream_t* st);
+int sug_bn_bwd_apply_groups(const float* a, const float* y, int64_t ldy, const float* coef, const double* red,
+                            int64_t rows_g, int groups, int C, float* dy, int64_t lddy, ihipStream_t* st);
 int sug_edgeconv_fwd_bn_act_groups(const float* pq, int64_t ldpq, const int32_t* idx, const float* gamma,
                                    const float* beta, int B, int N, int k, int Co, int groups, float eps, float momentum,
                                    float slope, float* running_mean, float* running_var, float* z, uint8_t* arg,
@@ -52,7 +64,12 @@ extern "C" int sug_edgeconv_layer_bwd(const float* gout, int64_t ldg, const floa
   const int Bg = B / groups;
   const int64_t rows = (int64_t)Bg * N;
   LAYER_TRY(sug_knn_reverse(idx, B, N, k, rev_off, rev_ent, stream));
-  for (int g = 0; g < groups; ++g) {
+  int grouped = 1;
+  if (groups > 1) {
+    grouped = sug_bwd_reduce_groups(gout, ldg, z, coef, rows, Co, groups, slope, a, red, ws, (ihipStream_t*)stream);
+    if (grouped < 0) return grouped;
+  }
+  for (int g = 0; grouped != 0 && g < groups; ++g) {
     const int64_t r0 = (int64_t)g * rows;
     const float* cg = coef + (int64_t)g * 5 * Co;
     double* rg = red + (int64_t)g * 2 * Co;                  // per group: dbeta | dgamma
@@ -75,6 +92,21 @@ extern "C" int sug_bn_act_rows_fwd(const float* y, int64_t ldy, int64_t rows, in
                 (long long)rows, groups);
   LAYER_REQUIRE(coef && out, "sug_bn_act_rows_fwd: null pointer");
   const int64_t rg = rows / groups;
+  ihipStream_t* st = (ihipStream_t*)stream;
+  if (groups > 1 && ldy == C) {                  // all groups per launch (3 launches instead of 3 per group)
+    int rc = training ? sug_col_stats_bn_groups(y, ldy, rg, C, groups, gamma, beta, eps, momentum, running_mean, running_var,
+                                                coef, ws, st)
+                      : 0;
+    if (rc < 0) return rc;
+    if (rc == 0) {
+      rc = sug_affine_act_groups(y, ldy, coef, rg, groups, C, slope, out, ldo, st);
+      if (rc <= 0) return rc;
+      // statistics done, activation not vectorisable: finish group by group
+      for (int g = 0; g < groups; ++g)
+        LAYER_TRY(sug_affine_act(y + g * rg * ldy, ldy, coef + (int64_t)g * 5 * C, rg, C, slope, out + g * rg * ldo, ldo, stream));
+      return SUG_OK;
+    }
+  }
   for (int g = 0; g < groups; ++g) {
     float* cg = coef + (int64_t)g * 5 * C;
     if (training)
@@ -92,12 +124,26 @@ extern "C" int sug_bn_act_rows_bwd(const float* gout, int64_t ldg, const float* 
                 (long long)rows, groups);
   LAYER_REQUIRE(ldy == C, "sug_bn_act_rows_bwd: y must be dense");
   const int64_t rg = rows / groups;
+  ihipStream_t* st = (ihipStream_t*)stream;
+  bool reduced = false;
+  if (groups > 1) {
+    const int rc = sug_bwd_reduce_groups(gout, ldg, y, coef, rg, C, groups, slope, a, red, ws, st);
+    if (rc < 0) return rc;
+    reduced = rc == 0;
+  }
+  bool applied = false;
+  if (reduced && training) {
+    const int rc = sug_bn_bwd_apply_groups(a, y, C, coef, red, rg, groups, C, dy, C, st);
+    if (rc < 0) return rc;
+    applied = rc == 0;
+  }
   for (int g = 0; g < groups; ++g) {
     const float* cg = coef + (int64_t)g * 5 * C;
     double* rd = red + (int64_t)g * 2 * C;
-    LAYER_TRY(sug_edgeconv_bwd_reduce(gout + g * rg * ldg, ldg, y + g * rg * C, cg, rg, C, slope, a + g * rg * C, rd, ws,
-                                      stream));
-    if (training)
+    if (!reduced)
+      LAYER_TRY(sug_edgeconv_bwd_reduce(gout + g * rg * ldg, ldg, y + g * rg * C, cg, rg, C, slope, a + g * rg * C, rd, ws,
+                                        stream));
+    if (training && !applied)
       LAYER_TRY(sug_bn_bwd_apply(a + g * rg * C, y + g * rg * C, C, cg, rd, rg, C, dy + g * rg * C, C, stream));
   }
   if (dgb) LAYER_TRY(sug_fold_groups(red, groups, 2 * C, dgb, stream));
