@@ -35,12 +35,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_vec4_kernel(const float* __r
   }
 }
 
-// bn_bwd_apply_vec4_kernel over `rows` rows in domain groups of rows_g: coefficient set and sums of each row's group
-__global__ __launch_bounds__(256) void bn_bwd_apply_vec4_groups_kernel(const float* __restrict__ a,
+// bn_bwd_apply_vec4_kernel over `rows` rows in domain groups of rows_g: coefficient set and sums of each row's group.
+// FROM_G: `a` is the upstream gradient (row stride lda) and a = scale * g * act'(scale*y + shift) is formed here
+// (the reduce kernel then writes no [rows, C] tensor: 5 passes over the layer instead of 6).
+template <bool FROM_G>
+__global__ __launch_bounds__(256) void bn_bwd_apply_vec4_groups_kernel(const float* __restrict__ a, int64_t lda,
                                                                        const float* __restrict__ y, int64_t ldy,
                                                                        const float* __restrict__ coef,
                                                                        const double* __restrict__ red, int64_t rows,
-                                                                       int64_t rows_g, int C, float invM,
+                                                                       int64_t rows_g, int C, float invM, float slope,
                                                                        float* __restrict__ dy, int64_t lddy) {
   const int C4 = C >> 2;
   const int64_t total = rows * C4;
@@ -50,11 +53,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_vec4_groups_kernel(const flo
     const int64_t g = r / rows_g;
     const float* cg = coef + g * 5 * C;
     const double* rg = red + g * 2 * C;
-    const float4 av = *reinterpret_cast<const float4*>(a + r * C + c);
+    float4 av = *reinterpret_cast<const float4*>(a + r * lda + c);
     const float4 yv = *reinterpret_cast<const float4*>(y + r * ldy + c);
     const float4 sc = *reinterpret_cast<const float4*>(cg + c);
     const float4 mean = *reinterpret_cast<const float4*>(cg + 2 * C + c);
     const float4 rstd = *reinterpret_cast<const float4*>(cg + 3 * C + c);
+    if (FROM_G) {
+      const float4 sh = *reinterpret_cast<const float4*>(cg + C + c);
+      av.x = sc.x * (av.x * (fmaf(sc.x, yv.x, sh.x) > 0.f ? 1.f : slope));
+      av.y = sc.y * (av.y * (fmaf(sc.y, yv.y, sh.y) > 0.f ? 1.f : slope));
+      av.z = sc.z * (av.z * (fmaf(sc.z, yv.z, sh.z) > 0.f ? 1.f : slope));
+      av.w = sc.w * (av.w * (fmaf(sc.w, yv.w, sh.w) > 0.f ? 1.f : slope));
+    }
     float4 o;
     o.x = av.x - sc.x * invM * ((float)rg[c + 0] + (yv.x - mean.x) * rstd.x * (float)rg[C + c + 0]);
     o.y = av.y - sc.y * invM * ((float)rg[c + 1] + (yv.y - mean.y) * rstd.y * (float)rg[C + c + 1]);
@@ -370,15 +380,22 @@ extern "C" int sug_bn_bwd_apply(const float* a, const float* y, int64_t ldy, con
   return SUG_OK;
 }
 
-// all domain groups (rows_g rows each) in one launch; 1 = layout does not allow it
-int sug_bn_bwd_apply_groups(const float* a, const float* y, int64_t ldy, const float* coef, const double* red,
-                            int64_t rows_g, int groups, int C, float* dy, int64_t lddy, hipStream_t st) {
-  const bool vec = (C % 4 == 0) && (ldy % 4 == 0) && (lddy % 4 == 0) && ((uintptr_t)a % 16 == 0) &&
+// all domain groups (rows_g rows each) in one launch; 1 = layout does not allow it.  from_g: `a` is the upstream
+// gradient gout (row stride lda) instead of the precomputed a = scale*G
+int sug_bn_bwd_apply_groups(const float* a, int64_t lda, int from_g, float slope, const float* y, int64_t ldy,
+                            const float* coef, const double* red, int64_t rows_g, int groups, int C, float* dy,
+                            int64_t lddy, hipStream_t st) {
+  const bool vec = (C % 4 == 0) && (ldy % 4 == 0) && (lddy % 4 == 0) && (lda % 4 == 0) && ((uintptr_t)a % 16 == 0) &&
                    ((uintptr_t)y % 16 == 0) && ((uintptr_t)dy % 16 == 0) && ((uintptr_t)coef % 16 == 0);
   if (!vec) return 1;
   const int64_t rows = rows_g * groups;
-  hipLaunchKernelGGL(bn_bwd_apply_vec4_groups_kernel, dim3(ew_grid(rows * C / 4)), dim3(256), 0, st, a, y, ldy, coef, red,
-                     rows, rows_g, C, (float)(1.0 / (double)rows_g), dy, lddy);
+  const float invM = (float)(1.0 / (double)rows_g);
+  if (from_g)
+    hipLaunchKernelGGL((bn_bwd_apply_vec4_groups_kernel<true>), dim3(ew_grid(rows * C / 4)), dim3(256), 0, st, a, lda, y, ldy,
+                       coef, red, rows, rows_g, C, invM, slope, dy, lddy);
+  else
+    hipLaunchKernelGGL((bn_bwd_apply_vec4_groups_kernel<false>), dim3(ew_grid(rows * C / 4)), dim3(256), 0, st, a, lda, y, ldy,
+                       coef, red, rows, rows_g, C, invM, slope, dy, lddy);
   SUG_LAUNCH_CHECK("sug_bn_bwd_apply");
   return SUG_OK;
 }

@@ -434,17 +434,32 @@ __global__ __launch_bounds__(256) void affine_act_vec4_groups_kernel(const float
                                                                      float* __restrict__ out, int64_t ldo) {
   const int C4 = C >> 2;
   const int64_t total = rows * C4;
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-    const int c = (int)(e % C4) * 4;
-    const int64_t r = e / C4;
-    const float* cg = coef + (r / rows_g) * 5 * C;
-    const float4 zv = ld4(z + r * ldz + c), sc = ld4(cg + c), sh = ld4(cg + C + c);
-    float4 u;
-    u.x = fmaf(sc.x, zv.x, sh.x); u.y = fmaf(sc.y, zv.y, sh.y);
-    u.z = fmaf(sc.z, zv.z, sh.z); u.w = fmaf(sc.w, zv.w, sh.w);
-    u.x = u.x > 0.f ? u.x : u.x * slope; u.y = u.y > 0.f ? u.y : u.y * slope;
-    u.z = u.z > 0.f ? u.z : u.z * slope; u.w = u.w > 0.f ? u.w : u.w * slope;
-    st4(out + r * ldo + c, u);
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  constexpr int U = 4;                            // independent 16-byte loads in flight per thread
+  for (int64_t e0 = (int64_t)blockIdx.x * 256 + threadIdx.x; e0 < total; e0 += U * stride) {
+    float4 zv[U];
+    int c[U];
+    int64_t r[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t e = e0 + u * stride;
+      const int64_t ee = e < total ? e : e0;
+      c[u] = (int)(ee % C4) * 4;
+      r[u] = ee / C4;
+      zv[u] = ld4(z + r[u] * ldz + c[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (e0 + u * stride >= total) continue;
+      const float* cg = coef + (r[u] / rows_g) * 5 * C;
+      const float4 sc = ld4(cg + c[u]), sh = ld4(cg + C + c[u]);
+      float4 v;
+      v.x = fmaf(sc.x, zv[u].x, sh.x); v.y = fmaf(sc.y, zv[u].y, sh.y);
+      v.z = fmaf(sc.z, zv[u].z, sh.z); v.w = fmaf(sc.w, zv[u].w, sh.w);
+      v.x = v.x > 0.f ? v.x : v.x * slope; v.y = v.y > 0.f ? v.y : v.y * slope;
+      v.z = v.z > 0.f ? v.z : v.z * slope; v.w = v.w > 0.f ? v.w : v.w * slope;
+      st4(out + r[u] * ldo + c[u], v);
+    }
   }
 }
 
@@ -511,9 +526,9 @@ __global__ __launch_bounds__(256) void col_reduce_vec4_kernel(const float* __res
   // [g * gridDim.x + blockIdx.x]
   const int64_t g0 = (int64_t)blockIdx.y * rows;
   y += g0 * ldy;
-  if (MODE == 1) {
+  if (MODE >= 1) {
     z += g0 * C;
-    a += g0 * C;
+    if (MODE == 1) a += g0 * C;
     coef += (int64_t)blockIdx.y * 5 * C;
   }
   ws += (size_t)blockIdx.y * gridDim.x * 2 * C;
@@ -527,7 +542,7 @@ __global__ __launch_bounds__(256) void col_reduce_vec4_kernel(const float* __res
     const int c = c4 * 4;
     float4 s = make_float4(0, 0, 0, 0), q = make_float4(0, 0, 0, 0);
     float4 sc = s, sh = s, mean = s, rstd = s;
-    if (MODE == 1) {
+    if (MODE >= 1) {
       sc = *reinterpret_cast<const float4*>(coef + c);
       sh = *reinterpret_cast<const float4*>(coef + C + c);
       mean = *reinterpret_cast<const float4*>(coef + 2 * C + c);
@@ -546,7 +561,8 @@ __global__ __launch_bounds__(256) void col_reduce_vec4_kernel(const float* __res
         g.y = v.y * (fmaf(sc.y, zv.y, sh.y) > 0.f ? 1.f : slope);
         g.z = v.z * (fmaf(sc.z, zv.z, sh.z) > 0.f ? 1.f : slope);
         g.w = v.w * (fmaf(sc.w, zv.w, sh.w) > 0.f ? 1.f : slope);
-        *reinterpret_cast<float4*>(a + r * C + c) = make_float4(sc.x * g.x, sc.y * g.y, sc.z * g.z, sc.w * g.w);
+        if (MODE == 1)      // MODE 2: sums only (the apply kernel recomputes a = scale*G from gout and z)
+          *reinterpret_cast<float4*>(a + r * C + c) = make_float4(sc.x * g.x, sc.y * g.y, sc.z * g.z, sc.w * g.w);
         s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;
         q.x = fmaf(g.x, (zv.x - mean.x) * rstd.x, q.x); q.y = fmaf(g.y, (zv.y - mean.y) * rstd.y, q.y);
         q.z = fmaf(g.z, (zv.z - mean.z) * rstd.z, q.z); q.w = fmaf(g.w, (zv.w - mean.w) * rstd.w, q.w);
@@ -913,8 +929,8 @@ int sug_edgeconv_fwd_bn_act_groups(const float* pq, int64_t ldpq, const int32_t*
                        gamma, beta, (double)rows * k, eps, momentum, running_mean, running_var, coef);
     SUG_LAUNCH_CHECK("sug_edgeconv_layer_fwd(finalize)");
     const int64_t total = (int64_t)B * N * (Co / 4);
-    int64_t g = (total + 255) / 256;
-    if (g > 4096) g = 4096;
+    int64_t g = (total + 1023) / 1024;
+    if (g > 8192) g = 8192;
     hipLaunchKernelGGL(affine_act_vec4_groups_kernel, dim3((int)g), dim3(256), 0, st, z, (int64_t)Co, coef, (int64_t)B * N, rows,
                        Co, slope, out, ldo);
     SUG_LAUNCH_CHECK("sug_edgeconv_layer_fwd(act)");
@@ -988,7 +1004,7 @@ template <int MODE>
 static int launch_col_reduce(const float* y, int64_t ldy, const float* z, const float* coef, int64_t rows,
                              int C, float slope, float* a, float* ws, hipStream_t st, int groups) {
   const bool vec = (C % 4 == 0) && (ldy % 4 == 0) && ((uintptr_t)y % 16 == 0) &&
-                   (MODE == 0 || (((uintptr_t)z % 16 == 0) && ((uintptr_t)a % 16 == 0) && ((uintptr_t)coef % 16 == 0)));
+                   (MODE == 0 || (((uintptr_t)z % 16 == 0) && (MODE == 2 || (uintptr_t)a % 16 == 0) && ((uintptr_t)coef % 16 == 0)));
   if (vec) {
     int lx = 1;
     while (lx < (C >> 2) && lx < 256) lx <<= 1;
@@ -1002,7 +1018,7 @@ static int launch_col_reduce(const float* y, int64_t ldy, const float* z, const 
                        st, y, ldy, z, coef, rows, C, slope, a, ws, lx, (int)rpb);
     return grid;
   }
-  if (groups > 1) return -1;
+  if (groups > 1 || MODE == 2) return -1;
   const int cw = col_width(C);
   const int rpb = col_rows_per_block(rows, cw);
   const int grid = sug_divup(rows, rpb);
@@ -1059,8 +1075,9 @@ int sug_affine_act_groups(const float* z, int64_t ldz, const float* coef, int64_
                    ((uintptr_t)out % 16 == 0) && ((uintptr_t)coef % 16 == 0);
   if (!vec) return 1;
   const int64_t total = rows * groups * (C / 4);
-  int64_t g = (total + 255) / 256;
-  if (g > 4096) g = 4096;
+  int64_t g = (total + 1023) / 1024;             // 4 float4 per thread and iteration
+  if (g > 8192) g = 8192;
+  if (g < 1) g = 1;
   hipLaunchKernelGGL(affine_act_vec4_groups_kernel, dim3((int)g), dim3(256), 0, st, z, ldz, coef, rows * groups, rows, C,
                      slope, out, ldo);
   SUG_LAUNCH_CHECK("sug_bn_act_rows_fwd(act)");
@@ -1069,7 +1086,9 @@ int sug_affine_act_groups(const float* z, int64_t ldz, const float* coef, int64_
 //   a = scale*G and the BatchNorm backward sums red [groups, 2C]
 int sug_bwd_reduce_groups(const float* gout, int64_t ldg, const float* z, const float* coef, int64_t rows, int Co,
                           int groups, float slope, float* a, double* red, float* ws, hipStream_t st) {
-  const int grid = launch_col_reduce<1>(gout, ldg, z, coef, rows, Co, slope, a, ws, st, groups);
+  // a == nullptr: sums only
+  const int grid = a ? launch_col_reduce<1>(gout, ldg, z, coef, rows, Co, slope, a, ws, st, groups)
+                     : launch_col_reduce<2>(gout, ldg, z, coef, rows, Co, slope, nullptr, ws, st, groups);
   if (grid < 0) return 1;
   SUG_LAUNCH_CHECK("sug_edgeconv_bwd_reduce");
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(sug_divup(2 * Co, 16), groups), dim3(256), 0, st, ws, grid, 2 * Co, red);

@@ -19,8 +19,9 @@ int sug_affine_act_groups(const float* z, int64_t ldz, const float* coef, int64_
                           float* out, int64_t ldo, ihipStream_t* st);
 int sug_bwd_reduce_groups(const float* gout, int64_t ldg, const float* z, const float* coef, int64_t rows, int Co,
                           int groups, float slope, float* a, double* red, float* ws, ihipStream_t* st);
-int sug_bn_bwd_apply_groups(const float* a, const float* y, int64_t ldy, const float* coef, const double* red,
-                            int64_t rows_g, int groups, int C, float* dy, int64_t lddy, ihipStream_t* st);
+int sug_bn_bwd_apply_groups(const float* a, int64_t lda, int from_g, float slope, const float* y, int64_t ldy,
+                            const float* coef, const double* red, int64_t rows_g, int groups, int C, float* dy,
+                            int64_t lddy, ihipStream_t* st);
 int sug_edgeconv_fwd_bn_act_groups(const float* pq, int64_t ldpq, const int32_t* idx, const float* gamma,
                                    const float* beta, int B, int N, int k, int Co, int groups, float eps, float momentum,
                                    float slope, float* running_mean, float* running_var, float* z, uint8_t* arg,
@@ -125,6 +126,19 @@ extern "C" int sug_bn_act_rows_bwd(const float* gout, int64_t ldg, const float* 
   LAYER_REQUIRE(ldy == C, "sug_bn_act_rows_bwd: y must be dense");
   const int64_t rg = rows / groups;
   ihipStream_t* st = (ihipStream_t*)stream;
+  // train mode, vectorisable layout: sums without the [rows, C] intermediate a = scale*G, the apply kernel forms it
+  // from gout and y (5 passes over the layer instead of 6), all groups per launch
+  if (training && ldg % 4 == 0 && C % 4 == 0 && ((uintptr_t)gout % 16) == 0 && ((uintptr_t)y % 16) == 0 &&
+      ((uintptr_t)dy % 16) == 0 && ((uintptr_t)coef % 16) == 0) {
+    int rc = sug_bwd_reduce_groups(gout, ldg, y, coef, rg, C, groups, slope, nullptr, red, ws, st);
+    if (rc < 0) return rc;
+    if (rc == 0) {
+      rc = sug_bn_bwd_apply_groups(gout, ldg, 1, slope, y, C, coef, red, rg, groups, C, dy, C, st);
+      if (rc != 0) return rc < 0 ? rc : SUG_ERR_ARG;
+      if (dgb) LAYER_TRY(sug_fold_groups(red, groups, 2 * C, dgb, stream));
+      return SUG_OK;
+    }
+  }
   bool reduced = false;
   if (groups > 1) {
     const int rc = sug_bwd_reduce_groups(gout, ldg, y, coef, rg, C, groups, slope, a, red, ws, st);
@@ -133,7 +147,7 @@ extern "C" int sug_bn_act_rows_bwd(const float* gout, int64_t ldg, const float* 
   }
   bool applied = false;
   if (reduced && training) {
-    const int rc = sug_bn_bwd_apply_groups(a, y, C, coef, red, rg, groups, C, dy, C, st);
+    const int rc = sug_bn_bwd_apply_groups(a, C, 0, slope, y, C, coef, red, rg, groups, C, dy, C, st);
     if (rc < 0) return rc;
     applied = rc == 0;
   }
