@@ -229,7 +229,7 @@ int sug_adam_step_capturable(const int64_t* table, const int32_t* block_first, c
 /* ---- SA-node module glue (adapt_layer_off, model/model_utils.py:103-128) --------------------
  * off[b,s,:] = mean_j tanh(proj[b,g_j,:] - proj[b,f,:]) * (loc[b,g_j,:] - loc[b,f,:]),
  * nloc = loc[b,f,:] + off, with f = fidx[b,s], g_j = gidx[b,s,j], proj = fea . W_pred_offset^T
- * ([B,N,3]; :110-119).  Backward: dproj [B,N,3] (zero-initialised by the caller, atomics). */
+ * ([B,N,3]; :110-119).  Backward: dproj [B,N,3], written entirely by the call (accumulated per cloud in LDS). */
 int sug_node_offset_fwd(const float* proj, const float* loc, const int32_t* fidx,
                         const int32_t* gidx, int B, int N, int S, int ns, float* off, float* nloc,
                         void* stream);

@@ -45,13 +45,24 @@ __global__ __launch_bounds__(256) void group_max_kernel(const float* __restrict_
     const int32_t* ir = idx + row * ns;
     float best = -INFINITY;
     int bj = -1;
-    for (int t = 0; t < ns; ++t) {
-      const int j = ir[t];
-      if (j < 0 || j >= N) continue;
-      const float v = feat[((int64_t)b * N + j) * ldf + c];
-      if (v > best || bj < 0) {
-        best = v;
-        bj = j;
+    // 8 neighbours at a time: all index loads, then all feature loads, then the comparisons in list order
+    for (int t0 = 0; t0 < ns; t0 += 8) {
+      int j[8];
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) j[u] = ir[t0 + u < ns ? t0 + u : ns - 1];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int jc = j[u] < 0 ? 0 : (j[u] >= N ? N - 1 : j[u]);
+        v[u] = feat[((int64_t)b * N + jc) * ldf + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (t0 + u >= ns || j[u] < 0 || j[u] >= N) continue;
+        if (v[u] > best || bj < 0) {
+          best = v[u];
+          bj = j[u];
+        }
       }
     }
     out[e] = bj < 0 ? 0.f : best;

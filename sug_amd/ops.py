@@ -376,7 +376,7 @@ class _NodeOffset(torch.autograd.Function):
         B, N, _ = proj.shape
         S, ns = gidx.shape[1], gidx.shape[2]
         g = (goff + gnloc).contiguous()                 # nloc = loc[f] + off
-        dproj = torch.zeros_like(proj)
+        dproj = torch.empty_like(proj)              # written (or zeroed) entirely by the entry point
         check(lib().sug_node_offset_bwd(_p(proj), _p(loc), _p(fidx), _p(gidx), _p(g), B, N, S, ns, _p(dproj), _st()),
               'sug_node_offset_bwd')
         return dproj, None, None, None
