@@ -329,47 +329,55 @@ __global__ __launch_bounds__(256) void stats_finalize_groups_kernel(const float*
                                                                     const float* __restrict__ beta, double count,
                                                                     float eps, float momentum, float* __restrict__ rmean,
                                                                     float* __restrict__ rvar, float* __restrict__ coef) {
-  __shared__ double s_p[16][17];
-  __shared__ double s_tot[16];
+  constexpr int GMAX = 4;                        // groups folded in one pass over the partial rows (loads of all
+  __shared__ double s_p[GMAX][16][17];           // groups in flight together); more groups: further passes
+  __shared__ double s_tot[GMAX][16];
   const int cl = threadIdx.x & 15, p = threadIdx.x >> 4;
   const int ch = blockIdx.x * 8 + (cl & 7);                 // cl < 8: sum column, cl >= 8: sum of squares
   const int col = (cl < 8) ? ch : C + ch;
   const int W = 2 * C;
   const bool fin = threadIdx.x < 8 && ch < C;
   float rm = (fin && rmean) ? rmean[ch] : 0.f, rv = (fin && rvar) ? rvar[ch] : 0.f;
-  for (int g = 0; g < groups; ++g) {
-    const float* wg = ws + (size_t)g * nblk * W;
-    float* cg = coef + (size_t)g * 5 * C;
-    double acc = 0.0;
+  for (int g0 = 0; g0 < groups; g0 += GMAX) {
+    const int ng = groups - g0 < GMAX ? groups - g0 : GMAX;
+    double acc[GMAX] = {0.0, 0.0, 0.0, 0.0};
     if (ch < C) {
-#pragma unroll 8
-      for (int b = p; b < nblk; b += 16) acc += (double)wg[(size_t)b * W + col];
+#pragma unroll 4
+      for (int b = p; b < nblk; b += 16) {
+#pragma unroll
+        for (int g = 0; g < GMAX; ++g)
+          if (g < ng) acc[g] += (double)ws[((size_t)(g0 + g) * nblk + b) * W + col];
+      }
     }
     __syncthreads();
-    s_p[p][cl] = acc;
+#pragma unroll
+    for (int g = 0; g < GMAX; ++g) s_p[g][p][cl] = acc[g];
     __syncthreads();
-    if (p == 0) {
+    if (p < ng) {                                 // row-lane p folds group p
       double t = 0.0;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) t += s_p[i][cl];
-      s_tot[cl] = t;
+      for (int i = 0; i < 16; ++i) t += s_p[p][i][cl];
+      s_tot[p][cl] = t;
     }
     __syncthreads();
     if (fin) {
       const int c = ch;
-      const double mean = s_tot[threadIdx.x] / count;
-      double var = s_tot[8 + threadIdx.x] / count - mean * mean;
-      if (var < 0) var = 0;
-      const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-      const float scale = gamma[c] * rstd;
-      cg[c] = scale;
-      cg[C + c] = beta[c] - (float)mean * scale;
-      cg[2 * C + c] = (float)mean;
-      cg[3 * C + c] = rstd;
-      const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
-      cg[4 * C + c] = (float)unb;
-      rm = (1.f - momentum) * rm + momentum * (float)mean;
-      rv = (1.f - momentum) * rv + momentum * (float)unb;
+      for (int g = 0; g < ng; ++g) {               // in group order: the running buffers see one update after the other
+        float* cg = coef + (size_t)(g0 + g) * 5 * C;
+        const double mean = s_tot[g][threadIdx.x] / count;
+        double var = s_tot[g][8 + threadIdx.x] / count - mean * mean;
+        if (var < 0) var = 0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float scale = gamma[c] * rstd;
+        cg[c] = scale;
+        cg[C + c] = beta[c] - (float)mean * scale;
+        cg[2 * C + c] = (float)mean;
+        cg[3 * C + c] = rstd;
+        const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+        cg[4 * C + c] = (float)unb;
+        rm = (1.f - momentum) * rm + momentum * (float)mean;
+        rv = (1.f - momentum) * rv + momentum * (float)unb;
+      }
     }
   }
   if (fin) {

@@ -393,14 +393,15 @@ __global__ __launch_bounds__(256) void pointmlp_bwd_dw_fold_kernel(const float* 
 // Coefficients from the folded statistics (fp64, as the torch expressions they replace):
 //   k2 = scale/M * rstd * dgamma,  kb = scale/M * (dbeta - mean*rstd*dgamma) + k2*b
 // One launch: block i < K writes row i of -A; block K writes -v, kb, k2.  (A dozen torch launches per group before.)
-__global__ __launch_bounds__(128) void pointmlp_bwd_coef_kernel(const float* __restrict__ coef, const double* __restrict__ red,
+__global__ __launch_bounds__(256) void pointmlp_bwd_coef_kernel(const float* __restrict__ coef, const double* __restrict__ red,
                                                                  const float* __restrict__ bias, const float* __restrict__ w,
                                                                  double M, int K, int Co, float* __restrict__ kb,
                                                                  float* __restrict__ k2, float* __restrict__ negA,
                                                                  float* __restrict__ negv) {
-  extern __shared__ float s_k[];                 // [Co] k2 or kb of this block
+  extern __shared__ float s_k[];                 // [Co] k2 or kb of this block | [256] partial sums
+  float* s_part = s_k + Co;
   const bool vrow = (int)blockIdx.x == K;
-  for (int c = threadIdx.x; c < Co; c += 128) {
+  for (int c = threadIdx.x; c < Co; c += 256) {
     const double scale = coef[c], mean = coef[2 * Co + c], rstd = coef[3 * Co + c];
     const double dbeta = red[c], dgamma = red[Co + c];
     const double k2d = scale / M * rstd * dgamma;
@@ -413,16 +414,33 @@ __global__ __launch_bounds__(128) void pointmlp_bwd_coef_kernel(const float* __r
     }
   }
   __syncthreads();
-  const int j = threadIdx.x;
-  if (j >= K) return;
+  // thread = (column j, half h of the Co range); 8 rows of w in flight per thread (a plain loop waits for every load)
+  const int j = threadIdx.x & 127, h = threadIdx.x >> 7;
+  const int i = vrow ? 0 : blockIdx.x;
+  const int c0 = h * (Co / 2), c1 = h ? Co : Co / 2;
   float acc = 0.f;
-  if (vrow) {
-    for (int c = 0; c < Co; ++c) acc = fmaf(s_k[c], w[(size_t)c * K + j], acc);
-    negv[j] = -acc;
-  } else {
-    const int i = blockIdx.x;
-    for (int c = 0; c < Co; ++c) acc = fmaf(s_k[c] * w[(size_t)c * K + i], w[(size_t)c * K + j], acc);
-    negA[(size_t)i * K + j] = -acc;
+  if (j < K) {
+    for (int c = c0; c < c1; c += 8) {
+      float wi[8], wj[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int cc = c + u < c1 ? c + u : c1 - 1;
+        wi[u] = vrow ? 1.f : w[(size_t)cc * K + i];
+        wj[u] = w[(size_t)cc * K + j];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (c + u < c1) acc = fmaf(s_k[c + u] * wi[u], wj[u], acc);
+    }
+  }
+  s_part[threadIdx.x] = acc;
+  __syncthreads();
+  if (h == 0 && j < K) {
+    const float t = -(s_part[j] + s_part[128 + j]);
+    if (vrow)
+      negv[j] = t;
+    else
+      negA[(size_t)i * K + j] = t;
   }
 }
 
@@ -535,8 +553,8 @@ extern "C" int sug_pointmlp_max_bwd_coef(const float* coef, const double* red, c
                                         int64_t rows, int K, int Co, float* kb, float* k2, float* negA, float* negv,
                                         void* stream) {
   SUG_REQUIRE(coef && red && w && kb && k2 && negA && negv, "sug_pointmlp_max_bwd_coef: null pointer");
-  SUG_REQUIRE(K > 0 && K <= 128 && Co > 0 && Co <= 8192 && rows > 0, "sug_pointmlp_max_bwd_coef: bad shape");
-  hipLaunchKernelGGL(pointmlp_bwd_coef_kernel, dim3(K + 1), dim3(128), (size_t)Co * sizeof(float), (hipStream_t)stream, coef,
+  SUG_REQUIRE(K > 0 && K <= 128 && Co > 1 && Co % 2 == 0 && Co <= 8192 && rows > 0, "sug_pointmlp_max_bwd_coef: bad shape");
+  hipLaunchKernelGGL(pointmlp_bwd_coef_kernel, dim3(K + 1), dim3(256), (size_t)(Co + 256) * sizeof(float), (hipStream_t)stream, coef,
                      red, bias, w, (double)rows, K, Co, kb, k2, negA, negv);
   SUG_LAUNCH_CHECK("sug_pointmlp_max_bwd_coef");
   return SUG_OK;

@@ -34,5 +34,7 @@ for e in prof.events():
         agg[key][1] += t
 tot = sum(v[1] for v in agg.values())
 print('total kernel time %.2f ms' % (tot / 1e3))
-for (name, shp), (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
+by_count = os.environ.get('BY_COUNT') == '1'
+print('launches %d' % sum(v[0] for v in agg.values()))
+for (name, shp), (n, t) in sorted(agg.items(), key=lambda kv: -(kv[1][0] if by_count else kv[1][1]))[:45]:
     print('%8.1f us %3d  %-34s %s' % (t, n, name[:34], shp))
