@@ -371,12 +371,12 @@ int sug_pointmlp_max_layer_fwd(const float* x, int64_t ldx, int64_t rows, int K,
 /* The dense (rank-K) BatchNorm-statistics terms of the same backward, dy = a_full - k1 - k2*y over ALL rows:
  *   dx = ... - (x.A + v),  A = W^T diag(k2) W,  v = (k1 + k2*b).W;   dW = ... - kb (x) sum(x) - diag(k2) W.(X^T X)
  * _coef: from one group's coefficients coef [5,Co] and folded sums red [2Co] (dbeta | dgamma) over `rows` rows:
- *   k2 = scale/rows*rstd*dgamma, kb = scale/rows*(dbeta - mean*rstd*dgamma) + k2*bias (fp64), and -A [K,K], -v [K]
- *   (the operands of one library GEMM with a bias epilogue that forms the dense part of dx).
+ *   k2 = scale/rows*rstd*dgamma, kb = scale/rows*(dbeta - mean*rstd*dgamma) + k2*bias (fp64), and the operands
+ *   nkb = -kb [Co], nwk = -diag(k2).W [Co,K] of the two small library products -A = nwk^T.W, -v = nkb.W.
  * _dwfix: dw += dws - (kb (x) sx + diag(k2) W.XtX) with XtX [K,K], sx [K] from sug_linear_dw_bias(x, x)
  *   (with_stats = 0, eval mode: dw += dws). */
 int sug_pointmlp_max_bwd_coef(const float* coef, const double* red, const float* bias, const float* w, int64_t rows,
-                              int K, int Co, float* kb, float* k2, float* negA, float* negv, void* stream);
+                              int K, int Co, float* kb, float* k2, float* nkb, float* nwk, void* stream);
 int sug_pointmlp_max_bwd_dwfix(float* dw, const float* dws, const float* kb, const float* k2, const float* w,
                                const float* xtx, const float* sx, int K, int Co, int with_stats, void* stream);
 int64_t sug_pointmlp_max_bwd_workspace(int64_t rows, int K, int Co, int seg);

@@ -324,14 +324,15 @@ __global__ __launch_bounds__(256) void stats_finalize_kernel(const float* __rest
 
 // stats_finalize_kernel for `groups` consecutive blocks of nblk partial rows (one BatchNorm call per domain group,
 // in group order: the running statistics see the groups' updates one after the other, as separate calls would).
-__global__ __launch_bounds__(256) void stats_finalize_groups_kernel(const float* __restrict__ ws, int nblk, int C, int groups,
+__global__ __launch_bounds__(1024) void stats_finalize_groups_kernel(const float* __restrict__ ws, int nblk, int C, int groups,
                                                                     const float* __restrict__ gamma,
                                                                     const float* __restrict__ beta, double count,
                                                                     float eps, float momentum, float* __restrict__ rmean,
                                                                     float* __restrict__ rvar, float* __restrict__ coef) {
   constexpr int GMAX = 4;                        // groups folded in one pass over the partial rows (loads of all
-  __shared__ double s_p[GMAX][16][17];           // groups in flight together); more groups: further passes
-  __shared__ double s_tot[GMAX][16];
+  constexpr int RL = 64;                         // groups in flight together); more groups: further passes.  64 row
+  __shared__ double s_p[GMAX][RL][17];           // lanes (1024 threads): hundreds of partial rows, walked serially by
+  __shared__ double s_tot[GMAX][16];             // 16 row lanes, made this launch 22 us
   const int cl = threadIdx.x & 15, p = threadIdx.x >> 4;
   const int ch = blockIdx.x * 8 + (cl & 7);                 // cl < 8: sum column, cl >= 8: sum of squares
   const int col = (cl < 8) ? ch : C + ch;
@@ -343,7 +344,7 @@ __global__ __launch_bounds__(256) void stats_finalize_groups_kernel(const float*
     double acc[GMAX] = {0.0, 0.0, 0.0, 0.0};
     if (ch < C) {
 #pragma unroll 4
-      for (int b = p; b < nblk; b += 16) {
+      for (int b = p; b < nblk; b += RL) {
 #pragma unroll
         for (int g = 0; g < GMAX; ++g)
           if (g < ng) acc[g] += (double)ws[((size_t)(g0 + g) * nblk + b) * W + col];
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(256) void stats_finalize_groups_kernel(const float*
     if (p < ng) {                                 // row-lane p folds group p
       double t = 0.0;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) t += s_p[p][i][cl];
+      for (int i = 0; i < RL; ++i) t += s_p[p][i][cl];
       s_tot[p][cl] = t;
     }
     __syncthreads();
@@ -933,7 +934,7 @@ int sug_edgeconv_fwd_bn_act_groups(const float* pq, int64_t ldpq, const int32_t*
   if (one) {
     int nblk = 0;
     if (int rc = edgeconv_fwd_partials(pq, ldpq, idx, gamma, B, N, k, Co, z, arg, s1, ws, &nblk, stream)) return rc;
-    hipLaunchKernelGGL(stats_finalize_groups_kernel, dim3(sug_divup(Co, 8)), dim3(256), 0, st, ws, nblk / groups, Co, groups,
+    hipLaunchKernelGGL(stats_finalize_groups_kernel, dim3(sug_divup(Co, 8)), dim3(1024), 0, st, ws, nblk / groups, Co, groups,
                        gamma, beta, (double)rows * k, eps, momentum, running_mean, running_var, coef);
     SUG_LAUNCH_CHECK("sug_edgeconv_layer_fwd(finalize)");
     const int64_t total = (int64_t)B * N * (Co / 4);
@@ -1071,7 +1072,7 @@ int sug_col_stats_bn_groups(const float* y, int64_t ldy, int64_t rows, int C, in
   const int grid = launch_col_reduce<0>(y, ldy, nullptr, nullptr, rows, C, 0.f, nullptr, ws, st, groups);
   if (grid < 0) return 1;
   SUG_LAUNCH_CHECK("sug_bn_act_rows_fwd(stats)");
-  hipLaunchKernelGGL(stats_finalize_groups_kernel, dim3(sug_divup(C, 8)), dim3(256), 0, st, ws, grid, C, groups, gamma, beta,
+  hipLaunchKernelGGL(stats_finalize_groups_kernel, dim3(sug_divup(C, 8)), dim3(1024), 0, st, ws, grid, C, groups, gamma, beta,
                      (double)rows, eps, momentum, running_mean, running_var, coef);
   SUG_LAUNCH_CHECK("sug_bn_act_rows_fwd(finalize)");
   return SUG_OK;

@@ -392,56 +392,25 @@ __global__ __launch_bounds__(256) void pointmlp_bwd_dw_fold_kernel(const float* 
 // gives dx = ... - (x.A + v), A = W^T diag(k2) W, v = (k1 + k2*b).W, and dW = ... - kb (x) sum(x) - diag(k2) W.(X^T X).
 // Coefficients from the folded statistics (fp64, as the torch expressions they replace):
 //   k2 = scale/M * rstd * dgamma,  kb = scale/M * (dbeta - mean*rstd*dgamma) + k2*b
-// One launch: block i < K writes row i of -A; block K writes -v, kb, k2.  (A dozen torch launches per group before.)
+// One elementwise launch writes kb, k2, -kb and -diag(k2).W; the two small products -A = (-diag(k2) W)^T.W and
+// -v = (-kb).W are left to the library (a one-workgroup-per-row version of them ran at 94 us: 1024 dependent steps).
 __global__ __launch_bounds__(256) void pointmlp_bwd_coef_kernel(const float* __restrict__ coef, const double* __restrict__ red,
                                                                  const float* __restrict__ bias, const float* __restrict__ w,
                                                                  double M, int K, int Co, float* __restrict__ kb,
-                                                                 float* __restrict__ k2, float* __restrict__ negA,
-                                                                 float* __restrict__ negv) {
-  extern __shared__ float s_k[];                 // [Co] k2 or kb of this block | [256] partial sums
-  float* s_part = s_k + Co;
-  const bool vrow = (int)blockIdx.x == K;
-  for (int c = threadIdx.x; c < Co; c += 256) {
-    const double scale = coef[c], mean = coef[2 * Co + c], rstd = coef[3 * Co + c];
-    const double dbeta = red[c], dgamma = red[Co + c];
-    const double k2d = scale / M * rstd * dgamma;
-    const double k1d = scale / M * (dbeta - mean * rstd * dgamma);
-    const float k2f = (float)k2d, kbf = (float)(k1d + (bias ? k2d * (double)bias[c] : 0.0));
-    s_k[c] = vrow ? kbf : k2f;
-    if (vrow) {
-      kb[c] = kbf;
-      k2[c] = k2f;
-    }
+                                                                 float* __restrict__ k2, float* __restrict__ nkb,
+                                                                 float* __restrict__ nwk) {
+  const int c = blockIdx.x;
+  const double scale = coef[c], mean = coef[2 * Co + c], rstd = coef[3 * Co + c];
+  const double dbeta = red[c], dgamma = red[Co + c];
+  const double k2d = scale / M * rstd * dgamma;
+  const double k1d = scale / M * (dbeta - mean * rstd * dgamma);
+  const float k2f = (float)k2d, kbf = (float)(k1d + (bias ? k2d * (double)bias[c] : 0.0));
+  if (threadIdx.x == 0) {
+    kb[c] = kbf;
+    k2[c] = k2f;
+    nkb[c] = -kbf;
   }
-  __syncthreads();
-  // thread = (column j, half h of the Co range); 8 rows of w in flight per thread (a plain loop waits for every load)
-  const int j = threadIdx.x & 127, h = threadIdx.x >> 7;
-  const int i = vrow ? 0 : blockIdx.x;
-  const int c0 = h * (Co / 2), c1 = h ? Co : Co / 2;
-  float acc = 0.f;
-  if (j < K) {
-    for (int c = c0; c < c1; c += 8) {
-      float wi[8], wj[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int cc = c + u < c1 ? c + u : c1 - 1;
-        wi[u] = vrow ? 1.f : w[(size_t)cc * K + i];
-        wj[u] = w[(size_t)cc * K + j];
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (c + u < c1) acc = fmaf(s_k[c + u] * wi[u], wj[u], acc);
-    }
-  }
-  s_part[threadIdx.x] = acc;
-  __syncthreads();
-  if (h == 0 && j < K) {
-    const float t = -(s_part[j] + s_part[128 + j]);
-    if (vrow)
-      negv[j] = t;
-    else
-      negA[(size_t)i * K + j] = t;
-  }
+  for (int j = threadIdx.x; j < K; j += 256) nwk[(size_t)c * K + j] = -(k2f * w[(size_t)c * K + j]);
 }
 
 // dw[c,:] += dws[c,:] - (kb[c]*sx[:] + k2[c] * w[c,:].XtX)   (with_stats = 0: dw += dws)
@@ -550,12 +519,12 @@ extern "C" int sug_pointmlp_max_layer_fwd(const float* x, int64_t ldx, int64_t r
 }
 
 extern "C" int sug_pointmlp_max_bwd_coef(const float* coef, const double* red, const float* bias, const float* w,
-                                        int64_t rows, int K, int Co, float* kb, float* k2, float* negA, float* negv,
+                                        int64_t rows, int K, int Co, float* kb, float* k2, float* nkb, float* nwk,
                                         void* stream) {
-  SUG_REQUIRE(coef && red && w && kb && k2 && negA && negv, "sug_pointmlp_max_bwd_coef: null pointer");
-  SUG_REQUIRE(K > 0 && K <= 128 && Co > 1 && Co % 2 == 0 && Co <= 8192 && rows > 0, "sug_pointmlp_max_bwd_coef: bad shape");
-  hipLaunchKernelGGL(pointmlp_bwd_coef_kernel, dim3(K + 1), dim3(256), (size_t)(Co + 256) * sizeof(float), (hipStream_t)stream, coef,
-                     red, bias, w, (double)rows, K, Co, kb, k2, negA, negv);
+  SUG_REQUIRE(coef && red && w && kb && k2 && nkb && nwk, "sug_pointmlp_max_bwd_coef: null pointer");
+  SUG_REQUIRE(K > 0 && Co > 0 && Co <= 65535 && rows > 0, "sug_pointmlp_max_bwd_coef: bad shape");
+  hipLaunchKernelGGL(pointmlp_bwd_coef_kernel, dim3(Co), dim3(256), 0, (hipStream_t)stream, coef, red, bias, w, (double)rows, K,
+                     Co, kb, k2, nkb, nwk);
   SUG_LAUNCH_CHECK("sug_pointmlp_max_bwd_coef");
   return SUG_OK;
 }

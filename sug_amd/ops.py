@@ -854,6 +854,7 @@ class _PointMLPMax(torch.autograd.Function):
         L = lib()
         f32 = dict(dtype=torch.float32, device=dev)
         kbk2, negA, negv = torch.empty(2, Co, **f32), torch.empty(K, K, **f32), torch.empty(K, **f32)
+        nkb, nwk = torch.empty(Co, **f32), torch.empty(Co, K, **f32)
         xtx, sx = torch.empty(K, K, **f32), torch.empty(K, **f32)
         wsx = torch.empty(int(L.sug_linear_dw_workspace(rg, K, K)), **f32) if training else None
         for gi in range(G):
@@ -865,9 +866,11 @@ class _PointMLPMax(torch.autograd.Function):
             dxg = dx[gi * rg:(gi + 1) * rg]
             if training:
                 # dy = a_full - (scale/M)(dbeta + xhat*dgamma) = a_full - k1 - k2*y over ALL rows, y = x.W^T + b:
-                # the rank-K operands -A, -v and the coefficients kb, k2 from one launch (sug_pointmlp_max_bwd_coef)
+                # the coefficients kb, k2 and the operands of -A, -v from one launch (sug_pointmlp_max_bwd_coef)
                 check(L.sug_pointmlp_max_bwd_coef(_p(cg), _p(red[gi]), _p(b1), _p(w2), rg, K, Co, _p(kbk2[0]), _p(kbk2[1]),
-                                                  _p(negA), _p(negv), _st()), 'sug_pointmlp_max_bwd_coef')
+                                                  _p(nkb), _p(nwk), _st()), 'sug_pointmlp_max_bwd_coef')
+                torch.mm(nwk.t(), w2, out=negA)                         # -A = -(W^T diag(k2) W)   [K,K]
+                torch.mv(w2.t(), nkb, out=negv)                         # -v = -(kb . W)           [K]
                 check(L.sug_linear_dw_bias(_p(xg), xg.stride(0), _p(xg), xg.stride(0), rg, K, K, _p(xtx), _p(sx), _p(wsx),
                                            _st()), 'sug_linear_dw_bias')        # X^T X and the column sums of x
                 # -(x.A + v): alpha = beta = 1 keeps the library's bias epilogue (any other alpha first expands
