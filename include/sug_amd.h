@@ -206,6 +206,15 @@ int sug_linear_dw(const float* g, int64_t ldg, const float* x, int64_t ldx, int6
 int sug_linear_dw_bias(const float* g, int64_t ldg, const float* x, int64_t ldx, int64_t R, int M, int N,
                        float* dw, float* db, float* ws, void* stream);
 
+/* ---- LayerNorm + (Leaky)ReLU of the FC heads ---------------------------------------------------
+ * fc_layer (model/model_utils.py:35-57: nn.Linear -> nn.LayerNorm -> LeakyReLU(0.2) / ReLU) behind the Linear:
+ * y = act(LN(x)) over rows of x [rows, C] (C <= 1024), stat [rows, 2] = mean | rstd for the backward.
+ * Backward: dx [rows,C], dgamma, dbeta [C] (rows summed in order); ws: rows*C floats. */
+int sug_ln_act_fwd(const float* x, const float* gamma, const float* beta, int rows, int C, float eps, float slope,
+                   float* y, float* stat, void* stream);
+int sug_ln_act_bwd(const float* g, const float* x, const float* gamma, const float* beta, const float* stat, int rows,
+                   int C, float slope, float* dx, float* dgamma, float* dbeta, float* ws, void* stream);
+
 /* ---- optimizer step ------------------------------------------------------------------------
  * torch.optim.Adam (no amsgrad; L2 weight decay added to the gradient; bias correction; eps
  * outside the square root) over T tensors in one launch per 384 tensors: the update of

@@ -400,6 +400,109 @@ int sug_bn_bwd_apply_groups(const float* a, int64_t lda, int from_g, float slope
   return SUG_OK;
 }
 
+// ---- LayerNorm + (Leaky)ReLU of the FC heads (fc_layer, model/model_utils.py:35-57): rows <= a few hundred,
+// C <= 1024.  Forward: one wave per row (mean, biased variance like nn.LayerNorm, two-pass over registers).
+// Backward: wave per row for dx, then one thread per column for dgamma / dbeta (rows walked in order:
+// bit-reproducible); torch's own pair of kernels for the parameter gradients takes 21 us at [64, 512].
+constexpr int LN_MAXV = 16;                     // C <= 64 * 16
+
+__global__ __launch_bounds__(256) void ln_act_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, int rows, int C, float eps,
+                                                         float slope, float* __restrict__ y, float* __restrict__ stat) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= rows) return;
+  const float* xr = x + (size_t)r * C;
+  float v[LN_MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int u = 0; u < LN_MAXV; ++u) {
+    const int c = lane + 64 * u;
+    v[u] = c < C ? xr[c] : 0.f;
+    s += v[u];
+  }
+  const float mean = wave_sum_f(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int u = 0; u < LN_MAXV; ++u) {
+    const int c = lane + 64 * u;
+    const float d = c < C ? v[u] - mean : 0.f;
+    q = fmaf(d, d, q);
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum_f(q) / (float)C + eps);
+#pragma unroll
+  for (int u = 0; u < LN_MAXV; ++u) {
+    const int c = lane + 64 * u;
+    if (c < C) {
+      const float t = fmaf((v[u] - mean) * rstd, gamma[c], beta[c]);
+      y[(size_t)r * C + c] = t > 0.f ? t : t * slope;
+    }
+  }
+  if (lane == 0) {
+    stat[2 * r] = mean;
+    stat[2 * r + 1] = rstd;
+  }
+}
+
+// dx = rstd * (gh - mean_c(gh) - xhat * mean_c(gh * xhat)), gh = g * act' * gamma; ga = g * act' kept for the column pass
+__global__ __launch_bounds__(256) void ln_act_bwd_dx_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const float* __restrict__ stat, int rows, int C, float slope,
+                                                            float* __restrict__ dx, float* __restrict__ ga) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= rows) return;
+  const float mean = stat[2 * r], rstd = stat[2 * r + 1];
+  float xh[LN_MAXV], gh[LN_MAXV];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int u = 0; u < LN_MAXV; ++u) {
+    const int c = lane + 64 * u;
+    xh[u] = 0.f;
+    gh[u] = 0.f;
+    if (c < C) {
+      xh[u] = (x[(size_t)r * C + c] - mean) * rstd;
+      const float t = fmaf(xh[u], gamma[c], beta[c]);
+      const float a = g[(size_t)r * C + c] * (t > 0.f ? 1.f : slope);
+      ga[(size_t)r * C + c] = a;
+      gh[u] = a * gamma[c];
+      s1 += gh[u];
+      s2 = fmaf(gh[u], xh[u], s2);
+    }
+  }
+  s1 = wave_sum_f(s1) / (float)C;
+  s2 = wave_sum_f(s2) / (float)C;
+#pragma unroll
+  for (int u = 0; u < LN_MAXV; ++u) {
+    const int c = lane + 64 * u;
+    if (c < C) dx[(size_t)r * C + c] = rstd * (gh[u] - s1 - xh[u] * s2);
+  }
+}
+
+__global__ __launch_bounds__(256) void ln_act_bwd_param_kernel(const float* __restrict__ ga, const float* __restrict__ x,
+                                                               const float* __restrict__ stat, int rows, int C,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float dg = 0.f, db = 0.f;
+  for (int r0 = 0; r0 < rows; r0 += 8) {
+    float a[8], xv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int r = r0 + u < rows ? r0 + u : rows - 1;
+      a[u] = ga[(size_t)r * C + c];
+      xv[u] = x[(size_t)r * C + c];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (r0 + u >= rows) continue;
+      const int r = r0 + u;
+      dg = fmaf(a[u], (xv[u] - stat[2 * r]) * stat[2 * r + 1], dg);
+      db += a[u];
+    }
+  }
+  dgamma[c] = dg;
+  dbeta[c] = db;
+}
+
 static bool vec4_ok(const float* y, int64_t ld, int C) {
   return (C % 4 == 0) && (ld % 4 == 0) && ((uintptr_t)y % 16 == 0);
 }
@@ -476,5 +579,28 @@ extern "C" int sug_fold_groups(const double* red, int groups, int n, float* out,
   SUG_REQUIRE(red && out && groups >= 1 && n > 0, "sug_fold_groups: bad argument");
   hipLaunchKernelGGL(fold_groups_kernel, dim3(sug_divup(n, 256)), dim3(256), 0, (hipStream_t)stream, red, groups, n, out);
   SUG_LAUNCH_CHECK("sug_fold_groups");
+  return SUG_OK;
+}
+
+extern "C" int sug_ln_act_fwd(const float* x, const float* gamma, const float* beta, int rows, int C, float eps, float slope,
+                              float* y, float* stat, void* stream) {
+  SUG_REQUIRE(x && gamma && beta && y && stat, "sug_ln_act_fwd: null pointer");
+  SUG_REQUIRE(rows > 0 && C > 0 && C <= 64 * LN_MAXV, "sug_ln_act_fwd: rows=%d C=%d (C <= %d)", rows, C, 64 * LN_MAXV);
+  hipLaunchKernelGGL(ln_act_fwd_kernel, dim3(sug_divup(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, rows, C, eps,
+                     slope, y, stat);
+  SUG_LAUNCH_CHECK("sug_ln_act_fwd");
+  return SUG_OK;
+}
+
+extern "C" int sug_ln_act_bwd(const float* g, const float* x, const float* gamma, const float* beta, const float* stat, int rows,
+                              int C, float slope, float* dx, float* dgamma, float* dbeta, float* ws, void* stream) {
+  SUG_REQUIRE(g && x && gamma && beta && stat && dx && dgamma && dbeta && ws, "sug_ln_act_bwd: null pointer");
+  SUG_REQUIRE(rows > 0 && C > 0 && C <= 64 * LN_MAXV, "sug_ln_act_bwd: rows=%d C=%d (C <= %d)", rows, C, 64 * LN_MAXV);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(ln_act_bwd_dx_kernel, dim3(sug_divup(rows, 4)), dim3(256), 0, st, g, x, gamma, beta, stat, rows, C, slope, dx,
+                     ws);
+  SUG_LAUNCH_CHECK("sug_ln_act_bwd");
+  hipLaunchKernelGGL(ln_act_bwd_param_kernel, dim3(sug_divup(C, 256)), dim3(256), 0, st, ws, x, stat, rows, C, dgamma, dbeta);
+  SUG_LAUNCH_CHECK("sug_ln_act_bwd(param)");
   return SUG_OK;
 }

@@ -575,6 +575,45 @@ def sa_first_layer(P, Q, idx, bn):
                                bn.momentum, BN_GROUPS)
 
 
+class _LNAct(torch.autograd.Function):
+    """act(LayerNorm(x)) over the rows of a small [rows, C] tensor (sug_ln_act_fwd / bwd)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, slope):
+        _need_gpu(x, gamma)
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        rows, C = x2.shape
+        g, b = gamma.detach().contiguous(), beta.detach().contiguous()
+        y = torch.empty_like(x2)
+        stat = torch.empty(rows, 2, dtype=torch.float32, device=x.device)
+        check(lib().sug_ln_act_fwd(_p(x2), _p(g), _p(b), rows, C, eps, float(slope), _p(y), _p(stat), _st()), 'sug_ln_act_fwd')
+        ctx.save_for_backward(x2, g, b, stat)
+        ctx.meta = (float(slope), tuple(x.shape))
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, g, b, stat = ctx.saved_tensors
+        slope, shape = ctx.meta
+        rows, C = x2.shape
+        gy = gy.reshape(rows, C).contiguous()
+        dx, ws = torch.empty_like(x2), torch.empty_like(x2)
+        dgb = torch.empty(2, C, dtype=torch.float32, device=x2.device)
+        check(lib().sug_ln_act_bwd(_p(gy), _p(x2), _p(g), _p(b), _p(stat), rows, C, slope, _p(dx), _p(dgb[0]), _p(dgb[1]),
+                                   _p(ws), _st()), 'sug_ln_act_bwd')
+        return dx.view(shape), dgb[0], dgb[1], None, None
+
+
+def ln_act_supported(x, ln):
+    return x.is_cuda and x.dtype == torch.float32 and x.shape[-1] <= 1024 and ln.elementwise_affine and \
+        len(ln.normalized_shape) == 1 and ln.weight is not None and ln.bias is not None
+
+
+def ln_act(x, ln, slope):
+    """leaky_relu(ln(x), slope) for an nn.LayerNorm over the last dimension (slope 0: ReLU)."""
+    return _LNAct.apply(x, ln.weight, ln.bias, ln.eps, slope)
+
+
 # num_batches_tracked increments: one tiny launch per BatchNorm call unless deferred; inside a
 # `deferred_bn_counts()` block they are collected and applied with one foreach add at the end.
 _PENDING_COUNTS = None

@@ -425,3 +425,35 @@ def test_knn_packed_key_paths_match_exact_lists(force):
         else:
             os.environ['SUG_KNN_FORCE'] = keep
     assert not bad, bad
+
+
+@pytest.mark.parametrize('rows,C,slope', [(64, 512, 0.2), (64, 256, 0.2), (7, 1024, 0.0), (130, 100, 0.2)])
+def test_ln_act_vs_torch(rows, C, slope):
+    """LayerNorm + (Leaky)ReLU of the FC heads (fc_layer, model_utils.py:35-57) in one launch: forward within 1e-5 of
+    nn.LayerNorm + F.leaky_relu, gradients (input, weight, bias) within 1e-4 relative; bit-reproducible."""
+    from sug_amd import ops
+    g = torch.Generator().manual_seed(rows + C)
+    x = (torch.randn(rows, C, generator=g) * 2 + 0.5).cuda()
+    ln_r, ln_k = torch.nn.LayerNorm(C).cuda(), torch.nn.LayerNorm(C).cuda()
+    with torch.no_grad():
+        for ln in (ln_r, ln_k):
+            ln.weight.copy_(torch.linspace(-1.0, 1.5, C))
+            ln.bias.copy_(torch.linspace(-0.3, 0.3, C))
+    probe = torch.randn(rows, C, generator=g).cuda()
+    xr, xk = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ref = torch.nn.functional.leaky_relu(ln_r(xr), slope)
+    (ref * probe).sum().backward()
+    assert ops.ln_act_supported(xk, ln_k)
+    out = ops.ln_act(xk, ln_k, slope)
+    (out * probe).sum().backward()
+    torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-5)
+
+    def rel(a, b):
+        return float((a - b).norm() / b.norm().clamp_min(1e-12))
+
+    assert rel(xk.grad, xr.grad) < 1e-4 and rel(ln_k.weight.grad, ln_r.weight.grad) < 1e-4
+    assert rel(ln_k.bias.grad, ln_r.bias.grad) < 1e-4
+    g1 = (xk.grad.clone(), ln_k.weight.grad.clone())
+    xk.grad, ln_k.weight.grad, ln_k.bias.grad = None, None, None
+    (ops.ln_act(xk, ln_k, slope) * probe).sum().backward()
+    assert torch.equal(g1[0], xk.grad) and torch.equal(g1[1], ln_k.weight.grad)
