@@ -34,7 +34,12 @@ extern "C" {
 /* Per-channel sums (BN statistics, BN gradients) are reduced without atomics so that
  * results are bit-reproducible run to run: kernels write one fp32 partial row per
  * workgroup into a caller-provided workspace `ws` of SUG_STATS_BLOCKS * 2*C floats,
- * then an ordered fp64 pass fills the 2*C-double result (no zeroing needed). */
+ * then an ordered fp64 pass fills the 2*C-double result (no zeroing needed).
+ * The BatchNorm entry points (sug_col_stats_bn, sug_bn_act_rows_fwd, sug_pointmlp_max_layer_fwd,
+ * sug_sa_first_fwd, sug_bn_act_pool_layer_fwd) take the batch statistics about a pivot row (one value of
+ * the group's data per channel: sum(x - p), sum((x - p)^2) in fp32, mean = p + S1/n and
+ * var = S2/n - (S1/n)^2 in fp64), so that data with |mean| >> std keeps its variance, like the two-pass /
+ * Welford forms of nn.BatchNorm; the pivot rows live in the last 8 rows of the same workspace. */
 #define SUG_STATS_BLOCKS 1024
 
 const char* sug_last_error(void);

@@ -28,10 +28,19 @@ void sug_set_error(const char* fmt, ...);
 int sug_knn_mfma_supported(const float* x, int64_t ldx, int C, int k);
 int sug_knn_mfma(const float* x, int64_t ldx, int B, int N, int C, int k, int32_t* idx, hipStream_t st);
 
-// edgeconv.hip: fold `nblk` per-workgroup partial rows ws[nblk][2C] (sum | sum of squares, fixed
-// order, fp64) into the BatchNorm coefficients coef[5][C] and update the running buffers
+// BatchNorm batch statistics are accumulated about a PIVOT p[c] (one value of the group's data per channel): the
+// partial rows hold sum(x - p) | sum((x - p)^2) in fp32, the finalize kernels form mean = p + S1/n and
+// var = S2/n - (S1/n)^2 in fp64.  Unshifted fp32 partials lose the variance when |mean| >> std (E[x^2] - mean^2).
+// The pivot row of group g lives in the caller's workspace behind the partial rows: producers use at most
+// SUG_STATS_ROWS of its SUG_STATS_BLOCKS rows.
+#define SUG_STATS_ROWS (SUG_STATS_BLOCKS - 8)
+#define SUG_PIVOT_OFFSET(C) ((size_t)SUG_STATS_ROWS * 2 * (C))      /* + g*C: pivot row of group g (<= 16 groups) */
+
+// edgeconv.hip: fold `nblk` per-workgroup partial rows ws[nblk][2C] (sum | sum of squares about `pivot` [C], or plain
+// sums when pivot == nullptr; fixed order, fp64) into the BatchNorm coefficients coef[5][C] and update the running buffers
 int sug_stats_finalize(const float* ws, int nblk, int C, const float* gamma, const float* beta, double count, float eps,
-                       float momentum, float* running_mean, float* running_var, float* coef, hipStream_t st);
+                       float momentum, float* running_mean, float* running_var, float* coef, hipStream_t st,
+                       const float* pivot = nullptr);
 
 // knn.hip: reverse lists of B clouds with E index entries each (destinations in [0, N)): rev_off [B, N+1],
 // rev_ent [B, E] (entry positions; ascending per destination when sorted != 0)

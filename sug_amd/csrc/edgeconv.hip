@@ -283,7 +283,8 @@ __global__ __launch_bounds__(256) void stats_finalize_kernel(const float* __rest
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, double count,
                                                              float eps, float momentum, float* __restrict__ rmean,
-                                                             float* __restrict__ rvar, float* __restrict__ coef) {
+                                                             float* __restrict__ rvar, float* __restrict__ coef,
+                                                             const float* __restrict__ pivot) {
   __shared__ double s_p[16][17];
   __shared__ double s_tot[16];
   const int cl = threadIdx.x & 15, p = threadIdx.x >> 4;
@@ -306,9 +307,10 @@ __global__ __launch_bounds__(256) void stats_finalize_kernel(const float* __rest
   __syncthreads();
   if (threadIdx.x < 8 && ch < C) {
     const int c = ch;
-    const double mean = s_tot[threadIdx.x] / count;
-    double var = s_tot[8 + threadIdx.x] / count - mean * mean;
+    const double m1 = s_tot[threadIdx.x] / count;           // mean of (x - pivot)
+    double var = s_tot[8 + threadIdx.x] / count - m1 * m1;
     if (var < 0) var = 0;
+    const double mean = (pivot ? (double)pivot[c] : 0.0) + m1;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
     const float scale = gamma[c] * rstd;
     coef[c] = scale;
@@ -328,7 +330,8 @@ __global__ __launch_bounds__(1024) void stats_finalize_groups_kernel(const float
                                                                     const float* __restrict__ gamma,
                                                                     const float* __restrict__ beta, double count,
                                                                     float eps, float momentum, float* __restrict__ rmean,
-                                                                    float* __restrict__ rvar, float* __restrict__ coef) {
+                                                                    float* __restrict__ rvar, float* __restrict__ coef,
+                                                                    const float* __restrict__ pivot) {
   constexpr int GMAX = 4;                        // groups folded in one pass over the partial rows (loads of all
   constexpr int RL = 64;                         // groups in flight together); more groups: further passes.  64 row
   __shared__ double s_p[GMAX][RL][17];           // lanes (1024 threads): hundreds of partial rows, walked serially by
@@ -365,9 +368,10 @@ __global__ __launch_bounds__(1024) void stats_finalize_groups_kernel(const float
       const int c = ch;
       for (int g = 0; g < ng; ++g) {               // in group order: the running buffers see one update after the other
         float* cg = coef + (size_t)(g0 + g) * 5 * C;
-        const double mean = s_tot[g][threadIdx.x] / count;
-        double var = s_tot[g][8 + threadIdx.x] / count - mean * mean;
+        const double m1 = s_tot[g][threadIdx.x] / count;      // mean of (x - pivot)
+        double var = s_tot[g][8 + threadIdx.x] / count - m1 * m1;
         if (var < 0) var = 0;
+        const double mean = (pivot ? (double)pivot[(size_t)(g0 + g) * C + c] : 0.0) + m1;
         const float rstd = (float)(1.0 / sqrt(var + (double)eps));
         const float scale = gamma[c] * rstd;
         cg[c] = scale;
@@ -480,7 +484,7 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict
                                                          const float* __restrict__ coef, int64_t rows,
                                                          int C, float slope, float* __restrict__ a,
                                                          float* __restrict__ ws, int CW,
-                                                         int rows_per_block) {
+                                                         int rows_per_block, int pivoted) {
   extern __shared__ float s_red[];  // [256/CW][2*C]
   const int RY = 256 / CW;
   const int cx = threadIdx.x % CW, ry = threadIdx.x / CW;
@@ -490,12 +494,15 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict
   for (int c = cx; c < C; c += CW) {
     float s = 0.f, q = 0.f;
     float scale = 0.f, shift = 0.f, mean = 0.f, rstd = 0.f;
+    // MODE 0: sums about the pivot = first row of the data (common.h); workgroup 0 publishes it for the finalize
+    const float pv = (MODE == 0 && pivoted) ? y[c] : 0.f;
+    if (MODE == 0 && pivoted && blockIdx.x == 0 && ry == 0) ws[SUG_PIVOT_OFFSET(C) + c] = pv;
     if (MODE == 1) {
       scale = coef[c]; shift = coef[C + c]; mean = coef[2 * C + c]; rstd = coef[3 * C + c];
     }
     for (int64_t r = r0 + ry; r < r1; r += RY) {
       if (MODE == 0) {
-        const float v = y[r * ldy + c];
+        const float v = y[r * ldy + c] - pv;
         s += v;
         q = fmaf(v, v, q);
       } else {
@@ -529,8 +536,9 @@ __global__ __launch_bounds__(256) void col_reduce_vec4_kernel(const float* __res
                                                               int64_t rows, int C, float slope,
                                                               float* __restrict__ a,
                                                               float* __restrict__ ws, int LX,
-                                                              int rows_per_block) {
+                                                              int rows_per_block, int pivoted) {
   extern __shared__ __attribute__((aligned(16))) float s_red[];  // [LY][2*C]
+  float* const ws_pivot = ws + SUG_PIVOT_OFFSET(C) + (size_t)blockIdx.y * C;      // pivot row of this group
   // blockIdx.y = domain group: `rows` rows each, consecutive in y / z / a; coefficient set g; partial rows
   // [g * gridDim.x + blockIdx.x]
   const int64_t g0 = (int64_t)blockIdx.y * rows;
@@ -551,6 +559,12 @@ __global__ __launch_bounds__(256) void col_reduce_vec4_kernel(const float* __res
     const int c = c4 * 4;
     float4 s = make_float4(0, 0, 0, 0), q = make_float4(0, 0, 0, 0);
     float4 sc = s, sh = s, mean = s, rstd = s;
+    // MODE 0: sums about the pivot = first row of the group's data (common.h); workgroup 0 publishes it
+    float4 pv = s;
+    if (MODE == 0 && pivoted) {
+      pv = *reinterpret_cast<const float4*>(y + c);
+      if (blockIdx.x == 0 && ly == 0) *reinterpret_cast<float4*>(ws_pivot + c) = pv;
+    }
     if (MODE >= 1) {
       sc = *reinterpret_cast<const float4*>(coef + c);
       sh = *reinterpret_cast<const float4*>(coef + C + c);
@@ -559,8 +573,9 @@ __global__ __launch_bounds__(256) void col_reduce_vec4_kernel(const float* __res
     }
 #pragma unroll 4
     for (int64_t r = r0 + ly; r < r1; r += LY) {
-      const float4 v = *reinterpret_cast<const float4*>(y + r * ldy + c);
+      float4 v = *reinterpret_cast<const float4*>(y + r * ldy + c);
       if (MODE == 0) {
+        v.x -= pv.x; v.y -= pv.y; v.z -= pv.z; v.w -= pv.w;
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         q.x = fmaf(v.x, v.x, q.x); q.y = fmaf(v.y, v.y, q.y); q.z = fmaf(v.z, v.z, q.z); q.w = fmaf(v.w, v.w, q.w);
       } else {
@@ -822,10 +837,11 @@ int sug_reduce_partials(const float* ws, int nblk, int W, double* out, hipStream
 }
 
 int sug_stats_finalize(const float* ws, int nblk, int C, const float* gamma, const float* beta, double count, float eps,
-                       float momentum, float* running_mean, float* running_var, float* coef, hipStream_t st) {
+                       float momentum, float* running_mean, float* running_var, float* coef, hipStream_t st,
+                       const float* pivot) {
   SUG_REQUIRE(ws && gamma && beta && coef && nblk > 0 && C > 0 && count > 0, "sug_stats_finalize: bad argument");
   hipLaunchKernelGGL(stats_finalize_kernel, dim3(sug_divup(C, 8)), dim3(256), 0, st, ws, nblk, C, gamma, beta, count, eps,
-                     momentum, running_mean, running_var, coef);
+                     momentum, running_mean, running_var, coef, pivot);
   SUG_LAUNCH_CHECK("sug_stats_finalize");
   return SUG_OK;
 }
@@ -905,8 +921,10 @@ extern "C" int sug_edgeconv_fwd_bn(const float* pq, int64_t ldpq, const int32_t*
   int grid = 0;
   const int rc = edgeconv_fwd_partials(pq, ldpq, idx, gamma, B, N, k, Co, z, arg, s1, ws, &grid, stream);
   if (rc != SUG_OK) return rc;
+  // plain sums here (no pivot): y = P[idx] + Q comes from bias-free convolutions of normalised activations, its mean
+  // is of the order of its spread, and the un-shifted maximum keeps z bit-identical to the validated kernel
   hipLaunchKernelGGL(stats_finalize_kernel, dim3(sug_divup(Co, 8)), dim3(256), 0, (hipStream_t)stream, ws, grid, Co,
-                     gamma, beta, (double)B * N * k, eps, momentum, running_mean, running_var, coef);
+                     gamma, beta, (double)B * N * k, eps, momentum, running_mean, running_var, coef, nullptr);
   SUG_LAUNCH_CHECK("sug_edgeconv_fwd_bn(finalize)");
   return SUG_OK;
 }
@@ -935,7 +953,7 @@ int sug_edgeconv_fwd_bn_act_groups(const float* pq, int64_t ldpq, const int32_t*
     int nblk = 0;
     if (int rc = edgeconv_fwd_partials(pq, ldpq, idx, gamma, B, N, k, Co, z, arg, s1, ws, &nblk, stream)) return rc;
     hipLaunchKernelGGL(stats_finalize_groups_kernel, dim3(sug_divup(Co, 8)), dim3(1024), 0, st, ws, nblk / groups, Co, groups,
-                       gamma, beta, (double)rows * k, eps, momentum, running_mean, running_var, coef);
+                       gamma, beta, (double)rows * k, eps, momentum, running_mean, running_var, coef, nullptr);
     SUG_LAUNCH_CHECK("sug_edgeconv_layer_fwd(finalize)");
     const int64_t total = (int64_t)B * N * (Co / 4);
     int64_t g = (total + 1023) / 1024;
@@ -998,12 +1016,12 @@ extern "C" int sug_affine_act(const float* z, int64_t ldz, const float* coef, in
 // Launch the column reduction (vectorised when layout allows); returns the number of partial rows.
 template <int MODE>
 static int launch_col_reduce(const float* y, int64_t ldy, const float* z, const float* coef, int64_t rows,
-                             int C, float slope, float* a, float* ws, hipStream_t st, int groups = 1);
+                             int C, float slope, float* a, float* ws, hipStream_t st, int groups = 1, int pivoted = 0);
 
 // rows per block such that the grid stays within SUG_STATS_BLOCKS
 static int col_rows_per_block(int64_t rows, int cw) {
   int64_t rpb = 64 * (256 / cw) > 256 ? 64 * (256 / cw) : 256;
-  while ((rows + rpb - 1) / rpb > SUG_STATS_BLOCKS) rpb *= 2;
+  while ((rows + rpb - 1) / rpb > SUG_STATS_ROWS) rpb *= 2;
   return (int)rpb;
 }
 
@@ -1011,20 +1029,20 @@ static int col_rows_per_block(int64_t rows, int cw) {
 // [group][block]; returns the number of partial rows PER GROUP
 template <int MODE>
 static int launch_col_reduce(const float* y, int64_t ldy, const float* z, const float* coef, int64_t rows,
-                             int C, float slope, float* a, float* ws, hipStream_t st, int groups) {
+                             int C, float slope, float* a, float* ws, hipStream_t st, int groups, int pivoted) {
   const bool vec = (C % 4 == 0) && (ldy % 4 == 0) && ((uintptr_t)y % 16 == 0) &&
                    (MODE == 0 || (((uintptr_t)z % 16 == 0) && (MODE == 2 || (uintptr_t)a % 16 == 0) && ((uintptr_t)coef % 16 == 0)));
   if (vec) {
     int lx = 1;
     while (lx < (C >> 2) && lx < 256) lx <<= 1;
     const int ly = 256 / lx;
-    int64_t rpb = (rows * groups + SUG_STATS_BLOCKS - 1) / SUG_STATS_BLOCKS;
+    int64_t rpb = (rows * groups + SUG_STATS_ROWS - 1) / SUG_STATS_ROWS;
     if (rpb < 4 * ly) rpb = 4 * ly;
     rpb = (rpb + ly - 1) / ly * ly;
     const int grid = sug_divup(rows, rpb);
-    if ((int64_t)grid * groups > SUG_STATS_BLOCKS) return -1;
+    if ((int64_t)grid * groups > SUG_STATS_ROWS || groups > 16) return -1;
     hipLaunchKernelGGL((col_reduce_vec4_kernel<MODE>), dim3(grid, groups), dim3(256), (size_t)ly * 2 * C * sizeof(float),
-                       st, y, ldy, z, coef, rows, C, slope, a, ws, lx, (int)rpb);
+                       st, y, ldy, z, coef, rows, C, slope, a, ws, lx, (int)rpb, pivoted);
     return grid;
   }
   if (groups > 1 || MODE == 2) return -1;
@@ -1032,7 +1050,7 @@ static int launch_col_reduce(const float* y, int64_t ldy, const float* z, const 
   const int rpb = col_rows_per_block(rows, cw);
   const int grid = sug_divup(rows, rpb);
   hipLaunchKernelGGL((col_reduce_kernel<MODE>), dim3(grid), dim3(256), (size_t)(256 / cw) * 2 * C * sizeof(float),
-                     st, y, ldy, z, coef, rows, C, slope, a, ws, cw, rpb);
+                     st, y, ldy, z, coef, rows, C, slope, a, ws, cw, rpb, pivoted);
   return grid;
 }
 
@@ -1055,10 +1073,10 @@ extern "C" int sug_col_stats_bn(const float* y, int64_t ldy, int64_t rows, int C
   SUG_REQUIRE(y && gamma && beta && coef && ws, "sug_col_stats_bn: null pointer");
   SUG_REQUIRE(rows > 0 && C > 0 && C <= 4096 && ldy >= C, "sug_col_stats_bn: bad shape");
   hipStream_t st = (hipStream_t)stream;
-  const int grid = launch_col_reduce<0>(y, ldy, nullptr, nullptr, rows, C, 0.f, nullptr, ws, st);
+  const int grid = launch_col_reduce<0>(y, ldy, nullptr, nullptr, rows, C, 0.f, nullptr, ws, st, 1, 1);
   SUG_LAUNCH_CHECK("sug_col_stats_bn");
   hipLaunchKernelGGL(stats_finalize_kernel, dim3(sug_divup(C, 8)), dim3(256), 0, st, ws, grid, C, gamma, beta,
-                     (double)rows, eps, momentum, running_mean, running_var, coef);
+                     (double)rows, eps, momentum, running_mean, running_var, coef, ws + SUG_PIVOT_OFFSET(C));
   SUG_LAUNCH_CHECK("sug_col_stats_bn(finalize)");
   return SUG_OK;
 }
@@ -1069,11 +1087,11 @@ extern "C" int sug_col_stats_bn(const float* y, int64_t ldy, int64_t rows, int C
 int sug_col_stats_bn_groups(const float* y, int64_t ldy, int64_t rows, int C, int groups, const float* gamma,
                             const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                             float* coef, float* ws, hipStream_t st) {
-  const int grid = launch_col_reduce<0>(y, ldy, nullptr, nullptr, rows, C, 0.f, nullptr, ws, st, groups);
+  const int grid = launch_col_reduce<0>(y, ldy, nullptr, nullptr, rows, C, 0.f, nullptr, ws, st, groups, 1);
   if (grid < 0) return 1;
   SUG_LAUNCH_CHECK("sug_bn_act_rows_fwd(stats)");
   hipLaunchKernelGGL(stats_finalize_groups_kernel, dim3(sug_divup(C, 8)), dim3(1024), 0, st, ws, grid, C, groups, gamma, beta,
-                     (double)rows, eps, momentum, running_mean, running_var, coef);
+                     (double)rows, eps, momentum, running_mean, running_var, coef, ws + SUG_PIVOT_OFFSET(C));
   SUG_LAUNCH_CHECK("sug_bn_act_rows_fwd(finalize)");
   return SUG_OK;
 }

@@ -29,7 +29,7 @@ template <int CP>
 __global__ __launch_bounds__(256, 2) void pointmlp_max_kernel(
     const float* __restrict__ x, int64_t ldx, int R, const float* __restrict__ W,
     const float* __restrict__ bias, const float* __restrict__ gamma, int Co, int L, int rows_per_wg, int nrb,
-    float* __restrict__ zext, int32_t* __restrict__ arg, float* __restrict__ ws) {
+    float* __restrict__ zext, int32_t* __restrict__ arg, float* __restrict__ ws, int pivoted) {
   constexpr int RS = CP + 4;
   constexpr int HALF = CP / 2;
   constexpr int P = HALF / 16;                       // MFMAs per accumulator slot (2 or 4)
@@ -71,6 +71,16 @@ __global__ __launch_bounds__(256, 2) void pointmlp_max_kernel(
   }
   const float bj = bias ? bias[col] : 0.f;
   const float sgn = gamma[col] >= 0.f ? 1.f : -1.f;
+  // pivot of the BatchNorm sums (common.h): y of the launch's first row for this channel, the same fma chain in every
+  // workgroup (each lane half over its half of k, halves added): the sums below are taken about it
+  float pvt = 0.f;
+  if (pivoted) {
+    float d = 0.f;
+#pragma unroll
+    for (int e = 0; e < HALF; ++e) d = fmaf(x[2 * e + h], bq[e], d);
+    pvt = __fadd_rn(d + __shfl_xor(d, 32), bj);
+    if (rb == 0 && h == 0) ws[SUG_PIVOT_OFFSET(Co) + col] = pvt;
+  }
 
   float s1 = 0.f, s2 = 0.f;                          // BN sums of this lane's rows of this channel
   float best = -INFINITY;
@@ -100,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void pointmlp_max_kernel(
         const int rt = (c & 3) + 8 * (c >> 2);       // row inside the tile (+ 4h)
         const bool valid = rt < lim;
         const float y = __fadd_rn(acc_cur[c], bj);
-        const float yv = valid ? y : 0.f;
+        const float yv = valid ? y - pvt : 0.f;
         s1 += yv;
         s2 = fmaf(yv, yv, s2);
         const float tt = valid ? sgn * y : -INFINITY;
@@ -437,13 +447,23 @@ __global__ __launch_bounds__(128) void pointmlp_bwd_dwfix_kernel(float* __restri
 static int pointmlp_rows_per_wg(int64_t rows, int L) {
   // whole segments per workgroup, ~1024 rows, at most SUG_STATS_BLOCKS row blocks
   int64_t rpw = L >= 1024 ? L : (1024 / L) * L;
-  while ((rows + rpw - 1) / rpw > SUG_STATS_BLOCKS) rpw *= 2;
+  while ((rows + rpw - 1) / rpw > SUG_STATS_ROWS) rpw *= 2;
   return (int)rpw;
 }
+
+static int pointmlp_max_fwd(const float* x, int64_t ldx, int64_t rows, int K, const float* w, const float* bias,
+                            const float* gamma, int Co, int seg, float* zext, int32_t* arg, float* ws, int* nblk,
+                            void* stream, int pivoted);
 
 extern "C" int sug_pointmlp_max_fwd(const float* x, int64_t ldx, int64_t rows, int K, const float* w, const float* bias,
                                     const float* gamma, int Co, int seg, float* zext, int32_t* arg, float* ws,
                                     int* nblk, void* stream) {
+  return pointmlp_max_fwd(x, ldx, rows, K, w, bias, gamma, Co, seg, zext, arg, ws, nblk, stream, 0);   // plain sums
+}
+
+static int pointmlp_max_fwd(const float* x, int64_t ldx, int64_t rows, int K, const float* w, const float* bias,
+                            const float* gamma, int Co, int seg, float* zext, int32_t* arg, float* ws, int* nblk,
+                            void* stream, int pivoted) {
   SUG_REQUIRE(x && w && gamma && zext && arg && ws && nblk, "sug_pointmlp_max_fwd: null pointer");
   SUG_REQUIRE(K == 64 || K == 128, "sug_pointmlp_max_fwd: K=%d (64 or 128 input channels)", K);
   SUG_REQUIRE(Co > 0 && Co % 128 == 0, "sug_pointmlp_max_fwd: Co=%d must be a multiple of 128", Co);
@@ -459,11 +479,11 @@ extern "C" int sug_pointmlp_max_fwd(const float* x, int64_t ldx, int64_t rows, i
   if (K == 128) {
     const size_t sh = (size_t)3 * TJ * (128 + 4) * sizeof(float);
     hipLaunchKernelGGL((pointmlp_max_kernel<128>), dim3(grid), dim3(256), sh, st, x, ldx, (int)rows, w, bias, gamma, Co,
-                       seg, rpw, nrb, zext, arg, ws);
+                       seg, rpw, nrb, zext, arg, ws, pivoted);
   } else {
     const size_t sh = (size_t)3 * TJ * (64 + 4) * sizeof(float);
     hipLaunchKernelGGL((pointmlp_max_kernel<64>), dim3(grid), dim3(256), sh, st, x, ldx, (int)rows, w, bias, gamma, Co,
-                       seg, rpw, nrb, zext, arg, ws);
+                       seg, rpw, nrb, zext, arg, ws, pivoted);
   }
   SUG_LAUNCH_CHECK("sug_pointmlp_max_fwd");
   *nblk = nrb;
@@ -504,12 +524,12 @@ extern "C" int sug_pointmlp_max_layer_fwd(const float* x, int64_t ldx, int64_t r
   for (int g = 0; g < groups; ++g) {
     float* cg = coef + (int64_t)g * 5 * Co;
     int nblk = 0;
-    int rc = sug_pointmlp_max_fwd(x + g * rg * ldx, ldx, rg, K, w, bias, gamma, Co, seg, zext + g * sg * Co,
-                                  arg + g * sg * Co, ws, &nblk, stream);
+    int rc = pointmlp_max_fwd(x + g * rg * ldx, ldx, rg, K, w, bias, gamma, Co, seg, zext + g * sg * Co,
+                              arg + g * sg * Co, ws, &nblk, stream, 1);
     if (rc != SUG_OK) return rc;
     if (training) {
       rc = sug_stats_finalize(ws, nblk, Co, gamma, beta, (double)rg, eps, momentum, running_mean, running_var, cg,
-                              (hipStream_t)stream);
+                              (hipStream_t)stream, ws + SUG_PIVOT_OFFSET(Co));
       if (rc != SUG_OK) return rc;
     }
     rc = sug_affine_act(zext + g * sg * Co, Co, cg, sg, Co, slope, out + g * sg * ldo, ldo, stream);

@@ -49,6 +49,14 @@ __global__ __launch_bounds__(256) void sa_first_kernel(
     mean = ld4(coef + 2 * C + c); rstd = ld4(coef + 3 * C + c);
   }
   float4 a1 = make_float4(0, 0, 0, 0), a2 = a1;
+  // MODE 0: sums about the pivot y of the group's first row (common.h); workgroup 0 publishes it for the finalize
+  float4 piv = make_float4(0, 0, 0, 0);
+  if (MODE == 0) {
+    const int m0 = min(max(idx[seg0 * ns], 0), N - 1);
+    const float4 p0 = ld4(P + ((seg0 / S) * N + m0) * ldp + c), q0 = ld4(Q + seg0 * C + c);
+    piv = make_float4(p0.x - q0.x, p0.y - q0.y, p0.z - q0.z, p0.w - q0.w);
+    if (blockIdx.x == 0 && slot == 0) st4(ws + SUG_PIVOT_OFFSET(C) + c, piv);
+  }
   for (int64_t seg = b0 + slot; seg < b1; seg += slots) {
     const int64_t b = seg / S;
     const int32_t* ir = idx + seg * ns;
@@ -74,6 +82,7 @@ __global__ __launch_bounds__(256) void sa_first_kernel(
         float4 y;
         y.x = pv[t].x - q.x; y.y = pv[t].y - q.y; y.z = pv[t].z - q.z; y.w = pv[t].w - q.w;
         if (MODE == 0) {
+          y.x -= piv.x; y.y -= piv.y; y.z -= piv.z; y.w -= piv.w;
           a1.x += y.x; a1.y += y.y; a1.z += y.z; a1.w += y.w;
           a2.x = fmaf(y.x, y.x, a2.x); a2.y = fmaf(y.y, y.y, a2.y); a2.z = fmaf(y.z, y.z, a2.z); a2.w = fmaf(y.w, y.w, a2.w);
         } else {
@@ -194,7 +203,7 @@ struct Plan {
 };
 inline Plan plan(int64_t segs, int C) {
   const int slots = 256 / (C >> 2);
-  int64_t nblk = 1024;                               // <= SUG_STATS_BLOCKS partial rows per group
+  int64_t nblk = SUG_STATS_ROWS;                     // partial rows per group (the pivot row lives behind them)
   int64_t spb = (segs + nblk - 1) / nblk;
   spb = (spb + slots - 1) / slots * slots;           // whole passes
   if (spb < slots) spb = slots;
@@ -225,7 +234,7 @@ extern "C" int sug_sa_first_fwd(const float* P, int64_t ldp, const float* Q, con
                          pl.segs_per_block, nullptr, nullptr, nullptr, nullptr, 0, ws);
       SUG_LAUNCH_CHECK("sug_sa_first_fwd(stats)");
       if (int rc = sug_stats_finalize(ws, pl.nblk, C, gamma, beta, (double)segs_g * ns, eps, momentum, running_mean,
-                                      running_var, cg, st))
+                                      running_var, cg, st, ws + SUG_PIVOT_OFFSET(C)))
         return rc;
     }
     hipLaunchKernelGGL((sa_first_kernel<1>), dim3(pl.nblk), dim3(256), 0, st, P, ldp, Q, idx, N, S, ns, C, s0, s1,

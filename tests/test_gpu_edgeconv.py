@@ -219,3 +219,62 @@ def test_edgeconv_groups():
             return (out,)
 
     _grouped_vs_separate(_Run(), pq, Co, 5)
+
+
+@pytest.mark.parametrize('rows,C,groups', [(32768, 64, 2), (4096, 512, 1), (1000, 7, 1)])
+def test_bn_rows_large_offset(rows, C, groups):
+    """Batch statistics of data whose mean dwarfs its spread (y = 100 + 0.01*randn: E[x^2] - mean^2 in fp32 partial
+    sums would return noise): the partial sums are taken about a pivot row and combined in fp64, so the normalised
+    output matches an fp64 BatchNorm."""
+    from sug_amd import ops
+    g = torch.Generator().manual_seed(rows + C)
+    y = (100.0 + 0.01 * torch.randn(rows, C, generator=g)).cuda()
+    bn = torch.nn.BatchNorm1d(C).cuda().train()
+    with ops.bn_groups(groups):
+        out = ops.bn_act_rows(y, bn, 1.0)                       # slope 1: no activation
+    refs = []
+    for yg in y.double().chunk(groups, dim=0):
+        m, v = yg.mean(0), yg.var(0, unbiased=False)
+        refs.append((yg - m) / torch.sqrt(v + bn.eps))
+    ref = torch.cat(refs).float()
+    # x - mean carries the fp32 rounding of x itself (ulp(100) = 7.6e-6 against a spread of 0.01): 1e-3 of a unit-variance output
+    assert float((out - ref).abs().max()) < 5e-3, float((out - ref).abs().max())
+    assert abs(float(out.var(0, unbiased=False).mean()) - 1e-4 / (1e-4 + bn.eps)) < 2e-3      # var / (var + eps)
+    rv = torch.ones(C, dtype=torch.float64)
+    for yg in y.double().chunk(groups, dim=0):
+        rv = 0.9 * rv + 0.1 * yg.var(0, unbiased=True).cpu()
+    torch.testing.assert_close(bn.running_var.cpu().double(), rv, rtol=1e-3, atol=1e-7)
+
+
+def test_pointmlp_and_sa_first_large_offset():
+    """The same large-offset check for the fused layers that form their BatchNorm sums inside the kernel:
+    the per-point MLP + max (bias 100, spread ~1) and the set-abstraction first layer (P - Q about 100).
+    (EdgeConv keeps plain sums: its y = P[idx] + Q comes from bias-free convolutions of normalised activations.)"""
+    from sug_amd import ops
+    g = torch.Generator().manual_seed(12)
+    R, K, C2, seg = 8192, 64, 128, 32
+    x = torch.randn(R, K, generator=g).cuda()
+    W = (torch.randn(C2, K, generator=g) / 8).cuda()
+    b = torch.full((C2,), 100.0).cuda()
+    bn = torch.nn.BatchNorm1d(C2).cuda().train()
+    out = ops.pointmlp_max(x, W, b, bn, 0.0, seg)
+    yd = x.double() @ W.double().t() + 100.0
+    u = (yd - yd.mean(0)) / torch.sqrt(yd.var(0, unbiased=False) + bn.eps)
+    ref = torch.relu(u).view(-1, seg, C2).max(dim=1)[0].float()
+    assert float((out - ref).abs().max()) < 2e-4, float((out - ref).abs().max())
+
+    B, N, S, ns, C = 4, 256, 64, 32, 64
+    P = (100.0 + 0.01 * torch.randn(B, N, C, generator=g)).cuda()
+    Q = (0.01 * torch.randn(B, S, C, generator=g)).cuda()
+    idx = torch.randint(0, N, (B, S, ns), generator=g, dtype=torch.int32).cuda()
+    bn = torch.nn.BatchNorm1d(C).cuda().train()
+    with ops.bn_groups(2):
+        z = ops.sa_first_layer(P, Q, idx, bn)
+    bi = torch.arange(B, device='cuda').view(B, 1, 1)
+    y = (P[bi, idx.long()] - Q.unsqueeze(2)).double()
+    refs = []
+    for yg in y.chunk(2, dim=0):
+        m, v = yg.mean((0, 1, 2)), yg.var((0, 1, 2), unbiased=False)
+        refs.append(torch.relu((yg - m) / torch.sqrt(v + bn.eps)))
+    ref = torch.cat(refs).float()
+    assert float((z - ref).abs().max()) < 1e-2, float((z - ref).abs().max())           # input rounding: ulp(100) / 0.014
