@@ -143,8 +143,8 @@ class fc_layer(nn.Module):
         self.fc = nn.Sequential(*layers)
 
     def forward(self, x):
-        if len(self.fc) == 3 and x.is_cuda and ops.ln_act_supported(x, self.fc[1]):
-            # LayerNorm + activation in one launch (two in the backward) instead of 2 + 4
+        if ops.FUSED_HEADS and len(self.fc) == 3 and x.is_cuda and ops.ln_act_supported(x, self.fc[1]):
+            # LayerNorm + activation in one launch (two in the backward) instead of 2 + 4 (graph replay only: ops.FUSED_HEADS)
             slope = 0.0 if isinstance(self.ac, nn.ReLU) else self.ac.negative_slope
             return ops.ln_act(self.fc[0](x), self.fc[1], slope)
         return self.fc(x)

@@ -604,6 +604,12 @@ class _LNAct(torch.autograd.Function):
         return dx.view(shape), dgb[0], dgb[1], None, None
 
 
+# The fused LayerNorm + activation of the FC heads saves 3 launches per layer on the GPU but costs more host time than
+# the native ops it replaces (a Python autograd.Function per call): worth it when the step is replayed from a hipGraph
+# (SUGStep(use_graph=True) switches it on), not when every launch is issued from Python.
+FUSED_HEADS = False
+
+
 def ln_act_supported(x, ln):
     return x.is_cuda and x.dtype == torch.float32 and x.shape[-1] <= 1024 and ln.elementwise_affine and \
         len(ln.normalized_shape) == 1 and ln.weight is not None and ln.bias is not None

@@ -279,6 +279,7 @@ class SUGStep:
         from .optim import Adam as _SugAdam
         AdamCls = _SugAdam if own_adam else torch.optim.Adam
         if self.use_graph:
+            ops.FUSED_HEADS = True                      # fused small ops pay off once the host no longer launches
             if own_adam:
                 kw['graph_capturable'] = True           # step count / bias corrections on the device
             else:
