@@ -208,6 +208,7 @@ __global__ __launch_bounds__(512, 2) void knn_pc_kernel(const float* __restrict_
       __syncthreads();
     }
   } else {
+    __builtin_amdgcn_s_setprio(1);     // the selection waves are the second-dispatched half of the workgroup: static priority (-5 us at C=3)
     // ---- consumer: lane = one query; |x_i|^2 from the staged query tiles
     float ni = 0.f;
 #pragma unroll
