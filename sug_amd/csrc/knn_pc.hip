@@ -49,9 +49,14 @@ __device__ __forceinline__ unsigned lds_addr(const float* p) {
 // A key that is not smaller than L[KP-1] leaves the list unchanged.  (asm: hipcc's register allocation of
 // the C++ loop copies the list registers every iteration.)
 template <int KP>
-__device__ __forceinline__ void insert_key(int (&L)[KP], int x) {
+__device__ __forceinline__ void insert_key_hi(int (&L)[KP], int x) {          // slots KP-1 .. KP/2
 #pragma unroll
-  for (int u = KP - 1; u >= 1; --u) asm volatile("v_med3_i32 %0, %1, %2, %0" : "+v"(L[u]) : "v"(x), "v"(L[u - 1]));
+  for (int u = KP - 1; u >= KP / 2; --u) asm volatile("v_med3_i32 %0, %1, %2, %0" : "+v"(L[u]) : "v"(x), "v"(L[u - 1]));
+}
+template <int KP>
+__device__ __forceinline__ void insert_key_lo(int (&L)[KP], int x) {          // slots KP/2-1 .. 0
+#pragma unroll
+  for (int u = KP / 2 - 1; u >= 1; --u) asm volatile("v_med3_i32 %0, %1, %2, %0" : "+v"(L[u]) : "v"(x), "v"(L[u - 1]));
   asm volatile("v_min_i32 %0, %0, %1" : "+v"(L[0]) : "v"(x));
 }
 
@@ -295,30 +300,43 @@ __global__ __launch_bounds__(512, 2) void knn_pc_kernel(const float* __restrict_
       // The LDS reads are issued by hand and waited for only after the insertion of the previous entry
       // (loads are unconditional -- an unmarked lane re-reads slot 0 -- so that no branch wraps them).
       const unsigned srow_a = lds_addr(srow), nrm_a = lds_addr(nrm);
-      float dot, nj;
-      bool valid;
-      int c;
-      auto fetch_issue = [&]() {
+      // Two entries in flight (register sets A and B): the LDS reads of entry n+2 are issued before entry n is
+      // inserted, the key of entry n+1 is formed between the two halves of that insertion (its reads have had a
+      // whole iteration; lgkmcnt(2) waits for the older pair only) -- with one entry in flight the read latency
+      // plus the dependent key arithmetic (~25 quad-cycles) sat on the critical path of every iteration.
+      float dotA, njA, dotB, njB;
+      bool vA, vB;
+      int cA, cB;
+      auto fetch_issue = [&](float& dot, float& nj, bool& valid, int& c) {
         valid = mask != 0u;
         c = valid ? __builtin_clz(mask) : 0;
         mask &= ~(0x80000000u >> c);
         asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3" : "=&v"(dot), "=&v"(nj) : "v"(srow_a + 4u * c), "v"(nrm_a + 4u * c));
       };
-      auto fetch_finish = [&](int& key_out) {
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dot), "+v"(nj));
+      auto fetch_finish = [&](float& dot, float& nj, bool valid, int c, int& key_out) {
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(dot), "+v"(nj));
         // key: bucket of d = -score (v_cvt_u32_f32 truncates, maps negative rounding noise to 0 and saturates),
         // low bits = candidate index
         const unsigned fx = min(__float2uint_rz(-score(dot, nj) * scale), FXMAX);
         key_out = valid ? (int)((fx << idb) | (unsigned)(t * TJ + c)) : EMPTY;
       };
-      int key_cur;
-      fetch_issue();
-      fetch_finish(key_cur);
-      for (int it = 0; it < nit; ++it) {
-        fetch_issue();
-        insert_key<KP>(L, key_cur);
-        fetch_finish(key_cur);
+      int key_cur, key_nxt;
+      fetch_issue(dotA, njA, vA, cA);
+      fetch_issue(dotB, njB, vB, cB);
+      fetch_finish(dotA, njA, vA, cA, key_cur);
+      for (int it = 0; it < nit; it += 2) {
+        fetch_issue(dotA, njA, vA, cA);                         // entry it+2
+        insert_key_hi<KP>(L, key_cur);
+        fetch_finish(dotB, njB, vB, cB, key_nxt);               // entry it+1
+        insert_key_lo<KP>(L, key_cur);
+        if (it + 1 < nit) {
+          fetch_issue(dotB, njB, vB, cB);                       // entry it+3
+          insert_key_hi<KP>(L, key_nxt);
+          fetch_finish(dotA, njA, vA, cA, key_cur);             // entry it+2
+          insert_key_lo<KP>(L, key_nxt);
+        }
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dotA), "+v"(njA), "+v"(dotB), "+v"(njB));
       // a candidate whose key is below L[KP-1] has floor(d*scale) <= its bucket, so d < (bucket + 1) / scale: the
       // margin (+3, 2e-6 relative) covers the roundings of d*scale, of scale and of this product (buckets < 2^21)
       const int lk = L[KP - 1];
