@@ -256,6 +256,7 @@ def main():
     elif graph_mode:
         # eager steps of the same trainer: per-kernel event timings of every hand-written family + eager ms/step
         trainer.use_graph = False
+        ops.FUSED_HEADS = False                 # the eager launch mode as a caller without graphs runs it
         for _ in range(2):
             trainer.step(data, lab, data_t, lab_t)
         sync()
