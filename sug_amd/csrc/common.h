@@ -97,6 +97,31 @@ __device__ __forceinline__ float sqdist_expanded(float dot, float nq, float np) 
   return __fadd_rn(__fadd_rn(__fmul_rn(-2.0f, dot), nq), np);
 }
 
+// Wave-wide max / min over all 64 lanes through the DPP cross-lane paths (quad_perm, row_half_mirror, row_mirror,
+// row_bcast:15 / :31) instead of six dependent LDS-crossbar shuffles: the result is returned to every lane.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int sug_dpp(int v) {
+  return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ float wave_max_f(float v) {
+  v = fmaxf(v, __int_as_float(sug_dpp<0xB1, 0xf>(__float_as_int(v))));    // quad_perm [1,0,3,2]
+  v = fmaxf(v, __int_as_float(sug_dpp<0x4E, 0xf>(__float_as_int(v))));    // quad_perm [2,3,0,1]
+  v = fmaxf(v, __int_as_float(sug_dpp<0x141, 0xf>(__float_as_int(v))));   // row_half_mirror
+  v = fmaxf(v, __int_as_float(sug_dpp<0x140, 0xf>(__float_as_int(v))));   // row_mirror: every lane = its row's max
+  v = fmaxf(v, __int_as_float(sug_dpp<0x142, 0xa>(__float_as_int(v))));   // row_bcast:15 into rows 1, 3
+  v = fmaxf(v, __int_as_float(sug_dpp<0x143, 0xc>(__float_as_int(v))));   // row_bcast:31 into rows 2, 3
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ int wave_min_i(int v) {
+  v = min(v, sug_dpp<0xB1, 0xf>(v));
+  v = min(v, sug_dpp<0x4E, 0xf>(v));
+  v = min(v, sug_dpp<0x141, 0xf>(v));
+  v = min(v, sug_dpp<0x140, 0xf>(v));
+  v = min(v, sug_dpp<0x142, 0xa>(v));
+  v = min(v, sug_dpp<0x143, 0xc>(v));
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -53,15 +53,10 @@ __global__ __launch_bounds__(BLOCK) void fps_kernel(const float* __restrict__ xy
         bi = p * BLOCK + threadIdx.x;
       }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float ov = __shfl_xor(bv, o);
-      const int oi = __shfl_xor(bi, o);
-      if (ov > bv || (ov == bv && oi < bi)) {
-        bv = ov;
-        bi = oi;
-      }
-    }
+    // wave arg-max: greatest value, lowest index among equals (two DPP reductions: the value, then the index)
+    const float wm = wave_max_f(bv);
+    bi = wave_min_i(bv == wm ? bi : 0x7fffffff);
+    bv = wm;
     const int par = i & 1;
     if (lane == 0) {
       s_v[par][wv] = bv;
