@@ -112,6 +112,15 @@ __device__ __forceinline__ float wave_max_f(float v) {
   v = fmaxf(v, __int_as_float(sug_dpp<0x143, 0xc>(__float_as_int(v))));   // row_bcast:31 into rows 2, 3
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
+__device__ __forceinline__ float wave_min_f(float v) {
+  v = fminf(v, __int_as_float(sug_dpp<0xB1, 0xf>(__float_as_int(v))));
+  v = fminf(v, __int_as_float(sug_dpp<0x4E, 0xf>(__float_as_int(v))));
+  v = fminf(v, __int_as_float(sug_dpp<0x141, 0xf>(__float_as_int(v))));
+  v = fminf(v, __int_as_float(sug_dpp<0x140, 0xf>(__float_as_int(v))));
+  v = fminf(v, __int_as_float(sug_dpp<0x142, 0xa>(__float_as_int(v))));
+  v = fminf(v, __int_as_float(sug_dpp<0x143, 0xc>(__float_as_int(v))));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
 __device__ __forceinline__ int wave_min_i(int v) {
   v = min(v, sug_dpp<0xB1, 0xf>(v));
   v = min(v, sug_dpp<0x4E, 0xf>(v));

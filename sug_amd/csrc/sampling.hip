@@ -159,17 +159,9 @@ __global__ __launch_bounds__(256) void knn_query_kernel(const float* __restrict_
         li = j;
       }
     }
-    float bv = lv;
-    int bi = li;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float ov = __shfl_xor(bv, o);
-      const int oi = __shfl_xor(bi, o);
-      if (ov < bv || (ov == bv && oi < bi)) {
-        bv = ov;
-        bi = oi;
-      }
-    }
+    // wave arg-min: smallest value, lowest index among equals (DPP reductions; all candidates +inf: index out of range)
+    const float bv = wave_min_f(lv);
+    const int bi = wave_min_i(lv == bv ? li : 0x7fffffff);
     if (lane == (t & (WAVE - 1))) {
       res_i = bi;
       res_d = bv;
