@@ -81,9 +81,14 @@ __device__ __forceinline__ void tile_store(const TileRegs<CP>& t, float* __restr
         float p = __fmul_rn(a.x, a.x);
         p = fmaf(a.y, a.y, p); p = fmaf(a.z, a.z, p); p = fmaf(a.w, a.w, p);
         p = fmaf(b.x, b.x, p); p = fmaf(b.y, b.y, p); p = fmaf(b.z, b.z, p); p = fmaf(b.w, b.w, p);
-        // fixed-order tree over the CH lanes of this row (consecutive lanes)
-#pragma unroll
-        for (int o = 1; o < CH; o <<= 1) p += __shfl_xor(p, o);
+        // fixed-order tree over the CH lanes of this row (consecutive lanes, CH <= 16: inside one DPP row).  The DPP
+        // partners (quad_perm, row_half_mirror, row_mirror) hold the same partial sums as the xor partners of a
+        // shuffle tree, so the result is bit for bit that tree's -- without four trips through the LDS crossbar.
+        static_assert(CH <= 16, "one DPP row");
+        if (CH > 1) p += __int_as_float(sug_dpp<0xB1, 0xf>(__float_as_int(p)));      // xor 1
+        if (CH > 2) p += __int_as_float(sug_dpp<0x4E, 0xf>(__float_as_int(p)));      // xor 2
+        if (CH > 4) p += __int_as_float(sug_dpp<0x141, 0xf>(__float_as_int(p)));     // other quad of the 8
+        if (CH > 8) p += __int_as_float(sug_dpp<0x140, 0xf>(__float_as_int(p)));     // other half of the 16
         if (c8 == 0) s_norm[r] = (row0 + r < N) ? p : INFINITY;
       }
     }
