@@ -319,15 +319,58 @@ __global__ __launch_bounds__(256) void pointmlp_bwd_dx_kernel(const float* __res
     __syncthreads();
     const int r0 = ch * rows_per_chunk;
     const int r1 = (r0 + rows_per_chunk < L) ? r0 + rows_per_chunk : L;
-    for (int r = r0 + wv; r < r1; r += 4) {
+    if (Co <= 256) {
+      // few channels per row: every row scans all of them (a ballot per 64 channels)
+      for (int r = r0 + wv; r < r1; r += 4) {
+        float acc[KV];
+#pragma unroll
+        for (int u = 0; u < KV; ++u) acc[u] = 0.f;
+        bool any = false;
+        for (int c0 = 0; c0 < Co; c0 += 64) {
+          unsigned long long m = __ballot(c0 + lane < Co && s_arg[c0 + lane] == r);
+          while (m) {
+            const int c = c0 + __builtin_ctzll(m);
+            m &= m - 1;
+            const float av = s_a[c];
+            const float* wr = W + (int64_t)c * K + lane * KV;
+#pragma unroll
+            for (int u = 0; u < KV; ++u) acc[u] = fmaf(av, wr[u], acc[u]);
+            any = true;
+          }
+        }
+        if (any) {
+          float* d = dx + ((int64_t)s * L + r) * lddx + lane * KV;
+#pragma unroll
+          for (int u = 0; u < KV; ++u) d[u] += acc[u];
+        }
+      }
+      continue;
+    }
+    // Many channels per row block (the global-max layers: every row scanned all Co channels for the ~1 that picked
+    // it): a wave owns a contiguous quarter of the chunk's rows, compacts -- in ascending channel order, one ballot
+    // per 64 channels -- the channels whose arg falls into its quarter, and every row scans only that short list.
+    // Same channels in the same order per row: the sums are bit for bit those of the full scan.
+    const int per_wave = (r1 - r0 + 3) / 4;
+    const int ra = r0 + wv * per_wave, rb = (ra + per_wave < r1) ? ra + per_wave : r1;
+    int* s_list = reinterpret_cast<int*>(s_mem + 2 * Co) + wv * Co;            // [4][Co] compacted channels
+    int nlist = 0;
+    for (int c0 = 0; c0 < Co; c0 += 64) {
+      const int c = c0 + lane;
+      const bool in = c < Co && s_arg[c] >= ra && s_arg[c] < rb;
+      const unsigned long long m = __ballot(in);
+      if (in) s_list[nlist + __popcll(m & ((1ull << lane) - 1ull))] = c;
+      nlist += __popcll(m);
+    }
+    for (int r = ra; r < rb; ++r) {
       float acc[KV];
 #pragma unroll
       for (int u = 0; u < KV; ++u) acc[u] = 0.f;
       bool any = false;
-      for (int c0 = 0; c0 < Co; c0 += 64) {
-        unsigned long long m = __ballot(c0 + lane < Co && s_arg[c0 + lane] == r);
+      for (int i0 = 0; i0 < nlist; i0 += 64) {
+        const int cl = (i0 + lane < nlist) ? s_list[i0 + lane] : -1;
+        unsigned long long m = __ballot(cl >= 0 && s_arg[cl >= 0 ? cl : 0] == r);
         while (m) {
-          const int c = c0 + __builtin_ctzll(m);
+          const int c = s_list[i0 + __builtin_ctzll(m)];
           m &= m - 1;
           const float av = s_a[c];
           const float* wr = W + (int64_t)c * K + lane * KV;
@@ -580,7 +623,7 @@ extern "C" int sug_pointmlp_max_bwd_sparse(const float* a, const int32_t* arg, c
   const int chunks = sug_divup(seg, 128);
   int64_t g64 = S * chunks;
   const int grid = (int)(g64 < 4096 ? g64 : 4096);
-  const size_t sh = (size_t)Co * 8;
+  const size_t sh = (size_t)Co * 8 + (Co > 256 ? (size_t)Co * 16 : 0);      // a, arg (+ 4 compacted channel lists)
   int nsc = (int)(S < 256 ? S : 256);
   dim3 g2(sug_divup(Co, 64), nsc);
   if (K == 128) {
