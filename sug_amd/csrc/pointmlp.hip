@@ -388,6 +388,52 @@ __global__ __launch_bounds__(256) void pointmlp_bwd_dx_kernel(const float* __res
   }
 }
 
+// The same for short segments (L <= 64 rows, Co <= 256: the set-abstraction layers, 65 k segments of 32 rows at
+// config 3): one WAVE per segment, its a / arg values in registers (channel = lane + 64 i), no LDS staging and
+// no workgroup barriers (the kernel above spends its time in two barriers per 32-row item).  Channels of a row
+// are taken in ascending order (i, then lane): the sums are those of the kernel above.
+template <int KV, int CV>
+__global__ __launch_bounds__(256) void pointmlp_bwd_dx_seg_kernel(const float* __restrict__ a, const int32_t* __restrict__ arg,
+                                                                  const float* __restrict__ W, int Co, int L, int S,
+                                                                  float* __restrict__ dx, int64_t lddx) {
+  constexpr int K = KV * 64;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int s = blockIdx.x * 4 + wv; s < S; s += gridDim.x * 4) {
+    float av[CV];
+    int rg[CV];
+#pragma unroll
+    for (int i = 0; i < CV; ++i) {
+      const int c = lane + 64 * i;
+      av[i] = c < Co ? a[(int64_t)s * Co + c] : 0.f;
+      rg[i] = c < Co ? arg[(int64_t)s * Co + c] : -1;
+    }
+    for (int r = 0; r < L; ++r) {
+      float acc[KV];
+#pragma unroll
+      for (int u = 0; u < KV; ++u) acc[u] = 0.f;
+      bool any = false;
+#pragma unroll
+      for (int i = 0; i < CV; ++i) {
+        unsigned long long m = __ballot(rg[i] == r);
+        while (m) {
+          const int l = __builtin_ctzll(m);
+          m &= m - 1;
+          const float ac = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(av[i]), l));
+          const float* wr = W + (int64_t)(l + 64 * i) * K + lane * KV;
+#pragma unroll
+          for (int u = 0; u < KV; ++u) acc[u] = fmaf(ac, wr[u], acc[u]);
+          any = true;
+        }
+      }
+      if (any) {
+        float* d = dx + ((int64_t)s * L + r) * lddx + lane * KV;
+#pragma unroll
+        for (int u = 0; u < KV; ++u) d[u] += acc[u];
+      }
+    }
+  }
+}
+
 // dW partials: grid (channel blocks of 64, segment chunks); a wave owns 16 channels and sums
 // a[s,c] * x[n*(s,c),:] over the segments of its chunk in ascending s; one partial row per chunk
 // (dwp [nsc][Co][K]), folded in order by pointmlp_bwd_dw_fold_kernel.
@@ -626,11 +672,23 @@ extern "C" int sug_pointmlp_max_bwd_sparse(const float* a, const int32_t* arg, c
   const size_t sh = (size_t)Co * 8 + (Co > 256 ? (size_t)Co * 16 : 0);      // a, arg (+ 4 compacted channel lists)
   int nsc = (int)(S < 256 ? S : 256);
   dim3 g2(sug_divup(Co, 64), nsc);
+  const bool per_wave = seg <= 64 && Co <= 256;          // short segments: a wave per segment, no barriers
+  const int gseg = (int)(S / 4 < 8192 ? (S + 3) / 4 : 8192);
   if (K == 128) {
-    hipLaunchKernelGGL((pointmlp_bwd_dx_kernel<2>), dim3(grid), dim3(256), sh, st, a, arg, w, Co, seg, (int)S, chunks, dx, lddx);
+    if (per_wave && Co <= 128)
+      hipLaunchKernelGGL((pointmlp_bwd_dx_seg_kernel<2, 2>), dim3(gseg), dim3(256), 0, st, a, arg, w, Co, seg, (int)S, dx, lddx);
+    else if (per_wave)
+      hipLaunchKernelGGL((pointmlp_bwd_dx_seg_kernel<2, 4>), dim3(gseg), dim3(256), 0, st, a, arg, w, Co, seg, (int)S, dx, lddx);
+    else
+      hipLaunchKernelGGL((pointmlp_bwd_dx_kernel<2>), dim3(grid), dim3(256), sh, st, a, arg, w, Co, seg, (int)S, chunks, dx, lddx);
     hipLaunchKernelGGL((pointmlp_bwd_dw_kernel<2>), g2, dim3(256), 0, st, a, arg, x, ldx, Co, seg, (int)S, nsc, ws);
   } else {
-    hipLaunchKernelGGL((pointmlp_bwd_dx_kernel<1>), dim3(grid), dim3(256), sh, st, a, arg, w, Co, seg, (int)S, chunks, dx, lddx);
+    if (per_wave && Co <= 128)
+      hipLaunchKernelGGL((pointmlp_bwd_dx_seg_kernel<1, 2>), dim3(gseg), dim3(256), 0, st, a, arg, w, Co, seg, (int)S, dx, lddx);
+    else if (per_wave)
+      hipLaunchKernelGGL((pointmlp_bwd_dx_seg_kernel<1, 4>), dim3(gseg), dim3(256), 0, st, a, arg, w, Co, seg, (int)S, dx, lddx);
+    else
+      hipLaunchKernelGGL((pointmlp_bwd_dx_kernel<1>), dim3(grid), dim3(256), sh, st, a, arg, w, Co, seg, (int)S, chunks, dx, lddx);
     hipLaunchKernelGGL((pointmlp_bwd_dw_kernel<1>), g2, dim3(256), 0, st, a, arg, x, ldx, Co, seg, (int)S, nsc, ws);
   }
   SUG_LAUNCH_CHECK("sug_pointmlp_max_bwd_sparse");
