@@ -886,8 +886,8 @@ class _PointMLPMax(torch.autograd.Function):
         S = rows // seg
         rg, sg = rows // G, S // G
         gout = gout.reshape(S, Co)
-        if gout.stride(1) != 1:
-            gout = gout.contiguous()
+        if gout.stride(1) != 1 or gout.stride(0) % 4 or gout.data_ptr() % 16:
+            gout = gout.contiguous()        # e.g. a column slice of a [.., 3 + C] gradient: the float4 kernels need aligned rows
         a = torch.empty(S, Co, dtype=torch.float32, device=dev)
         red = torch.empty(G, 2 * Co, dtype=torch.float64, device=dev)
         ws = torch.empty(STATS_BLOCKS * 2 * Co, dtype=torch.float32, device=dev)
