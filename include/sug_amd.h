@@ -260,6 +260,12 @@ int sug_interp3_cat_fwd(const float* fea, int64_t ldf, int C1, const float* node
 int sug_interp3_cat_bwd(const float* g, int64_t ldg, int C1, const float* node, const int32_t* idx3,
                         const float* d3, const float* xyz, const float* nloc, int B, int N, int S,
                         int C2, float* dnode, float* dnloc, void* stream);
+/* The same gradient by destination node over the (sorted) reverse lists of idx3: no accumulation in LDS, fixed
+ * summation order; dnode / dnloc are written entirely.  Scratch: rev_off [B,S+1], rev_ent [B,3N] ints, ddw [B,N,6] floats. */
+int sug_interp3_cat_bwd_lists(const float* g, int64_t ldg, int C1, const float* node, const int32_t* idx3,
+                              const float* d3, const float* xyz, const float* nloc, int B, int N, int S, int C2,
+                              int32_t* rev_off, int32_t* rev_ent, float* ddw, float* dnode, float* dnloc,
+                              void* stream);
 
 /* ---- BatchNorm(+act) on rows: backward, and the fused DGCNN tail ----------------------------
  * Exact train-mode BN gradient for a per-point layer (conv_2d on [B,C,N,1],

@@ -73,6 +73,7 @@ SIGNATURES = {
     'sug_pointmlp_max_bwd_dwfix': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
     'sug_ln_act_fwd': [_vp, _vp, _vp, _i32, _i32, _f32, _f32, _vp, _vp, _vp],
     'sug_ln_act_bwd': [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp],
+    'sug_interp3_cat_bwd_lists': [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     'sug_linear_dw_bias': [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp],
     'sug_node_offset_fwd': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
     'sug_node_offset_bwd': [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp],

@@ -235,6 +235,107 @@ __global__ __launch_bounds__(256) void interp3_cat_bwd_kernel(const float* __res
   for (int i = threadIdx.x; i < S * 3; i += 256) atomicAdd(&dlb[i], s_dl[i]);
 }
 
+// interp3_cat backward without atomics, in two launches over the reverse lists of idx3 (which points interpolate from
+// which node: sug_reverse_lists, sorted, so the sums have a fixed order):
+//   A (per point):  o = sum_t w_t node_t,  s_t = sum_c g_c (node_t,c - o_c),  dd_t = -(r_t^2 / R) s_t  -> ddw[p] = dd | w
+//   B (per node s): dnode[s,:] = sum_{(n,t) -> s} w_t(n) g[n, C1:],  dnloc[s] = sum dd_t(n) * 2 (nloc[s] - xyz[n])
+// (the LDS-accumulating kernel above spends its time in 12.6 M LDS float adds: 87 us at the C2 shape)
+__global__ __launch_bounds__(256) void interp3_bwd_point_kernel(const float* __restrict__ g, int64_t ldg, int C1,
+                                                                const float* __restrict__ node,
+                                                                const int32_t* __restrict__ idx3,
+                                                                const float* __restrict__ d3, int N, int S, int C2,
+                                                                int64_t BN, float* __restrict__ ddw) {
+  const int64_t p = (int64_t)blockIdx.x * 16 + threadIdx.x / 16;
+  if (p >= BN) return;
+  const int lane = threadIdx.x & 15;
+  const int64_t b = p / N;
+  const float d0 = d3[p * 3 + 0], d1 = d3[p * 3 + 1], d2 = d3[p * 3 + 2];
+  const float r0 = 1.0f / fmaxf(d0, 1e-10f), r1 = 1.0f / fmaxf(d1, 1e-10f), r2 = 1.0f / fmaxf(d2, 1e-10f);
+  const float R = (r0 + r1) + r2;
+  const float w0 = r0 / R, w1 = r1 / R, w2 = r2 / R;
+  const float* n0 = node + (b * S + idx3[p * 3 + 0]) * C2;
+  const float* n1 = node + (b * S + idx3[p * 3 + 1]) * C2;
+  const float* n2 = node + (b * S + idx3[p * 3 + 2]) * C2;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  for (int c = lane * 4; c < C2; c += 64) {
+    const float4 gv = *reinterpret_cast<const float4*>(g + p * ldg + C1 + c);
+    const float4 a = *reinterpret_cast<const float4*>(n0 + c), bq = *reinterpret_cast<const float4*>(n1 + c),
+                 cq = *reinterpret_cast<const float4*>(n2 + c);
+    const float gg[4] = {gv.x, gv.y, gv.z, gv.w};
+    const float aa[4] = {a.x, a.y, a.z, a.w}, bb[4] = {bq.x, bq.y, bq.z, bq.w}, cc[4] = {cq.x, cq.y, cq.z, cq.w};
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const float o = (aa[v] * w0 + bb[v] * w1) + cc[v] * w2;
+      s0 += gg[v] * (aa[v] - o); s1 += gg[v] * (bb[v] - o); s2 += gg[v] * (cc[v] - o);
+    }
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) {
+    s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o);
+  }
+  if (lane < 3) {
+    const float sv = lane == 0 ? s0 : (lane == 1 ? s1 : s2);
+    const float d = lane == 0 ? d0 : (lane == 1 ? d1 : d2);
+    const float r = lane == 0 ? r0 : (lane == 1 ? r1 : r2);
+    const float w = lane == 0 ? w0 : (lane == 1 ? w1 : w2);
+    ddw[p * 6 + lane] = (d < 1e-10f) ? 0.f : -(r * r / R) * sv;     // clamp region: no gradient
+    ddw[p * 6 + 3 + lane] = w;
+  }
+}
+
+__global__ __launch_bounds__(256) void interp3_bwd_node_kernel(const float* __restrict__ g, int64_t ldg, int C1,
+                                                               const float* __restrict__ ddw,
+                                                               const int32_t* __restrict__ rev_off,
+                                                               const int32_t* __restrict__ rev_ent,
+                                                               const float* __restrict__ xyz,
+                                                               const float* __restrict__ nloc, int N, int S, int C2,
+                                                               int64_t BS, float* __restrict__ dnode,
+                                                               float* __restrict__ dnloc) {
+  const int64_t q = (int64_t)blockIdx.x * 16 + threadIdx.x / 16;    // node (b, s)
+  if (q >= BS) return;
+  const int lane = threadIdx.x & 15;
+  const int64_t b = q / S;
+  const int sn = (int)(q - b * S);
+  const int32_t* offb = rev_off + b * (S + 1);
+  const int off = offb[sn], cnt = offb[sn + 1] - off;
+  const int32_t* ent = rev_ent + b * 3 * N + off;
+  const int ax = lane < 3 ? lane : 0;
+  const float cpos = nloc[q * 3 + ax];
+  float dl = 0.f;
+  const int npass = (C2 + 63) / 64;                                 // one pass for C2 <= 64 (the SA-node shapes)
+  for (int pass = 0; pass < npass; ++pass) {
+    const int c0 = pass * 64 + lane * 4;
+    const bool chan = c0 < C2;
+    float4 acc = make_float4(0, 0, 0, 0);
+    constexpr int JB = 8;
+    for (int t0 = 0; t0 < cnt; t0 += JB) {
+      int en[JB];
+      float4 gv[JB];
+      float wv[JB], dv[JB], xv[JB];
+#pragma unroll
+      for (int t = 0; t < JB; ++t) en[t] = ent[t0 + t < cnt ? t0 + t : cnt - 1];
+#pragma unroll
+      for (int t = 0; t < JB; ++t) {
+        const int n = en[t] / 3, tt = en[t] - 3 * n;
+        const int64_t p = b * N + n;
+        gv[t] = chan ? *reinterpret_cast<const float4*>(g + p * ldg + C1 + c0) : make_float4(0, 0, 0, 0);
+        wv[t] = ddw[p * 6 + 3 + tt];
+        dv[t] = ddw[p * 6 + tt];
+        xv[t] = xyz[p * 3 + ax];
+      }
+#pragma unroll
+      for (int t = 0; t < JB; ++t) {
+        if (t0 + t >= cnt) continue;
+        acc.x = fmaf(wv[t], gv[t].x, acc.x); acc.y = fmaf(wv[t], gv[t].y, acc.y);
+        acc.z = fmaf(wv[t], gv[t].z, acc.z); acc.w = fmaf(wv[t], gv[t].w, acc.w);
+        if (pass == 0) dl += dv[t] * 2.f * (cpos - xv[t]);
+      }
+    }
+    if (chan) *reinterpret_cast<float4*>(dnode + q * C2 + c0) = acc;
+  }
+  if (lane < 3) dnloc[q * 3 + lane] = dl;
+}
+
 }  // namespace
 
 extern "C" int sug_node_offset_fwd(const float* proj, const float* loc, const int32_t* fidx,
@@ -304,5 +405,28 @@ extern "C" int sug_interp3_cat_bwd(const float* g, int64_t ldg, int C1, const fl
   hipLaunchKernelGGL(interp3_cat_bwd_kernel, dim3(chunks, B), dim3(256), sh, (hipStream_t)stream, g, ldg, C1, node,
                      idx3, d3, xyz, nloc, N, S, C2, chunks, dnode, dnloc);
   SUG_LAUNCH_CHECK("sug_interp3_cat_bwd");
+  return SUG_OK;
+}
+
+// The same gradient without LDS accumulation: scratch rev_off [B,S+1], rev_ent [B,3N] (ints), ddw [B,N,6] (floats);
+// dnode / dnloc are written entirely (no zero fill); fixed summation order (sorted reverse lists).
+extern "C" int sug_interp3_cat_bwd_lists(const float* g, int64_t ldg, int C1, const float* node, const int32_t* idx3,
+                                         const float* d3, const float* xyz, const float* nloc, int B, int N, int S, int C2,
+                                         int32_t* rev_off, int32_t* rev_ent, float* ddw, float* dnode, float* dnloc,
+                                         void* stream) {
+  SUG_REQUIRE(g && node && idx3 && d3 && xyz && nloc && rev_off && rev_ent && ddw && dnode && dnloc,
+              "sug_interp3_cat_bwd_lists: null pointer");
+  SUG_REQUIRE(B > 0 && N > 0 && S >= 3 && C2 > 0 && C1 % 4 == 0 && C2 % 4 == 0 && ldg % 4 == 0 &&
+                  ldg >= C1 + C2 && ((uintptr_t)g % 16 == 0) && ((uintptr_t)node % 16 == 0) && ((uintptr_t)dnode % 16 == 0),
+              "sug_interp3_cat_bwd_lists: bad shape / alignment");
+  hipStream_t st = (hipStream_t)stream;
+  if (int rc = sug_reverse_lists(idx3, B, 3 * N, S, 1, rev_off, rev_ent, st)) return rc;
+  const int64_t BN = (int64_t)B * N, BS = (int64_t)B * S;
+  hipLaunchKernelGGL(interp3_bwd_point_kernel, dim3(sug_divup(BN, 16)), dim3(256), 0, st, g, ldg, C1, node, idx3, d3, N, S, C2,
+                     BN, ddw);
+  SUG_LAUNCH_CHECK("sug_interp3_cat_bwd_lists(point)");
+  hipLaunchKernelGGL(interp3_bwd_node_kernel, dim3(sug_divup(BS, 16)), dim3(256), 0, st, g, ldg, C1, ddw, rev_off, rev_ent, xyz,
+                     nloc, N, S, C2, BS, dnode, dnloc);
+  SUG_LAUNCH_CHECK("sug_interp3_cat_bwd_lists(node)");
   return SUG_OK;
 }

@@ -411,10 +411,14 @@ class _Interp3Cat(torch.autograd.Function):
         node, idx3, d3, xyz, nloc = ctx.saved_tensors
         B, N, S, C1, C2 = ctx.meta
         g = g.contiguous()
-        dnode = torch.zeros_like(node)
-        dnloc = torch.zeros_like(nloc)
-        check(lib().sug_interp3_cat_bwd(_p(g), C1 + C2, C1, _p(node), _p(idx3), _p(d3), _p(xyz), _p(nloc), B, N, S,
-                                        C2, _p(dnode), _p(dnloc), _st()), 'sug_interp3_cat_bwd')
+        dnode = torch.empty_like(node)
+        dnloc = torch.empty_like(nloc)
+        off = torch.empty(B, S + 1, dtype=torch.int32, device=g.device)
+        ent = torch.empty(B, 3 * N, dtype=torch.int32, device=g.device)
+        ddw = torch.empty(B, N, 6, dtype=torch.float32, device=g.device)
+        check(lib().sug_interp3_cat_bwd_lists(_p(g), C1 + C2, C1, _p(node), _p(idx3), _p(d3), _p(xyz), _p(nloc), B, N, S,
+                                              C2, _p(off), _p(ent), _p(ddw), _p(dnode), _p(dnloc), _st()),
+              'sug_interp3_cat_bwd_lists')
         return g[:, :, :C1], dnode, None, dnloc
 
 
