@@ -457,3 +457,16 @@ def test_ln_act_vs_torch(rows, C, slope):
     xk.grad, ln_k.weight.grad, ln_k.bias.grad = None, None, None
     (ops.ln_act(xk, ln_k, slope) * probe).sum().backward()
     assert torch.equal(g1[0], xk.grad) and torch.equal(g1[1], ln_k.weight.grad)
+
+
+@pytest.mark.parametrize('N', [20, 21, 33, 64, 100])
+@pytest.mark.parametrize('C', [3, 64])
+def test_knn_tiny_clouds(N, C):
+    """Clouds smaller than a candidate tile / barely larger than k: the packed-key list never fills its spare slots,
+    the first tile carries rows past N; neighbour lists equal the oracle's."""
+    from sug_amd import ops
+    g = torch.Generator().manual_seed(N + C)
+    x = torch.randn(3, C, N, generator=g)
+    idx = ops.knn(x.transpose(1, 2).contiguous().cuda(), 20).cpu().long()
+    ref = O.knn_idx(x, 20)
+    assert_same_or_tied(idx, ref, O.knn_neg_dist(x), ulps=8 if C > 3 else 0)
