@@ -978,7 +978,7 @@ class _PTranAttention(torch.autograd.Function):
         delta = torch.addmm(wl[1], T0, wl[0].t())
         U = torch.empty(R, d, dtype=lo, device=dev)
         check(L_.sug_ptran_qk_fwd(_p(q), _p(kf), _p(delta), _p(nbr), B, n, k, d, code, _p(U), _st()), 'sug_ptran_qk_fwd')
-        T1 = torch.addmm(wl[3], U, wl[2].t()).relu_()
+        T1 = torch._addmm_activation(wl[3], U, wl[2].t())          # bias + ReLU in the library GEMM's epilogue
         Lg = torch.addmm(wl[5], T1, wl[4].t())
         mixed = torch.empty(B, n, d, dtype=torch.float32, device=dev)
         mx, sm = torch.empty_like(mixed), torch.empty_like(mixed)
