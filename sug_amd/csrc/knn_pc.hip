@@ -3,9 +3,10 @@
 //
 // The score tiles <x_i, x_j> run on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32: bit for bit the
 // ascending-k fmaf chain of the scalar kernel and of the CPU reference's K=3 sgemm), the top-k
-// selection is VALU work.  A wave issues in order, so one wave cannot keep both pipes busy; here
-// the two kinds of work live in DIFFERENT waves of one 512-thread workgroup and every SIMD hosts
-// one of each:
+// selection is VALU work.  On gfx950 fp32 MFMA time and VALU time ADD on a SIMD (tools/ubench, DESIGN.md
+// section 7), and a VALU instruction between two dependent MFMAs also breaks the accumulator forwarding:
+// the two kinds of work live in DIFFERENT waves of one 512-thread workgroup, every SIMD hosts one of
+// each, the MFMA chains stay back to back and the selection is kept as short as it can be made:
 //   waves 0-3  producers: stream 32-candidate tiles global -> registers -> LDS (mfma_tile.h), run
 //              the MFMA chains of 64 queries each (two 32-query column blocks sharing the A
 //              operand) and write the 64 x 32 score tile to LDS, row = query;
@@ -15,8 +16,8 @@
 //              pass are marked in a 32-bit mask and then inserted -- all lanes of the wave in lockstep, one
 //              marked candidate per lane per iteration -- into the lane's sorted list of PACKED KEYS in
 //              registers: key = (fixed-point bucket of d = -score over the query's range of the first tile)
-//              << ceil(log2 N) | candidate index, one v_med3_i32 per slot (the exact (score, index) lists of the first
-//              round-2 kernel cost 4 VALU per slot: the selection, not the MFMA chain, bounds this kernel).
+//              << ceil(log2 N) | candidate index, one v_med3_i32 per slot (the exact (score, index) lists
+//              of the first round-2 kernel cost 4 VALU per slot).
 //              The bucket map is a monotone coarsening of d, so the K+2 smallest keys contain the exact
 //              top K whenever fewer than 3 keys share the boundary bucket; at the end a lane whose first
 //              K+1 keys lie in distinct buckets has the exact answer in key order (the common case), a lane
@@ -26,8 +27,8 @@
 //              give the lists of the exact consumer bit for bit (tests/golden/knn_pc_hashes.json).
 // One barrier per tile hands tile t's scores to the consumers while the producers work on tile
 // t+1.  No candidate ring, no compaction, no merge.
-// LDS: tiles 3 x 32 x (C+4) + score tiles 2 x 4 x 64 x 36 floats = 100 / 125 KB (C = 64 / 128).  Workgroup = 256 queries of one cloud; the 4 workgroups of a 1024-point cloud
-// share an XCD (one L2).
+// LDS: tiles 3 x 32 x (C+4) + score tiles 2 x 4 x 64 x 36 floats = 100 / 125 KB (C = 64 / 128).
+// Workgroup = 256 queries of one cloud; the 4 workgroups of a 1024-point cloud share an XCD (one L2).
 //
 // FLOPs N^2*(2C+3) per cloud on the matrix pipe (157 TFLOP/s); algorithmic bytes 4*C*N + 4*N*k.
 #include <float.h>
