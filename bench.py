@@ -193,6 +193,7 @@ def main():
     if args.fp16:
         from sug_amd.model import Ptran_transformer as PT
         PT.GEMM_DTYPE = torch.float16
+        PT.PROJ_16BIT = True               # every 512-wide linear of the transformer blocks on the fp16 MFMA path
     torch.manual_seed(666)                              # train_dg_single_gpu.py:65
     model = Net_MDA(args.model).to(dev).train()
     if world > 1:                                       # same initial weights on every rank
@@ -364,7 +365,9 @@ def main():
                           'eager_ms_per_step': eager_ms,
                           'share_prefix': trainer.share_prefix, 'pair_domains': trainer.pair_domains,
                           'tuned_gemms': tuned, 'geo_weights': 'mean2one', 'sem_weights': 'mean2one',
-                          'unchanged_caller_ms_per_step': caller_ms},
+                          'unchanged_caller_ms_per_step': caller_ms,
+                          **({'fp16_linears': 'k-expanded and per-point 512-wide linears of the transformer blocks'}
+                             if (args.fp16 and args.model == 'PTran') else {})},
                'roofline': roofline, 'cpu_baseline': cpu, 'losses': loss_vals,
                'kernels': {k: {kk: (round(vv, 5) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in kern.items()}}
         print(json.dumps(out))
