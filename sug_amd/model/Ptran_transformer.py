@@ -32,12 +32,17 @@ GEMM_DTYPE = None
 PROJ_16BIT = False
 
 
+def _w16(p, lo):
+    """16-bit copy of a parameter (ops.cast_cached: shared by the calls of one step when SUGStep's cache is on)."""
+    return ops.cast_cached(p, lo)
+
+
 def _apply(layer, rows, wide=False):
     """nn.Linear on [..., d] rows.  fp32: split-K weight-gradient kernel; `wide` rows (the k-expanded
     tensors) may take the reduced-precision library GEMM when GEMM_DTYPE is set."""
     if wide and GEMM_DTYPE is not None:
         lo = GEMM_DTYPE
-        y = F.linear(rows.to(lo), layer.weight.to(lo), None if layer.bias is None else layer.bias.to(lo))
+        y = F.linear(rows.to(lo), _w16(layer.weight, lo), _w16(layer.bias, lo))
         return y.float()
     return ops.linear_rows(rows, layer.weight, layer.bias)
 
@@ -81,8 +86,8 @@ class TransformerBlock(nn.Module):
         p16 = PROJ_16BIT and GEMM_DTYPE is not None
         if p16:     # the lifted features stay in 16 bits between fc1 and the three projections (one rounding, no re-casts)
             lo = GEMM_DTYPE
-            lifted = F.linear(features.to(lo), self.fc1.weight.to(lo), self.fc1.bias.to(lo))
-            q, kf, vf = (F.linear(lifted, w.weight.to(lo)).float() for w in (self.w_qs, self.w_ks, self.w_vs))
+            lifted = F.linear(features.to(lo), _w16(self.fc1.weight, lo), _w16(self.fc1.bias, lo))
+            q, kf, vf = (F.linear(lifted, _w16(w.weight, lo)).float() for w in (self.w_qs, self.w_ks, self.w_vs))
         else:
             lifted = _apply(self.fc1, features)
             q, kf, vf = _apply(self.w_qs, lifted), _apply(self.w_ks, lifted), _apply(self.w_vs, lifted)

@@ -946,6 +946,26 @@ def pointmlp_max(x, weight, bias, bn, slope, seg):
                               slope, bn.eps, bn.momentum, seg, BN_GROUPS)
 
 
+# Step-scoped cache of 16-bit copies of weights / biases (opt-in: SUGStep sets a dict before the forwards of a step and
+# drops it after them).  Without it every call re-casts its operands: ~280 tiny launches per step at config 5.
+W16_CACHE = None
+
+
+def cast_cached(p, lo, detach=False):
+    """16-bit copy of a parameter; shared by the calls of one step when the cache is on.  Attached copies
+    (detach=False) stay in the autograd graph: the fp32 parameter receives the sum of their gradients."""
+    if p is None:
+        return None
+    if W16_CACHE is None:
+        return (p.detach() if detach else p).to(lo)
+    key = (id(p), lo, bool(detach) or not torch.is_grad_enabled())
+    hit = W16_CACHE.get(key)
+    if hit is None or hit[0] != p._version:
+        hit = (p._version, (p.detach() if key[2] else p).to(lo))
+        W16_CACHE[key] = hit
+    return hit[1]
+
+
 # ----------------------------------------------------------------------------- Point Transformer attention
 class _PTranAttention(torch.autograd.Function):
     """Vector attention of one TransformerBlock (model/Ptran_transformer.py:39-44) from the projected
@@ -971,7 +991,7 @@ class _PTranAttention(torch.autograd.Function):
         xyz, nbr = xyz.detach().contiguous(), _i32(nbr).contiguous()
         q, kf, vf = q.contiguous(), kf.contiguous(), vf.contiguous()
         w1c, b1c = w1.detach().contiguous(), b1.detach().contiguous()
-        wl = [t.detach().to(lo) for t in (w2, b2, wg1, bg1, wg2, bg2)]
+        wl = [cast_cached(t, lo, detach=True) for t in (w2, b2, wg1, bg1, wg2, bg2)]
         L_ = lib()
         T0 = torch.empty(R, d, dtype=lo, device=dev)
         check(L_.sug_ptran_pos1_fwd(_p(xyz), _p(nbr), _p(w1c), _p(b1c), B, n, k, d, code, _p(T0), _st()), 'sug_ptran_pos1_fwd')

@@ -457,7 +457,12 @@ class SUGStep:
 
     def _eager_step(self, data, label, data_t, label_t, epoch=0):
         mmd_on = epoch >= self.methods['PURE_CLS_EPOCH']
-        loss_cls, loss_geo, loss_sem = self.losses(data, label, data_t, label_t, mmd_on)
+        from .model import Ptran_transformer as _PT
+        ops.W16_CACHE = {} if _PT.GEMM_DTYPE is not None else None      # 16-bit weight copies shared by this step's forwards
+        try:
+            loss_cls, loss_geo, loss_sem = self.losses(data, label, data_t, label_t, mmd_on)
+        finally:
+            ops.W16_CACHE = None
         loss = loss_cls
         if loss_geo is not None:
             loss = loss + loss_geo
