@@ -417,7 +417,12 @@ int sug_pointmlp_max_bwd_sparse(const float* a, const int32_t* arg, const float*
  * Backward: rev_off / rev_ent = sug_knn_reverse(nbr) (dK and dV are gathered over reverse neighbour lists:
  * no atomics).  sug_ptran_attn_bwd: g = d mixed -> dlogits, da = the gradient of delta through (v + delta),
  * dv [B,n,512].  sug_ptran_qk_bwd: du = dU; da is read and overwritten with d delta = du + da; dq, dk
- * [B,n,512].  sug_ptran_pos1_bwd: g = dT0 -> dw1 [512,3], db1 [512]; ws: 1024*4*512 floats. */
+ * [B,n,512].  sug_ptran_pos1_bwd: g = dT0 -> dw1 [512,3], db1 [512]; ws: 1024*4*512 floats.
+ * The _db forms also return the column sums (the bias gradients the caller needs next: model/Ptran_transformer.py's
+ * nn.Linear biases of fc_gamma / fc_delta) of the [B*n*k,512] gradient they write - dlogits for attn, d delta for
+ * qk - from the same pass instead of one more read of that tensor: db [512] (NULL = skip), ws =
+ * sug_ptran_colsum_workspace(B*n) floats.  sug_ptran_relu_bwd_db: in place G <- G*[T1>0] over `rows` rows (the ReLU
+ * inside fc_gamma), db [512] = its column sums, ws = sug_ptran_colsum_workspace(rows) floats. */
 int sug_ptran_pos1_fwd(const float* xyz, const int32_t* nbr, const float* w1, const float* b1, int B, int n, int k,
                        int d, int dtype, void* out, void* stream);
 int sug_ptran_pos1_bwd(const void* g, const float* xyz, const int32_t* nbr, const float* w1, const float* b1, int B,
@@ -431,6 +436,14 @@ int sug_ptran_attn_fwd(const void* logits, const void* delta, const float* vf, c
 int sug_ptran_attn_bwd(const float* g, const void* logits, const void* delta, const float* vf, const int32_t* nbr,
                        const float* mx, const float* sm, const int32_t* rev_off, const int32_t* rev_ent, int B, int n,
                        int k, int d, int dtype, float scale, void* dlogits, void* da, float* dv, void* stream);
+int64_t sug_ptran_colsum_workspace(int64_t rows);
+int sug_ptran_qk_bwd_db(const void* du, void* da, const int32_t* rev_off, const int32_t* rev_ent, int B, int n, int k,
+                        int d, int dtype, float* dq, float* dk, float* db, float* ws, void* stream);
+int sug_ptran_attn_bwd_db(const float* g, const void* logits, const void* delta, const float* vf, const int32_t* nbr,
+                          const float* mx, const float* sm, const int32_t* rev_off, const int32_t* rev_ent, int B, int n,
+                          int k, int d, int dtype, float scale, void* dlogits, void* da, float* dv, float* db, float* ws,
+                          void* stream);
+int sug_ptran_relu_bwd_db(void* G, const void* T1, int64_t rows, int d, int dtype, float* db, float* ws, void* stream);
 
 /* out[i] = (float) sum over g of red[g][i], i < n (fp64 partial rows of `groups` domain groups, in order). */
 int sug_fold_groups(const double* red, int groups, int n, float* out, void* stream);

@@ -58,6 +58,10 @@ SIGNATURES = {
     'sug_ptran_qk_bwd': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
     'sug_ptran_attn_fwd': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp],
     'sug_ptran_attn_bwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp],
+    'sug_ptran_qk_bwd_db': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
+    'sug_ptran_attn_bwd_db': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp,
+                              _vp, _vp, _vp],
+    'sug_ptran_relu_bwd_db': [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp],
     'sug_mmd_rbf_value': [_vp, _i64, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp],
     'sug_mmd_rbf_rows': [_vp, _i64, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
     'sug_mmd_rbf_rows_bwd': [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _f32, _vp, _i64, _vp],
@@ -114,6 +118,8 @@ def lib():
         L.sug_linear_dw_workspace.argtypes = [_i64, _i32, _i32]
         L.sug_pointmlp_max_bwd_workspace.restype = ctypes.c_int64
         L.sug_pointmlp_max_bwd_workspace.argtypes = [_i64, _i32, _i32, _i32]
+        L.sug_ptran_colsum_workspace.restype = ctypes.c_int64
+        L.sug_ptran_colsum_workspace.argtypes = [_i64]
         L.sug_adam_chunk.restype = ctypes.c_int
         L.sug_adam_chunk.argtypes = []
         L.sug_last_error.restype = ctypes.c_char_p

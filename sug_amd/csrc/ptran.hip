@@ -171,13 +171,71 @@ __global__ __launch_bounds__(256) void ptran_qk_kernel(const float* __restrict__
   }
 }
 
+// Column sums (bias gradients) as a by-product of the kernels that produce the [rows, 512] gradient tensors: every
+// lane keeps the running sum of its 8 channels over the rows its wave handles; the four waves of a workgroup are
+// combined in LDS in wave order and written as one partial row ws[blockIdx.x][512]; ptran_fold_kernel adds the
+// partial rows in a fixed order (fp64).  Replaces a separate torch.sum pass over each of these tensors (1 GB at
+// block 1 of config 5).
+__device__ __forceinline__ void colsum_flush(const float (&cs)[8], float* __restrict__ ws) {
+  __shared__ float s_cs[4][D];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) s_cs[wv][lane * 8 + u] = cs[u];
+  __syncthreads();
+  for (int c = threadIdx.x; c < D; c += 256)
+    ws[(size_t)blockIdx.x * D + c] = ((s_cs[0][c] + s_cs[1][c]) + s_cs[2][c]) + s_cs[3][c];
+}
+
+__global__ __launch_bounds__(256) void ptran_fold_kernel(const float* __restrict__ ws, int nblk, float* __restrict__ out) {
+  __shared__ double s_p[16][17];
+  const int cl = threadIdx.x & 15, p = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  double acc = 0.0;
+#pragma unroll 8
+  for (int b = p; b < nblk; b += 16) acc += (double)ws[(size_t)b * D + c];
+  s_p[p][cl] = acc;
+  __syncthreads();
+  if (p == 0) {
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += s_p[i][cl];
+    out[c] = (float)t;
+  }
+}
+
+// in place: G <- G * [T1 > 0] (ReLU backward), column sums as above
+template <typename T>
+__global__ __launch_bounds__(256) void ptran_relu_bwd_kernel(T* __restrict__ G, const T* __restrict__ T1, int64_t R,
+                                                             float* __restrict__ ws) {
+  const int lane = threadIdx.x & 63;
+  const int64_t w0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * 256) >> 6;
+  float cs[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) cs[u] = 0.f;
+  for (int64_t r = w0; r < R; r += nw) {
+    float g[8], t[8];
+    ld8<T>(G + r * D + lane * 8, g);
+    ld8<T>(T1 + r * D + lane * 8, t);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      g[u] = t[u] > 0.f ? g[u] : 0.f;
+      cs[u] += g[u];
+    }
+    st8<T>(G + r * D + lane * 8, g);
+  }
+  colsum_flush(cs, ws);
+}
+
 // backward of qk, fused with the sum of delta's two gradients: da (in: the attention's gradient of
 // delta, out: d delta = dU + da); dq[p] = sum_j dU[p,j]  (dK: ptran_rev_sum_kernel on dU)
 template <typename T>
 __global__ __launch_bounds__(256) void ptran_qk_bwd_kernel(const T* __restrict__ dU, T* __restrict__ da, int64_t P, int n,
-                                                           int k, float* __restrict__ dq) {
+                                                           int k, float* __restrict__ dq, float* __restrict__ ws) {
   const int lane = threadIdx.x & 63;
   const int64_t w0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * 256) >> 6;
+  float cs[8];                                   // column sums of d delta (ws != nullptr)
+#pragma unroll
+  for (int u = 0; u < 8; ++u) cs[u] = 0.f;
   for (int64_t p = w0; p < P; p += nw) {
     float aq[8];
 #pragma unroll
@@ -188,11 +246,12 @@ __global__ __launch_bounds__(256) void ptran_qk_bwd_kernel(const T* __restrict__
       ld8<T>(dU + r * D + lane * 8, uv);
       ld8<T>(da + r * D + lane * 8, av);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { aq[u] += uv[u]; av[u] += uv[u]; }
+      for (int u = 0; u < 8; ++u) { aq[u] += uv[u]; av[u] += uv[u]; cs[u] += av[u]; }
       st8<T>(da + r * D + lane * 8, av);
     }
     st8<float>(dq + p * D + lane * 8, aq);
   }
+  if (ws) colsum_flush(cs, ws);
 }
 
 // ---- attn: softmax over the k neighbours (per channel) of L * scale, applied to V_nbr + delta
@@ -246,9 +305,13 @@ __global__ __launch_bounds__(256) void ptran_attn_bwd_kernel(const float* __rest
                                                              const T* __restrict__ delta, const float* __restrict__ vf,
                                                              const int32_t* __restrict__ nbr, const float* __restrict__ mx,
                                                              const float* __restrict__ sm, int64_t P, int n, int k,
-                                                             float scale, T* __restrict__ dL, T* __restrict__ da) {
+                                                             float scale, T* __restrict__ dL, T* __restrict__ da,
+                                                             float* __restrict__ ws) {
   const int lane = threadIdx.x & 63;
   const int64_t w0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * 256) >> 6;
+  float cs[8];                                   // column sums of dL (ws != nullptr)
+#pragma unroll
+  for (int u = 0; u < 8; ++u) cs[u] = 0.f;
   for (int64_t p = w0; p < P; p += nw) {
     const int64_t b = p / n;
     float gv[8], zmax[8], rs[8];
@@ -284,11 +347,15 @@ __global__ __launch_bounds__(256) void ptran_attn_bwd_kernel(const float* __rest
       if (j < k) {
         float o[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) o[u] = pr[j][u] * (dp[j][u] - dot[u]) * scale;
+        for (int u = 0; u < 8; ++u) {
+          o[u] = pr[j][u] * (dp[j][u] - dot[u]) * scale;
+          cs[u] += o[u];
+        }
         st8<T>(dL + (p * k + j) * D + lane * 8, o);
       }
     }
   }
+  if (ws) colsum_flush(cs, ws);
 }
 
 // out[m,:] = sign * sum over the reverse neighbour list of m of src[e,:] (entries ascending: fixed order).
@@ -373,21 +440,58 @@ extern "C" int sug_ptran_qk_fwd(const float* q, const float* kf, const void* del
   return SUG_OK;
 }
 
-extern "C" int sug_ptran_qk_bwd(const void* du, void* da, const int32_t* rev_off, const int32_t* rev_ent, int B, int n,
-                                int k, int d, int dtype, float* dq, float* dk, void* stream) {
+static int ptran_fold(const float* ws, int nblk, float* out, hipStream_t st, const char* name) {
+  hipLaunchKernelGGL(ptran_fold_kernel, dim3(D / 16), dim3(256), 0, st, ws, nblk, out);
+  hipError_t e_ = hipGetLastError();
+  if (e_ != hipSuccess) {
+    sug_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));
+    return SUG_ERR_LAUNCH;
+  }
+  return SUG_OK;
+}
+
+extern "C" int64_t sug_ptran_colsum_workspace(int64_t rows) {
+  return (int64_t)grid_for(rows) * D;
+}
+
+// db (nullable): column sums of d delta [512]; ws: sug_ptran_colsum_workspace(B*n) floats
+extern "C" int sug_ptran_qk_bwd_db(const void* du, void* da, const int32_t* rev_off, const int32_t* rev_ent, int B, int n,
+                                   int k, int d, int dtype, float* dq, float* dk, float* db, float* ws, void* stream) {
   SUG_REQUIRE(du && da && rev_off && rev_ent && dq && dk, "sug_ptran_qk_bwd: null pointer");
+  SUG_REQUIRE(!db || ws, "sug_ptran_qk_bwd: db needs a workspace");
   PT_REQ_COMMON("sug_ptran_qk_bwd");
   const int64_t P = (int64_t)B * n;
   hipStream_t st = (hipStream_t)stream;
+  float* w = db ? ws : nullptr;
   if (dtype == 0) {
     hipLaunchKernelGGL(ptran_rev_sum_kernel<float>, dim3(grid_for(P)), dim3(256), 0, st, (const float*)du, rev_off, rev_ent, P, n, k, -1.0f, dk);
-    hipLaunchKernelGGL(ptran_qk_bwd_kernel<float>, dim3(grid_for(P)), dim3(256), 0, st, (const float*)du, (float*)da, P, n, k, dq);
+    hipLaunchKernelGGL(ptran_qk_bwd_kernel<float>, dim3(grid_for(P)), dim3(256), 0, st, (const float*)du, (float*)da, P, n, k, dq, w);
   } else {
     hipLaunchKernelGGL(ptran_rev_sum_kernel<__half>, dim3(grid_for(P)), dim3(256), 0, st, (const __half*)du, rev_off, rev_ent, P, n, k, -1.0f, dk);
-    hipLaunchKernelGGL(ptran_qk_bwd_kernel<__half>, dim3(grid_for(P)), dim3(256), 0, st, (const __half*)du, (__half*)da, P, n, k, dq);
+    hipLaunchKernelGGL(ptran_qk_bwd_kernel<__half>, dim3(grid_for(P)), dim3(256), 0, st, (const __half*)du, (__half*)da, P, n, k, dq, w);
   }
   SUG_LAUNCH_CHECK("sug_ptran_qk_bwd");
+  if (db) return ptran_fold(ws, grid_for(P), db, st, "sug_ptran_qk_bwd(fold)");
   return SUG_OK;
+}
+
+extern "C" int sug_ptran_qk_bwd(const void* du, void* da, const int32_t* rev_off, const int32_t* rev_ent, int B, int n,
+                                int k, int d, int dtype, float* dq, float* dk, void* stream) {
+  return sug_ptran_qk_bwd_db(du, da, rev_off, rev_ent, B, n, k, d, dtype, dq, dk, nullptr, nullptr, stream);
+}
+
+// in place G <- G * [T1 > 0] over `rows` rows of 512 (the ReLU between the two linears of fc_gamma), db = column sums
+extern "C" int sug_ptran_relu_bwd_db(void* G, const void* T1, int64_t rows, int d, int dtype, float* db, float* ws,
+                                     void* stream) {
+  SUG_REQUIRE(G && T1 && db && ws, "sug_ptran_relu_bwd_db: null pointer");
+  SUG_REQUIRE(rows > 0 && d == D && (dtype == 0 || dtype == 1), "sug_ptran_relu_bwd_db: bad shape / dtype");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == 0)
+    hipLaunchKernelGGL(ptran_relu_bwd_kernel<float>, dim3(grid_for(rows)), dim3(256), 0, st, (float*)G, (const float*)T1, rows, ws);
+  else
+    hipLaunchKernelGGL(ptran_relu_bwd_kernel<__half>, dim3(grid_for(rows)), dim3(256), 0, st, (__half*)G, (const __half*)T1, rows, ws);
+  SUG_LAUNCH_CHECK("sug_ptran_relu_bwd_db");
+  return ptran_fold(ws, grid_for(rows), db, st, "sug_ptran_relu_bwd_db(fold)");
 }
 
 extern "C" int sug_ptran_attn_fwd(const void* logits, const void* delta, const float* vf, const int32_t* nbr, int B, int n,
@@ -402,22 +506,34 @@ extern "C" int sug_ptran_attn_fwd(const void* logits, const void* delta, const f
   return SUG_OK;
 }
 
+// db (nullable): column sums of dlogits [512]; ws: sug_ptran_colsum_workspace(B*n) floats
+extern "C" int sug_ptran_attn_bwd_db(const float* g, const void* logits, const void* delta, const float* vf, const int32_t* nbr,
+                                     const float* mx, const float* sm, const int32_t* rev_off, const int32_t* rev_ent, int B,
+                                     int n, int k, int d, int dtype, float scale, void* dlogits, void* da, float* dv,
+                                     float* db, float* ws, void* stream) {
+  SUG_REQUIRE(g && logits && delta && vf && nbr && mx && sm && rev_off && rev_ent && dlogits && da && dv,
+              "sug_ptran_attn_bwd: null pointer");
+  SUG_REQUIRE(!db || ws, "sug_ptran_attn_bwd: db needs a workspace");
+  PT_REQ_COMMON("sug_ptran_attn_bwd");
+  const int64_t P = (int64_t)B * n;
+  hipStream_t st = (hipStream_t)stream;
+  float* w = db ? ws : nullptr;
+  if (dtype == 0) {
+    hipLaunchKernelGGL((ptran_attn_bwd_kernel<float, 16>), dim3(grid_for(P)), dim3(256), 0, st, g, (const float*)logits, (const float*)delta, vf, nbr, mx, sm, P, n, k, scale, (float*)dlogits, (float*)da, w);
+    hipLaunchKernelGGL(ptran_rev_sum_kernel<float>, dim3(grid_for(P)), dim3(256), 0, st, (const float*)da, rev_off, rev_ent, P, n, k, 1.0f, dv);
+  } else {
+    hipLaunchKernelGGL((ptran_attn_bwd_kernel<__half, 16>), dim3(grid_for(P)), dim3(256), 0, st, g, (const __half*)logits, (const __half*)delta, vf, nbr, mx, sm, P, n, k, scale, (__half*)dlogits, (__half*)da, w);
+    hipLaunchKernelGGL(ptran_rev_sum_kernel<__half>, dim3(grid_for(P)), dim3(256), 0, st, (const __half*)da, rev_off, rev_ent, P, n, k, 1.0f, dv);
+  }
+  SUG_LAUNCH_CHECK("sug_ptran_attn_bwd");
+  if (db) return ptran_fold(ws, grid_for(P), db, st, "sug_ptran_attn_bwd(fold)");
+  return SUG_OK;
+}
+
 extern "C" int sug_ptran_attn_bwd(const float* g, const void* logits, const void* delta, const float* vf, const int32_t* nbr,
                                   const float* mx, const float* sm, const int32_t* rev_off, const int32_t* rev_ent, int B,
                                   int n, int k, int d, int dtype, float scale, void* dlogits, void* da, float* dv,
                                   void* stream) {
-  SUG_REQUIRE(g && logits && delta && vf && nbr && mx && sm && rev_off && rev_ent && dlogits && da && dv,
-              "sug_ptran_attn_bwd: null pointer");
-  PT_REQ_COMMON("sug_ptran_attn_bwd");
-  const int64_t P = (int64_t)B * n;
-  hipStream_t st = (hipStream_t)stream;
-  if (dtype == 0) {
-    hipLaunchKernelGGL((ptran_attn_bwd_kernel<float, 16>), dim3(grid_for(P)), dim3(256), 0, st, g, (const float*)logits, (const float*)delta, vf, nbr, mx, sm, P, n, k, scale, (float*)dlogits, (float*)da);
-    hipLaunchKernelGGL(ptran_rev_sum_kernel<float>, dim3(grid_for(P)), dim3(256), 0, st, (const float*)da, rev_off, rev_ent, P, n, k, 1.0f, dv);
-  } else {
-    hipLaunchKernelGGL((ptran_attn_bwd_kernel<__half, 16>), dim3(grid_for(P)), dim3(256), 0, st, g, (const __half*)logits, (const __half*)delta, vf, nbr, mx, sm, P, n, k, scale, (__half*)dlogits, (__half*)da);
-    hipLaunchKernelGGL(ptran_rev_sum_kernel<__half>, dim3(grid_for(P)), dim3(256), 0, st, (const __half*)da, rev_off, rev_ent, P, n, k, 1.0f, dv);
-  }
-  SUG_LAUNCH_CHECK("sug_ptran_attn_bwd");
-  return SUG_OK;
+  return sug_ptran_attn_bwd_db(g, logits, delta, vf, nbr, mx, sm, rev_off, rev_ent, B, n, k, d, dtype, scale, dlogits, da, dv,
+                               nullptr, nullptr, stream);
 }

@@ -1019,9 +1019,14 @@ class _PTranAttention(torch.autograd.Function):
         off, ent = knn_reverse(nbr)
         dL, da = torch.empty_like(Lg), torch.empty_like(Lg)
         dv = torch.empty(B, n, d, dtype=torch.float32, device=dev)
-        check(L_.sug_ptran_attn_bwd(_p(g), _p(Lg), _p(delta), _p(vf), _p(nbr), _p(mx), _p(sm), _p(off), _p(ent), B, n, k, d,
-                                    code, scale, _p(dL), _p(da), _p(dv), _st()), 'sug_ptran_attn_bwd')
         f32 = torch.float32
+        # bias gradients = column sums of the k-expanded gradients, produced by the kernels that write them
+        R = B * n * k
+        cws = torch.empty(L_.sug_ptran_colsum_workspace(R), dtype=f32, device=dev)
+        dbg2, dbg1, db2 = (torch.empty(d, dtype=f32, device=dev) for _ in range(3))
+        check(L_.sug_ptran_attn_bwd_db(_p(g), _p(Lg), _p(delta), _p(vf), _p(nbr), _p(mx), _p(sm), _p(off), _p(ent), B, n, k,
+                                       d, code, scale, _p(dL), _p(da), _p(dv), _p(dbg2), _p(cws), _st()),
+              'sug_ptran_attn_bwd_db')
 
         def dweight(gy, x):
             """gy^T . x over the R rows in row chunks (batched GEMM = split-K: one [512,512] product alone
@@ -1035,16 +1040,15 @@ class _PTranAttention(torch.autograd.Function):
             return torch.bmm(gy.view(S, R // S, d).transpose(1, 2), x.view(S, R // S, d)).sum(dim=0, dtype=f32)
 
         dwg2 = dweight(dL, T1)
-        dbg2 = dL.sum(dim=0, dtype=f32)
-        dT1 = torch.ops.aten.threshold_backward(dL @ wg2l, T1, 0)
+        dT1 = dL @ wg2l
+        check(L_.sug_ptran_relu_bwd_db(_p(dT1), _p(T1), R, d, code, _p(dbg1), _p(cws), _st()), 'sug_ptran_relu_bwd_db')
         dwg1 = dweight(dT1, U)
-        dbg1 = dT1.sum(dim=0, dtype=f32)
         dU = dT1 @ wg1l
         dq, dk = torch.empty_like(dv), torch.empty_like(dv)
-        check(L_.sug_ptran_qk_bwd(_p(dU), _p(da), _p(off), _p(ent), B, n, k, d, code, _p(dq), _p(dk), _st()), 'sug_ptran_qk_bwd')
+        check(L_.sug_ptran_qk_bwd_db(_p(dU), _p(da), _p(off), _p(ent), B, n, k, d, code, _p(dq), _p(dk), _p(db2), _p(cws),
+                                     _st()), 'sug_ptran_qk_bwd_db')
         ddelta = da                                            # = dU + da
         dw2 = dweight(ddelta, T0)
-        db2 = ddelta.sum(dim=0, dtype=f32)
         dT0 = ddelta @ w2l
         dw1 = torch.empty(d, 3, dtype=f32, device=dev)
         db1 = torch.empty(d, dtype=f32, device=dev)

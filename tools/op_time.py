@@ -15,6 +15,7 @@ dev = torch.device('cuda')
 if len(sys.argv) > 4 and sys.argv[4] == 'fp16':
     from sug_amd.model import Ptran_transformer as PT
     PT.GEMM_DTYPE = torch.float16
+    PT.PROJ_16BIT = True
 torch.manual_seed(666)
 net = Net_MDA(model).to(dev).train()
 tr = SUGStep(net, use_graph=False)
