@@ -415,10 +415,11 @@ int sug_pointmlp_max_bwd_sparse(const float* a, const int32_t* arg, const float*
  *   attn: mixed[i,:] = sum_j softmax_j(L[r,:]*scale) * (V[nbr,:] + delta[r,:]); mx / sm [B,n,512] = the
  *         per-channel max and sum of exponentials, kept for the backward               (:42-44)
  * Backward: rev_off / rev_ent = sug_knn_reverse(nbr) (dK and dV are gathered over reverse neighbour lists:
- * no atomics).  sug_ptran_attn_bwd: g = d mixed -> dlogits, da = the gradient of delta through (v + delta),
+ * no atomics).  sug_ptran_attn_bwd: g = d mixed, mixed = the forward's output (its product with g is the softmax
+ * backward's row term, so the rows are visited once) -> dlogits, da = the gradient of delta through (v + delta),
  * dv [B,n,512].  sug_ptran_qk_bwd: du = dU; da is read and overwritten with d delta = du + da; dq, dk
  * [B,n,512].  sug_ptran_pos1_bwd: g = dT0 -> dw1 [512,3], db1 [512]; ws: 1024*4*512 floats.
- * The _db forms also return the column sums (the bias gradients the caller needs next: model/Ptran_transformer.py's
+ * attn_bwd and qk_bwd also return the column sums (the bias gradients the caller needs next: model/Ptran_transformer.py's
  * nn.Linear biases of fc_gamma / fc_delta) of the [B*n*k,512] gradient they write - dlogits for attn, d delta for
  * qk - from the same pass instead of one more read of that tensor: db [512] (NULL = skip), ws =
  * sug_ptran_colsum_workspace(B*n) floats.  sug_ptran_relu_bwd_db: in place G <- G*[T1>0] over `rows` rows (the ReLU
@@ -430,19 +431,14 @@ int sug_ptran_pos1_bwd(const void* g, const float* xyz, const int32_t* nbr, cons
 int sug_ptran_qk_fwd(const float* q, const float* kf, const void* delta, const int32_t* nbr, int B, int n, int k, int d,
                      int dtype, void* out, void* stream);
 int sug_ptran_qk_bwd(const void* du, void* da, const int32_t* rev_off, const int32_t* rev_ent, int B, int n, int k, int d,
-                     int dtype, float* dq, float* dk, void* stream);
+                     int dtype, float* dq, float* dk, float* db, float* ws, void* stream);
 int sug_ptran_attn_fwd(const void* logits, const void* delta, const float* vf, const int32_t* nbr, int B, int n, int k,
                        int d, int dtype, float scale, float* mixed, float* mx, float* sm, void* stream);
-int sug_ptran_attn_bwd(const float* g, const void* logits, const void* delta, const float* vf, const int32_t* nbr,
-                       const float* mx, const float* sm, const int32_t* rev_off, const int32_t* rev_ent, int B, int n,
-                       int k, int d, int dtype, float scale, void* dlogits, void* da, float* dv, void* stream);
+int sug_ptran_attn_bwd(const float* g, const float* mixed, const void* logits, const void* delta, const float* vf,
+                       const int32_t* nbr, const float* mx, const float* sm, const int32_t* rev_off, const int32_t* rev_ent,
+                       int B, int n, int k, int d, int dtype, float scale, void* dlogits, void* da, float* dv, float* db,
+                       float* ws, void* stream);
 int64_t sug_ptran_colsum_workspace(int64_t rows);
-int sug_ptran_qk_bwd_db(const void* du, void* da, const int32_t* rev_off, const int32_t* rev_ent, int B, int n, int k,
-                        int d, int dtype, float* dq, float* dk, float* db, float* ws, void* stream);
-int sug_ptran_attn_bwd_db(const float* g, const void* logits, const void* delta, const float* vf, const int32_t* nbr,
-                          const float* mx, const float* sm, const int32_t* rev_off, const int32_t* rev_ent, int B, int n,
-                          int k, int d, int dtype, float scale, void* dlogits, void* da, float* dv, float* db, float* ws,
-                          void* stream);
 int sug_ptran_relu_bwd_db(void* G, const void* T1, int64_t rows, int d, int dtype, float* db, float* ws, void* stream);
 
 /* out[i] = (float) sum over g of red[g][i], i < n (fp64 partial rows of `groups` domain groups, in order). */

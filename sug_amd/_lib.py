@@ -55,12 +55,10 @@ SIGNATURES = {
     'sug_ptran_pos1_fwd': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
     'sug_ptran_pos1_bwd': [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
     'sug_ptran_qk_fwd': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
-    'sug_ptran_qk_bwd': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
+    'sug_ptran_qk_bwd': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
     'sug_ptran_attn_fwd': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp],
-    'sug_ptran_attn_bwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp],
-    'sug_ptran_qk_bwd_db': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
-    'sug_ptran_attn_bwd_db': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp,
-                              _vp, _vp, _vp],
+    'sug_ptran_attn_bwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp,
+                           _vp, _vp, _vp],
     'sug_ptran_relu_bwd_db': [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp],
     'sug_mmd_rbf_value': [_vp, _i64, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp],
     'sug_mmd_rbf_rows': [_vp, _i64, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],

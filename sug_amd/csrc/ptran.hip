@@ -55,43 +55,87 @@ __device__ __forceinline__ void st8<__half>(__half* __restrict__ p, const float 
   *reinterpret_cast<uint4*>(p) = u;
 }
 
-// ---- pos1: T0 = relu(W1 . rel + b1), rel = xyz_i - xyz_nbr
-template <typename T>
+// a lane's 8 channels of a row as loaded (fp16 rows stay packed: 4 registers instead of 8 while they wait)
+template <typename T> struct Raw8;
+template <> struct Raw8<float> { float4 a, b; };
+template <> struct Raw8<__half> { uint4 u; };
+__device__ __forceinline__ void ldraw(const float* __restrict__ p, Raw8<float>& r) {
+  r.a = *reinterpret_cast<const float4*>(p);
+  r.b = *reinterpret_cast<const float4*>(p + 4);
+}
+__device__ __forceinline__ void ldraw(const __half* __restrict__ p, Raw8<__half>& r) {
+  r.u = *reinterpret_cast<const uint4*>(p);
+}
+__device__ __forceinline__ void unpack(const Raw8<float>& r, float (&v)[8]) {
+  v[0] = r.a.x; v[1] = r.a.y; v[2] = r.a.z; v[3] = r.a.w; v[4] = r.b.x; v[5] = r.b.y; v[6] = r.b.z; v[7] = r.b.w;
+}
+__device__ __forceinline__ void unpack(const Raw8<__half>& r, float (&v)[8]) {
+  const __half2* h = reinterpret_cast<const __half2*>(&r.u);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float2 f = __half22float2(h[i]);
+    v[2 * i] = f.x;
+    v[2 * i + 1] = f.y;
+  }
+}
+// exp(l*scale - max) as one fma + v_exp_f32 (arguments <= ~0: no range handling needed; the forward and the
+// backward use the same form, so the weights the backward rebuilds are the forward's)
+constexpr float LOG2E = 1.44269504088896340736f;
+__device__ __forceinline__ float exp2_hw(float x) { return __builtin_amdgcn_exp2f(x); }
+// wave index of a 256-thread workgroup as a scalar: row / point addresses become SGPR bases
+__device__ __forceinline__ int wave_in_block() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
+__device__ __forceinline__ float lane_bcast(float v, int j) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j));
+}
+
+// ---- pos1: T0 = relu(W1 . rel + b1), rel = xyz_i - xyz_nbr.  Wave per point: lane j < k fetches neighbour j's
+// offset once (one dependent load chain per point, not per row), the rows then only compute and store.
+template <typename T, int KK>
 __global__ __launch_bounds__(256) void ptran_pos1_kernel(const float* __restrict__ xyz, const int32_t* __restrict__ nbr,
                                                          const float* __restrict__ W1, const float* __restrict__ b1,
-                                                         int64_t R, int n, int k, T* __restrict__ out) {
+                                                         int64_t P, int n, int k, T* __restrict__ out) {
   const int lane = threadIdx.x & 63;
-  const int64_t w0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * 256) >> 6;
+  const int64_t w0 = (int64_t)blockIdx.x * 4 + wave_in_block(), nw = (int64_t)gridDim.x * 4;
   float wx[8], wy[8], wz[8], bb[8];
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
     const int c = lane * 8 + u;
     wx[u] = W1[c * 3 + 0]; wy[u] = W1[c * 3 + 1]; wz[u] = W1[c * 3 + 2]; bb[u] = b1[c];
   }
-  for (int64_t r = w0; r < R; r += nw) {
-    const int64_t p = r / k, b = p / n;
-    const int m = nbr[r];
-    const float* xi = xyz + p * 3;
-    const float* xj = xyz + (b * n + m) * 3;
-    const float dx = xi[0] - xj[0], dy = xi[1] - xj[1], dz = xi[2] - xj[2];
-    float v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const float t = fmaf(wz[u], dz, fmaf(wy[u], dy, wx[u] * dx)) + bb[u];
-      v[u] = t > 0.f ? t : 0.f;
+  for (int64_t p = w0; p < P; p += nw) {
+    const int64_t b = p / n;
+    float dx = 0.f, dy = 0.f, dz = 0.f;
+    if (lane < k) {
+      const int m = nbr[p * k + lane];
+      const float* xi = xyz + p * 3;
+      const float* xj = xyz + (b * n + m) * 3;
+      dx = xi[0] - xj[0]; dy = xi[1] - xj[1]; dz = xi[2] - xj[2];
     }
-    st8<T>(out + r * D + lane * 8, v);
+#pragma unroll
+    for (int j = 0; j < KK; ++j) {
+      if (j < k) {
+        const float ex = lane_bcast(dx, j), ey = lane_bcast(dy, j), ez = lane_bcast(dz, j);
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const float t = fmaf(wz[u], ez, fmaf(wy[u], ey, wx[u] * ex)) + bb[u];
+          v[u] = t > 0.f ? t : 0.f;
+        }
+        st8<T>(out + (p * k + j) * D + lane * 8, v);
+      }
+    }
   }
 }
 
 // dW1[c,0..2] = sum_r g[r,c] * [pre(r,c) > 0] * rel(r), db1[c] likewise: per-workgroup partials [nb][4][512]
-template <typename T>
+template <typename T, int KK>
 __global__ __launch_bounds__(256) void ptran_pos1_bwd_kernel(const T* __restrict__ g, const float* __restrict__ xyz,
                                                              const int32_t* __restrict__ nbr, const float* __restrict__ W1,
-                                                             const float* __restrict__ b1, int64_t R, int n, int k,
+                                                             const float* __restrict__ b1, int64_t P, int n, int k,
                                                              float* __restrict__ part) {
   __shared__ float s_red[4][4][D];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wv = wave_in_block();
   const int64_t w0 = (int64_t)blockIdx.x * 4 + wv, nw = (int64_t)gridDim.x * 4;
   float wx[8], wy[8], wz[8], bb[8], ax[8], ay[8], az[8], ab[8];
 #pragma unroll
@@ -100,19 +144,35 @@ __global__ __launch_bounds__(256) void ptran_pos1_bwd_kernel(const T* __restrict
     wx[u] = W1[c * 3 + 0]; wy[u] = W1[c * 3 + 1]; wz[u] = W1[c * 3 + 2]; bb[u] = b1[c];
     ax[u] = ay[u] = az[u] = ab[u] = 0.f;
   }
-  for (int64_t r = w0; r < R; r += nw) {
-    const int64_t p = r / k, b = p / n;
-    const int m = nbr[r];
-    const float* xi = xyz + p * 3;
-    const float* xj = xyz + (b * n + m) * 3;
-    const float dx = xi[0] - xj[0], dy = xi[1] - xj[1], dz = xi[2] - xj[2];
-    float gv[8];
-    ld8<T>(g + r * D + lane * 8, gv);
+  for (int64_t p = w0; p < P; p += nw) {
+    const int64_t b = p / n;
+    float dx = 0.f, dy = 0.f, dz = 0.f;
+    if (lane < k) {
+      const int m = nbr[p * k + lane];
+      const float* xi = xyz + p * 3;
+      const float* xj = xyz + (b * n + m) * 3;
+      dx = xi[0] - xj[0]; dy = xi[1] - xj[1]; dz = xi[2] - xj[2];
+    }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const float t = fmaf(wz[u], dz, fmaf(wy[u], dy, wx[u] * dx)) + bb[u];
-      const float gg = t > 0.f ? gv[u] : 0.f;
-      ax[u] = fmaf(gg, dx, ax[u]); ay[u] = fmaf(gg, dy, ay[u]); az[u] = fmaf(gg, dz, az[u]); ab[u] += gg;
+    for (int j0 = 0; j0 < KK; j0 += 4) {
+      Raw8<T> gr[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (j0 + t < k) ldraw(g + (p * k + j0 + t) * D + lane * 8, gr[t]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (j0 + t < k) {
+          const float ex = lane_bcast(dx, j0 + t), ey = lane_bcast(dy, j0 + t), ez = lane_bcast(dz, j0 + t);
+          float gv[8];
+          unpack(gr[t], gv);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const float tt = fmaf(wz[u], ez, fmaf(wy[u], ey, wx[u] * ex)) + bb[u];
+            const float gg = tt > 0.f ? gv[u] : 0.f;
+            ax[u] = fmaf(gg, ex, ax[u]); ay[u] = fmaf(gg, ey, ay[u]); az[u] = fmaf(gg, ez, az[u]); ab[u] += gg;
+          }
+        }
+      }
     }
   }
 #pragma unroll
@@ -153,20 +213,33 @@ __global__ __launch_bounds__(256) void ptran_qk_kernel(const float* __restrict__
                                                        const T* __restrict__ delta, const int32_t* __restrict__ nbr,
                                                        int64_t P, int n, int k, T* __restrict__ out) {
   const int lane = threadIdx.x & 63;
-  const int64_t w0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * 256) >> 6;
+  const int64_t w0 = (int64_t)blockIdx.x * 4 + wave_in_block(), nw = (int64_t)gridDim.x * 4;
   for (int64_t p = w0; p < P; p += nw) {
     const int64_t b = p / n;
     float qv[8];
     ld8<float>(q + p * D + lane * 8, qv);
-    for (int j = 0; j < k; ++j) {
-      const int64_t r = p * k + j;
-      const int m = nbr[r];
-      float kv[8], dv[8], o[8];
-      ld8<float>(kf + (b * n + m) * D + lane * 8, kv);
-      ld8<T>(delta + r * D + lane * 8, dv);
+    for (int j0 = 0; j0 < k; j0 += 4) {          // 4 rows' gathers and delta rows in flight
+      float kv[4][8];
+      Raw8<T> dr[4];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) o[u] = (qv[u] - kv[u]) + dv[u];
-      st8<T>(out + r * D + lane * 8, o);
+      for (int t = 0; t < 4; ++t) {
+        if (j0 + t < k) {
+          const int64_t r = p * k + j0 + t;
+          const int m = nbr[r];
+          ld8<float>(kf + (b * n + m) * D + lane * 8, kv[t]);
+          ldraw(delta + r * D + lane * 8, dr[t]);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (j0 + t < k) {
+          float dv[8], o[8];
+          unpack(dr[t], dv);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) o[u] = (qv[u] - kv[t][u]) + dv[u];
+          st8<T>(out + (p * k + j0 + t) * D + lane * 8, o);
+        }
+      }
     }
   }
 }
@@ -261,33 +334,52 @@ __global__ __launch_bounds__(256) void ptran_attn_kernel(const T* __restrict__ L
                                                          int64_t P, int n, int k, float scale, float* __restrict__ mixed,
                                                          float* __restrict__ mx, float* __restrict__ sm) {
   const int lane = threadIdx.x & 63;
-  const int64_t w0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * 256) >> 6;
+  const int64_t w0 = (int64_t)blockIdx.x * 4 + wave_in_block(), nw = (int64_t)gridDim.x * 4;
   for (int64_t p = w0; p < P; p += nw) {
     const int64_t b = p / n;
-    float z[KK][8], zmax[8], zsum[8], acc[8];
+    Raw8<T> z[KK];                               // the k logit rows as loaded, converted twice (max, then exp)
+    float zmax[8], zsum[8], acc[8], zl[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) { zmax[u] = -INFINITY; zsum[u] = 0.f; acc[u] = 0.f; }
 #pragma unroll
+    for (int j = 0; j < KK; ++j)
+      if (j < k) ldraw(L + (p * k + j) * D + lane * 8, z[j]);
+#pragma unroll
     for (int j = 0; j < KK; ++j) {
       if (j < k) {
-        ld8<T>(L + (p * k + j) * D + lane * 8, z[j]);
+        float zv[8];
+        unpack(z[j], zv);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { z[j][u] *= scale; zmax[u] = fmaxf(zmax[u], z[j][u]); }
+        for (int u = 0; u < 8; ++u) zmax[u] = fmaxf(zmax[u], zv[u] * scale);
       }
     }
 #pragma unroll
-    for (int j = 0; j < KK; ++j) {
-      if (j < k) {
-        const int64_t r = p * k + j;
-        const int m = nbr[r];
-        float vv[8], dv[8];
-        ld8<float>(vf + (b * n + m) * D + lane * 8, vv);
-        ld8<T>(delta + r * D + lane * 8, dv);
+    for (int u = 0; u < 8; ++u) zl[u] = -zmax[u] * LOG2E;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const float e = expf(z[j][u] - zmax[u]);
-          zsum[u] += e;
-          acc[u] = fmaf(e, vv[u] + dv[u], acc[u]);
+    for (int j0 = 0; j0 < KK; j0 += 4) {
+      float vv[4][8];
+      Raw8<T> dr[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (j0 + t < k) {
+          const int64_t r = p * k + j0 + t;
+          const int m = nbr[r];
+          ld8<float>(vf + (b * n + m) * D + lane * 8, vv[t]);
+          ldraw(delta + r * D + lane * 8, dr[t]);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (j0 + t < k) {
+          float zv[8], dv[8];
+          unpack(z[j0 + t], zv);
+          unpack(dr[t], dv);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const float e = exp2_hw(fmaf(zv[u], scale * LOG2E, zl[u]));
+            zsum[u] += e;
+            acc[u] = fmaf(e, vv[t][u] + dv[u], acc[u]);
+          }
         }
       }
     }
@@ -299,59 +391,64 @@ __global__ __launch_bounds__(256) void ptran_attn_kernel(const T* __restrict__ L
   }
 }
 
-// backward: dL, da (the gradient of delta through v + delta) per row; dV[m] over the reverse list of m
-template <typename T, int KK>
-__global__ __launch_bounds__(256) void ptran_attn_bwd_kernel(const float* __restrict__ g, const T* __restrict__ L,
-                                                             const T* __restrict__ delta, const float* __restrict__ vf,
-                                                             const int32_t* __restrict__ nbr, const float* __restrict__ mx,
-                                                             const float* __restrict__ sm, int64_t P, int n, int k,
-                                                             float scale, T* __restrict__ dL, T* __restrict__ da,
-                                                             float* __restrict__ ws) {
+// backward: dL, da (the gradient of delta through v + delta) per row; dV[m] over the reverse list of m.
+// With a_j the softmax weights and y_j = V_nbr + delta, dL_j = scale * a_j * (g*y_j - sum_i a_i g*y_i) and the sum is
+// g * mixed (the forward's output): one pass over the rows, nothing per row kept in registers.
+template <typename T>
+__global__ __launch_bounds__(256) void ptran_attn_bwd_kernel(const float* __restrict__ g, const float* __restrict__ mixed,
+                                                             const T* __restrict__ L, const T* __restrict__ delta,
+                                                             const float* __restrict__ vf, const int32_t* __restrict__ nbr,
+                                                             const float* __restrict__ mx, const float* __restrict__ sm,
+                                                             int64_t P, int n, int k, float scale, T* __restrict__ dL,
+                                                             T* __restrict__ da, float* __restrict__ ws) {
   const int lane = threadIdx.x & 63;
-  const int64_t w0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * 256) >> 6;
+  const int64_t w0 = (int64_t)blockIdx.x * 4 + wave_in_block(), nw = (int64_t)gridDim.x * 4;
   float cs[8];                                   // column sums of dL (ws != nullptr)
 #pragma unroll
   for (int u = 0; u < 8; ++u) cs[u] = 0.f;
   for (int64_t p = w0; p < P; p += nw) {
     const int64_t b = p / n;
-    float gv[8], zmax[8], rs[8];
+    float gv[8], zmax[8], rs[8], dot[8];
     ld8<float>(g + p * D + lane * 8, gv);
     ld8<float>(mx + p * D + lane * 8, zmax);
     ld8<float>(sm + p * D + lane * 8, rs);
+    ld8<float>(mixed + p * D + lane * 8, dot);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) rs[u] = 1.0f / rs[u];
-    float pr[KK][8], dp[KK][8], dot[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) dot[u] = 0.f;
-#pragma unroll
-    for (int j = 0; j < KK; ++j) {
-      if (j < k) {
-        const int64_t r = p * k + j;
-        const int m = nbr[r];
-        float lv[8], vv[8], dlt[8], av[8];
-        ld8<T>(L + r * D + lane * 8, lv);
-        ld8<float>(vf + (b * n + m) * D + lane * 8, vv);
-        ld8<T>(delta + r * D + lane * 8, dlt);
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          pr[j][u] = expf(lv[u] * scale - zmax[u]) * rs[u];
-          dp[j][u] = gv[u] * (vv[u] + dlt[u]);
-          dot[u] = fmaf(pr[j][u], dp[j][u], dot[u]);
-          av[u] = gv[u] * pr[j][u];
-        }
-        st8<T>(da + r * D + lane * 8, av);
-      }
+    for (int u = 0; u < 8; ++u) {
+      rs[u] = 1.0f / rs[u];
+      dot[u] *= gv[u];
+      zmax[u] *= -LOG2E;
     }
+    for (int j0 = 0; j0 < k; j0 += 4) {
+      Raw8<T> lr[4], dr[4];
+      float vv[4][8];
 #pragma unroll
-    for (int j = 0; j < KK; ++j) {
-      if (j < k) {
-        float o[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          o[u] = pr[j][u] * (dp[j][u] - dot[u]) * scale;
-          cs[u] += o[u];
+      for (int t = 0; t < 4; ++t) {
+        if (j0 + t < k) {
+          const int64_t r = p * k + j0 + t;
+          const int m = nbr[r];
+          ldraw(L + r * D + lane * 8, lr[t]);
+          ld8<float>(vf + (b * n + m) * D + lane * 8, vv[t]);
+          ldraw(delta + r * D + lane * 8, dr[t]);
         }
-        st8<T>(dL + (p * k + j) * D + lane * 8, o);
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (j0 + t < k) {
+          const int64_t r = p * k + j0 + t;
+          float lv[8], dlt[8], av[8], o[8];
+          unpack(lr[t], lv);
+          unpack(dr[t], dlt);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const float pr = exp2_hw(fmaf(lv[u], scale * LOG2E, zmax[u])) * rs[u];
+            av[u] = gv[u] * pr;
+            o[u] = pr * (gv[u] * (vv[t][u] + dlt[u]) - dot[u]) * scale;
+            cs[u] += o[u];
+          }
+          st8<T>(da + r * D + lane * 8, av);
+          st8<T>(dL + r * D + lane * 8, o);
+        }
       }
     }
   }
@@ -404,10 +501,10 @@ extern "C" int sug_ptran_pos1_fwd(const float* xyz, const int32_t* nbr, const fl
                                   int k, int d, int dtype, void* out, void* stream) {
   SUG_REQUIRE(xyz && nbr && w1 && b1 && out, "sug_ptran_pos1_fwd: null pointer");
   PT_REQ_COMMON("sug_ptran_pos1_fwd");
-  const int64_t R = (int64_t)B * n * k;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == 0) hipLaunchKernelGGL(ptran_pos1_kernel<float>, dim3(grid_for(R)), dim3(256), 0, st, xyz, nbr, w1, b1, R, n, k, (float*)out);
-  else hipLaunchKernelGGL(ptran_pos1_kernel<__half>, dim3(grid_for(R)), dim3(256), 0, st, xyz, nbr, w1, b1, R, n, k, (__half*)out);
+  const int64_t P = (int64_t)B * n;
+  if (dtype == 0) hipLaunchKernelGGL((ptran_pos1_kernel<float, 16>), dim3(grid_for(P)), dim3(256), 0, st, xyz, nbr, w1, b1, P, n, k, (float*)out);
+  else hipLaunchKernelGGL((ptran_pos1_kernel<__half, 16>), dim3(grid_for(P)), dim3(256), 0, st, xyz, nbr, w1, b1, P, n, k, (__half*)out);
   SUG_LAUNCH_CHECK("sug_ptran_pos1_fwd");
   return SUG_OK;
 }
@@ -420,8 +517,9 @@ extern "C" int sug_ptran_pos1_bwd(const void* g, const float* xyz, const int32_t
   int nb = (int)((R + 63) / 64);
   if (nb > 1024) nb = 1024;                                 // ws: 1024 * 4 * 512 floats
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == 0) hipLaunchKernelGGL(ptran_pos1_bwd_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)g, xyz, nbr, w1, b1, R, n, k, ws);
-  else hipLaunchKernelGGL(ptran_pos1_bwd_kernel<__half>, dim3(nb), dim3(256), 0, st, (const __half*)g, xyz, nbr, w1, b1, R, n, k, ws);
+  const int64_t P = (int64_t)B * n;
+  if (dtype == 0) hipLaunchKernelGGL((ptran_pos1_bwd_kernel<float, 16>), dim3(nb), dim3(256), 0, st, (const float*)g, xyz, nbr, w1, b1, P, n, k, ws);
+  else hipLaunchKernelGGL((ptran_pos1_bwd_kernel<__half, 16>), dim3(nb), dim3(256), 0, st, (const __half*)g, xyz, nbr, w1, b1, P, n, k, ws);
   SUG_LAUNCH_CHECK("sug_ptran_pos1_bwd");
   hipLaunchKernelGGL(ptran_pos1_fold_kernel, dim3(4 * D / 32), dim3(256), 0, st, ws, nb, dw1, db1);
   SUG_LAUNCH_CHECK("sug_ptran_pos1_bwd(fold)");
@@ -455,8 +553,8 @@ extern "C" int64_t sug_ptran_colsum_workspace(int64_t rows) {
 }
 
 // db (nullable): column sums of d delta [512]; ws: sug_ptran_colsum_workspace(B*n) floats
-extern "C" int sug_ptran_qk_bwd_db(const void* du, void* da, const int32_t* rev_off, const int32_t* rev_ent, int B, int n,
-                                   int k, int d, int dtype, float* dq, float* dk, float* db, float* ws, void* stream) {
+extern "C" int sug_ptran_qk_bwd(const void* du, void* da, const int32_t* rev_off, const int32_t* rev_ent, int B, int n,
+                                int k, int d, int dtype, float* dq, float* dk, float* db, float* ws, void* stream) {
   SUG_REQUIRE(du && da && rev_off && rev_ent && dq && dk, "sug_ptran_qk_bwd: null pointer");
   SUG_REQUIRE(!db || ws, "sug_ptran_qk_bwd: db needs a workspace");
   PT_REQ_COMMON("sug_ptran_qk_bwd");
@@ -473,11 +571,6 @@ extern "C" int sug_ptran_qk_bwd_db(const void* du, void* da, const int32_t* rev_
   SUG_LAUNCH_CHECK("sug_ptran_qk_bwd");
   if (db) return ptran_fold(ws, grid_for(P), db, st, "sug_ptran_qk_bwd(fold)");
   return SUG_OK;
-}
-
-extern "C" int sug_ptran_qk_bwd(const void* du, void* da, const int32_t* rev_off, const int32_t* rev_ent, int B, int n,
-                                int k, int d, int dtype, float* dq, float* dk, void* stream) {
-  return sug_ptran_qk_bwd_db(du, da, rev_off, rev_ent, B, n, k, d, dtype, dq, dk, nullptr, nullptr, stream);
 }
 
 // in place G <- G * [T1 > 0] over `rows` rows of 512 (the ReLU between the two linears of fc_gamma), db = column sums
@@ -506,12 +599,12 @@ extern "C" int sug_ptran_attn_fwd(const void* logits, const void* delta, const f
   return SUG_OK;
 }
 
-// db (nullable): column sums of dlogits [512]; ws: sug_ptran_colsum_workspace(B*n) floats
-extern "C" int sug_ptran_attn_bwd_db(const float* g, const void* logits, const void* delta, const float* vf, const int32_t* nbr,
-                                     const float* mx, const float* sm, const int32_t* rev_off, const int32_t* rev_ent, int B,
-                                     int n, int k, int d, int dtype, float scale, void* dlogits, void* da, float* dv,
-                                     float* db, float* ws, void* stream) {
-  SUG_REQUIRE(g && logits && delta && vf && nbr && mx && sm && rev_off && rev_ent && dlogits && da && dv,
+// mixed = the forward's output; db (nullable): column sums of dlogits [512]; ws: sug_ptran_colsum_workspace(B*n) floats
+extern "C" int sug_ptran_attn_bwd(const float* g, const float* mixed, const void* logits, const void* delta, const float* vf,
+                                  const int32_t* nbr, const float* mx, const float* sm, const int32_t* rev_off,
+                                  const int32_t* rev_ent, int B, int n, int k, int d, int dtype, float scale, void* dlogits,
+                                  void* da, float* dv, float* db, float* ws, void* stream) {
+  SUG_REQUIRE(g && mixed && logits && delta && vf && nbr && mx && sm && rev_off && rev_ent && dlogits && da && dv,
               "sug_ptran_attn_bwd: null pointer");
   SUG_REQUIRE(!db || ws, "sug_ptran_attn_bwd: db needs a workspace");
   PT_REQ_COMMON("sug_ptran_attn_bwd");
@@ -519,21 +612,13 @@ extern "C" int sug_ptran_attn_bwd_db(const float* g, const void* logits, const v
   hipStream_t st = (hipStream_t)stream;
   float* w = db ? ws : nullptr;
   if (dtype == 0) {
-    hipLaunchKernelGGL((ptran_attn_bwd_kernel<float, 16>), dim3(grid_for(P)), dim3(256), 0, st, g, (const float*)logits, (const float*)delta, vf, nbr, mx, sm, P, n, k, scale, (float*)dlogits, (float*)da, w);
+    hipLaunchKernelGGL(ptran_attn_bwd_kernel<float>, dim3(grid_for(P)), dim3(256), 0, st, g, mixed, (const float*)logits, (const float*)delta, vf, nbr, mx, sm, P, n, k, scale, (float*)dlogits, (float*)da, w);
     hipLaunchKernelGGL(ptran_rev_sum_kernel<float>, dim3(grid_for(P)), dim3(256), 0, st, (const float*)da, rev_off, rev_ent, P, n, k, 1.0f, dv);
   } else {
-    hipLaunchKernelGGL((ptran_attn_bwd_kernel<__half, 16>), dim3(grid_for(P)), dim3(256), 0, st, g, (const __half*)logits, (const __half*)delta, vf, nbr, mx, sm, P, n, k, scale, (__half*)dlogits, (__half*)da, w);
+    hipLaunchKernelGGL(ptran_attn_bwd_kernel<__half>, dim3(grid_for(P)), dim3(256), 0, st, g, mixed, (const __half*)logits, (const __half*)delta, vf, nbr, mx, sm, P, n, k, scale, (__half*)dlogits, (__half*)da, w);
     hipLaunchKernelGGL(ptran_rev_sum_kernel<__half>, dim3(grid_for(P)), dim3(256), 0, st, (const __half*)da, rev_off, rev_ent, P, n, k, 1.0f, dv);
   }
   SUG_LAUNCH_CHECK("sug_ptran_attn_bwd");
   if (db) return ptran_fold(ws, grid_for(P), db, st, "sug_ptran_attn_bwd(fold)");
   return SUG_OK;
-}
-
-extern "C" int sug_ptran_attn_bwd(const float* g, const void* logits, const void* delta, const float* vf, const int32_t* nbr,
-                                  const float* mx, const float* sm, const int32_t* rev_off, const int32_t* rev_ent, int B,
-                                  int n, int k, int d, int dtype, float scale, void* dlogits, void* da, float* dv,
-                                  void* stream) {
-  return sug_ptran_attn_bwd_db(g, logits, delta, vf, nbr, mx, sm, rev_off, rev_ent, B, n, k, d, dtype, scale, dlogits, da, dv,
-                               nullptr, nullptr, stream);
 }

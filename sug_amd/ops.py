@@ -1005,13 +1005,13 @@ class _PTranAttention(torch.autograd.Function):
         scale = 1.0 / (d ** 0.5)
         check(L_.sug_ptran_attn_fwd(_p(Lg), _p(delta), _p(vf), _p(nbr), B, n, k, d, code, scale, _p(mixed), _p(mx), _p(sm),
                                     _st()), 'sug_ptran_attn_fwd')
-        ctx.save_for_backward(xyz, nbr, vf, w1c, b1c, wl[0], wl[2], wl[4], T0, delta, U, T1, Lg, mx, sm)
+        ctx.save_for_backward(xyz, nbr, vf, w1c, b1c, wl[0], wl[2], wl[4], T0, delta, U, T1, Lg, mx, sm, mixed)
         ctx.meta = (B, n, k, d, code, scale)
         return mixed
 
     @staticmethod
     def backward(ctx, g):
-        xyz, nbr, vf, w1c, b1c, w2l, wg1l, wg2l, T0, delta, U, T1, Lg, mx, sm = ctx.saved_tensors
+        xyz, nbr, vf, w1c, b1c, w2l, wg1l, wg2l, T0, delta, U, T1, Lg, mx, sm, mixed = ctx.saved_tensors
         B, n, k, d, code, scale = ctx.meta
         dev, lo = g.device, T0.dtype
         L_ = lib()
@@ -1024,9 +1024,9 @@ class _PTranAttention(torch.autograd.Function):
         R = B * n * k
         cws = torch.empty(L_.sug_ptran_colsum_workspace(R), dtype=f32, device=dev)
         dbg2, dbg1, db2 = (torch.empty(d, dtype=f32, device=dev) for _ in range(3))
-        check(L_.sug_ptran_attn_bwd_db(_p(g), _p(Lg), _p(delta), _p(vf), _p(nbr), _p(mx), _p(sm), _p(off), _p(ent), B, n, k,
-                                       d, code, scale, _p(dL), _p(da), _p(dv), _p(dbg2), _p(cws), _st()),
-              'sug_ptran_attn_bwd_db')
+        check(L_.sug_ptran_attn_bwd(_p(g), _p(mixed), _p(Lg), _p(delta), _p(vf), _p(nbr), _p(mx), _p(sm), _p(off), _p(ent), B,
+                                    n, k, d, code, scale, _p(dL), _p(da), _p(dv), _p(dbg2), _p(cws), _st()),
+              'sug_ptran_attn_bwd')
 
         def dweight(gy, x):
             """gy^T . x over the R rows in row chunks (batched GEMM = split-K: one [512,512] product alone
@@ -1045,8 +1045,8 @@ class _PTranAttention(torch.autograd.Function):
         dwg1 = dweight(dT1, U)
         dU = dT1 @ wg1l
         dq, dk = torch.empty_like(dv), torch.empty_like(dv)
-        check(L_.sug_ptran_qk_bwd_db(_p(dU), _p(da), _p(off), _p(ent), B, n, k, d, code, _p(dq), _p(dk), _p(db2), _p(cws),
-                                     _st()), 'sug_ptran_qk_bwd_db')
+        check(L_.sug_ptran_qk_bwd(_p(dU), _p(da), _p(off), _p(ent), B, n, k, d, code, _p(dq), _p(dk), _p(db2), _p(cws),
+                                  _st()), 'sug_ptran_qk_bwd')
         ddelta = da                                            # = dU + da
         dw2 = dweight(ddelta, T0)
         dT0 = ddelta @ w2l
