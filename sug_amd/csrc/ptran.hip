@@ -490,6 +490,12 @@ inline int grid_for(int64_t waves) {
   if (g < 1) g = 1;
   return (int)g;
 }
+// kernels that also emit a partial column-sum row per workgroup: 2048 workgroups (8 per CU: every resident slot
+// taken, grid-stride loops balance the rest) keep the partial rows at 4 MB and their fold at a few microseconds
+inline int grid_cs(int64_t waves) {
+  const int g = grid_for(waves);
+  return g > 2048 ? 2048 : g;
+}
 
 }  // namespace
 
@@ -549,7 +555,7 @@ static int ptran_fold(const float* ws, int nblk, float* out, hipStream_t st, con
 }
 
 extern "C" int64_t sug_ptran_colsum_workspace(int64_t rows) {
-  return (int64_t)grid_for(rows) * D;
+  return (int64_t)grid_cs(rows) * D;
 }
 
 // db (nullable): column sums of d delta [512]; ws: sug_ptran_colsum_workspace(B*n) floats
@@ -563,13 +569,13 @@ extern "C" int sug_ptran_qk_bwd(const void* du, void* da, const int32_t* rev_off
   float* w = db ? ws : nullptr;
   if (dtype == 0) {
     hipLaunchKernelGGL(ptran_rev_sum_kernel<float>, dim3(grid_for(P)), dim3(256), 0, st, (const float*)du, rev_off, rev_ent, P, n, k, -1.0f, dk);
-    hipLaunchKernelGGL(ptran_qk_bwd_kernel<float>, dim3(grid_for(P)), dim3(256), 0, st, (const float*)du, (float*)da, P, n, k, dq, w);
+    hipLaunchKernelGGL(ptran_qk_bwd_kernel<float>, dim3(grid_cs(P)), dim3(256), 0, st, (const float*)du, (float*)da, P, n, k, dq, w);
   } else {
     hipLaunchKernelGGL(ptran_rev_sum_kernel<__half>, dim3(grid_for(P)), dim3(256), 0, st, (const __half*)du, rev_off, rev_ent, P, n, k, -1.0f, dk);
-    hipLaunchKernelGGL(ptran_qk_bwd_kernel<__half>, dim3(grid_for(P)), dim3(256), 0, st, (const __half*)du, (__half*)da, P, n, k, dq, w);
+    hipLaunchKernelGGL(ptran_qk_bwd_kernel<__half>, dim3(grid_cs(P)), dim3(256), 0, st, (const __half*)du, (__half*)da, P, n, k, dq, w);
   }
   SUG_LAUNCH_CHECK("sug_ptran_qk_bwd");
-  if (db) return ptran_fold(ws, grid_for(P), db, st, "sug_ptran_qk_bwd(fold)");
+  if (db) return ptran_fold(ws, grid_cs(P), db, st, "sug_ptran_qk_bwd(fold)");
   return SUG_OK;
 }
 
@@ -580,11 +586,11 @@ extern "C" int sug_ptran_relu_bwd_db(void* G, const void* T1, int64_t rows, int 
   SUG_REQUIRE(rows > 0 && d == D && (dtype == 0 || dtype == 1), "sug_ptran_relu_bwd_db: bad shape / dtype");
   hipStream_t st = (hipStream_t)stream;
   if (dtype == 0)
-    hipLaunchKernelGGL(ptran_relu_bwd_kernel<float>, dim3(grid_for(rows)), dim3(256), 0, st, (float*)G, (const float*)T1, rows, ws);
+    hipLaunchKernelGGL(ptran_relu_bwd_kernel<float>, dim3(grid_cs(rows)), dim3(256), 0, st, (float*)G, (const float*)T1, rows, ws);
   else
-    hipLaunchKernelGGL(ptran_relu_bwd_kernel<__half>, dim3(grid_for(rows)), dim3(256), 0, st, (__half*)G, (const __half*)T1, rows, ws);
+    hipLaunchKernelGGL(ptran_relu_bwd_kernel<__half>, dim3(grid_cs(rows)), dim3(256), 0, st, (__half*)G, (const __half*)T1, rows, ws);
   SUG_LAUNCH_CHECK("sug_ptran_relu_bwd_db");
-  return ptran_fold(ws, grid_for(rows), db, st, "sug_ptran_relu_bwd_db(fold)");
+  return ptran_fold(ws, grid_cs(rows), db, st, "sug_ptran_relu_bwd_db(fold)");
 }
 
 extern "C" int sug_ptran_attn_fwd(const void* logits, const void* delta, const float* vf, const int32_t* nbr, int B, int n,
@@ -612,13 +618,13 @@ extern "C" int sug_ptran_attn_bwd(const float* g, const float* mixed, const void
   hipStream_t st = (hipStream_t)stream;
   float* w = db ? ws : nullptr;
   if (dtype == 0) {
-    hipLaunchKernelGGL(ptran_attn_bwd_kernel<float>, dim3(grid_for(P)), dim3(256), 0, st, g, mixed, (const float*)logits, (const float*)delta, vf, nbr, mx, sm, P, n, k, scale, (float*)dlogits, (float*)da, w);
+    hipLaunchKernelGGL(ptran_attn_bwd_kernel<float>, dim3(grid_cs(P)), dim3(256), 0, st, g, mixed, (const float*)logits, (const float*)delta, vf, nbr, mx, sm, P, n, k, scale, (float*)dlogits, (float*)da, w);
     hipLaunchKernelGGL(ptran_rev_sum_kernel<float>, dim3(grid_for(P)), dim3(256), 0, st, (const float*)da, rev_off, rev_ent, P, n, k, 1.0f, dv);
   } else {
-    hipLaunchKernelGGL(ptran_attn_bwd_kernel<__half>, dim3(grid_for(P)), dim3(256), 0, st, g, mixed, (const __half*)logits, (const __half*)delta, vf, nbr, mx, sm, P, n, k, scale, (__half*)dlogits, (__half*)da, w);
+    hipLaunchKernelGGL(ptran_attn_bwd_kernel<__half>, dim3(grid_cs(P)), dim3(256), 0, st, g, mixed, (const __half*)logits, (const __half*)delta, vf, nbr, mx, sm, P, n, k, scale, (__half*)dlogits, (__half*)da, w);
     hipLaunchKernelGGL(ptran_rev_sum_kernel<__half>, dim3(grid_for(P)), dim3(256), 0, st, (const __half*)da, rev_off, rev_ent, P, n, k, 1.0f, dv);
   }
   SUG_LAUNCH_CHECK("sug_ptran_attn_bwd");
-  if (db) return ptran_fold(ws, grid_for(P), db, st, "sug_ptran_attn_bwd(fold)");
+  if (db) return ptran_fold(ws, grid_cs(P), db, st, "sug_ptran_attn_bwd(fold)");
   return SUG_OK;
 }

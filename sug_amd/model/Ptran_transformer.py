@@ -86,14 +86,14 @@ class TransformerBlock(nn.Module):
         p16 = PROJ_16BIT and GEMM_DTYPE is not None
         if p16:     # the lifted features stay in 16 bits between fc1 and the three projections (one rounding, no re-casts)
             lo = GEMM_DTYPE
-            lifted = F.linear(features.to(lo), _w16(self.fc1.weight, lo), _w16(self.fc1.bias, lo))
-            q, kf, vf = (F.linear(lifted, _w16(w.weight, lo)).float() for w in (self.w_qs, self.w_ks, self.w_vs))
+            lifted = ops.linear16(features, self.fc1, lo, out32=False)
+            q, kf, vf = (ops.linear16(lifted, w, lo) for w in (self.w_qs, self.w_ks, self.w_vs))
         else:
             lifted = _apply(self.fc1, features)
             q, kf, vf = _apply(self.w_qs, lifted), _apply(self.w_ks, lifted), _apply(self.w_vs, lifted)
         if self.fc1.out_features == 512 and not need_attn and GEMM_DTYPE in (None, torch.float16):
             mixed = ops.ptran_attention(xyz, nbr, q, kf, vf, self.fc_delta, self.fc_gamma, GEMM_DTYPE)
-            return _apply(self.fc2, mixed, wide=p16) + features, None
+            return (ops.linear16(mixed, self.fc2, GEMM_DTYPE) if p16 else _apply(self.fc2, mixed)) + features, None
         # composition out of separate ops (other widths, bf16 experiments, or when the attention is wanted)
         key = ops.gather_rows(kf, nbr)                                         # [B,n,k,d]
         value = ops.gather_rows(vf, nbr)

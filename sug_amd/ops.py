@@ -966,6 +966,62 @@ def cast_cached(p, lo, detach=False):
     return hit[1]
 
 
+def _dweight(gy, x):
+    """gy^T . x over the R rows in row chunks (batched GEMM = split-K: one [M,K] product alone fills few
+    workgroups), chunk results summed in fp32; 16-bit operands give fp32 products straight out of the GEMM."""
+    f32 = torch.float32
+    R = gy.shape[0]
+    S = 1
+    while R % (2 * S) == 0 and R // (2 * S) >= 16384:
+        S *= 2
+    wide = {} if gy.dtype == f32 else {'out_dtype': f32}
+    if S == 1:
+        return torch.mm(gy.t(), x, **wide)
+    return torch.bmm(gy.view(S, R // S, gy.shape[1]).transpose(1, 2), x.view(S, R // S, x.shape[1]), **wide).sum(dim=0)
+
+
+class _Linear16(torch.autograd.Function):
+    """nn.Linear on [..., K] rows with 16-bit operands (MFMA, fp32 accumulation) and fp32 parameters: the weight's
+    16-bit copy comes from the step cache, the result leaves the GEMM as fp32 (`out32`) or stays 16-bit for a
+    following 16-bit GEMM, the parameter gradients leave their GEMMs as fp32 (split-K over row chunks).  Written
+    out so that no cast kernels surround the GEMMs (an F.linear on cast operands costs ~6 per call)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, lo, out32):
+        _need_gpu(x, w)
+        x2 = x.reshape(-1, x.shape[-1])
+        x16 = x2 if x2.dtype == lo else x2.to(lo)
+        w16 = cast_cached(w, lo, detach=True)
+        if out32:
+            y = torch.mm(x16, w16.t(), out_dtype=torch.float32)
+            if b is not None:
+                y += b
+        elif b is None:
+            y = torch.mm(x16, w16.t())
+        else:
+            y = torch.addmm(cast_cached(b, lo, detach=True), x16, w16.t())
+        ctx.save_for_backward(x16, w16)
+        ctx.meta = (x.shape, x.dtype, b is not None, lo)
+        return y.view(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, g):
+        x16, w16 = ctx.saved_tensors
+        xshape, xdtype, has_b, lo = ctx.meta
+        g2 = g.reshape(-1, g.shape[-1])
+        g16 = g2 if g2.dtype == lo else g2.to(lo)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = (torch.mm(g16, w16, out_dtype=torch.float32) if xdtype == torch.float32 else torch.mm(g16, w16)).view(xshape)
+        dw = _dweight(g16, x16) if ctx.needs_input_grad[1] else None
+        db = g2.sum(dim=0, dtype=torch.float32) if (has_b and ctx.needs_input_grad[2]) else None
+        return dx, dw, db, None, None
+
+
+def linear16(x, layer, lo, out32=True):
+    return _Linear16.apply(x, layer.weight, layer.bias, lo, out32)
+
+
 # ----------------------------------------------------------------------------- Point Transformer attention
 class _PTranAttention(torch.autograd.Function):
     """Vector attention of one TransformerBlock (model/Ptran_transformer.py:39-44) from the projected
@@ -1028,27 +1084,16 @@ class _PTranAttention(torch.autograd.Function):
                                     n, k, d, code, scale, _p(dL), _p(da), _p(dv), _p(dbg2), _p(cws), _st()),
               'sug_ptran_attn_bwd')
 
-        def dweight(gy, x):
-            """gy^T . x over the R rows in row chunks (batched GEMM = split-K: one [512,512] product alone
-            fills 32 workgroups), chunk results summed in fp32."""
-            R = gy.shape[0]
-            S = 1
-            while R % (2 * S) == 0 and R // (2 * S) >= 16384:
-                S *= 2
-            if S == 1:
-                return (gy.t() @ x).to(f32)
-            return torch.bmm(gy.view(S, R // S, d).transpose(1, 2), x.view(S, R // S, d)).sum(dim=0, dtype=f32)
-
-        dwg2 = dweight(dL, T1)
+        dwg2 = _dweight(dL, T1)
         dT1 = dL @ wg2l
         check(L_.sug_ptran_relu_bwd_db(_p(dT1), _p(T1), R, d, code, _p(dbg1), _p(cws), _st()), 'sug_ptran_relu_bwd_db')
-        dwg1 = dweight(dT1, U)
+        dwg1 = _dweight(dT1, U)
         dU = dT1 @ wg1l
         dq, dk = torch.empty_like(dv), torch.empty_like(dv)
         check(L_.sug_ptran_qk_bwd(_p(dU), _p(da), _p(off), _p(ent), B, n, k, d, code, _p(dq), _p(dk), _p(db2), _p(cws),
                                   _st()), 'sug_ptran_qk_bwd')
         ddelta = da                                            # = dU + da
-        dw2 = dweight(ddelta, T0)
+        dw2 = _dweight(ddelta, T0)
         dT0 = ddelta @ w2l
         dw1 = torch.empty(d, 3, dtype=f32, device=dev)
         db1 = torch.empty(d, dtype=f32, device=dev)
