@@ -14,6 +14,10 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// FULL: the 64x64 super-tile lies inside [M,N] and every wave owns a multiple of 8 whole rows: the operand loads
+// carry no guards (a guarded load compiles to a branch and the wait counters collapse to vmcnt(0): nothing stays
+// in flight across the MFMAs) and four row pairs are in flight ahead of the MFMAs; same accumulation order, same bits.
+template <bool FULL>
 __global__ __launch_bounds__(256) void linear_dw_kernel(const float* __restrict__ g, int64_t ldg,
                                                         const float* __restrict__ x, int64_t ldx,
                                                         int64_t R, int M, int N, int rows_per_block,
@@ -39,6 +43,31 @@ __global__ __launch_bounds__(256) void linear_dw_kernel(const float* __restrict_
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
   float sa0 = 0.f, sa1 = 0.f;                    // sum of this lane's g elements (rows of its parity)
+  if constexpr (FULL) {
+    constexpr int ST = 4;                        // (8 in flight measured no faster)
+    float a0[ST], a1[ST], b0[ST], b1[ST];
+    auto fetch = [&](int64_t r, int s) {
+      int64_t row = r + kh;
+      row = row < R ? row : R - 1;               // prefetches past the chunk are never consumed
+      const float* gr = g + row * ldg + i0 + col;
+      const float* xr = x + row * ldx + j0 + col;
+      a0[s] = gr[0]; a1[s] = gr[32]; b0[s] = xr[0]; b1[s] = xr[32];
+    };
+#pragma unroll
+    for (int s = 0; s < ST - 1; ++s) fetch(r0 + 2 * s, s);
+    for (int64_t r = r0; r < r1; r += 2 * ST) {
+#pragma unroll
+      for (int s = 0; s < ST; ++s) {
+        fetch(r + 2 * (s + ST - 1), (s + ST - 1) % ST);
+        sa0 += a0[s];
+        sa1 += a1[s];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b0[s], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b1[s], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b0[s], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b1[s], acc[1][1], 0, 0, 0);
+      }
+    }
+  } else
   for (int64_t r = r0; r < r1; r += 2) {
     const int64_t row = r + kh;
     const bool ok = row < r1;
@@ -89,6 +118,7 @@ __global__ __launch_bounds__(256) void linear_dw_kernel(const float* __restrict_
 // Large outputs (M, N >= 128): one wave per workgroup owns a 128x128 output tile (4x4 MFMA tiles,
 // 256 accumulator registers) over its row chunk: 8 coalesced 128-B loads feed 16 MFMAs, twice the
 // arithmetic intensity of the 64x64 kernel, and no cross-wave combine.
+template <bool FULL>
 __global__ __launch_bounds__(64) void linear_dw_big_kernel(const float* __restrict__ g, int64_t ldg,
                                                            const float* __restrict__ x, int64_t ldx,
                                                            int64_t R, int M, int N, int rows_per_block,
@@ -117,14 +147,20 @@ __global__ __launch_bounds__(64) void linear_dw_big_kernel(const float* __restri
   // one wave per SIMD: nothing else hides the load latency, so the operands of the next ST-1 row
   // pairs are in flight while the 16 MFMAs of a row pair are issued (rows past r1 load as zeros)
   auto fetch = [&](int64_t r, float (&av)[4], float (&bv)[4]) {
-    const int64_t row = r + kh;
+    int64_t row = r + kh;
+    if constexpr (FULL) row = row < R ? row : R - 1;   // full tile, whole row groups: no guards (see linear_dw_kernel)
     const bool ok = row < r1;
     const float* gr = g + row * ldg + i0 + col;
     const float* xr = x + row * ldx + j0 + col;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      av[t] = (ok && ia[t]) ? gr[32 * t] : 0.f;
-      bv[t] = (ok && jb[t]) ? xr[32 * t] : 0.f;
+      if constexpr (FULL) {
+        av[t] = gr[32 * t];
+        bv[t] = xr[32 * t];
+      } else {
+        av[t] = (ok && ia[t]) ? gr[32 * t] : 0.f;
+        bv[t] = (ok && jb[t]) ? xr[32 * t] : 0.f;
+      }
     }
   };
   constexpr int ST = 4;                       // row pairs in flight ahead of the MFMAs
@@ -216,12 +252,20 @@ extern "C" int sug_linear_dw_bias(const float* g, int64_t ldg, const float* x, i
   SUG_REQUIRE(sug_divup(M, 64) <= 65535 && sug_divup(N, 64) <= 65535, "sug_linear_dw: output too large");
   hipStream_t st = (hipStream_t)stream;
   const int with_db = db ? 1 : 0;
-  if (use_big(M, N))
-    hipLaunchKernelGGL(linear_dw_big_kernel, dim3(nchunk, sug_divup(M, 128), sug_divup(N, 128)), dim3(64), 0, st, g, ldg,
-                       x, ldx, R, M, N, rpb, ws, with_db);
-  else
-    hipLaunchKernelGGL(linear_dw_kernel, dim3(nchunk, sug_divup(M, 64), sug_divup(N, 64)), dim3(256), 0, st, g, ldg, x,
-                       ldx, R, M, N, rpb, ws, with_db);
+  const bool whole = R % rpb == 0 && rpb % 32 == 0;      // every wave of every chunk: a multiple of 8 rows
+  if (use_big(M, N)) {
+    const dim3 grid(nchunk, sug_divup(M, 128), sug_divup(N, 128));
+    if (R % rpb == 0 && M % 128 == 0 && N % 128 == 0)      // (rpb is a multiple of 8)
+      hipLaunchKernelGGL(linear_dw_big_kernel<true>, grid, dim3(64), 0, st, g, ldg, x, ldx, R, M, N, rpb, ws, with_db);
+    else
+      hipLaunchKernelGGL(linear_dw_big_kernel<false>, grid, dim3(64), 0, st, g, ldg, x, ldx, R, M, N, rpb, ws, with_db);
+  } else {
+    const dim3 grid(nchunk, sug_divup(M, 64), sug_divup(N, 64));
+    if (whole && M % 64 == 0 && N % 64 == 0)
+      hipLaunchKernelGGL(linear_dw_kernel<true>, grid, dim3(256), 0, st, g, ldg, x, ldx, R, M, N, rpb, ws, with_db);
+    else
+      hipLaunchKernelGGL(linear_dw_kernel<false>, grid, dim3(256), 0, st, g, ldg, x, ldx, R, M, N, rpb, ws, with_db);
+  }
   SUG_LAUNCH_CHECK("sug_linear_dw");
   const int64_t MN = (int64_t)M * N, P = MN + (with_db ? M : 0);
   hipLaunchKernelGGL(linear_dw_reduce_kernel, dim3(sug_divup(P, 16)), dim3(256), 0, st, ws, nchunk, MN, P, dw, db);
