@@ -252,16 +252,22 @@ class PTran_g(nn.Module):
     def clear_prefix_cache(self):
         self._prefix_cache = {}
 
+    def _lift(self, x_):
+        """fc1 (Linear 3->32, ReLU, Linear 32->32) on the [B,N,3] rows; on the GPU through ops.linear_rows: its
+        split-K weight gradient replaces two one-workgroup library GEMMs over all B*N rows (~0.5 ms at config 5)."""
+        h = F.relu(ops.linear_rows(x_, self.fc1[0].weight, self.fc1[0].bias))
+        return ops.linear_rows(h, self.fc1[2].weight, self.fc1[2].bias)
+
     def _prefix(self, x, x_, xyz):
         if not (self.share_prefix and self.training):
-            return self.transformer1(xyz, self.fc1(x_))[0]
+            return self.transformer1(xyz, self._lift(x_))[0]
         ver = sum(p._version for m in (self.fc1, self.transformer1) for p in m.parameters())
         key = (x.data_ptr(), x._version, tuple(x.shape), torch.is_grad_enabled(), ver)
         hit = self._prefix_cache.get(key)
         if hit is None:
             if len(self._prefix_cache) >= 4:
                 self._prefix_cache.clear()
-            hit = self._prefix_cache[key] = self.transformer1(xyz, self.fc1(x_))[0]
+            hit = self._prefix_cache[key] = self.transformer1(xyz, self._lift(x_))[0]
         return hit
 
     def fps_plan(self, N):

@@ -961,9 +961,22 @@ def cast_cached(p, lo, detach=False):
     key = (id(p), lo, bool(detach) or not torch.is_grad_enabled())
     hit = W16_CACHE.get(key)
     if hit is None or hit[0] != p._version:
-        hit = (p._version, (p.detach() if key[2] else p).to(lo))
+        hit = (p._version, (p.detach() if key[2] else p).to(lo), p)
         W16_CACHE[key] = hit
     return hit[1]
+
+
+def w16_plan(cache):
+    """The detached copies a step made, as (key, parameter, buffer) records: the next step refreshes all the buffers
+    with one multi-tensor copy (w16_prefill) instead of one cast launch per parameter."""
+    return [(key, hit[2], hit[1]) for key, hit in cache.items() if key[2]]
+
+
+def w16_prefill(plan):
+    """A cache for this step whose planned entries are already current."""
+    if plan:
+        torch._foreach_copy_([buf for _, _, buf in plan], [p.detach() for _, p, _ in plan])
+    return {key: (p._version, buf, p) for key, p, buf in plan}
 
 
 def _dweight(gy, x):
@@ -971,8 +984,10 @@ def _dweight(gy, x):
     workgroups), chunk results summed in fp32; 16-bit operands give fp32 products straight out of the GEMM."""
     f32 = torch.float32
     R = gy.shape[0]
+    # ~32 chunks (x 4 output tiles of the library's 256 x 256 macro tile = half the chip's workgroup slots), chunks of
+    # 512 .. 16384 rows: R = 2^20 -> 64 x 16384, 2^17 -> 32 x 4096, 2^15 -> 32 x 1024, 2^13 -> 16 x 512
     S = 1
-    while R % (2 * S) == 0 and R // (2 * S) >= 16384:
+    while R % (2 * S) == 0 and R // (2 * S) >= 512 and (S < 32 or R // S > 16384):
         S *= 2
     wide = {} if gy.dtype == f32 else {'out_dtype': f32}
     if S == 1:

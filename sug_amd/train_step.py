@@ -458,10 +458,14 @@ class SUGStep:
     def _eager_step(self, data, label, data_t, label_t, epoch=0):
         mmd_on = epoch >= self.methods['PURE_CLS_EPOCH']
         from .model import Ptran_transformer as _PT
-        ops.W16_CACHE = {} if _PT.GEMM_DTYPE is not None else None      # 16-bit weight copies shared by this step's forwards
+        # 16-bit weight copies shared by this step's forwards; from the second step on they are refreshed by one
+        # multi-tensor copy into the first step's buffers
+        ops.W16_CACHE = ops.w16_prefill(getattr(self, '_w16_plan', None) or []) if _PT.GEMM_DTYPE is not None else None
         try:
             loss_cls, loss_geo, loss_sem = self.losses(data, label, data_t, label_t, mmd_on)
         finally:
+            if ops.W16_CACHE is not None:
+                self._w16_plan = ops.w16_plan(ops.W16_CACHE)
             ops.W16_CACHE = None
         loss = loss_cls
         if loss_geo is not None:
