@@ -25,3 +25,4 @@ for _ in range(3):
 pr.disable()
 torch.cuda.synchronize()
 pstats.Stats(pr).sort_stats('tottime').print_stats(28)
+pstats.Stats(pr).sort_stats('cumtime').print_stats(45)
