@@ -488,6 +488,17 @@ int sug_sda_prob_weights(const float* pred_s, int64_t lds, const float* pred_t, 
                          const int64_t* label_s, const int64_t* label_t, int m, int num_class,
                          float label_weight, int method, float* weights, void* stream);
 
+/* Z [2m, D+num_class] = [feat_s ; feat_t | one-hot(label) * label_scale]: the label-augmented operand of soft_mmd
+ * (model/mmd.py:56-66, create_one_hot_labels utils/common_utils.py:161-164) in one launch; feat_* [m,D] with row
+ * strides lds / ldt, label_* int64 [m]. */
+int sug_mmd_assemble(const float* feat_s, int64_t lds, const float* feat_t, int64_t ldt, const int64_t* label_s,
+                     const int64_t* label_t, int m, int D, int num_class, float label_scale, float* z, void* stream);
+
+/* The EdgeConv GEMM operand of a conv_2d weight W [Co, 2C] (get_graph_feature's cat(x_j - x_i, x_i) folded into
+ * the weights, model/model_utils.py:188-210): backward = 0: in = W, out [2Co, C] = [W[:, :C] ; W[:, C:] - W[:, :C]];
+ * backward = 1: in = d out [2Co, C], out = dW [Co, 2C]. */
+int sug_edge_weight_split(const float* in, int Co, int C, int backward, float* out, void* stream);
+
 /* Chamfer distance per cloud pair (SDA geometric weights; geometric_weights(),
  * model/mmd.py:107-131 -- third-party op in the reference, parity unpinned):
  * out[b] = mean_i min_j |a_i-b_j|^2 + mean_j min_i |a_i-b_j|^2, direct-form distance.

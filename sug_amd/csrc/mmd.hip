@@ -378,3 +378,55 @@ extern "C" int sug_sda_prob_weights(const float* pred_s, int64_t lds, const floa
   SUG_LAUNCH_CHECK("sug_sda_prob_weights");
   return SUG_OK;
 }
+
+// ---- label-augmented MMD operand and the EdgeConv weight split: small assembly steps of a training step that cost
+// four to six tiny torch launches each (cat / scatter / mul / sub) in the reference's formulation
+namespace {
+
+__global__ __launch_bounds__(256) void mmd_assemble_kernel(const float* __restrict__ fs, int64_t lds,
+                                                           const float* __restrict__ ft, int64_t ldt,
+                                                           const int64_t* __restrict__ ls, const int64_t* __restrict__ lt,
+                                                           int m, int D, int ncls, float scale, float* __restrict__ z) {
+  const int row = blockIdx.x;
+  const float* src = row < m ? fs + (int64_t)row * lds : ft + (int64_t)(row - m) * ldt;
+  const int64_t lab = row < m ? ls[row] : lt[row - m];
+  float* dst = z + (int64_t)row * (D + ncls);
+  for (int c = threadIdx.x; c < D; c += 256) dst[c] = src[c];
+  for (int c = threadIdx.x; c < ncls; c += 256) dst[D + c] = (c == lab) ? scale : 0.f;
+}
+
+// forward: out [2Co, C] = [W[:, :C] ; W[:, C:] - W[:, :C]];  backward: dW [Co, 2C] = [g[:Co] - g[Co:] | g[Co:]]
+__global__ __launch_bounds__(256) void split_weight_kernel(const float* __restrict__ in, int Co, int C, int backward,
+                                                           float* __restrict__ out) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= 2 * Co * C) return;
+  if (!backward) {
+    const int r = e / C, c = e - r * C;
+    out[e] = r < Co ? in[(int64_t)r * 2 * C + c] : in[(int64_t)(r - Co) * 2 * C + C + c] - in[(int64_t)(r - Co) * 2 * C + c];
+  } else {
+    const int r = e / (2 * C), c = e - r * 2 * C;
+    out[e] = c < C ? in[(int64_t)r * C + c] - in[(int64_t)(Co + r) * C + c] : in[(int64_t)(Co + r) * C + c - C];
+  }
+}
+
+}  // namespace
+
+extern "C" int sug_mmd_assemble(const float* feat_s, int64_t lds, const float* feat_t, int64_t ldt, const int64_t* label_s,
+                                const int64_t* label_t, int m, int D, int num_class, float label_scale, float* z,
+                                void* stream) {
+  SUG_REQUIRE(feat_s && feat_t && label_s && label_t && z, "sug_mmd_assemble: null pointer");
+  SUG_REQUIRE(m > 0 && D > 0 && num_class > 0 && lds >= D && ldt >= D, "sug_mmd_assemble: bad shape");
+  hipLaunchKernelGGL(mmd_assemble_kernel, dim3(2 * m), dim3(256), 0, (hipStream_t)stream, feat_s, lds, feat_t, ldt, label_s,
+                     label_t, m, D, num_class, label_scale, z);
+  SUG_LAUNCH_CHECK("sug_mmd_assemble");
+  return SUG_OK;
+}
+
+extern "C" int sug_edge_weight_split(const float* in, int Co, int C, int backward, float* out, void* stream) {
+  SUG_REQUIRE(in && out, "sug_edge_weight_split: null pointer");
+  SUG_REQUIRE(Co > 0 && C > 0 && (int64_t)Co * C < (1 << 28), "sug_edge_weight_split: bad shape");
+  hipLaunchKernelGGL(split_weight_kernel, dim3(sug_divup(2 * Co * C, 256)), dim3(256), 0, (hipStream_t)stream, in, Co, C,
+                     backward, out);
+  SUG_LAUNCH_CHECK("sug_edge_weight_split");
+  return SUG_OK;
+}

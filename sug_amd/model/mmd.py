@@ -44,8 +44,7 @@ def cal_sample_weights(data_s, data_t, args, label_s=None, label_t=None, KPC=Fal
 def soft_mmd(label_s, feat_s, label_t, feat_t, label_weight, sample_weights=None):
     """model/mmd.py:56-66: MMD on [features | one-hot(label) * label_weight]."""
     m = feat_s.shape[0]
-    onehot = torch.cat((create_one_hot_labels(label_s), create_one_hot_labels(label_t)), 0) * label_weight
-    Z = torch.cat((torch.cat((feat_s, feat_t), 0), onehot), dim=1)          # [2m, D+10]
+    Z = ops.mmd_assemble(feat_s, feat_t, label_s, label_t, label_weight)    # [2m, D+10] = [feat | onehot * weight]
     return ops.mix_rbf_mmd2_rows(Z, m, sample_weights, sigma_list)
 
 
@@ -55,10 +54,8 @@ def soft_mmd_sharded(label_s, feat_s, label_t, feat_t, label_g, feat_g_s, label_
     rank's (differentiable) features, feat_g_s / feat_g_t [M, D] the gathered values of all ranks (this
     rank's rows at row0); equals soft_mmd(label_g, feat_g_s, label_tg, feat_g_t, ...) on every rank."""
     mloc, M = feat_s.shape[0], feat_g_s.shape[0]
-    oh = torch.cat((create_one_hot_labels(label_s), create_one_hot_labels(label_t)), 0) * label_weight
-    Zloc = torch.cat((torch.cat((feat_s, feat_t), 0), oh), dim=1)
-    ohg = torch.cat((create_one_hot_labels(label_g), create_one_hot_labels(label_tg)), 0) * label_weight
-    Zall = torch.cat((torch.cat((feat_g_s.detach(), feat_g_t.detach()), 0), ohg), dim=1)
+    Zloc = ops.mmd_assemble(feat_s, feat_t, label_s, label_t, label_weight)
+    Zall = ops.mmd_assemble(feat_g_s.detach(), feat_g_t.detach(), label_g, label_tg, label_weight)
     return ops.mix_rbf_mmd2_rows_sharded(Zloc, Zall, mloc, M, row0, sample_weights, sigma_list, world)
 
 

@@ -43,21 +43,6 @@ def _bn_rows(bn, y):
     return y2.view(shp)
 
 
-class _SplitWeight(torch.autograd.Function):
-    """W [Co, 2C] -> [W1 ; W2 - W1] [2Co, C] (the EdgeConv GEMM operand); backward in two launches
-    instead of autograd's slice / zero-fill / add chain: dW = [gP - gQ | gQ]."""
-
-    @staticmethod
-    def forward(ctx, W):
-        C = W.shape[1] // 2
-        return torch.cat((W[:, :C], W[:, C:] - W[:, :C]), dim=0)
-
-    @staticmethod
-    def backward(ctx, g):
-        Co = g.shape[0] // 2
-        return torch.cat((g[:Co] - g[Co:], g[Co:]), dim=1)
-
-
 class conv_2d(nn.Module):
     """1x1 Conv2d -> BatchNorm2d -> activation (model/model_utils.py:8-32)."""
 
@@ -111,7 +96,7 @@ class conv_2d(nn.Module):
         if hit is not None and hit[0] == W._version and (hit[1] or not grad):
             Wcat = hit[2]                  # same weights, same step (a graph-attached copy also serves no_grad)
         else:
-            Wcat = _SplitWeight.apply(W)                                  # [2Co, C] = [W1 ; W2-W1]
+            Wcat = ops.edge_weight_split(W)                                 # [2Co, C] = [W1 ; W2-W1]
             self._wcat = (W._version, grad, Wcat) if self.cache_weight_split else None
         pq = ops.linear_rows(x.reshape(B * N, C), Wcat)
         bias = self.conv[0].bias

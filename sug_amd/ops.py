@@ -1261,6 +1261,63 @@ def mix_rbf_mmd2_rows_sharded(Zloc, Zall, mloc, M, row0, sample_weights=None, si
     return _MixRbfMMD2Sharded.apply(Zloc, Zall, mloc, M, row0, sample_weights, tuple(sigmas), world, group)
 
 
+class _AssembleZ(torch.autograd.Function):
+    """[feat_s ; feat_t | one-hot(label) * scale] of soft_mmd (model/mmd.py:56-66) in one launch instead of
+    scatter + three cats + a mul; the gradient of the feature block is handed back as two row-slice views."""
+
+    @staticmethod
+    def forward(ctx, feat_s, feat_t, label_s, label_t, scale, num_class):
+        _need_gpu(feat_s, feat_t, label_s, label_t)
+        m, D = feat_s.shape
+        fs = feat_s if feat_s.stride(1) == 1 else feat_s.contiguous()
+        ft = feat_t if feat_t.stride(1) == 1 else feat_t.contiguous()
+        ls, lt = label_s.reshape(-1).long().contiguous(), label_t.reshape(-1).long().contiguous()
+        Z = torch.empty(2 * m, D + num_class, dtype=torch.float32, device=feat_s.device)
+        check(lib().sug_mmd_assemble(_p(fs), fs.stride(0), _p(ft), ft.stride(0), _p(ls), _p(lt), m, D, num_class,
+                                     float(scale), _p(Z), _st()), 'sug_mmd_assemble')
+        ctx.md = (m, D)
+        return Z
+
+    @staticmethod
+    def backward(ctx, g):
+        m, D = ctx.md
+        return g[:m, :D], g[m:, :D], None, None, None, None
+
+
+def mmd_assemble(feat_s, feat_t, label_s, label_t, scale, num_class=10):
+    if feat_s.dtype != torch.float32 or feat_t.dtype != torch.float32 or feat_s.shape != feat_t.shape or feat_s.dim() != 2:
+        raise RuntimeError('sug_amd.ops.mmd_assemble: two fp32 [m, D] feature blocks of one shape')
+    return _AssembleZ.apply(feat_s, feat_t, label_s, label_t, scale, num_class)
+
+
+class _EdgeWeightSplit(torch.autograd.Function):
+    """W [Co, 2C] -> [W1 ; W2 - W1] [2Co, C], the EdgeConv GEMM operand (one launch forward, one backward:
+    dW = [gP - gQ | gQ])."""
+
+    @staticmethod
+    def forward(ctx, W):
+        _need_gpu(W)
+        W = W.contiguous()
+        Co, C = W.shape[0], W.shape[1] // 2
+        out = torch.empty(2 * Co, C, dtype=torch.float32, device=W.device)
+        check(lib().sug_edge_weight_split(_p(W), Co, C, 0, _p(out), _st()), 'sug_edge_weight_split')
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        Co, C = g.shape[0] // 2, g.shape[1]
+        dW = torch.empty(Co, 2 * C, dtype=torch.float32, device=g.device)
+        check(lib().sug_edge_weight_split(_p(g), Co, C, 1, _p(dW), _st()), 'sug_edge_weight_split')
+        return dW
+
+
+def edge_weight_split(W):
+    if W.dtype != torch.float32 or W.dim() != 2 or W.shape[1] % 2:
+        raise RuntimeError('sug_amd.ops.edge_weight_split: fp32 [Co, 2C] weight')
+    return _EdgeWeightSplit.apply(W)
+
+
 _SDA_METHODS = {'none': 0, 'naive_inverse': 1, 'exp_inverse': 2, 'mean2one': 3}
 
 

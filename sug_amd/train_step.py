@@ -352,9 +352,9 @@ class SUGStep:
             w = None
             if sem.get('SEM_WEIGHTS'):
                 w = mmd.prob_weights_soft(gps, gpt, label_g, label_tg, sem['LABEL_WEIGHT'], sem['SEM_WEIGHTS'])
-            terms.append(sem['SEM_SCALE'] * mmd.soft_mmd_sharded(label, fs, label_t, ft, label_g, gs, label_tg, gt,
-                                                                 float(sem['LABEL_SCALE']), row0, w, self.world))
-        return loss_geo, M_['MMD_WEIGHT'] * (0.5 * terms[0] + 0.5 * terms[1])
+            terms.append(mmd.soft_mmd_sharded(label, fs, label_t, ft, label_g, gs, label_tg, gt,
+                                              float(sem['LABEL_SCALE']), row0, w, self.world))
+        return loss_geo, (0.5 * M_['MMD_WEIGHT'] * sem['SEM_SCALE']) * (terms[0] + terms[1])
 
     def losses(self, data, label, data_t, label_t, mmd_on=True):
         M = self.methods
@@ -366,15 +366,22 @@ class SUGStep:
         else:
             pred_s1, pred_s2, sem_s1, sem_s2 = model(data, semantic_adaption=True)
             pred_t1, pred_t2, sem_t1, sem_t2 = model(data_t, semantic_adaption=True)
-        loss_s = 0.5 * self.criterion(pred_s1, label) + 0.5 * self.criterion(pred_s2, label)
-        if M['ADV_WEIGHT'] > 0:
-            loss_s = loss_s - M['ADV_WEIGHT'] * discrepancy(pred_t1, pred_t2)
-        if M['TARGET_LOSS'] > 0:        # the reference scores the target predictions against `label` (:284-285)
-            loss_t = 0.5 * self.criterion(pred_t1, label) + 0.5 * self.criterion(pred_t2, label)
-            loss = 0.5 * loss_s + 0.5 * loss_t
+        # scalar algebra with the constant factors multiplied on the host: every tensor-scalar op is a launch forward
+        # and one backward (0.5*a + 0.5*b = 0.5*(a + b) exactly; the folded weights differ from the reference's
+        # left-to-right products by an ulp at most)
+        if M['ADV_WEIGHT'] > 0 or M['TARGET_LOSS'] > 0:
+            loss_s = 0.5 * (self.criterion(pred_s1, label) + self.criterion(pred_s2, label))
+            if M['ADV_WEIGHT'] > 0:
+                loss_s = loss_s - M['ADV_WEIGHT'] * discrepancy(pred_t1, pred_t2)
+            if M['TARGET_LOSS'] > 0:    # the reference scores the target predictions against `label` (:284-285)
+                loss_t = 0.5 * (self.criterion(pred_t1, label) + self.criterion(pred_t2, label))
+                loss = 0.5 * (loss_s + loss_t)
+            else:
+                loss = M['SRC_LOSS_WEIGHT'] * loss_s
+            loss_cls = M['CLS_WEIGHT'] * loss
         else:
-            loss = M['SRC_LOSS_WEIGHT'] * loss_s
-        loss_cls = M['CLS_WEIGHT'] * loss
+            loss_cls = (0.5 * M['SRC_LOSS_WEIGHT'] * M['CLS_WEIGHT']) * (self.criterion(pred_s1, label) +
+                                                                          self.criterion(pred_s2, label))
         if not mmd_on or M['MMD_WEIGHT'] <= 0:
             return loss_cls, None, None
         if pair is not None:
@@ -391,9 +398,9 @@ class SUGStep:
         loss_geo = M['MMD_WEIGHT'] * geo['GEO_SCALE'] * self._mmd(label, feat_node_s, label_t, feat_node_t, geo, data, data_t)
         loss_sem = None
         if sem['SEM_SCALE'] > 0:
-            l1 = sem['SEM_SCALE'] * self._mmd(label, sem_s1, label_t, sem_t1, sem, pred_s1, pred_t1)
-            l2 = sem['SEM_SCALE'] * self._mmd(label, sem_s2, label_t, sem_t2, sem, pred_s2, pred_t2)
-            loss_sem = M['MMD_WEIGHT'] * (0.5 * l1 + 0.5 * l2)
+            l1 = self._mmd(label, sem_s1, label_t, sem_t1, sem, pred_s1, pred_t1)
+            l2 = self._mmd(label, sem_s2, label_t, sem_t2, sem, pred_s2, pred_t2)
+            loss_sem = (0.5 * M['MMD_WEIGHT'] * sem['SEM_SCALE']) * (l1 + l2)
         return loss_cls, loss_geo, loss_sem
 
     # ------------------------------------------------------------------ step
