@@ -211,6 +211,11 @@ int sug_linear_dw(const float* g, int64_t ldg, const float* x, int64_t ldx, int6
 int sug_linear_dw_bias(const float* g, int64_t ldg, const float* x, int64_t ldx, int64_t R, int M, int N,
                        float* dw, float* db, float* ws, void* stream);
 
+/* Channel-attention gate of CALayer (model/Model.py:28-34): out = x * sigmoid(z) + x over n elements, z = the
+ * output of the second 1x1 conv; backward dx = g * sigmoid(z) + g, dz = g * x * sigmoid'(z). */
+int sug_gate_fwd(const float* x, const float* z, int64_t n, float* out, void* stream);
+int sug_gate_bwd(const float* g, const float* x, const float* z, int64_t n, float* dx, float* dz, void* stream);
+
 /* ---- LayerNorm + (Leaky)ReLU of the FC heads ---------------------------------------------------
  * fc_layer (model/model_utils.py:35-57: nn.Linear -> nn.LayerNorm -> LeakyReLU(0.2) / ReLU) behind the Linear:
  * y = act(LN(x)) over rows of x [rows, C] (C <= 1024), stat [rows, 2] = mean | rstd for the backward.

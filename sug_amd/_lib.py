@@ -64,6 +64,8 @@ SIGNATURES = {
     'sug_mmd_rbf_rows': [_vp, _i64, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
     'sug_mmd_rbf_rows_bwd': [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _f32, _vp, _i64, _vp],
     'sug_mmd_rbf_bwd': [_vp, _i64, _vp, _i32, _i32, _vp, _vp, _i64, _vp],
+    'sug_gate_fwd': [_vp, _vp, _i64, _vp, _vp],
+    'sug_gate_bwd': [_vp, _vp, _vp, _i64, _vp, _vp, _vp],
     'sug_mmd_assemble': [_vp, _i64, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp],
     'sug_edge_weight_split': [_vp, _i32, _i32, _i32, _vp, _vp],
     'sug_sda_prob_weights': [_vp, _i64, _vp, _i64, _vp, _vp, _i32, _i32, _f32, _i32, _vp, _vp],

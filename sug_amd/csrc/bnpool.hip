@@ -604,3 +604,44 @@ extern "C" int sug_ln_act_bwd(const float* g, const float* x, const float* gamma
   SUG_LAUNCH_CHECK("sug_ln_act_bwd(param)");
   return SUG_OK;
 }
+
+// ---- CALayer gate: out = x * sigmoid(z) + x (model/Model.py:28-34 behind the second 1x1 conv), the product and the
+// sum rounded separately as the reference's two ops are; backward dx = g*s + g, dz = g*x * s*(1-s)
+namespace {
+
+__global__ __launch_bounds__(256) void gate_fwd_kernel(const float* __restrict__ x, const float* __restrict__ z, int64_t n,
+                                                       float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float s = 1.0f / (1.0f + expf(-z[i]));
+  out[i] = __fadd_rn(__fmul_rn(x[i], s), x[i]);
+}
+
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                       const float* __restrict__ z, int64_t n, float* __restrict__ dx,
+                                                       float* __restrict__ dz) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float s = 1.0f / (1.0f + expf(-z[i]));
+  const float gi = g[i];
+  dx[i] = __fadd_rn(__fmul_rn(gi, s), gi);
+  dz[i] = __fmul_rn(__fmul_rn(gi, x[i]), __fmul_rn(__fsub_rn(1.0f, s), s));
+}
+
+}  // namespace
+
+extern "C" int sug_gate_fwd(const float* x, const float* z, int64_t n, float* out, void* stream) {
+  SUG_REQUIRE(x && z && out, "sug_gate_fwd: null pointer");
+  SUG_REQUIRE(n > 0, "sug_gate_fwd: empty input");
+  hipLaunchKernelGGL(gate_fwd_kernel, dim3((unsigned)sug_divup(n, 256)), dim3(256), 0, (hipStream_t)stream, x, z, n, out);
+  SUG_LAUNCH_CHECK("sug_gate_fwd");
+  return SUG_OK;
+}
+
+extern "C" int sug_gate_bwd(const float* g, const float* x, const float* z, int64_t n, float* dx, float* dz, void* stream) {
+  SUG_REQUIRE(g && x && z && dx && dz, "sug_gate_bwd: null pointer");
+  SUG_REQUIRE(n > 0, "sug_gate_bwd: empty input");
+  hipLaunchKernelGGL(gate_bwd_kernel, dim3((unsigned)sug_divup(n, 256)), dim3(256), 0, (hipStream_t)stream, g, x, z, n, dx, dz);
+  SUG_LAUNCH_CHECK("sug_gate_bwd");
+  return SUG_OK;
+}

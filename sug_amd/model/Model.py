@@ -37,10 +37,10 @@ class CALayer(nn.Module):
         v = x.reshape(x.shape[0], -1)
         c0, c2 = self.conv_du[0], self.conv_du[2]
         y = F.relu(F.linear(v, c0.weight.view(c0.weight.shape[0], -1), c0.bias))
-        y = torch.sigmoid(F.linear(y, c2.weight.view(c2.weight.shape[0], -1), c2.bias))
+        z = F.linear(y, c2.weight.view(c2.weight.shape[0], -1), c2.bias)
         # torch's BatchNorm1d here: statistics over the B samples only (B = 2..32), where its two-pass
         # variance is better conditioned than the sum / sum-of-squares form of the rows kernels
-        return self.bn(v * y + v)
+        return self.bn(ops.gate(v, z))                                      # v * sigmoid(z) + v
 
 
 class GradReverse(torch.autograd.Function):

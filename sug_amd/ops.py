@@ -1290,6 +1290,34 @@ def mmd_assemble(feat_s, feat_t, label_s, label_t, scale, num_class=10):
     return _AssembleZ.apply(feat_s, feat_t, label_s, label_t, scale, num_class)
 
 
+class _Gate(torch.autograd.Function):
+    """x * sigmoid(z) + x (CALayer, model/Model.py:28-34) in one launch forward and one backward instead of
+    sigmoid / mul / add and their four backward launches."""
+
+    @staticmethod
+    def forward(ctx, x, z):
+        _need_gpu(x, z)
+        x, z = x.contiguous(), z.contiguous()
+        out = torch.empty_like(x)
+        check(lib().sug_gate_fwd(_p(x), _p(z), x.numel(), _p(out), _st()), 'sug_gate_fwd')
+        ctx.save_for_backward(x, z)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, z = ctx.saved_tensors
+        g = g.contiguous()
+        dx, dz = torch.empty_like(x), torch.empty_like(x)
+        check(lib().sug_gate_bwd(_p(g), _p(x), _p(z), x.numel(), _p(dx), _p(dz), _st()), 'sug_gate_bwd')
+        return dx, dz
+
+
+def gate(x, z):
+    if x.dtype != torch.float32 or z.dtype != torch.float32 or x.shape != z.shape:
+        raise RuntimeError('sug_amd.ops.gate: two fp32 tensors of one shape')
+    return _Gate.apply(x, z)
+
+
 class _EdgeWeightSplit(torch.autograd.Function):
     """W [Co, 2C] -> [W1 ; W2 - W1] [2Co, C], the EdgeConv GEMM operand (one launch forward, one backward:
     dW = [gP - gQ | gQ])."""

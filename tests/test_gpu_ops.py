@@ -470,3 +470,44 @@ def test_knn_tiny_clouds(N, C):
     idx = ops.knn(x.transpose(1, 2).contiguous().cuda(), 20).cpu().long()
     ref = O.knn_idx(x, 20)
     assert_same_or_tied(idx, ref, O.knn_neg_dist(x), ulps=8 if C > 3 else 0)
+
+
+@pytest.mark.gpu
+def test_small_assembly_kernels_match_their_torch_formulations():
+    """sug_mmd_assemble, sug_edge_weight_split, sug_gate_*: single-launch forms of short torch op chains of the
+    reference (model/mmd.py:56-66, model_utils.py:188-210 folded into the weights, Model.py:28-34) -- bit for bit
+    forward, and the same gradients."""
+    from sug_amd import ops
+    g = torch.Generator().manual_seed(11)
+    dev = 'cuda'
+    # soft-MMD operand
+    m, D = 7, 301
+    fs = torch.randn(m, D, generator=g).to(dev).requires_grad_(True)
+    ft = torch.randn(m + 0, 2 * D, generator=g).to(dev)[:, ::2][:, :D].contiguous().requires_grad_(True)
+    ls, lt = torch.randint(0, 10, (m,), generator=g).to(dev), torch.randint(0, 10, (m,), generator=g).to(dev)
+    Z = ops.mmd_assemble(fs, ft, ls, lt, 2.5)
+    oh = torch.zeros(2 * m, 10, device=dev).scatter_(1, torch.cat((ls, lt)).view(-1, 1), 1.0) * 2.5
+    Zr = torch.cat((torch.cat((fs, ft), 0), oh), dim=1)
+    assert torch.equal(Z, Zr)
+    probe = torch.randn(2 * m, D + 10, generator=g).to(dev)
+    ga = torch.autograd.grad((Z * probe).sum(), (fs, ft))
+    gb = torch.autograd.grad((Zr * probe).sum(), (fs, ft))
+    assert all(torch.equal(a, b) for a, b in zip(ga, gb))
+    # EdgeConv weight split
+    W = torch.randn(24, 2 * 13, generator=g).to(dev).requires_grad_(True)
+    S = ops.edge_weight_split(W)
+    Sr = torch.cat((W[:, :13], W[:, 13:] - W[:, :13]), dim=0)
+    assert torch.equal(S, Sr)
+    probe = torch.randn(48, 13, generator=g).to(dev)
+    assert torch.equal(torch.autograd.grad((S * probe).sum(), W)[0], torch.autograd.grad((Sr * probe).sum(), W)[0])
+    # CALayer gate
+    x = torch.randn(5, 4096, generator=g).to(dev).requires_grad_(True)
+    z = (3 * torch.randn(5, 4096, generator=g)).to(dev).requires_grad_(True)
+    o = ops.gate(x, z)
+    orf = x * torch.sigmoid(z) + x
+    torch.testing.assert_close(o, orf, rtol=2e-7, atol=0)
+    probe = torch.randn(5, 4096, generator=g).to(dev)
+    ga = torch.autograd.grad((o * probe).sum(), (x, z))
+    gb = torch.autograd.grad((orf * probe).sum(), (x, z))
+    for a, b in zip(ga, gb):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-7)

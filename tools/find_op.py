@@ -8,7 +8,7 @@ from bench import synth
 from sug_amd.model.Model import Net_MDA
 from sug_amd.train_step import SUGStep
 model = sys.argv[1] if len(sys.argv) > 1 else 'DGCNN'
-names = set(sys.argv[2:] or ['cat', 'mul', 'add', 'fill_', 'zero_', 'copy_', 'sum', 'sub', 'div', 'mean', 'stack', 'clone', '_to_copy'])
+names = set(sys.argv[2:])        # empty: every op that is not a view / metadata op
 dev = torch.device('cuda')
 net = Net_MDA(model).to(dev).train()
 tr = SUGStep(net, use_graph=False)
@@ -17,12 +17,15 @@ for _ in range(2):
     tr.step(*data)
 torch.cuda.synchronize()
 agg = collections.Counter()
+SKIP = {'view', '_unsafe_view', 'reshape', 't', 'transpose', 'permute', 'slice', 'select', 'expand', 'unsqueeze', 'squeeze', 'detach', 'alias',
+        'empty', 'empty_like', 'empty_strided', 'as_strided', 'narrow', 'split', 'chunk', 'unbind', 'size', 'stride', 'is_same_size',
+        'split_with_sizes', 'lift_fresh', '_local_scalar_dense', 'new_empty', 'view_as', 'contiguous', 'unflatten', 'flatten'}
 
 
 class Spy(TorchDispatchMode):
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         name = func.overloadpacket.__name__
-        if name in names:
+        if (name in names) if names else name not in SKIP:
             site = '?'
             for fr in reversed(traceback.extract_stack()):
                 if ('sug_amd' in fr.filename or 'bench' in fr.filename) and 'find_op' not in fr.filename:
