@@ -511,3 +511,38 @@ def test_small_assembly_kernels_match_their_torch_formulations():
     gb = torch.autograd.grad((orf * probe).sum(), (x, z))
     for a, b in zip(ga, gb):
         torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('direct', [False, True])
+def test_knn_query_ties_beyond_candidate_buffer(direct):
+    """More than 128 candidates at the k-th distance (duplicated points): the select path hands over to the
+    round-by-round path; equal distances come out in index order (full-sort semantics, PTran_utils.py:99-136 /
+    point_utils.py:107-108)."""
+    from sug_amd import ops
+    g = torch.Generator().manual_seed(3)
+    N, k = 1024, 64
+    xyz = torch.rand(2, N, 3, generator=g)
+    dup = torch.randperm(N, generator=g)[:300].sort().values
+    xyz[0, dup] = xyz[0, dup[0]].clone()
+    xyz[1, dup[:140]] = xyz[1, dup[5]].clone()
+    qry = torch.stack((xyz[0, dup[0]], xyz[1, dup[5]])).view(2, 1, 3)
+    idx = ops.knn_query(xyz.cuda(), qry.cuda(), k, direct=direct).cpu()
+    assert idx[0, 0].tolist() == dup[:k].tolist()
+    assert idx[1, 0].tolist() == dup[:k].tolist()
+    # and a spread of k / N against a stable sort of the same distances (well separated random points)
+    for N2, k2 in ((100, 64), (257, 16), (2048, 16), (640, 32), (4096, 64), (64, 64)):
+        x = torch.rand(3, N2, 3, generator=g).cuda()
+        q = torch.rand(3, 5, 3, generator=g).cuda()
+        got, dist = ops.knn_query(x, q, k2, want_dist=True, direct=direct)
+        d = ((q[:, :, None, :] - x[:, None, :, :]) ** 2).sum(-1)
+        ref = d.sort(dim=-1, stable=True).indices[..., :k2]
+        same = (got.long() == ref)
+        # near-ties may swap between the two distance formulas: the distances at disagreeing ranks must agree to rounding
+        dg = torch.gather(d, 2, got.long())
+        dr = torch.gather(d, 2, ref)
+        assert torch.all(same | ((dg - dr).abs() <= 1e-6)), (N2, k2)
+        assert torch.all(dist[..., 1:] >= dist[..., :-1] - 0.0)
+        for b in range(3):
+            for s in range(5):
+                assert len(set(got[b, s].tolist())) == k2
