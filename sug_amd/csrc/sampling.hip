@@ -115,6 +115,46 @@ __global__ __launch_bounds__(256) void ball_query_kernel(const float* __restrict
   for (int p = cnt + lane; p < ns; p += WAVE) o[p] = first;
 }
 
+// The same with the cloud staged in LDS once per workgroup (N <= 4096) and qpw queries per wave: the 32 dependent
+// 12-byte-strided global loads of a query's scan become LDS reads.
+__global__ __launch_bounds__(256) void ball_query_lds_kernel(const float* __restrict__ xyz,
+                                                             const float* __restrict__ qry, int N, int S,
+                                                             float r2, int ns, int qpw, int32_t* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float s_pts[];             // [N*3]
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+  const float* pb = xyz + (int64_t)b * N * 3;
+  for (int i = threadIdx.x; i < 3 * N; i += 256) s_pts[i] = pb[i];
+  __syncthreads();
+  for (int qi = 0; qi < qpw; ++qi) {
+    const int s = (blockIdx.x * (256 / WAVE) + wv) * qpw + qi;
+    if (s >= S) break;
+    const float* q = qry + ((int64_t)b * S + s) * 3;
+    const float qx = q[0], qy = q[1], qz = q[2];
+    const float nq = sq3(qx, qy, qz);
+    int32_t* o = out + ((int64_t)b * S + s) * ns;
+    int cnt = 0, first = N;
+    for (int j0 = 0; j0 < N && cnt < ns; j0 += WAVE) {
+      const int j = j0 + lane;
+      bool hit = false;
+      if (j < N) {
+        const float x = s_pts[j * 3 + 0], y = s_pts[j * 3 + 1], z = s_pts[j * 3 + 2];
+        const float d = sqdist_expanded(dot3(qx, qy, qz, x, y, z), nq, sq3(x, y, z));
+        hit = !(d > r2);
+      }
+      const unsigned long long m = __ballot(hit);
+      if (m) {
+        if (cnt == 0) first = j0 + __builtin_ctzll(m);
+        const int pos = cnt + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+        if (hit && pos < ns) o[pos] = j;
+        cnt += __builtin_popcountll(m);
+      }
+    }
+    if (cnt > ns) cnt = ns;
+    for (int p = cnt + lane; p < ns; p += WAVE) o[p] = first;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // k nearest candidates for few queries (full-sort semantics: ascending distance, lower index first among equal
 // distances): one wave per query, the N distances live in registers (NPL per lane) as order-preserving integer keys.
@@ -358,9 +398,17 @@ extern "C" int sug_ball_query(const float* xyz, const float* query, int B, int N
   SUG_REQUIRE(xyz && query && out, "sug_ball_query: null pointer");
   SUG_REQUIRE(B > 0 && N > 0 && S > 0 && nsample > 0, "sug_ball_query: bad shape");
   SUG_REQUIRE(B <= 65535, "sug_ball_query: B too large");
-  dim3 grid(sug_divup(S, 256 / WAVE), B);
-  hipLaunchKernelGGL(ball_query_kernel, grid, dim3(256), 0, (hipStream_t)stream, xyz, query, N, S, r2,
-                     nsample, out);
+  if (N <= 4096) {
+    int qpw = 1;                  // plenty of workgroups first (>= 8 per CU), then up to 4 queries per staging
+    while (qpw < 4 && (int64_t)B * sug_divup(S, 4 * 2 * qpw) >= 2048) qpw *= 2;
+    dim3 grid(sug_divup(S, (256 / WAVE) * qpw), B);
+    hipLaunchKernelGGL(ball_query_lds_kernel, grid, dim3(256), (size_t)3 * N * sizeof(float), (hipStream_t)stream, xyz,
+                       query, N, S, r2, nsample, qpw, out);
+  } else {
+    dim3 grid(sug_divup(S, 256 / WAVE), B);
+    hipLaunchKernelGGL(ball_query_kernel, grid, dim3(256), 0, (hipStream_t)stream, xyz, query, N, S, r2,
+                       nsample, out);
+  }
   SUG_LAUNCH_CHECK("sug_ball_query");
   return SUG_OK;
 }
