@@ -2,6 +2,7 @@
 // Reference semantics: model/point_utils.py:5-26, :86-109, :134-165 and
 // model/pointnet2_utils.py:60-104 (the torch path, not the dead CUDA extension).
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -55,23 +56,31 @@ __global__ __launch_bounds__(BLOCK) void fps_kernel(const float* __restrict__ xy
     }
     // wave arg-max: greatest value, lowest index among equals (two DPP reductions: the value, then the index)
     const float wm = wave_max_f(bv);
-    bi = wave_min_i(bv == wm ? bi : 0x7fffffff);
-    bv = wm;
-    const int par = i & 1;
-    if (lane == 0) {
-      s_v[par][wv] = bv;
-      s_i[par][wv] = bi;
+    {
+      // the lanes that hold the maximum: almost always one -> its index by a scalar read; several (equal
+      // distances) -> the lowest index among them by the second reduction
+      const unsigned long long mm = __ballot(bv == wm);
+      if (__popcll(mm) == 1) bi = __builtin_amdgcn_readlane(bi, (int)__builtin_ctzll(mm));
+      else bi = wave_min_i(bv == wm ? bi : 0x7fffffff);
     }
-    __syncthreads();
-    bv = s_v[par][0];
-    bi = s_i[par][0];
+    bv = wm;
+    if constexpr (NW > 1) {
+      const int par = i & 1;
+      if (lane == 0) {
+        s_v[par][wv] = bv;
+        s_i[par][wv] = bi;
+      }
+      __syncthreads();
+      bv = s_v[par][0];
+      bi = s_i[par][0];
 #pragma unroll
-    for (int w = 1; w < NW; ++w) {
-      const float ov = s_v[par][w];
-      const int oi = s_i[par][w];
-      if (ov > bv || (ov == bv && oi < bi)) {
-        bv = ov;
-        bi = oi;
+      for (int w = 1; w < NW; ++w) {
+        const float ov = s_v[par][w];
+        const int oi = s_i[par][w];
+        if (ov > bv || (ov == bv && oi < bi)) {
+          bv = ov;
+          bi = oi;
+        }
       }
     }
     cur = bi < N ? bi : 0;
@@ -366,14 +375,24 @@ __global__ __launch_bounds__(256) void three_nn_kernel(const float* __restrict__
   dist3[o + 0] = d0; dist3[o + 1] = d1; dist3[o + 2] = d2;
 }
 
-template <int PPT>
+template <int PPT, int BLOCK>
 int launch_fps(const float* xyz, const int32_t* start, int B, int N, int npoint, int32_t* out,
                hipStream_t st) {
-  constexpr int BLOCK = 256;
   size_t sh = (size_t)N * 3 * sizeof(float);
   hipLaunchKernelGGL((fps_kernel<PPT, BLOCK>), dim3(B), dim3(BLOCK), sh, st, xyz, start, N, npoint, out);
   SUG_LAUNCH_CHECK("sug_fps");
   return SUG_OK;
+}
+
+template <int BLOCK>
+int dispatch_fps(const float* xyz, const int32_t* start, int B, int N, int npoint, int32_t* out, hipStream_t st) {
+  const int ppt = sug_divup(N, BLOCK);
+  if (ppt <= 1) return launch_fps<1, BLOCK>(xyz, start, B, N, npoint, out, st);
+  if (ppt <= 2) return launch_fps<2, BLOCK>(xyz, start, B, N, npoint, out, st);
+  if (ppt <= 4) return launch_fps<4, BLOCK>(xyz, start, B, N, npoint, out, st);
+  if (ppt <= 8) return launch_fps<8, BLOCK>(xyz, start, B, N, npoint, out, st);
+  if (ppt <= 16) return launch_fps<16, BLOCK>(xyz, start, B, N, npoint, out, st);
+  return launch_fps<32, BLOCK>(xyz, start, B, N, npoint, out, st);
 }
 
 }  // namespace
@@ -384,13 +403,14 @@ extern "C" int sug_fps(const float* xyz, const int32_t* start, int B, int N, int
   SUG_REQUIRE(B > 0 && N > 0 && npoint > 0, "sug_fps: bad shape B=%d N=%d npoint=%d", B, N, npoint);
   SUG_REQUIRE(N <= 8192, "sug_fps: N=%d > 8192", N);
   hipStream_t st = (hipStream_t)stream;
-  const int ppt = sug_divup(N, 256);
-  if (ppt <= 1) return launch_fps<1>(xyz, start, B, N, npoint, out, st);
-  if (ppt <= 2) return launch_fps<2>(xyz, start, B, N, npoint, out, st);
-  if (ppt <= 4) return launch_fps<4>(xyz, start, B, N, npoint, out, st);
-  if (ppt <= 8) return launch_fps<8>(xyz, start, B, N, npoint, out, st);
-  if (ppt <= 16) return launch_fps<16>(xyz, start, B, N, npoint, out, st);
-  return launch_fps<32>(xyz, start, B, N, npoint, out, st);
+  // every round is one dependent chain (winner's coordinates -> distances -> wave arg-max -> cross-wave exchange):
+  // ~0.33 us with one wave, ~0.45 with two, ~0.57 with four, plus ~0.02 us per point a thread holds -- fewer
+  // waves win for small clouds (measured, tools/bench_fps.py)
+  static const int forced = getenv("SUG_FPS_BLOCK") ? atoi(getenv("SUG_FPS_BLOCK")) : 0;
+  const int blk = forced ? forced : (N <= 768 ? 64 : (N <= 1536 ? 128 : 256));
+  if (blk == 64 && N <= 2048) return dispatch_fps<64>(xyz, start, B, N, npoint, out, st);
+  if (blk == 128 && N <= 4096) return dispatch_fps<128>(xyz, start, B, N, npoint, out, st);
+  return dispatch_fps<256>(xyz, start, B, N, npoint, out, st);
 }
 
 extern "C" int sug_ball_query(const float* xyz, const float* query, int B, int N, int S, float r2,
