@@ -63,3 +63,25 @@ def test_fused_attention_fp16_mode_deviation():
     print('fp16 mode, relative L2 deviation from fp32:', {k: '%.2e' % v for k, v in dev.items()})
     assert dev['out'] < 2e-3 and dev['dfeat'] < 2e-2
     assert all(v < 5e-2 for v in dev.values()), dev
+
+
+def test_linear16_matches_fp32_linear_to_fp16_rounding():
+    """ops.linear16 (16-bit operands, fp32 accumulation, fp32 results and parameter gradients without cast kernels):
+    values and gradients within fp16 operand rounding of nn.Linear in fp32."""
+    from sug_amd import ops
+    g = torch.Generator().manual_seed(2)
+    lin = torch.nn.Linear(96, 160).cuda()
+    x = torch.randn(3, 700, 96, generator=g).cuda().requires_grad_(True)
+    probe = torch.randn(3, 700, 160, generator=g).cuda()
+    y0 = lin(x)
+    g0 = torch.autograd.grad((y0 * probe).sum(), (x, lin.weight, lin.bias))
+    y1 = ops.linear16(x, lin, torch.float16)
+    assert y1.dtype == torch.float32
+    g1 = torch.autograd.grad((y1 * probe).sum(), (x, lin.weight, lin.bias))
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    assert rel(y1, y0) < 2e-3
+    assert all(a.dtype == torch.float32 for a in g1)
+    assert rel(g1[0], g0[0]) < 2e-3 and rel(g1[1], g0[1]) < 2e-3 and rel(g1[2], g0[2]) < 1e-5
+    # 16-bit output for a following 16-bit GEMM
+    y2 = ops.linear16(x, lin, torch.float16, out32=False)
+    assert y2.dtype == torch.float16 and rel(y2.float(), y0) < 3e-3

@@ -252,3 +252,46 @@ def test_graph_mode_follows_eager_through_an_lr_change():
             assert abs(x - y) <= 2e-2 * max(1.0, abs(x)), res        # trajectories: same noise bound as two eager runs
     for x, y in zip(res[0][0], res[1][0]):
         assert abs(x - y) <= 1e-5 * max(1.0, abs(x)), res
+
+
+def test_fp16_mode_weight_copies_follow_the_optimizer():
+    """Point Transformer 16-bit mode: from the second step on the 16-bit weight copies are refreshed by one
+    multi-tensor copy into the first step's buffers (ops.w16_prefill).  Three steps with that plan must equal three
+    steps that rebuild every copy (plan dropped before each step): a stale buffer would show after the first update."""
+    from sug_amd.model.Model import Net_MDA
+    from sug_amd.model import Ptran_transformer as PT
+    from sug_amd.train_step import SUGStep
+    g = torch.Generator().manual_seed(7)
+    B, N = 2, 256
+    data = (torch.rand(B, 3, N, 1, generator=g) * 2 - 1).cuda()
+    data_t = (torch.rand(B, 3, N, 1, generator=g) * 2 - 1).cuda()
+    label = torch.randint(0, 10, (B,), generator=g).cuda()
+    label_t = torch.randint(0, 10, (B,), generator=g).cuda()
+    out = []
+    try:
+        PT.GEMM_DTYPE, PT.PROJ_16BIT = torch.float16, True
+        for keep_plan in (True, False):
+            torch.manual_seed(5)
+            net = Net_MDA('PTran').cuda().train()
+            for m in net.modules():
+                if isinstance(m, torch.nn.Dropout2d):
+                    m.p = 0.0
+            tr = SUGStep(net, lr=2e-3, use_graph=False)
+            torch.manual_seed(9)
+            losses = []
+            for _ in range(3):
+                if not keep_plan:
+                    tr._w16_plan = None
+                losses.append([float(v) for v in tr.step(data, label, data_t, label_t) if v is not None])
+            if keep_plan:
+                assert tr._w16_plan, 'the step recorded no 16-bit copies'
+            out.append((losses, {k: v.clone() for k, v in net.state_dict().items()}))
+    finally:
+        PT.GEMM_DTYPE, PT.PROJ_16BIT = None, False
+    # (the library's 16-bit GEMMs are not bit-reproducible run to run: equality to 1e-3, where a stale copy after the
+    # first update would repeat the first step's losses)
+    assert out[0][0][0] == out[1][0][0], (out[0][0], out[1][0])
+    assert abs(out[0][0][1][0] - out[0][0][0][0]) > 0.05, 'the first update should move the classification loss'
+    for step, (a, b) in enumerate(zip(out[0][0], out[1][0])):
+        tol = 2e-3 if step < 2 else 2e-2                        # the third step sees the amplified GEMM noise
+        assert all(abs(x - y) <= tol * max(1.0, abs(y)) for x, y in zip(a, b)), (out[0][0], out[1][0])
