@@ -287,7 +287,10 @@ class PTran_g(nn.Module):
                 xyz, points = self.transition_downs[i](xyz, points)
                 points = self.transformers[i](xyz, points)[0]
             xyz_and_feats.append((xyz, points))
-        node_features = self.conv1d(xyz_and_feats[2][1])              # [B,64 points,128] -> [B,64,64]
+        # Conv1d(64, 64, 1, stride=2) over [B, 64 points (as channels), 128]: a [64,64] product on every second column
+        # (MIOpen runs this shape through its naive double-accumulating kernels, ~30 us per direction)
+        nf = xyz_and_feats[2][1]
+        node_features = torch.matmul(self.conv1d.weight.squeeze(-1), nf[:, :, ::2]) + self.conv1d.bias.view(1, -1, 1)
         points = points.mean(1)
         if node:
             return points, node_features, None
