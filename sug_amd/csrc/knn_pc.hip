@@ -165,13 +165,20 @@ __global__ __launch_bounds__(512, 2) void knn_pc_kernel(const float* __restrict_
 #pragma unroll
       for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
       // the two column blocks share the A operand; their chains alternate on the matrix pipe
+#ifdef SUG_KNN_ABL_NOMFMA                        // timing experiments only (tools/bench_knn_pc.py): wrong results
+      if constexpr (CP < 0) {
+#else
       if constexpr (CP == 4) {
+#endif
         const float2 a2 = *reinterpret_cast<const float2*>(arow);
         acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.x, bq0[0], acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.x, bq1[0], acc1, 0, 0, 0);
         acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.y, bq0[1], acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.y, bq1[1], acc1, 0, 0, 0);
       } else {
+#ifdef SUG_KNN_ABL_NOMFMA
+        acc0[0] = arow[0]; acc1[0] = bq0[0] + bq1[0];
+#else
 #pragma unroll
         for (int g = 0; g < HALF / 4; ++g) {
           const float4 a4 = *reinterpret_cast<const float4*>(arow + 4 * g);
@@ -184,6 +191,7 @@ __global__ __launch_bounds__(512, 2) void knn_pc_kernel(const float* __restrict_
           acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, bq0[4 * g + 3], acc0, 0, 0, 0);
           acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, bq1[4 * g + 3], acc1, 0, 0, 0);
         }
+#endif
       }
       // S^T tile: lane = query column, registers 4g..4g+3 = candidate rows 8g + 4h .. +3: one b128 per g
       float* d0 = s_score + ((buf * 4 + wv) * 64 + qj) * SROW + 4 * h;
@@ -247,6 +255,10 @@ __global__ __launch_bounds__(512, 2) void knn_pc_kernel(const float* __restrict_
     __syncthreads();                            // pipeline fill: tile 0 staged
     __syncthreads();                            // tile 0 scored
     for (int t = 0; t < ntile; ++t) {
+#ifdef SUG_KNN_ABL_NOCONS
+      __syncthreads();
+      continue;
+#endif
       const float* srow = s_score + (((t & 1) * 4 + wv) * 64 + lane) * SROW;
       const float* nrm = nbuf(t);
       // pass 1: which of the 32 candidates can still enter (thr: from the (K+2)-th key as of the previous tile:
@@ -287,6 +299,9 @@ __global__ __launch_bounds__(512, 2) void knn_pc_kernel(const float* __restrict_
       // pass 2: the marked candidates in ascending index order, one per lane per iteration (all lanes in
       // lockstep); iterations = the largest number of marked candidates of any lane: a wave-wide maximum built
       // bit by bit from ballots (scalar unit only; a shuffle tree would cost six LDS round trips per tile)
+#ifdef SUG_KNN_ABL_NOINSERT
+      if (t > 0) mask = 0u;
+#endif
       const int pc = __popc(mask);
       unsigned long long cand = ~0ull;
       int nit = 0;

@@ -1,0 +1,44 @@
+"""Diagnostic: where does knn_pc_kernel's time go?  Builds ablation variants of knn_pc.hip on the GPU box (timing only:
+their results are wrong) and times them next to the product build.  usage: python tools/bench_knn_pc.py"""
+import ctypes, os, subprocess, sys, tempfile
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+
+SRC = os.path.join(ROOT, 'sug_amd', 'csrc')
+FLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-ffp-contract=off', '-shared', '-I' + os.path.join(ROOT, 'include')]
+
+
+def build(tag, defs):
+    out = os.path.join(tempfile.gettempdir(), 'libknnpc_%s.so' % tag)
+    files = [os.path.join(SRC, f) for f in ('knn.hip', 'knn_mfma.hip', 'knn_pc.hip', 'capi.cpp')]
+    subprocess.run(['/opt/rocm/bin/hipcc'] + FLAGS + defs + files + ['-o', out], check=True)
+    return ctypes.CDLL(out)
+
+
+def time_knn(L, x, k, iters=20):
+    B, N, C = x.shape
+    idx = torch.empty(B, N, k, dtype=torch.int32, device=x.device)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    L.sug_knn.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                          ctypes.c_void_p, ctypes.c_void_p]
+    for _ in range(3):
+        L.sug_knn(x.data_ptr(), C, B, N, C, k, idx.data_ptr(), st)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        L.sug_knn(x.data_ptr(), C, B, N, C, k, idx.data_ptr(), st)
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e3
+
+
+if __name__ == '__main__':
+    torch.manual_seed(0)
+    variants = [('product', []), ('no insertion', ['-DSUG_KNN_ABL_NOINSERT']), ('no consumer', ['-DSUG_KNN_ABL_NOCONS']),
+                ('no MFMA', ['-DSUG_KNN_ABL_NOMFMA']), ('no MFMA, no consumer', ['-DSUG_KNN_ABL_NOMFMA', '-DSUG_KNN_ABL_NOCONS']),
+                ('no MFMA, no insertion', ['-DSUG_KNN_ABL_NOMFMA', '-DSUG_KNN_ABL_NOINSERT'])]
+    libs = [(t, build(t.replace(' ', '_').replace(',', ''), d)) for t, d in variants]
+    for C in (3, 64, 128):
+        x = torch.randn(64, 1024, C, device='cuda')
+        print('C=%3d  ' % C + '  '.join('%s %6.1f' % (t, time_knn(L, x, 20)) for t, L in libs))
