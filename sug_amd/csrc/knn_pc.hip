@@ -137,12 +137,13 @@ __global__ __launch_bounds__(512, 2) void knn_pc_kernel(const float* __restrict_
     // multiplication per candidate
     float bq0[HALF], bq1[HALF];
     {
-      TileRegs<CP> tr;
+      TileRegs<CP> tq[2];                        // the next query tile's loads fly under this one's staging
+      tile_load<CP>(tq[0], xb, ldx, N, q0);
 #pragma unroll
       for (int w = 0; w < 8; ++w) {
         __syncthreads();
-        tile_load<CP>(tr, xb, ldx, N, q0 + w * TJ);
-        tile_store<CP, true>(tr, s_tile, s_norm, N, q0 + w * TJ);
+        if (w + 1 < 8) tile_load<CP>(tq[(w + 1) & 1], xb, ldx, N, q0 + (w + 1) * TJ);
+        tile_store<CP, true>(tq[w & 1], s_tile, s_norm, N, q0 + w * TJ);
         __syncthreads();
         if ((w >> 1) == wv) {
           const float* qrow = s_tile + qj * RS + h * HALF;

@@ -26,28 +26,26 @@ struct TileRegs {
 template <int CP>
 __device__ __forceinline__ void tile_load(TileRegs<CP>& t, const float* __restrict__ xb, int64_t ldx,
                                           int N, int row0) {
+  // The loads carry no guards (a guarded load compiles to a branch and the wait counters around it collapse to
+  // vmcnt(0), which would serialise a prefetch with the loads before it): rows past N read row N-1 and are zeroed
+  // by a select.
   if constexpr (CP == 4) {
-    const int r = row0 + (int)threadIdx.x;
-    float x = 0.f, y = 0.f, z = 0.f;
-    if (threadIdx.x < TJ && r < N) {
-      const float* p = xb + (int64_t)r * ldx;
-      x = p[0]; y = p[1]; z = p[2];
-    }
-    t.lo[0] = make_float4(x, y, z, 0.f);
+    const int r = row0 + (int)(threadIdx.x & (TJ - 1));
+    const bool ok = r < N;
+    const float* p = xb + (int64_t)(ok ? r : N - 1) * ldx;
+    const float x = p[0], y = p[1], z = p[2];
+    t.lo[0] = make_float4(ok ? x : 0.f, ok ? y : 0.f, ok ? z : 0.f, 0.f);
   } else {
     constexpr int CH = CP / 8;                 // chunks per row
 #pragma unroll
     for (int u = 0; u < TileRegs<CP>::NV; ++u) {
       const int item = (int)threadIdx.x + u * 256;
       const int r = row0 + item / CH, c8 = item % CH;
-      if (r < N) {
-        const float4* p = reinterpret_cast<const float4*>(xb + (int64_t)r * ldx + c8 * 8);
-        t.lo[u] = p[0];
-        t.hi[u] = p[1];
-      } else {
-        t.lo[u] = make_float4(0, 0, 0, 0);
-        t.hi[u] = make_float4(0, 0, 0, 0);
-      }
+      const bool ok = r < N;
+      const float4* p = reinterpret_cast<const float4*>(xb + (int64_t)(ok ? r : N - 1) * ldx + c8 * 8);
+      const float4 a = p[0], b = p[1];
+      t.lo[u] = ok ? a : make_float4(0, 0, 0, 0);
+      t.hi[u] = ok ? b : make_float4(0, 0, 0, 0);
     }
   }
 }
