@@ -217,10 +217,20 @@ __global__ __launch_bounds__(512, 2) void knn_pc_kernel(const float* __restrict_
     if (ntile > 2) tile_load<CP>(tr, xb, ldx, N, 2 * TJ);
     __syncthreads();
     for (int t = 0; t < ntile; ++t) {
+#ifdef SUG_KNN_SERIAL
+      // experiment (tools/bench_knn_pc.py): the MFMA chain of tile t+1 only after the selection of tile t instead of
+      // next to it -- the two share the SIMD's FMA lanes, but alternating them measured 7 us slower (138 vs 131 at C=64)
+      if (t + 2 < ntile) tile_store<CP, true>(tr, tbuf(t + 2), nbuf(t + 2), N, (t + 2) * TJ);
+      if (t + 3 < ntile) tile_load<CP>(tr, xb, ldx, N, (t + 3) * TJ);
+      __syncthreads();
+      if (t + 1 < ntile) produce(t + 1, (t + 1) & 1);
+      __syncthreads();
+#else
       if (t + 1 < ntile) produce(t + 1, (t + 1) & 1);
       if (t + 2 < ntile) tile_store<CP, true>(tr, tbuf(t + 2), nbuf(t + 2), N, (t + 2) * TJ);
       if (t + 3 < ntile) tile_load<CP>(tr, xb, ldx, N, (t + 3) * TJ);
       __syncthreads();
+#endif
     }
   } else {
     __builtin_amdgcn_s_setprio(1);     // the selection waves are the second-dispatched half of the workgroup: static priority (-5 us at C=3)
@@ -358,6 +368,9 @@ __global__ __launch_bounds__(512, 2) void knn_pc_kernel(const float* __restrict_
       // margin (+3, 2e-6 relative) covers the roundings of d*scale, of scale and of this product (buckets < 2^21)
       const int lk = L[KP - 1];
       thr = lk == EMPTY ? -FLT_MAX : -((float)((lk >> idb) + 3) * inv_scale * 1.000002f);
+#ifdef SUG_KNN_SERIAL
+      __syncthreads();
+#endif
       __syncthreads();
     }
 
