@@ -416,12 +416,35 @@ __global__ __launch_bounds__(256) void pointmlp_bwd_dx_seg_kernel(const float* _
       for (int i = 0; i < CV; ++i) {
         unsigned long long m = __ballot(rg[i] == r);
         while (m) {
-          const int l = __builtin_ctzll(m);
+          // up to NB channels per trip: their weight rows are requested together (one dependent load per
+          // channel left the wave waiting on L2 latency ~130 times per segment); absent slots repeat the first
+          // channel with a zero coefficient, the order of the sums is unchanged
+          constexpr int NB = CV <= 2 ? 4 : 1;     // (Co = 256 over 64 rows: one channel per ballot on average)
+          int l[NB];
+          float ac[NB];
+          l[0] = __builtin_ctzll(m);
           m &= m - 1;
-          const float ac = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(av[i]), l));
-          const float* wr = W + (int64_t)(l + 64 * i) * K + lane * KV;
 #pragma unroll
-          for (int u = 0; u < KV; ++u) acc[u] = fmaf(ac, wr[u], acc[u]);
+          for (int t = 1; t < NB; ++t) {
+            l[t] = m ? (int)__builtin_ctzll(m) : -1;
+            if (m) m &= m - 1;
+          }
+          float wv4[NB][KV];
+#pragma unroll
+          for (int t = 0; t < NB; ++t) {
+            const int lt = l[t] >= 0 ? l[t] : l[0];
+            ac[t] = l[t] >= 0 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(av[i]), lt)) : 0.f;
+            const float* wr = W + (int64_t)(lt + 64 * i) * K + lane * KV;
+#pragma unroll
+            for (int u = 0; u < KV; ++u) wv4[t][u] = wr[u];
+          }
+#pragma unroll
+          for (int t = 0; t < NB; ++t) {
+            if (l[t] >= 0) {
+#pragma unroll
+              for (int u = 0; u < KV; ++u) acc[u] = fmaf(ac[t], wv4[t][u], acc[u]);
+            }
+          }
           any = true;
         }
       }
