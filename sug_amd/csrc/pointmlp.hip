@@ -475,12 +475,19 @@ __global__ __launch_bounds__(256) void pointmlp_bwd_dw_kernel(const float* __res
   for (int i = 0; i < 16; ++i)
 #pragma unroll
     for (int u = 0; u < KV; ++u) acc[i][u] = 0.f;
+  const bool mine = lane < 16 && c0 + lane < Co;
+  float av_n = 0.f;
+  int rw_n = 0;
+  if (mine && sa < sb) {
+    av_n = a[(int64_t)sa * Co + c0 + lane];
+    rw_n = arg[(int64_t)sa * Co + c0 + lane];
+  }
   for (int s = sa; s < sb; ++s) {
-    float av = 0.f;
-    int rw = 0;
-    if (lane < 16 && c0 + lane < Co) {
-      av = a[(int64_t)s * Co + c0 + lane];
-      rw = arg[(int64_t)s * Co + c0 + lane];
+    const float av = av_n;
+    const int rw = rw_n;
+    if (mine && s + 1 < sb) {                    // the next segment's coefficients fly under this one's gathers
+      av_n = a[(int64_t)(s + 1) * Co + c0 + lane];
+      rw_n = arg[(int64_t)(s + 1) * Co + c0 + lane];
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -503,11 +510,23 @@ __global__ __launch_bounds__(256) void pointmlp_bwd_dw_kernel(const float* __res
 
 __global__ __launch_bounds__(256) void pointmlp_bwd_dw_fold_kernel(const float* __restrict__ dwp, int nsc, int64_t n,
                                                                    float* __restrict__ dw) {
-  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= n) return;
+  // 16 elements x 16 chunk-lanes per workgroup (chunk-lane p sums chunks p, p+16, ... in fp64), combined in lane order
+  __shared__ double s_p[16][17];
+  const int el = threadIdx.x & 15, p = threadIdx.x >> 4;
+  const int64_t e = (int64_t)blockIdx.x * 16 + el;
   double t = 0.0;
-  for (int i = 0; i < nsc; ++i) t += (double)dwp[(int64_t)i * n + e];
-  dw[e] = (float)t;
+  if (e < n) {
+#pragma unroll 4
+    for (int i = p; i < nsc; i += 16) t += (double)dwp[(int64_t)i * n + e];
+  }
+  s_p[p][el] = t;
+  __syncthreads();
+  if (p == 0 && e < n) {
+    double r = s_p[0][el];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) r += s_p[i][el];
+    dw[e] = (float)r;
+  }
 }
 
 // The dense BatchNorm-statistics terms of the backward are of rank K: dy = a_full - k1 - k2*y with y = x.W^T + b
@@ -672,11 +691,18 @@ extern "C" int sug_pointmlp_max_bwd_dwfix(float* dw, const float* dws, const flo
   return SUG_OK;
 }
 
+// segment chunks of the dW pass: every wave walks its chunk serially (a / arg of a segment, then 16 gathered rows:
+// one L2 latency per segment), so many short chunks hide that latency by occupancy; 1024 chunks of >= 16 segments
+static int64_t dw_chunks(int64_t S) {
+  int64_t nsc = S / 16;
+  if (nsc > 1024) nsc = 1024;
+  if (nsc < 256) nsc = S < 256 ? S : 256;
+  return nsc < 1 ? 1 : nsc;
+}
+
 extern "C" int64_t sug_pointmlp_max_bwd_workspace(int64_t rows, int K, int Co, int seg) {
   const int64_t S = rows / (seg > 0 ? seg : 1);
-  int64_t nsc = S < 256 ? S : 256;
-  if (nsc < 1) nsc = 1;
-  return nsc * (int64_t)Co * K;
+  return dw_chunks(S) * (int64_t)Co * K;
 }
 
 extern "C" int sug_pointmlp_max_bwd_sparse(const float* a, const int32_t* arg, const float* x, int64_t ldx,
@@ -693,7 +719,7 @@ extern "C" int sug_pointmlp_max_bwd_sparse(const float* a, const int32_t* arg, c
   int64_t g64 = S * chunks;
   const int grid = (int)(g64 < 4096 ? g64 : 4096);
   const size_t sh = (size_t)Co * 8 + (Co > 256 ? (size_t)Co * 16 : 0);      // a, arg (+ 4 compacted channel lists)
-  int nsc = (int)(S < 256 ? S : 256);
+  const int nsc = (int)dw_chunks(S);
   dim3 g2(sug_divup(Co, 64), nsc);
   const bool per_wave = seg <= 64 && Co <= 256;          // short segments: a wave per segment, no barriers
   const int gseg = (int)(S / 4 < 8192 ? (S + 3) / 4 : 8192);
@@ -716,7 +742,7 @@ extern "C" int sug_pointmlp_max_bwd_sparse(const float* a, const int32_t* arg, c
   }
   SUG_LAUNCH_CHECK("sug_pointmlp_max_bwd_sparse");
   const int64_t n = (int64_t)Co * K;
-  hipLaunchKernelGGL(pointmlp_bwd_dw_fold_kernel, dim3(sug_divup(n, 256)), dim3(256), 0, st, ws, nsc, n, dw);
+  hipLaunchKernelGGL(pointmlp_bwd_dw_fold_kernel, dim3(sug_divup(n, 16)), dim3(256), 0, st, ws, nsc, n, dw);
   SUG_LAUNCH_CHECK("sug_pointmlp_max_bwd_sparse(fold)");
   return SUG_OK;
 }
