@@ -225,11 +225,16 @@ __global__ __launch_bounds__(256) void linear_dw_reduce_kernel(const float* __re
   }
 }
 
-bool use_big(int M, int N) { return M >= 128 && N >= 128; }
+// one-wave 128x128 tiles for outputs of at least 128 x 128 -- except a single such tile over few rows, where the
+// 64x64 kernel's four super-tiles bring four times the waves (128x128 at 65536 rows: 49 against 59 us; at 2^20
+// rows the big tile's operand reuse wins, 360 against 578 us)
+bool use_big(int64_t R, int M, int N) { return M >= 128 && N >= 128 && ((int64_t)M * N > 128 * 128 || R > 262144); }
 
 int plan_rows_per_block(int64_t R, int M, int N) {
-  const int tiles = use_big(M, N) ? sug_divup(M, 128) * sug_divup(N, 128) : sug_divup(M, 64) * sug_divup(N, 64);
-  int64_t nchunk = 1024 / tiles;                 // ~1024 workgroups in total
+  const int tiles = use_big(R, M, N) ? sug_divup(M, 128) * sug_divup(N, 128) : sug_divup(M, 64) * sug_divup(N, 64);
+  // ~1024 one-wave workgroups (128x128 tiles) or ~512 four-wave workgroups (64x64 super-tiles: twice the rows per
+  // chunk halve the partial rows the fold reads; measured best of 256 / 512 / 768 / 1024, tools/bench_dw.py)
+  int64_t nchunk = (use_big(R, M, N) ? 1024 : 512) / tiles;
   if (nchunk < 8) nchunk = 8;
   int64_t rpb = (R + nchunk - 1) / nchunk;
   if (rpb < 128) rpb = 128;
@@ -253,7 +258,7 @@ extern "C" int sug_linear_dw_bias(const float* g, int64_t ldg, const float* x, i
   hipStream_t st = (hipStream_t)stream;
   const int with_db = db ? 1 : 0;
   const bool whole = R % rpb == 0 && rpb % 32 == 0;      // every wave of every chunk: a multiple of 8 rows
-  if (use_big(M, N)) {
+  if (use_big(R, M, N)) {
     const dim3 grid(nchunk, sug_divup(M, 128), sug_divup(N, 128));
     if (R % rpb == 0 && M % 128 == 0 && N % 128 == 0)      // (rpb is a multiple of 8)
       hipLaunchKernelGGL(linear_dw_big_kernel<true>, grid, dim3(64), 0, st, g, ldg, x, ldx, R, M, N, rpb, ws, with_db);
