@@ -210,8 +210,17 @@ __global__ __launch_bounds__(256) void linear_dw_reduce_kernel(const float* __re
   const int el = threadIdx.x & 15, cl = threadIdx.x >> 4;
   const int64_t e = (int64_t)blockIdx.x * 16 + el;
   double acc = 0.0;
-  if (e < P)
-    for (int c = cl; c < nchunk; c += 16) acc += (double)part[(size_t)c * P + e];
+  if (e < P) {
+    int c = cl;
+    for (; c + 112 < nchunk; c += 128) {          // eight rows in flight, added in the order of the plain loop
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(c + 16 * u) * P + e];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += (double)v[u];
+    }
+    for (; c < nchunk; c += 16) acc += (double)part[(size_t)c * P + e];
+  }
   s_p[cl][el] = acc;
   __syncthreads();
   if (cl == 0 && e < P) {
