@@ -194,7 +194,15 @@ __global__ __launch_bounds__(256) void ptran_pos1_fold_kernel(const float* __res
   const int o = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int e = blockIdx.x * 32 + o;
   double t = 0.0;
-  for (int i = grp; i < nb; i += 8) t += (double)part[(int64_t)i * 4 * D + e];
+  int i = grp;
+  for (; i + 56 < nb; i += 64) {                 // eight partial rows in flight, added in the plain loop's order
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = part[(int64_t)(i + 8 * u) * 4 * D + e];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t += (double)v[u];
+  }
+  for (; i < nb; i += 8) t += (double)part[(int64_t)i * 4 * D + e];
   s_p[grp][o] = t;
   __syncthreads();
   if (grp == 0) {
@@ -264,8 +272,15 @@ __global__ __launch_bounds__(256) void ptran_fold_kernel(const float* __restrict
   const int cl = threadIdx.x & 15, p = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + cl;
   double acc = 0.0;
-#pragma unroll 8
-  for (int b = p; b < nblk; b += 16) acc += (double)ws[(size_t)b * D + c];
+  int b = p;
+  for (; b + 112 < nblk; b += 128) {             // eight partial rows in flight
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = ws[(size_t)(b + 16 * u) * D + c];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += (double)v[u];
+  }
+  for (; b < nblk; b += 16) acc += (double)ws[(size_t)b * D + c];
   s_p[p][cl] = acc;
   __syncthreads();
   if (p == 0) {
