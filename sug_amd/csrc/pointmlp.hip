@@ -516,8 +516,15 @@ __global__ __launch_bounds__(256) void pointmlp_bwd_dw_fold_kernel(const float* 
   const int64_t e = (int64_t)blockIdx.x * 16 + el;
   double t = 0.0;
   if (e < n) {
-#pragma unroll 4
-    for (int i = p; i < nsc; i += 16) t += (double)dwp[(int64_t)i * n + e];
+    int i = p;
+    for (; i + 112 < nsc; i += 128) {             // eight partial rows in flight
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = dwp[(int64_t)(i + 16 * u) * n + e];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t += (double)v[u];
+    }
+    for (; i < nsc; i += 16) t += (double)dwp[(int64_t)i * n + e];
   }
   s_p[p][el] = t;
   __syncthreads();
