@@ -66,14 +66,13 @@ __global__ __launch_bounds__(256) void mmd_rbf_kernel(const float* __restrict__ 
                                                       float* __restrict__ wt) {
   __shared__ float s_a[TI][DK + 1];
   __shared__ float s_b[TI][DK + 1];
-  __shared__ double s_sum[3];
+  __shared__ double s_sum[256 / WAVE][3];          // per-wave partial sums, combined in wave order
   const int M2 = 2 * m;
   const int ti = threadIdx.x / TI, tj = threadIdx.x % TI;
   const int i0 = blockIdx.y * TI, j0 = blockIdx.x * TI;        // i0: LOCAL row of the tile
   const int li = i0 + ti, j = j0 + tj;
   const int ML = 2 * mloc;
   const int i = li < ML ? global_row(li, m, row0, mloc) : M2;
-  if (threadIdx.x < 3) s_sum[threadIdx.x] = 0.0;
   float g = 0.f, ni = 0.f, nj = 0.f;
   for (int d0 = 0; d0 < D; d0 += DK) {
     __syncthreads();
@@ -97,12 +96,16 @@ __global__ __launch_bounds__(256) void mmd_rbf_kernel(const float* __restrict__ 
   if (i < M2 && j < M2) pair_epilogue(li, i, j, m, g, ni, nj, w, neg_gamma, ns, wt, kxx, kyy, kxy);
   double dxx = wave_sum_d((double)kxx), dyy = wave_sum_d((double)kyy), dxy = wave_sum_d((double)kxy);
   if ((threadIdx.x & (WAVE - 1)) == 0) {
-    atomicAdd(&s_sum[0], dxx);
-    atomicAdd(&s_sum[1], dyy);
-    atomicAdd(&s_sum[2], dxy);
+    double* sw = s_sum[threadIdx.x / WAVE];
+    sw[0] = dxx;
+    sw[1] = dyy;
+    sw[2] = dxy;
   }
   __syncthreads();
-  if (threadIdx.x < 3) atomicAdd(&sums[threadIdx.x], s_sum[threadIdx.x]);
+  // one hardware fp64 add per workgroup and sum (atomicAdd(double*) is a compare-and-swap loop without
+  // -munsafe-fp-atomics: hundreds of workgroups on three addresses)
+  if (threadIdx.x < 3)
+    unsafeAtomicAdd(&sums[threadIdx.x], ((s_sum[0][threadIdx.x] + s_sum[1][threadIdx.x]) + s_sum[2][threadIdx.x]) + s_sum[3][threadIdx.x]);
 }
 
 
@@ -115,12 +118,11 @@ __global__ __launch_bounds__(256) void mmd_rbf_small_kernel(const float* __restr
                                                             const float* __restrict__ neg_gamma, int ns, int row0,
                                                             int mloc, double* __restrict__ sums,
                                                             float* __restrict__ wt) {
-  __shared__ double s_sum[3];
+  __shared__ double s_sum[256 / WAVE][3];          // per-wave partial sums, combined in wave order
   const int M2 = 2 * m;
   const int l16 = threadIdx.x & 15, pr = threadIdx.x >> 4;
   const int li = blockIdx.y * 4 + (pr >> 2), j = blockIdx.x * 4 + (pr & 3);
   const int i = li < 2 * mloc ? global_row(li, m, row0, mloc) : M2;
-  if (threadIdx.x < 3) s_sum[threadIdx.x] = 0.0;
   __syncthreads();
   float g = 0.f, ni = 0.f, nj = 0.f;
   if (i < M2 && j < M2) {
@@ -144,12 +146,16 @@ __global__ __launch_bounds__(256) void mmd_rbf_small_kernel(const float* __restr
   if (l16 == 0 && i < M2 && j < M2) pair_epilogue(li, i, j, m, g, ni, nj, w, neg_gamma, ns, wt, kxx, kyy, kxy);
   double dxx = wave_sum_d((double)kxx), dyy = wave_sum_d((double)kyy), dxy = wave_sum_d((double)kxy);
   if ((threadIdx.x & (WAVE - 1)) == 0) {
-    atomicAdd(&s_sum[0], dxx);
-    atomicAdd(&s_sum[1], dyy);
-    atomicAdd(&s_sum[2], dxy);
+    double* sw = s_sum[threadIdx.x / WAVE];
+    sw[0] = dxx;
+    sw[1] = dyy;
+    sw[2] = dxy;
   }
   __syncthreads();
-  if (threadIdx.x < 3) atomicAdd(&sums[threadIdx.x], s_sum[threadIdx.x]);
+  // one hardware fp64 add per workgroup and sum (atomicAdd(double*) is a compare-and-swap loop without
+  // -munsafe-fp-atomics: hundreds of workgroups on three addresses)
+  if (threadIdx.x < 3)
+    unsafeAtomicAdd(&sums[threadIdx.x], ((s_sum[0][threadIdx.x] + s_sum[1][threadIdx.x]) + s_sum[2][threadIdx.x]) + s_sum[3][threadIdx.x]);
 }
 
 // out[b] += (1/N) * sum_i min_j |a_i - b_j|^2   (one direction; called twice)
