@@ -322,7 +322,13 @@ def main():
         roofline = None
         if kern:
             fam = [n for n in kern if n.startswith(tuple(timed_family))]
-            dom = max(timed_names or fam or set(kern), key=lambda n: kern[n]['total_ms'])
+            cands = timed_names or fam or set(kern)
+            top = max(kern[n]['total_ms'] for n in cands)
+            # the two feature-space kNN instances share the step almost evenly (3 x C=64 against 2 x C=128): among
+            # kernels within 5 % of the largest summed time the one with the most algorithmic work per step is named,
+            # so that the line does not flip from run to run (every kernel's figures are under `kernels` regardless)
+            near = [n for n in cands if kern[n]['total_ms'] >= 0.95 * top]
+            dom = max(near, key=lambda n: (kernel_model(n, allprof[n][0][2])['flops'] * kern[n]['launches'], kern[n]['total_ms']))
             kd = kern[dom]
             ai = kernel_model(dom, allprof[dom][0][2])
             compute_bound = ai['flops'] / max(ai['bytes'], 1) > FP32_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS
