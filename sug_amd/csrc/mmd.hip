@@ -371,16 +371,20 @@ namespace {
 __global__ void mmd_value_kernel(const double* __restrict__ sums, double mm, float* __restrict__ out) {
   if (threadIdx.x == 0) out[0] = (float)((sums[0] + sums[1] - 2.0 * sums[2]) / mm);
 }
+__global__ void mmd_zero_sums_kernel(double* __restrict__ sums) {
+  if (threadIdx.x < 3) sums[threadIdx.x] = 0.0;
+}
 }  // namespace
 
 extern "C" int sug_mmd_rbf_value(const float* z, int64_t ldz, int m, int D, const float* w, const float* neg_gamma,
                                  int nsigma, double* sums, float* wt, float* value, void* stream) {
   SUG_REQUIRE(sums && value, "sug_mmd_rbf_value: null pointer");
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(sums, 0, 3 * sizeof(double), st) != hipSuccess) {
-    sug_set_error("sug_mmd_rbf_value: memset failed");
-    return SUG_ERR_LAUNCH;
-  }
+  // a kernel, not hipMemsetAsync: as a memset node of a captured step graph the clear was not reliably ordered in
+  // front of the accumulating kernel on ROCm 7 (after a few hundred replays the reported MMD values turned into
+  // constants of the size of whatever had occupied the buffer, for several replays at a time; training itself,
+  // which does not read the sums, was unaffected)
+  hipLaunchKernelGGL(mmd_zero_sums_kernel, dim3(1), dim3(64), 0, st, sums);
   const int rc = sug_mmd_rbf_rows(z, ldz, m, D, w, neg_gamma, nsigma, 0, m, sums, wt, stream);
   if (rc != SUG_OK) return rc;
   hipLaunchKernelGGL(mmd_value_kernel, dim3(1), dim3(64), 0, st, sums, (double)m * (double)m, value);

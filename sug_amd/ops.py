@@ -330,7 +330,12 @@ class _LinearRows(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             if DW_SHAPE_LOG is not None:
                 DW_SHAPE_LOG.append((R, M, N))
-            if M * N > 512 * 512 or DW_FORCE_LIBRARY or (R, M, N) in DW_LIBRARY_SHAPES:
+            # (not while a step graph is being captured: the library's split-K solutions for these K = rows shapes
+            # clear their output with a memset, and memset nodes of a replayed hipGraph were not reliably ordered in
+            # front of the accumulating kernels on ROCm 7 -- see sug_mmd_rbf_value -- which showed as NaN weights
+            # after tens to hundreds of replays)
+            lib_ok = DW_FORCE_LIBRARY or ((R, M, N) in DW_LIBRARY_SHAPES and not torch.cuda.is_current_stream_capturing())
+            if M * N > 512 * 512 or lib_ok:
                 dw = g2.t() @ x2            # larger than any encoder layer, or the tuned library GEMM is faster
             else:
                 dw = torch.empty(M, N, dtype=torch.float32, device=g.device)
