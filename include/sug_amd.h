@@ -211,6 +211,13 @@ int sug_linear_dw(const float* g, int64_t ldg, const float* x, int64_t ldx, int6
 int sug_linear_dw_bias(const float* g, int64_t ldg, const float* x, int64_t ldx, int64_t R, int M, int N,
                        float* dw, float* db, float* ws, void* stream);
 
+/* out[c] = sign * sum over rows of x[r, c] (fp32 sums of fp32 (dtype 0) or fp16 (1) rows, row stride ld): the bias
+ * gradients autograd forms with sum(dim=0) / sum_to_size (nn.Linear / Conv biases, model/pointnet2_utils.py:172,
+ * model/Ptran_transformer.py:17-33), without the memset torch's reduction issues for tall shapes.
+ * ws: sug_colsum_workspace(rows, C) floats. */
+int64_t sug_colsum_workspace(int64_t rows, int C);
+int sug_colsum(const void* x, int64_t ld, int64_t rows, int C, int dtype, float sign, float* out, float* ws, void* stream);
+
 /* Channel-attention gate of CALayer (model/Model.py:28-34): out = x * sigmoid(z) + x over n elements, z = the
  * output of the second 1x1 conv; backward dx = g * sigmoid(z) + g, dz = g * x * sigmoid'(z). */
 int sug_gate_fwd(const float* x, const float* z, int64_t n, float* out, void* stream);

@@ -64,6 +64,7 @@ SIGNATURES = {
     'sug_mmd_rbf_rows': [_vp, _i64, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
     'sug_mmd_rbf_rows_bwd': [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _f32, _vp, _i64, _vp],
     'sug_mmd_rbf_bwd': [_vp, _i64, _vp, _i32, _i32, _vp, _vp, _i64, _vp],
+    'sug_colsum': [_vp, _i64, _i64, _i32, _i32, _f32, _vp, _vp, _vp],
     'sug_gate_fwd': [_vp, _vp, _i64, _vp, _vp],
     'sug_gate_bwd': [_vp, _vp, _vp, _i64, _vp, _vp, _vp],
     'sug_mmd_assemble': [_vp, _i64, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp],
@@ -120,6 +121,8 @@ def lib():
         L.sug_linear_dw_workspace.argtypes = [_i64, _i32, _i32]
         L.sug_pointmlp_max_bwd_workspace.restype = ctypes.c_int64
         L.sug_pointmlp_max_bwd_workspace.argtypes = [_i64, _i32, _i32, _i32]
+        L.sug_colsum_workspace.restype = ctypes.c_int64
+        L.sug_colsum_workspace.argtypes = [_i64, _i32]
         L.sug_ptran_colsum_workspace.restype = ctypes.c_int64
         L.sug_ptran_colsum_workspace.argtypes = [_i64]
         L.sug_adam_chunk.restype = ctypes.c_int

@@ -6,6 +6,7 @@
 //   bn_act_pool_fwd   reads y once (4 B/elem), writes 3 x [B,C]
 //   pool_bwd_reduce   reads y once; pool_bwd_apply reads y once, writes dy once.
 #include "common.h"
+#include <hip/hip_fp16.h>
 
 namespace {
 
@@ -643,5 +644,62 @@ extern "C" int sug_gate_bwd(const float* g, const float* x, const float* z, int6
   SUG_REQUIRE(n > 0, "sug_gate_bwd: empty input");
   hipLaunchKernelGGL(gate_bwd_kernel, dim3((unsigned)sug_divup(n, 256)), dim3(256), 0, (hipStream_t)stream, g, x, z, n, dx, dz);
   SUG_LAUNCH_CHECK("sug_gate_bwd");
+  return SUG_OK;
+}
+
+// ---- column sums of [R, C] rows (bias gradients): per-workgroup partial rows + an ordered fp64 fold.  torch's
+// sum(dim=0) clears a semaphore buffer with a memset for these tall shapes, and memset nodes are what a replayed
+// step graph must not contain.
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_part_kernel(const T* __restrict__ x, int64_t ld, int64_t R, int C,
+                                                          float* __restrict__ part) {
+  __shared__ float s_p[8][33];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cx;
+  float acc = 0.f;
+  if (c < C)
+    for (int64_t r = (int64_t)blockIdx.y * 8 + ry; r < R; r += (int64_t)gridDim.y * 8) acc += (float)x[r * ld + c];
+  s_p[ry][cx] = acc;
+  __syncthreads();
+  if (ry == 0 && c < C) {
+    float t = s_p[0][cx];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) t += s_p[i][cx];
+    part[(int64_t)blockIdx.y * C + c] = t;
+  }
+}
+
+__global__ __launch_bounds__(256) void colsum_fold_kernel(const float* __restrict__ part, int nblk, int C, float sign,
+                                                          float* __restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double t = 0.0;
+  for (int b = 0; b < nblk; ++b) t += (double)part[(int64_t)b * C + c];
+  out[c] = sign * (float)t;
+}
+
+}  // namespace
+
+extern "C" int64_t sug_colsum_workspace(int64_t rows, int C) {
+  int64_t nblk = (rows + 63) / 64;
+  if (nblk > 128) nblk = 128;
+  if (nblk < 1) nblk = 1;
+  return nblk * (int64_t)C;
+}
+
+extern "C" int sug_colsum(const void* x, int64_t ld, int64_t rows, int C, int dtype, float sign, float* out, float* ws,
+                          void* stream) {
+  SUG_REQUIRE(x && out && ws, "sug_colsum: null pointer");
+  SUG_REQUIRE(rows > 0 && C > 0 && ld >= C && (dtype == 0 || dtype == 1), "sug_colsum: bad shape / dtype (0 fp32, 1 fp16)");
+  const int nblk = (int)(sug_colsum_workspace(rows, C) / C);
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(sug_divup(C, 32), nblk);
+  if (dtype == 0) hipLaunchKernelGGL(colsum_part_kernel<float>, grid, dim3(256), 0, st, (const float*)x, ld, rows, C, ws);
+  else hipLaunchKernelGGL(colsum_part_kernel<__half>, grid, dim3(256), 0, st, (const __half*)x, ld, rows, C, ws);
+  SUG_LAUNCH_CHECK("sug_colsum");
+  hipLaunchKernelGGL(colsum_fold_kernel, dim3(sug_divup(C, 256)), dim3(256), 0, st, ws, nblk, C, sign, out);
+  SUG_LAUNCH_CHECK("sug_colsum(fold)");
   return SUG_OK;
 }

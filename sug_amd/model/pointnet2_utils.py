@@ -102,7 +102,7 @@ class PointNetSetAbstraction(nn.Module):
             conv = self.mlp_convs[0]
             w = conv.weight.view(conv.weight.shape[0], -1)
             P = ops.linear_rows(xyz if points is None else torch.cat((xyz, points), dim=-1), w)
-            Q = ops.linear_rows(new_xyz, w[:, :3]) - conv.bias
+            Q = ops.sub_row_bias(ops.linear_rows(new_xyz, w[:, :3]), conv.bias)
             g = ops.sa_first_layer(P, Q, idx, self.mlp_bns[0])
             first = 1
         else:

@@ -345,7 +345,7 @@ class _LinearRows(torch.autograd.Function):
                 check(lib().sug_linear_dw_bias(_p(g2), g2.stride(0), _p(x2), x2.stride(0), R, M, N, _p(dw), _p(db), _p(ws),
                                                _st()), 'sug_linear_dw_bias')
         if ctx.has_bias and ctx.needs_input_grad[2] and db is None:
-            db = g2.sum(dim=0)
+            db = colsum(g2)
         return dx, dw, db
 
 
@@ -1034,7 +1034,7 @@ class _Linear16(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = (torch.mm(g16, w16, out_dtype=torch.float32) if xdtype == torch.float32 else torch.mm(g16, w16)).view(xshape)
         dw = _dweight(g16, x16) if ctx.needs_input_grad[1] else None
-        db = g2.sum(dim=0, dtype=torch.float32) if (has_b and ctx.needs_input_grad[2]) else None
+        db = colsum(g2) if (has_b and ctx.needs_input_grad[2]) else None
         return dx, dw, db, None, None
 
 
@@ -1293,6 +1293,38 @@ def mmd_assemble(feat_s, feat_t, label_s, label_t, scale, num_class=10):
     if feat_s.dtype != torch.float32 or feat_t.dtype != torch.float32 or feat_s.shape != feat_t.shape or feat_s.dim() != 2:
         raise RuntimeError('sug_amd.ops.mmd_assemble: two fp32 [m, D] feature blocks of one shape')
     return _AssembleZ.apply(feat_s, feat_t, label_s, label_t, scale, num_class)
+
+
+def colsum(x2, sign=1.0):
+    """fp32 column sums [C] of a [R, C] fp32 / fp16 matrix (sug_colsum: no memset, fixed order)."""
+    _need_gpu(x2)
+    if x2.dim() != 2 or x2.dtype not in (torch.float32, torch.float16):
+        raise RuntimeError('sug_amd.ops.colsum: a 2-D fp32 / fp16 matrix')
+    if x2.stride(1) != 1:
+        x2 = x2.contiguous()
+    R, C = x2.shape
+    out = torch.empty(C, dtype=torch.float32, device=x2.device)
+    ws = torch.empty(int(lib().sug_colsum_workspace(R, C)), dtype=torch.float32, device=x2.device)
+    check(lib().sug_colsum(_p(x2), x2.stride(0), R, C, 0 if x2.dtype == torch.float32 else 1, float(sign), _p(out), _p(ws),
+                           _st()), 'sug_colsum')
+    return out
+
+
+class _SubRowBias(torch.autograd.Function):
+    """rows [..., C] - bias [C]; the bias gradient by sug_colsum instead of autograd's sum_to_size."""
+
+    @staticmethod
+    def forward(ctx, rows, bias):
+        return rows - bias
+
+    @staticmethod
+    def backward(ctx, g):
+        db = colsum(g.reshape(-1, g.shape[-1]), -1.0) if ctx.needs_input_grad[1] else None
+        return g, db
+
+
+def sub_row_bias(rows, bias):
+    return _SubRowBias.apply(rows, bias)
 
 
 class _Gate(torch.autograd.Function):

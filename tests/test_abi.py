@@ -36,7 +36,7 @@ def test_library_built_and_exports_header_symbols():
 def test_ctypes_table_matches_header():
     from sug_amd import _lib
     names = [n for n in _declared() if n not in ('sug_last_error', 'sug_abi_version', 'sug_linear_dw_workspace', 'sug_adam_chunk',
-                                               'sug_pointmlp_max_bwd_workspace', 'sug_ptran_colsum_workspace')]
+                                               'sug_pointmlp_max_bwd_workspace', 'sug_ptran_colsum_workspace', 'sug_colsum_workspace')]
     assert sorted(_lib.SIGNATURES) == names
     for n in names:
         assert len(_lib.SIGNATURES[n]) == _count_args(n), n

@@ -561,3 +561,22 @@ def test_ball_query_lds_and_global_paths_vs_oracle(N, S, ns, r):
     ref = O.ball_query_cl(r, ns, xyz, q)
     # a candidate within an ulp of the radius may differ between the two evaluations of the same formula: none expected
     assert torch.equal(out, ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('R,C,dt', [(65536, 64, torch.float32), (16384, 1024, torch.float32), (8192, 512, torch.float16),
+                                     (77, 3, torch.float32), (1, 130, torch.float16)])
+def test_colsum_matches_torch(R, C, dt):
+    """sug_colsum (bias gradients without the memset of torch's tall reductions) against a float64 sum."""
+    from sug_amd import ops
+    g = torch.Generator().manual_seed(R + C)
+    x = torch.randn(R, C, generator=g).to(dt).cuda()
+    ref = x.double().sum(dim=0)
+    out = ops.colsum(x)
+    assert out.dtype == torch.float32
+    torch.testing.assert_close(out.double(), ref, rtol=1e-5, atol=1e-4 * (R ** 0.5))
+    torch.testing.assert_close(ops.colsum(x, -1.0).double(), -ref, rtol=1e-5, atol=1e-4 * (R ** 0.5))
+    # strided rows (a column slice of a wider buffer)
+    wide = torch.randn(R, C + 5, generator=g).to(dt).cuda()
+    torch.testing.assert_close(ops.colsum(wide[:, 2:2 + C]).double(), wide[:, 2:2 + C].double().sum(dim=0), rtol=1e-5,
+                               atol=1e-4 * (R ** 0.5))
