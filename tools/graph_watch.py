@@ -1,3 +1,7 @@
+"""Watch a long run of training steps for non-finite or absurd loss values / parameters (every step is checked, anomalies and
+every 100th step are printed).  usage: python tools/graph_watch.py MODEL graph|eager STEPS [tuned] [FROM_STEP]
+Found the memset-node problem of replayed step graphs: eager runs stay clean, graph runs showed constant
+garbage MMD values after ~200 replays and NaN weights with library split-K weight gradients."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
