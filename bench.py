@@ -371,6 +371,8 @@ def main():
                           'eager_ms_per_step': eager_ms,
                           'share_prefix': trainer.share_prefix, 'pair_domains': trainer.pair_domains,
                           'tuned_gemms': tuned, 'geo_weights': 'mean2one', 'sem_weights': 'mean2one',
+                          'weight_gradients': ('own split-K kernels (no library split-K, hence no memset nodes, inside the captured graph)'
+                                               if graph_mode else 'own kernels, tuned library GEMMs for the listed shapes'),
                           'unchanged_caller_ms_per_step': caller_ms,
                           **({'fp16_linears': 'k-expanded and per-point 512-wide linears of the transformer blocks'}
                              if (args.fp16 and args.model == 'PTran') else {})},
