@@ -34,5 +34,14 @@ for e in prof.events():
         if n and not any(any('emset' in k.name or 'fillBuffer' in k.name for k in c.kernels) for c in e.cpu_children):
             agg[(e.name, str(e.input_shapes)[:100])] += n
 print('memsets per step: %d' % sum(agg.values()))
+cp = collections.Counter()
+for e in prof.events():
+    if e.device_type == torch.autograd.DeviceType.CPU and e.kernels:
+        n = sum(1 for k in e.kernels if 'emcpy' in k.name)
+        if n and not any(any('emcpy' in k.name for k in c.kernels) for c in e.cpu_children):
+            cp[(e.name, str(e.input_shapes)[:100])] += n
+print('device memcpys per step: %d' % sum(cp.values()))
+for (name, shp), n in cp.most_common(12):
+    print('%3d  %-32s %s' % (n, name, shp))
 for (name, shp), n in agg.most_common():
     print('%3d  %-32s %s' % (n, name, shp))
