@@ -144,7 +144,6 @@ def main():
     ap.add_argument('--fp16', action='store_true',
                     help='Point Transformer only (BASELINE config 5): k-expanded attention tensors and their 512x512 linears in '
                          'fp16 (MFMA, fp32 accumulation); default fp32 = the reference arithmetic')
-    ap.add_argument('--graph', action='store_true', help='(default on one GPU) replay the whole step from a hipGraph')
     ap.add_argument('--eager', action='store_true',
                     help='launch every kernel of the timed steps from Python instead of replaying a captured hipGraph '
                          '(the default on one GPU: an eager step is host-bound on this path -- ~450 launches in ~6.5 ms -- '

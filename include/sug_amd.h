@@ -247,10 +247,13 @@ int sug_adam_step(const int64_t* table, const int32_t* block_first, const int32_
                   double weight_decay, double bias_corr1, double bias_corr2, void* stream);
 /* Same update for replay from a hipGraph: the step count is a device int32 (advanced by the call),
  * the bias-correction scalars are derived on the device into scalars_dev[2]; gradient pointers must
- * be stable across replays (graph-private allocations are). */
+ * be stable across replays (graph-private allocations are).  lr_dev (may be null): the learning rate as
+ * one device-resident double that overrides `lr`, so that a learning-rate schedule
+ * (train_dg_single_gpu.py:194-212) changes a value in memory and ONE captured graph serves every epoch. */
 int sug_adam_step_capturable(const int64_t* table, const int32_t* block_first, const int32_t* block_first_host,
                              int T, const void* const* grads_host, double lr, double beta1, double beta2,
-                             double eps, double weight_decay, int32_t* step_dev, float* scalars_dev, void* stream);
+                             double eps, double weight_decay, int32_t* step_dev, float* scalars_dev,
+                             const double* lr_dev, void* stream);
 
 /* ---- SA-node module glue (adapt_layer_off, model/model_utils.py:103-128) --------------------
  * off[b,s,:] = mean_j tanh(proj[b,g_j,:] - proj[b,f,:]) * (loc[b,g_j,:] - loc[b,f,:]),

@@ -71,10 +71,13 @@ __global__ __launch_bounds__(256) void adam_kernel(const int64_t* __restrict__ t
 
 // Capturable mode (hipGraph replay): the step count lives on the device; one thread advances it and
 // derives lr / (1 - beta1^t) and 1 / sqrt(1 - beta2^t) for the update kernel of the same replay.
-__global__ void adam_prepare_kernel(int32_t* __restrict__ step, double lr, double beta1, double beta2,
-                                    float* __restrict__ scalars) {
+// lr_dev (optional): the learning rate as a device-resident double, so that a schedule step changes a value in
+// memory instead of a kernel argument baked into a captured graph.
+__global__ void adam_prepare_kernel(int32_t* __restrict__ step, double lr, const double* __restrict__ lr_dev,
+                                    double beta1, double beta2, float* __restrict__ scalars) {
   const int t = step[0] + 1;
   step[0] = t;
+  if (lr_dev) lr = lr_dev[0];
   scalars[0] = (float)(lr / (1.0 - pow(beta1, (double)t)));
   scalars[1] = (float)(1.0 / sqrt(1.0 - pow(beta2, (double)t)));
 }
@@ -107,12 +110,12 @@ extern "C" int sug_adam_step(const int64_t* table, const int32_t* block_first, c
 extern "C" int sug_adam_step_capturable(const int64_t* table, const int32_t* block_first,
                                         const int32_t* block_first_host, int T, const void* const* grads_host,
                                         double lr, double beta1, double beta2, double eps, double weight_decay,
-                                        int32_t* step_dev, float* scalars_dev, void* stream) {
+                                        int32_t* step_dev, float* scalars_dev, const double* lr_dev, void* stream) {
   SUG_REQUIRE(table && block_first && block_first_host && grads_host && step_dev && scalars_dev,
               "sug_adam_step_capturable: null pointer");
   SUG_REQUIRE(T > 0, "sug_adam_step_capturable: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(1), 0, st, step_dev, lr, beta1, beta2, scalars_dev);
+  hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(1), 0, st, step_dev, lr, lr_dev, beta1, beta2, scalars_dev);
   SUG_LAUNCH_CHECK("sug_adam_step_capturable(prepare)");
   for (int t0 = 0; t0 < T; t0 += SUG_ADAM_ARGS) {
     const int tn = T - t0 < SUG_ADAM_ARGS ? T - t0 : SUG_ADAM_ARGS;

@@ -330,6 +330,17 @@ class Pointnet_c(nn.Module):
         return x
 
 
+def _check_input(x):
+    """The GPU-only contract at the model boundary: the encoders are HIP kernels behind a C ABI,
+    there is no CPU or 16-bit-input path -- fail here with a clear message instead of deep inside an op."""
+    if not x.is_cuda or x.dtype != torch.float32:
+        raise RuntimeError('sug_amd.Net_MDA runs on a HIP device with fp32 clouds [B,3,N,1] only (got %s on %s): '
+                           'there is no CPU / eager fallback; move the model and the batch to the GPU (.cuda())'
+                           % (x.dtype, x.device))
+    if x.dim() != 4 or x.shape[1] < 3 or x.shape[3] != 1:
+        raise RuntimeError('sug_amd.Net_MDA expects clouds as [B,3,N,1] (model/Model.py:485), got %s' % (tuple(x.shape),))
+
+
 class Net_MDA(nn.Module):
     """model/Model.py:452-520.  model_name in {'Pointnet', 'Pointnet2', 'DGCNN', 'PTran'}."""
 
@@ -356,6 +367,7 @@ class Net_MDA(nn.Module):
 
     def forward(self, x, constant=1, adaptation=False, node_vis=False, mid_feat=False, node_adaptation_s=False,
                 node_adaptation_t=False, semantic_adaption=False):
+        _check_input(x)
         only_node = (node_adaptation_s or node_adaptation_t) and not (node_vis or mid_feat)
         if only_node:
             x, feat_ori, node_idx = self.g(x, node=True, feat_grad=False)       # the pooled feature is not used
@@ -386,6 +398,7 @@ class Net_MDA(nn.Module):
         (ops.bn_groups), everything else is per cloud / per row.
         semantic (default): ((y1,y2,f1,f2) of the source, (y1,y2,f1,f2) of the target);
         node_adaptation:    (attention_s(source nodes), attention_t(target nodes))."""
+        _check_input(x_pair)
         B2 = x_pair.size(0)
         assert B2 % 2 == 0
         B = B2 // 2

@@ -13,21 +13,48 @@ from ._lib import lib, check
 
 
 class _Bucket:
-    __slots__ = ('params', 'steps', 'table', 'first_dev', 'first_host', 'hyper', 'step_val', 'T', 'step_dev', 'scalars')
+    __slots__ = ('params', 'steps', 'table', 'first_dev', 'first_host', 'hyper', 'step_val', 'T', 'step_dev', 'scalars',
+                 'groups', 'lr_dev', 'lr_written')
 
 
 class Adam(torch.optim.Adam):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, graph_capturable=False):
-        """graph_capturable: the step count and bias corrections live on the device, so a step can be
-        captured in a hipGraph and replayed (state['step'] entries are then not maintained)."""
+        """graph_capturable: the step count, the bias corrections AND the learning rate live on the device, so a
+        step can be captured in a hipGraph and replayed through a learning-rate schedule (state['step'] entries are
+        then not maintained; a new lr reaches the device in `refresh_device_scalars`, which every step() calls
+        unless a capture is in progress -- the owner of a captured graph calls it before each replay)."""
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, foreach=False, fused=False)
         self._plan = None
         self._plan_key = None
         self._graph_capturable = bool(graph_capturable)
+        # bumped whenever the device-side plan (pointer table, step / scalar buffers) is dropped or rebuilt: a captured
+        # graph holds raw pointers into the plan it was captured with and must not be replayed after a change
+        self.plan_generation = 0
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
         self._plan = None
+        self.plan_generation += 1
+
+    def graph_key(self):
+        """What a captured step bakes in by value: every group's (betas, eps, weight_decay) -- not lr (device)."""
+        return tuple(self._hyper(g)[1:] for g in self.param_groups)
+
+    def refresh_device_scalars(self):
+        """graph_capturable mode: write each group's current lr to the device where it changed (eager fills; never
+        called while capturing)."""
+        if not (self._graph_capturable and self._plan):
+            return
+        for b in self._plan:
+            lrs = {float(self.param_groups[gi]['lr']) for gi in b.groups}
+            if len(lrs) > 1:                # groups that shared a bucket now have different rates: new plan
+                self._plan = None
+                self.plan_generation += 1
+                return
+            lr = lrs.pop()
+            if b.lr_written != lr:
+                b.lr_dev.fill_(lr)
+                b.lr_written = lr
 
     def _sync_steps_from_device(self):
         """graph_capturable mode keeps the step count on the device (replays advance it without the
@@ -55,9 +82,10 @@ class Adam(torch.optim.Adam):
             raise RuntimeError('sug_amd.optim.Adam: the update plan changed (other hyper-parameters or another set of '
                                'parameters with gradients) while a hipGraph is being captured; run one eager step first')
         self._sync_steps_from_device()              # a rebuilt plan continues the old step counts
+        self.plan_generation += 1
         chunk = lib().sug_adam_chunk()
-        buckets = {}
-        for g in self.param_groups:
+        buckets, members = {}, {}
+        for gi, g in enumerate(self.param_groups):
             hyper = self._hyper(g)
             for p in g['params']:
                 if p.grad is None:
@@ -71,11 +99,15 @@ class Adam(torch.optim.Adam):
                     st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 if st['step'].is_cuda:
                     st['step'] = st['step'].cpu()
-                buckets.setdefault((hyper, float(st['step']), p.device), []).append(p)
+                bk = (hyper, float(st['step']), p.device)
+                buckets.setdefault(bk, []).append(p)
+                members.setdefault(bk, set()).add(gi)
         plan = []
         for (hyper, step_val, dev), ps in buckets.items():
             b = _Bucket()
             b.params, b.hyper, b.step_val, b.T = ps, hyper, int(step_val), len(ps)
+            # capturable mode: lr is a device value per bucket (groups with one rate share a bucket, as before)
+            b.groups, b.lr_dev, b.lr_written = members[(hyper, step_val, dev)], None, None
             b.steps = [self.state[p]['step'] for p in ps]
             rows, first = [], [0]
             for p in ps:
@@ -87,6 +119,9 @@ class Adam(torch.optim.Adam):
             b.first_dev = torch.tensor(first, dtype=torch.int32).to(dev)
             b.step_dev = torch.full((1,), b.step_val, dtype=torch.int32, device=dev)
             b.scalars = torch.zeros(2, dtype=torch.float32, device=dev)
+            if self._graph_capturable:
+                b.lr_written = float(hyper[0])
+                b.lr_dev = torch.full((1,), b.lr_written, dtype=torch.float64, device=dev)
             plan.append(b)
         self._plan, self._plan_key = plan, key
         return plan
@@ -96,7 +131,9 @@ class Adam(torch.optim.Adam):
         if closure is not None:
             raise RuntimeError('sug_amd.optim.Adam: closures are not supported')
         key = (tuple(p.grad is not None for g in self.param_groups for p in g['params']),
-               tuple(self._hyper(g) for g in self.param_groups))
+               tuple(self._hyper(g)[1 if self._graph_capturable else 0:] for g in self.param_groups))
+        if self._graph_capturable and not torch.cuda.is_current_stream_capturing():
+            self.refresh_device_scalars()
         plan = self._plan if (self._plan is not None and key == self._plan_key) else self._build(key)
         L = lib()
         for b in plan:
@@ -111,12 +148,13 @@ class Adam(torch.optim.Adam):
                 if not g.is_contiguous():
                     g = p.grad = g.contiguous()
                 ptrs.append(g.data_ptr())
-            lr, b1, b2, eps, wd = b.hyper
+            lr, b1, b2, eps, wd = b.hyper           # capturable mode: the rate in force is b.lr_dev (device)
             stream = torch._C._cuda_getCurrentRawStream(b.table.device.index)
             if self._graph_capturable:
                 check(L.sug_adam_step_capturable(b.table.data_ptr(), b.first_dev.data_ptr(), b.first_host, b.T,
-                                                 (ctypes.c_void_p * b.T)(*ptrs), lr, b1, b2, eps, wd,
-                                                 b.step_dev.data_ptr(), b.scalars.data_ptr(), ctypes.c_void_p(stream)),
+                                                 (ctypes.c_void_p * b.T)(*ptrs), b.lr_written, b1, b2, eps, wd,
+                                                 b.step_dev.data_ptr(), b.scalars.data_ptr(), b.lr_dev.data_ptr(),
+                                                 ctypes.c_void_p(stream)),
                       'sug_adam_step_capturable')
                 torch.autograd.graph.increment_version(b.params)
                 continue

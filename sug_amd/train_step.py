@@ -275,13 +275,18 @@ class SUGStep:
         # replays, tools/graph_soak.py).  Single-GPU only.
         self.use_graph = bool(use_graph) and self.world == 1 and next(model.parameters()).is_cuda
         self._graphs = None
-        self._tick = torch.zeros(1, device=next(model.parameters()).device) if self.use_graph else None
+        self.max_graphs = 4                             # captured steps kept (each owns a private memory pool)
+        # SUG_GRAPH_GUARD=1 restores the historical guard (one eager op between two replays)
+        self._tick = torch.zeros(1, device=next(model.parameters()).device) \
+            if (self.use_graph and os.environ.get('SUG_GRAPH_GUARD') == '1') else None
         from .optim import Adam as _SugAdam
         AdamCls = _SugAdam if own_adam else torch.optim.Adam
+        # fused small ops (LayerNorm heads) pay off once the host no longer launches; scoped to this trainer's
+        # forwards (set and restored around self.losses())
+        self.fused_heads = self.use_graph
         if self.use_graph:
-            ops.FUSED_HEADS = True                      # fused small ops pay off once the host no longer launches
             if own_adam:
-                kw['graph_capturable'] = True           # step count / bias corrections on the device
+                kw['graph_capturable'] = True           # step count / bias corrections / lr on the device
             else:
                 kw['capturable'] = True
                 kw['fused'] = True
@@ -411,20 +416,51 @@ class SUGStep:
             return self._graph_step(data, label, data_t, label_t, epoch)
         return self._eager_step(data, label, data_t, label_t, epoch)
 
+    def _opts(self):
+        return (self.optimizer_g, self.optimizer_c, self.optimizer_dis)
+
+    def _graph_key(self, mmd_on, tensors):
+        """Everything a captured step bakes in by value.  sug_amd.optim.Adam keeps lr on the device (one graph serves a
+        whole schedule); any other optimizer takes lr by value, so its lr of every group is part of the key."""
+        hyp = []
+        for o in self._opts():
+            if hasattr(o, 'graph_key'):
+                hyp.append(o.graph_key())
+            else:
+                hyp.append(tuple((g['lr'], tuple(g['betas']), g['eps'], g['weight_decay']) for g in o.param_groups))
+        return (mmd_on, tuple(tuple(t.shape) for t in tensors), tuple(hyp))
+
+    def _plan_generations(self):
+        return tuple(getattr(o, 'plan_generation', 0) for o in self._opts())
+
+    def drop_graphs(self):
+        """Forget every captured step (their private pools are released).  Called automatically when an optimizer's
+        device-side plan changed under a graph (load_state_dict, another set of parameters with gradients)."""
+        self._graphs = None
+
     def _graph_step(self, data, label, data_t, label_t, epoch):
-        """hipGraph mode (bench.py's default launch mode on one GPU; opt-in for callers: use_graph=True).  One captured graph
-        per configuration key = (MMD on/off, input shapes, the learning rates of the three optimizers):
-        the kernels take lr by value, so a schedule step simply selects / captures another graph.  The
-        first step of a key runs eagerly (it records the FPS start-draw plan and builds the Adam update
-        plans OUTSIDE any capture), the second captures, later ones replay."""
+        """hipGraph mode (bench.py's default launch mode on one GPU; opt-in for callers: use_graph=True).  One captured
+        graph per configuration key = (MMD on/off, input shapes, the by-value hyper-parameters of the optimizers).  The
+        learning rates are NOT part of the key: sug_amd.optim.Adam reads them from device memory, so one graph serves a
+        whole schedule (`set_epoch`).  The first step of a key runs eagerly (it records the FPS start-draw plan and
+        builds the Adam update plans OUTSIDE any capture), the second captures, later ones replay.  At most
+        `max_graphs` captured steps are kept (least recently used first out); a graph whose optimizers have rebuilt
+        their device-side plan since the capture (load_state_dict, ...) is dropped and captured again."""
         mmd_on = epoch >= self.methods['PURE_CLS_EPOCH']
-        lrs = tuple(g['lr'] for o in (self.optimizer_g, self.optimizer_c, self.optimizer_dis) for g in o.param_groups[:1])
-        key = (mmd_on, tuple(tuple(t.shape) for t in (data, label, data_t, label_t)), lrs)
+        key = self._graph_key(mmd_on, (data, label, data_t, label_t))
         if self._graphs is None:
             self._graphs = {}
+        for o in self._opts():                              # a schedule step since the last replay: new lr -> device
+            if hasattr(o, 'refresh_device_scalars'):
+                o.refresh_device_scalars()
         st = self._graphs.get(key)
+        if st is not None and st['graph'] is not None and st['gens'] != self._plan_generations():
+            del self._graphs[key]                           # raw pointers into a freed Adam plan: never replay
+            st = None
         if st is None:
-            st = {'feeder': _StartFeeder(data.device), 'graph': None}
+            while len(self._graphs) >= self.max_graphs:
+                self._graphs.pop(next(iter(self._graphs)))  # dicts keep insertion order; a hit re-inserts (below)
+            st = {'feeder': _StartFeeder(data.device), 'graph': None, 'gens': None}
             self._graphs[key] = st
             ops.START_PROVIDER = st['feeder'].record
             try:
@@ -433,9 +469,10 @@ class SUGStep:
                 ops.START_PROVIDER = None
             st['feeder'].build()
             return out
+        self._graphs[key] = self._graphs.pop(key)           # most recently used last
         if st['graph'] is None:
             st['in'] = [t.clone() for t in (data, label, data_t, label_t)]
-            for o in (self.optimizer_g, self.optimizer_c, self.optimizer_dis):
+            for o in self._opts():
                 o.zero_grad(set_to_none=True)
             st['feeder'].cursor = 0
             st['graph'] = torch.cuda.CUDAGraph()
@@ -447,18 +484,19 @@ class SUGStep:
                     st['out'] = self._eager_step(*st['in'], epoch)
             finally:
                 ops.START_PROVIDER = None
+            st['gens'] = self._plan_generations()
             if os.environ.get('SUG_GRAPH_DUMP'):
                 st['graph'].debug_dump(os.environ['SUG_GRAPH_DUMP'])
         for dst, src in zip(st['in'], (data, label, data_t, label_t)):
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
         st['feeder'].refill()
-        # One eager op on ordinary (non-graph-pool) memory between two replays: an early version of the
-        # step faulted in its second back-to-back replay on ROCm 7.0 / gfx950 (a torch scatter read
-        # out-of-range indices; any eager kernel in between avoided it, a sleep or a device sync did not).
-        # Not root-caused and not reproduced since the pooling tail became one kernel (3000 clean replays,
-        # tools/graph_soak.py); the op stays as a guard, and the mode stays experimental for that reason.
-        self._tick.add_(1)
+        if self._tick is not None:
+            # Historical guard (SUG_GRAPH_GUARD=1): an early round-1 version of the step faulted in its second
+            # back-to-back replay (a torch scatter kernel that has since left the step read out-of-range indices; an
+            # eager op between replays avoided it).  Never reproduced after the memset nodes were removed (DESIGN
+            # section 5); tests/test_gpu_graph.py soaks 300 back-to-back replays without it.
+            self._tick.add_(1)
         st['graph'].replay()
         return st['out']
 
@@ -468,9 +506,11 @@ class SUGStep:
         # 16-bit weight copies shared by this step's forwards; from the second step on they are refreshed by one
         # multi-tensor copy into the first step's buffers
         ops.W16_CACHE = ops.w16_prefill(getattr(self, '_w16_plan', None) or []) if _PT.GEMM_DTYPE is not None else None
+        fused_before, ops.FUSED_HEADS = ops.FUSED_HEADS, (self.fused_heads or ops.FUSED_HEADS)
         try:
             loss_cls, loss_geo, loss_sem = self.losses(data, label, data_t, label_t, mmd_on)
         finally:
+            ops.FUSED_HEADS = fused_before
             if ops.W16_CACHE is not None:
                 self._w16_plan = ops.w16_plan(ops.W16_CACHE)
             ops.W16_CACHE = None

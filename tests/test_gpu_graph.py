@@ -1,0 +1,189 @@
+"""hipGraph launch mode of SUGStep (the mode bench.py measures on one GPU): back-to-back replay soak WITHOUT the
+historical guard op, one captured graph through a learning-rate schedule (lr lives on the device), bounded graph
+cache, invalidation when an optimizer rebuilds its device-side plan (stale raw pointers)."""
+import os
+
+import pytest
+import torch
+
+import bench
+from oracle import ref_cpu as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _net(model_name='DGCNN', wseed=5):
+    from sug_amd.model.Model import Net_MDA
+    net = Net_MDA(model_name)
+    net.load_state_dict(O.fill_params({k: tuple(v.shape) for k, v in net.state_dict().items()}, wseed))
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout2d):
+            m.p = 0.0
+    return net.cuda().train()
+
+
+def _batch(B, N=1024, seed=11):
+    g = torch.Generator().manual_seed(seed)
+    data, data_t = O.synth_clouds(B, N, g), O.synth_clouds(B, N, g)
+    lab, lab_t = torch.randint(0, 10, (B,), generator=g), torch.randint(0, 10, (B,), generator=g)
+    return [t.cuda() for t in (data, lab, data_t, lab_t)]
+
+
+def test_graph_soak_300_back_to_back_replays_without_guard():
+    """300 replays issued back to back (no eager op, no sync between them; the `_tick` guard of rounds 1-2 is off by
+    default now).  Phase 1, lr = 0: the weights stay put and the FPS starts are re-seeded, so EVERY replay must return
+    the planning step's losses (a misordered node, a stale buffer or a clobbered graph-pool allocation shows as a
+    different value).  Phase 2, lr = 1e-3 written to the device between replays of the SAME graph: training on the fixed
+    batch must lower the classification loss and keep every parameter finite."""
+    from sug_amd.train_step import SUGStep
+    assert os.environ.get('SUG_GRAPH_GUARD') != '1'
+    B = 8
+    batch = _batch(B)
+    net = _net()
+    tr = SUGStep(net, lr=0.0, weight_decay=5e-5, use_graph=True, methods=bench.BENCH_METHODS)
+    assert tr._tick is None
+    torch.manual_seed(21)
+    first = [float(v) for v in tr.step(*batch)]
+    outs = []
+    for i in range(300):
+        torch.manual_seed(21)
+        l = tr.step(*batch)
+        outs.append(torch.stack([v.clone() for v in l]))          # device-side copies: no host sync between replays
+    torch.cuda.synchronize()
+    vals = torch.stack(outs).cpu()
+    assert len(tr._graphs) == 1
+    want = torch.tensor(first)
+    bad = ((vals - want).abs() > 1e-5 * want.abs().clamp(min=1.0)).any(dim=1)
+    assert not bool(bad.any()), 'replays %s differ from the planning step: %s vs %s' % (
+        bad.nonzero().flatten().tolist()[:10], vals[bad][:3].tolist(), first)
+    # phase 2: same graph, learning rate switched on through the device scalar
+    for o in (tr.optimizer_g, tr.optimizer_c, tr.optimizer_dis):
+        for g in o.param_groups:
+            g['lr'] = 1e-3
+    gens = tr._plan_generations()
+    outs = []
+    for i in range(100):
+        l = tr.step(*batch)
+        outs.append(torch.stack([v.clone() for v in l]))
+    torch.cuda.synchronize()
+    assert len(tr._graphs) == 1 and tr._plan_generations() == gens, 'an lr change must not capture or re-plan'
+    vals = torch.stack(outs).cpu()
+    assert bool(torch.isfinite(vals).all()), vals[~torch.isfinite(vals).all(dim=1)][:3]
+    assert float(vals[-1, 0]) < 0.5 * first[0], (first, vals[-1].tolist())
+    assert all(bool(torch.isfinite(p).all()) for p in net.parameters())
+
+
+def test_graph_follows_eager_through_lr_schedule_with_one_graph():
+    """lr A -> B -> A (a warm restart / `set_epoch` with an earlier epoch): the graph trainer follows its eager twin,
+    keeps ONE captured graph, and the step counts on the device come back through state_dict()."""
+    from sug_amd.train_step import SUGStep
+    batch = _batch(4)
+    lrs = [1e-3] * 3 + [4e-4] * 2 + [1e-3] * 2
+    res = {}
+    for use_graph in (False, True):
+        tr = SUGStep(_net(), lr=1e-3, weight_decay=5e-5, use_graph=use_graph)
+        torch.manual_seed(3)
+        out = []
+        for lr in lrs:
+            for o in (tr.optimizer_g, tr.optimizer_c):
+                for g in o.param_groups:
+                    g['lr'] = lr
+            out.append([float(v) for v in tr.step(*batch)])
+        res[use_graph] = out
+        if use_graph:
+            assert len(tr._graphs) == 1, 'one graph serves every learning rate'
+            steps = {float(v['step']) for v in tr.optimizer_c.state_dict()['state'].values()}
+            assert steps == {float(len(lrs))}, steps
+    for x, y in zip(res[False][0], res[True][0]):
+        assert abs(x - y) <= 1e-5 * max(1.0, abs(x)), res
+    for a, b in zip(res[False], res[True]):
+        for x, y in zip(a, b):
+            assert abs(x - y) <= 2e-2 * max(1.0, abs(x)), res       # same noise bound as two eager runs
+
+
+def test_device_lr_is_what_the_update_uses():
+    """One parameter tensor, one known gradient: sug_amd.optim.Adam(graph_capturable=True) with the lr changed between
+    steps equals torch.optim.Adam stepped with the same schedule (the update reads lr from device memory)."""
+    from sug_amd.optim import Adam
+    torch.manual_seed(0)
+    w0 = torch.randn(1000, device='cuda')
+    grads = [torch.randn(1000, device='cuda') for _ in range(4)]
+    lrs = [1e-2, 1e-2, 3e-3, 1e-2]
+    res = []
+    for own in (True, False):
+        w = w0.clone().requires_grad_(True)
+        opt = Adam([w], lr=lrs[0], weight_decay=1e-3, graph_capturable=True) if own else \
+            torch.optim.Adam([w], lr=lrs[0], weight_decay=1e-3)
+        for lr, g in zip(lrs, grads):
+            opt.param_groups[0]['lr'] = lr
+            w.grad = g.clone()
+            opt.step()
+        res.append(w.detach().clone())
+        if own:
+            assert len(opt._plan) == 1 and opt.plan_generation == 1
+    torch.testing.assert_close(res[0], res[1], rtol=1e-5, atol=1e-6)
+
+
+def test_graph_dropped_when_an_optimizer_plan_changes():
+    """A captured step holds raw pointers into the Adam plans (pointer table, moment tensors).  load_state_dict
+    replaces the moments and frees the plan: the next step must NOT replay the old graph -- it plans and captures
+    again -- and the trajectory continues as the eager twin's does."""
+    from sug_amd.train_step import SUGStep
+    batch = _batch(4)
+    res = {}
+    for use_graph in (False, True):
+        tr = SUGStep(_net(), lr=1e-3, weight_decay=5e-5, use_graph=use_graph)
+        torch.manual_seed(3)
+        out = [[float(v) for v in tr.step(*batch)] for _ in range(3)]
+        if use_graph:
+            st = next(iter(tr._graphs.values()))
+            assert st['graph'] is not None
+            old = st['graph']
+        for o in (tr.optimizer_g, tr.optimizer_c, tr.optimizer_dis):
+            o.load_state_dict(o.state_dict())
+        out += [[float(v) for v in tr.step(*batch)] for _ in range(3)]
+        if use_graph:
+            st = next(iter(tr._graphs.values()))
+            assert len(tr._graphs) == 1 and st['graph'] is not None and st['graph'] is not old
+            steps = {float(v['step']) for v in tr.optimizer_g.state_dict()['state'].values()}
+            assert steps == {6.0}, steps
+        res[use_graph] = out
+    for a, b in zip(res[False], res[True]):
+        for x, y in zip(a, b):
+            assert abs(x - y) <= 2e-2 * max(1.0, abs(x)), res
+
+
+def test_graph_cache_is_bounded():
+    """Tail batches / other shapes capture further graphs, but never more than max_graphs (each owns a private pool)."""
+    from sug_amd.train_step import SUGStep
+    tr = SUGStep(_net('Pointnet'), lr=1e-3, use_graph=True)
+    tr.max_graphs = 2
+    for B in (2, 3, 4, 2):
+        batch = _batch(B, N=256)
+        for _ in range(3):
+            l = tr.step(*batch)
+        assert all(float(v) == float(v) for v in l)
+        assert len(tr._graphs) <= 2
+    assert len(tr._graphs) == 2
+
+
+def test_fused_heads_flag_is_scoped_to_the_trainer():
+    """SUGStep(use_graph=True) used to set the module global ops.FUSED_HEADS and leave it on."""
+    from sug_amd import ops
+    from sug_amd.train_step import SUGStep
+    assert ops.FUSED_HEADS is False
+    tr = SUGStep(_net('Pointnet'), lr=1e-3, use_graph=True)
+    assert ops.FUSED_HEADS is False
+    batch = _batch(2, N=256)
+    for _ in range(3):
+        tr.step(*batch)
+    assert ops.FUSED_HEADS is False
+
+
+def test_model_boundary_rejects_cpu_input_with_a_clear_message():
+    from sug_amd.model.Model import Net_MDA
+    net = Net_MDA('Pointnet')
+    with pytest.raises(RuntimeError, match='HIP device'):
+        net(torch.zeros(2, 3, 64, 1), semantic_adaption=True)
+    with pytest.raises(RuntimeError, match=r'\[B,3,N,1\]'):
+        net.cuda()(torch.zeros(2, 3, 64, device='cuda'), semantic_adaption=True)
