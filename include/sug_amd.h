@@ -317,6 +317,22 @@ int sug_edgeconv_layer_fwd(const float* pq, int64_t ldpq, const int32_t* idx, co
                            float eps, float momentum, float slope, float* running_mean,
                            float* running_var, float* z, uint8_t* arg, float* s1, float* coef,
                            float* out, int64_t ldo, double* stats, float* ws, void* stream);
+/* The same layer with the 1x1 convolution inside the gather kernel (edgeconv_fused.hip): x [B*N, Cin] rows (row
+ * stride ldx; Cin in {3, 64, 128}), wcat [2Co, Cin] = [W1 ; W2-W1] of the layer's weight W = [W1 | W2] [Co, 2Cin]
+ * (sug_edge_weight_split), qbias [Co] = the conv bias or NULL.  A workgroup = (cloud, 16-channel slice) forms its
+ * slice of [P | Q] = x.wcat^T with v_mfma_f32_32x32x2_f32 straight into the LDS image its gathers read; [P|Q] is
+ * never written to HBM unless pq_out (row stride ldpq >= 2Co) is given -- sug_edgeconv_layer_bwd wants it.  Two
+ * launches: MFMA + gather + BatchNorm partial rows, then statistics fold + BatchNorm + LeakyReLU (the fold runs in
+ * every workgroup of the second launch; coef [groups,5,Co] and the running buffers are written by one of them).
+ * Requires k == 20, Co % 16 == 0, N*64 bytes of LDS (N <= 2400): sug_edgeconv_fused_supported.
+ * ws: SUG_STATS_BLOCKS*2*Co floats.  training = 0: coef is an input (running-statistics coefficients). */
+int sug_edgeconv_fused_supported(int N, int k, int Cin, int Co);
+int sug_edgeconv_fused_layer_fwd(const float* x, int64_t ldx, int Cin, const float* wcat, const float* qbias,
+                                 const int32_t* idx, const float* gamma, const float* beta, int B, int N, int k,
+                                 int Co, int groups, int training, float eps, float momentum, float slope,
+                                 float* running_mean, float* running_var, float* z, uint8_t* arg, float* s1,
+                                 float* pq_out, int64_t ldpq, float* coef, float* out, int64_t ldo, float* ws,
+                                 void* stream);
 /* (All three layer backward entry points take `dgb`: NULL, or fp32 [2C] receiving the BatchNorm parameter
  * gradients dbeta | dgamma summed over the groups -- sug_fold_groups on `red`.)
  * Its backward: reverse neighbour lists (rev_off [B,N+1], rev_ent [B,N*k], scratch), per-group BN

@@ -38,6 +38,9 @@ SIGNATURES = {
                                  _vp, _i64, _vp],
     'sug_edgeconv_layer_fwd': [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _vp, _vp,
                                _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp],
+    'sug_edgeconv_fused_layer_fwd': [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _f32,
+                                     _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp],
+    'sug_edgeconv_fused_supported': [_i32, _i32, _i32, _i32],
     'sug_edgeconv_layer_bwd': [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32,
                                _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp],
     'sug_bn_act_rows_fwd': [_vp, _i64, _i64, _i32, _i32, _vp, _vp, _i32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _i64,

@@ -1,0 +1,377 @@
+// EdgeConv layer with the 1x1 convolution INSIDE the gather kernel (get_graph_feature + conv_2d + max over k,
+// model/model_utils.py:188-210, :8-32, model/Model.py:88-109).
+//
+//   y[b,n,j,c] = W.[x_j - x_n ; x_n] = P[b,idx[b,n,j],c] + Q[b,n,c],   [P | Q] = x.[W1 ; W2-W1]^T
+//
+// edgeconv.hip's kernels take [P|Q] from a library GEMM through HBM (written once, read once: 16*Co bytes per point)
+// and re-stage a 16-channel slice of P in LDS.  Here a workgroup = (cloud, 16-channel slice) forms that slice itself:
+// the cloud's x rows stream from L2 in 32-row tiles straight into the B operand of v_mfma_f32_32x32x2_f32 (the A
+// operand holds the slice's 16 P rows and 16 Q rows of the weight matrix), the 32x32 result tile is
+// [P slice ; Q slice]^T of 32 points: the P half goes into the LDS image the gathers read, the Q half (needed only by
+// its own point) waits in the z buffer -- the location its point's result overwrites -- so [P|Q] never exists in
+// HBM as a tensor.  The gather / reduce phase is edgeconv_fwd_lds_kernel's: 4 lanes per point, first maximum wins,
+// sign(gamma)-folded so that max/min is a plain max, per-(cloud) BatchNorm partial rows in a fixed order.
+//
+// MFMA orientation (M = channels, N = points): lane l holds D[i][j] for column j = l & 31 (a point) and rows
+// i = (r & 3) + 8 (r >> 2) + 4 (l >> 5), r = 0..15.  Weight row of A-row i: P channel r' for (i >> 2) & 1 == 0,
+// Q channel r' otherwise, r' = (i & 3) + 4 (i >> 3): lanes 0..31 then hold P[j][c0 .. c0+15], lanes 32..63
+// Q[j][c0 .. c0+15] -- one 64-byte row each.  k order: lane half h takes features h*C/2 + t at step t, so a lane
+// reads its x row as contiguous float4s (the sum over k is a reordered fma chain: results equal a GEMM's to fp32
+// rounding, not bit for bit).
+//
+// Per cloud and layer (fp32): x once per slice through L2 (HBM: once), idx, z / arg / s1 once.  FLOPs 2*N*C*2Co on
+// the fp32 matrix pipe + 6*N*k*Co VALU.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+constexpr int FT = 512;        // threads per workgroup (8 waves)
+constexpr int SW = 16;         // channels per slice
+constexpr int LP = SW / 4;     // lanes per point in the gather phase
+constexpr int PPP = FT / LP;   // points per pass
+
+// CIN: features per point as the MFMA sees them (4 = xyz padded with a zero feature, else 64 / 128); CR: real
+// feature count = row length of wcat.  KK: neighbours per point.
+template <int CIN, int KK>
+__global__ __launch_bounds__(FT) void edgeconv_fused_fwd_kernel(
+    const float* __restrict__ x, int64_t ldx, const float* __restrict__ wcat, const float* __restrict__ qbias,
+    const int32_t* __restrict__ idx, const float* __restrict__ gamma, int B, int N, int Co,
+    float* __restrict__ z, uint8_t* __restrict__ arg, float* __restrict__ s1, float* __restrict__ pq_out,
+    int64_t ldpq, float* __restrict__ ws) {
+  static_assert(KK % 4 == 0, "neighbour rows are fetched as int4");
+  constexpr int CR = CIN == 4 ? 3 : CIN;
+  constexpr int HALF = CIN / 2;                    // MFMA k-steps per tile
+  constexpr int KC = HALF < 32 ? HALF : 32;        // k-steps per register chunk of the x operand
+  constexpr int NCH = HALF / KC;
+  extern __shared__ __attribute__((aligned(16))) float s_lds[];
+  float* s_p = s_lds;                              // [N][SW]  sign(gamma) * P slice; later the reduction scratch
+  const int nslice = Co / SW;
+  int b, sl;
+  if ((B & 7) == 0) {                              // the slices of a cloud share an XCD (its L2 holds x once)
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    b = (j / nslice) * 8 + xcd;
+    sl = j % nslice;
+  } else {
+    b = blockIdx.x / nslice;
+    sl = blockIdx.x % nslice;
+  }
+  const int c0 = sl * SW;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int jl = lane & 31, h = lane >> 5;
+  const float* xb = x + (int64_t)b * N * ldx;
+  // the Q half waits where z will be written (or in the caller's [P|Q] buffer when the backward wants it)
+  float* qdst = pq_out ? pq_out + (int64_t)b * N * ldpq + Co + c0 : z + (int64_t)b * N * Co + c0;
+  const int64_t ldq = pq_out ? ldpq : (int64_t)Co;
+
+  // ---------------------------------------------------------------- phase 1: [P ; Q] slice by MFMA
+  {
+    // A operand: weight row of A-row jl, features h*HALF + t (CIN = 4: features 2h + t, the 4th is zero)
+    const int arow = ((jl >> 2) & 1) * Co + c0 + (jl & 3) + 4 * (jl >> 3);
+    float areg[HALF];
+    if constexpr (CIN == 4) {
+      const float* wr = wcat + (int64_t)arow * CR;
+      areg[0] = wr[2 * h];
+      areg[1] = h ? 0.f : wr[1];
+    } else {
+      const float* wr = wcat + (int64_t)arow * CR + h * HALF;
+#pragma unroll
+      for (int g = 0; g < HALF / 4; ++g) {
+        const float4 w4 = ld4(wr + 4 * g);
+        areg[4 * g + 0] = w4.x; areg[4 * g + 1] = w4.y; areg[4 * g + 2] = w4.z; areg[4 * g + 3] = w4.w;
+      }
+    }
+    // epilogue constants of this lane's 16 output channels (P lanes: sign(gamma); Q lanes: the conv bias)
+    float4 eg[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (h == 0) {
+        const float4 g4 = ld4(gamma + c0 + 4 * q);
+        eg[q] = make_float4(g4.x >= 0.f ? 1.f : -1.f, g4.y >= 0.f ? 1.f : -1.f, g4.z >= 0.f ? 1.f : -1.f,
+                            g4.w >= 0.f ? 1.f : -1.f);
+      } else {
+        eg[q] = qbias ? ld4(qbias + c0 + 4 * q) : make_float4(0, 0, 0, 0);
+      }
+    }
+    const int ntile = (N + 31) >> 5;
+    const int nmine = wv < ntile ? (ntile - wv + 7) >> 3 : 0;      // tiles wv, wv + 8, ...
+    const int nit = nmine * NCH;
+    auto loadB = [&](float (&bv)[KC], int it) {
+      const int tile = wv + 8 * (it / NCH), ch = it % NCH;
+      int r = tile * 32 + jl;
+      r = r < N ? r : N - 1;
+      if constexpr (CIN == 4) {
+        const float* p = xb + (int64_t)r * ldx;
+        bv[0] = p[2 * h];
+        const float y = p[1];
+        bv[1] = h ? 0.f : y;
+      } else {
+        const float* p = xb + (int64_t)r * ldx + h * HALF + ch * KC;
+#pragma unroll
+        for (int g = 0; g < KC / 4; ++g) {
+          const float4 v = ld4(p + 4 * g);
+          bv[4 * g + 0] = v.x; bv[4 * g + 1] = v.y; bv[4 * g + 2] = v.z; bv[4 * g + 3] = v.w;
+        }
+      }
+    };
+    f32x16 acc;
+    auto compute = [&](const float (&bv)[KC], int it) {
+      const int tile = wv + 8 * (it / NCH), ch = it % NCH;
+      if (ch == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      }
+#pragma unroll
+      for (int t = 0; t < KC; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[ch * KC + t], bv[t], acc, 0, 0, 0);
+      if (ch == NCH - 1) {
+        const int n = tile * 32 + jl;
+        if (n < N) {
+          if (h == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float4 pv = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+              if (pq_out) st4(pq_out + ((int64_t)b * N + n) * ldpq + c0 + 4 * q, pv);
+              st4(s_p + n * SW + 4 * q, make_float4(pv.x * eg[q].x, pv.y * eg[q].y, pv.z * eg[q].z, pv.w * eg[q].w));
+            }
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              st4(qdst + (int64_t)n * ldq + 4 * q,
+                  make_float4(__fadd_rn(acc[4 * q], eg[q].x), __fadd_rn(acc[4 * q + 1], eg[q].y),
+                              __fadd_rn(acc[4 * q + 2], eg[q].z), __fadd_rn(acc[4 * q + 3], eg[q].w)));
+          }
+        }
+      }
+    };
+    float b0[KC], b1[KC];
+    if (nit > 0) loadB(b0, 0);
+    for (int it = 0; it < nit; it += 2) {
+      if (it + 1 < nit) loadB(b1, it + 1);
+      compute(b0, it);
+      if (it + 2 < nit) loadB(b0, it + 2);
+      if (it + 1 < nit) compute(b1, it + 1);
+    }
+  }
+  __syncthreads();          // P slice complete in LDS; the Q rows of every wave are visible (vmcnt(0) + barrier)
+
+  // ---------------------------------------------------------------- phase 2: gather, reduce over k
+  const int lp = threadIdx.x % LP, slot = threadIdx.x / LP;
+  const float4 g4 = ld4(gamma + c0 + lp * 4);
+  const float4 sg = make_float4(g4.x >= 0.f ? 1.f : -1.f, g4.y >= 0.f ? 1.f : -1.f, g4.z >= 0.f ? 1.f : -1.f,
+                                g4.w >= 0.f ? 1.f : -1.f);
+  float4 a1 = make_float4(0, 0, 0, 0), a2 = make_float4(0, 0, 0, 0);
+  int4 nv[KK / 4], nvn[KK / 4];
+  float4 q = make_float4(0, 0, 0, 0), qn = q;
+  auto fetch = [&](int n, int4 (&iv)[KK / 4], float4& qq) {
+    if (n < N) {
+      const int64_t p = (int64_t)b * N + n;
+      const int4* ir = reinterpret_cast<const int4*>(idx + p * KK);
+#pragma unroll
+      for (int t = 0; t < KK / 4; ++t) iv[t] = ir[t];
+      qq = ld4(qdst + (int64_t)n * ldq + lp * 4);
+      qq.x *= sg.x; qq.y *= sg.y; qq.z *= sg.z; qq.w *= sg.w;
+    }
+  };
+  fetch(slot, nv, q);
+  for (int n = slot; n < N; n += PPP) {
+    fetch(n + PPP, nvn, qn);
+    float bx = 0, by = 0, bz = 0, bw = 0;
+    int jx = 0, jy = 0, jz = 0, jw = 0;
+    float sx = 0, sy = 0, sz = 0, sw = 0, qx = 0, qy = 0, qz = 0, qw = 0;
+#pragma unroll
+    for (int t = 0; t < KK / 4; ++t) {
+      const int m4[4] = {nv[t].x, nv[t].y, nv[t].z, nv[t].w};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = t * 4 + u;
+        const int m = min(max(m4[u], 0), N - 1);                      // clamp to the cloud (v_med3_i32)
+        const float4 pv = ld4(s_p + m * SW + lp * 4);
+        const float yx = __fadd_rn(pv.x, q.x), yy = __fadd_rn(pv.y, q.y);
+        const float yz = __fadd_rn(pv.z, q.z), yw = __fadd_rn(pv.w, q.w);
+        sx += yx; sy += yy; sz += yz; sw += yw;
+        qx = fmaf(yx, yx, qx); qy = fmaf(yy, yy, qy); qz = fmaf(yz, yz, qz); qw = fmaf(yw, yw, qw);
+        if (j == 0 || yx > bx) { bx = yx; jx = j; }                  // first maximum wins, as torch.max
+        if (j == 0 || yy > by) { by = yy; jy = j; }
+        if (j == 0 || yz > bz) { bz = yz; jz = j; }
+        if (j == 0 || yw > bw) { bw = yw; jw = j; }
+      }
+    }
+    bx *= sg.x; by *= sg.y; bz *= sg.z; bw *= sg.w;                   // back to the true sign
+    sx *= sg.x; sy *= sg.y; sz *= sg.z; sw *= sg.w;
+    const int64_t o = ((int64_t)b * N + n) * Co + c0 + lp * 4;
+    st4(z + o, make_float4(bx, by, bz, bw));                          // (overwrites this point's parked Q quarter)
+    *reinterpret_cast<uint32_t*>(arg + o) =
+        (uint32_t)jx | ((uint32_t)jy << 8) | ((uint32_t)jz << 16) | ((uint32_t)jw << 24);
+    if (s1) st4(s1 + o, make_float4(sx, sy, sz, sw));
+    a1.x += sx; a1.y += sy; a1.z += sz; a1.w += sw;
+    a2.x += qx; a2.y += qy; a2.z += qz; a2.w += qw;
+#pragma unroll
+    for (int t = 0; t < KK / 4; ++t) nv[t] = nvn[t];
+    q = qn;
+  }
+  // fixed-order reduction over the point slots (fp64), one partial row per cloud; the scratch reuses the P image
+  __syncthreads();
+  float* s_red = s_lds;                            // [PPP][2*SW]
+  st4(s_red + slot * 2 * SW + lp * 4, a1);
+  st4(s_red + slot * 2 * SW + SW + lp * 4, a2);
+  __syncthreads();
+  if (threadIdx.x < 2 * SW) {
+    double acc = 0.0;
+    for (int t = 0; t < PPP; ++t) acc += (double)s_red[t * 2 * SW + threadIdx.x];
+    const int col = threadIdx.x < SW ? c0 + threadIdx.x : Co + c0 + (threadIdx.x - SW);
+    ws[(size_t)b * 2 * Co + col] = (float)acc;
+  }
+}
+
+// Second (and last) launch of a fused layer forward: fold the per-cloud partial rows into the BatchNorm coefficients
+// (every workgroup folds its own group's rows redundantly, in one fixed order: <= 64 rows of 2*Co columns out of
+// L2), then out = LeakyReLU_slope(scale * z + shift) for the workgroup's rows.  Workgroup (0, 0) additionally writes
+// coef [G,5,Co] and updates the running statistics with the groups' batch statistics in group order (one
+// nn.BatchNorm2d call per domain group, as the reference's separate forward calls).
+__global__ __launch_bounds__(256) void edgeconv_bn_act_kernel(
+    const float* __restrict__ ws, int nblk, int Co, int groups, const float* __restrict__ gamma,
+    const float* __restrict__ beta, double count, float eps, float momentum, float* __restrict__ rmean,
+    float* __restrict__ rvar, float* __restrict__ coef, const float* __restrict__ z, int64_t rows_g, float slope,
+    float* __restrict__ out, int64_t ldo, int rows_per_wg) {
+  extern __shared__ __attribute__((aligned(16))) float s_c[];      // scale [Co] | shift [Co]
+  const int g = blockIdx.y;
+  const bool writer = blockIdx.x == 0 && blockIdx.y == 0;
+  auto fold = [&](int gg, int c, double& mean, double& var) {
+    const float* w = ws + (size_t)gg * nblk * 2 * Co;
+    double s = 0.0, q = 0.0;
+#pragma unroll 8
+    for (int r = 0; r < nblk; ++r) {
+      s += (double)w[(size_t)r * 2 * Co + c];
+      q += (double)w[(size_t)r * 2 * Co + Co + c];
+    }
+    mean = s / count;
+    var = q / count - mean * mean;
+    if (var < 0) var = 0;
+  };
+  for (int c = threadIdx.x; c < Co; c += 256) {
+    double mean, var;
+    fold(g, c, mean, var);
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float scale = gamma[c] * rstd;
+    s_c[c] = scale;
+    s_c[Co + c] = beta[c] - (float)mean * scale;
+    if (writer) {
+      float rm = rmean ? rmean[c] : 0.f, rv = rvar ? rvar[c] : 0.f;
+      for (int gg = 0; gg < groups; ++gg) {
+        double m2, v2;
+        fold(gg, c, m2, v2);
+        const float rs = (float)(1.0 / sqrt(v2 + (double)eps));
+        const float sc = gamma[c] * rs;
+        float* cg = coef + (size_t)gg * 5 * Co;
+        const double unb = count > 1.0 ? v2 * count / (count - 1.0) : v2;
+        cg[c] = sc;
+        cg[Co + c] = beta[c] - (float)m2 * sc;
+        cg[2 * Co + c] = (float)m2;
+        cg[3 * Co + c] = rs;
+        cg[4 * Co + c] = (float)unb;
+        rm = (1.f - momentum) * rm + momentum * (float)m2;
+        rv = (1.f - momentum) * rv + momentum * (float)unb;
+      }
+      if (rmean) rmean[c] = rm;
+      if (rvar) rvar[c] = rv;
+    }
+  }
+  __syncthreads();
+  const int C4 = Co >> 2;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
+  int64_t r1 = r0 + rows_per_wg;
+  if (r1 > rows_g) r1 = rows_g;
+  const int64_t total = (r1 - r0) * C4;
+  const float* zg = z + ((int64_t)g * rows_g + r0) * Co;
+  float* og = out + ((int64_t)g * rows_g + r0) * ldo;
+  constexpr int U = 4;
+  for (int64_t e0 = threadIdx.x; e0 < total; e0 += U * 256) {
+    float4 zv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t e = e0 + u * 256;
+      zv[u] = ld4(zg + 4 * (e < total ? e : e0));
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t e = e0 + u * 256;
+      if (e >= total) continue;
+      const int c = (int)(e % C4) * 4;
+      const int64_t r = e / C4;
+      const float4 sc = ld4(s_c + c), sh = ld4(s_c + Co + c);
+      float4 v;
+      v.x = fmaf(sc.x, zv[u].x, sh.x); v.y = fmaf(sc.y, zv[u].y, sh.y);
+      v.z = fmaf(sc.z, zv[u].z, sh.z); v.w = fmaf(sc.w, zv[u].w, sh.w);
+      v.x = v.x > 0.f ? v.x : v.x * slope; v.y = v.y > 0.f ? v.y : v.y * slope;
+      v.z = v.z > 0.f ? v.z : v.z * slope; v.w = v.w > 0.f ? v.w : v.w * slope;
+      st4(og + r * ldo + c, v);
+    }
+  }
+}
+
+template <int CIN>
+int launch_fused(const float* x, int64_t ldx, const float* wcat, const float* qbias, const int32_t* idx,
+                 const float* gamma, int B, int N, int Co, float* z, uint8_t* arg, float* s1, float* pq_out,
+                 int64_t ldpq, float* ws, hipStream_t st) {
+  const size_t plds = (size_t)N * SW * sizeof(float);
+  const size_t rlds = (size_t)PPP * 2 * SW * sizeof(float);
+  const size_t sh = plds > rlds ? plds : rlds;
+  static SugLdsOptIn note;
+  if (int rc = sug_allow_dynamic_lds(note, &edgeconv_fused_fwd_kernel<CIN, 20>, 150 * 1024, "sug_edgeconv_fused_layer_fwd"))
+    return rc;
+  hipLaunchKernelGGL((edgeconv_fused_fwd_kernel<CIN, 20>), dim3(B * (Co / SW)), dim3(FT), sh, st, x, ldx, wcat, qbias, idx,
+                     gamma, B, N, Co, z, arg, s1, pq_out, ldpq, ws);
+  SUG_LAUNCH_CHECK("sug_edgeconv_fused_layer_fwd");
+  return SUG_OK;
+}
+
+}  // namespace
+
+int sug_affine_act_groups(const float* z, int64_t ldz, const float* coef, int64_t rows, int groups, int C, float slope,
+                          float* out, int64_t ldo, hipStream_t st);
+
+extern "C" int sug_edgeconv_fused_supported(int N, int k, int Cin, int Co) {
+  return k == 20 && (Cin == 3 || Cin == 64 || Cin == 128) && Co % 16 == 0 && Co >= 16 && Co <= 1024 && N >= 32 &&
+         (size_t)N * SW * 4 <= 150 * 1024;
+}
+
+extern "C" int sug_edgeconv_fused_layer_fwd(const float* x, int64_t ldx, int Cin, const float* wcat, const float* qbias,
+                                            const int32_t* idx, const float* gamma, const float* beta, int B, int N,
+                                            int k, int Co, int groups, int training, float eps, float momentum,
+                                            float slope, float* running_mean, float* running_var, float* z,
+                                            uint8_t* arg, float* s1, float* pq_out, int64_t ldpq, float* coef,
+                                            float* out, int64_t ldo, float* ws, void* stream) {
+  SUG_REQUIRE(x && wcat && idx && gamma && beta && z && arg && coef && out && ws, "sug_edgeconv_fused_layer_fwd: null pointer");
+  SUG_REQUIRE(B > 0 && groups >= 1 && B % groups == 0, "sug_edgeconv_fused_layer_fwd: B=%d does not split into %d groups", B, groups);
+  SUG_REQUIRE(sug_edgeconv_fused_supported(N, k, Cin, Co), "sug_edgeconv_fused_layer_fwd: unsupported shape N=%d k=%d Cin=%d Co=%d", N, k, Cin, Co);
+  SUG_REQUIRE(B <= SUG_STATS_ROWS, "sug_edgeconv_fused_layer_fwd: B=%d exceeds the statistics workspace", B);
+  SUG_REQUIRE(ldx >= Cin && (Cin == 3 || (ldx % 4 == 0 && ((uintptr_t)x % 16) == 0)), "sug_edgeconv_fused_layer_fwd: x rows must be 16-byte aligned");
+  SUG_REQUIRE(((uintptr_t)wcat % 16) == 0 && ((uintptr_t)gamma % 16) == 0 && ((uintptr_t)z % 16) == 0 && ((uintptr_t)idx % 16) == 0 &&
+                  ((uintptr_t)arg % 4) == 0 && (!s1 || ((uintptr_t)s1 % 16) == 0) && (!qbias || ((uintptr_t)qbias % 16) == 0) &&
+                  ((uintptr_t)out % 16) == 0 && ldo % 4 == 0 && ldo >= Co,
+              "sug_edgeconv_fused_layer_fwd: pointers must be 16-byte aligned");
+  SUG_REQUIRE(!pq_out || (ldpq >= 2 * Co && ldpq % 4 == 0 && ((uintptr_t)pq_out % 16) == 0), "sug_edgeconv_fused_layer_fwd: bad [P|Q] buffer");
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if (Cin == 3)
+    rc = launch_fused<4>(x, ldx, wcat, qbias, idx, gamma, B, N, Co, z, arg, s1, pq_out, ldpq, ws, st);
+  else if (Cin == 64)
+    rc = launch_fused<64>(x, ldx, wcat, qbias, idx, gamma, B, N, Co, z, arg, s1, pq_out, ldpq, ws, st);
+  else
+    rc = launch_fused<128>(x, ldx, wcat, qbias, idx, gamma, B, N, Co, z, arg, s1, pq_out, ldpq, ws, st);
+  if (rc != SUG_OK) return rc;
+  const int64_t rows_g = (int64_t)(B / groups) * N;
+  if (!training)               // eval mode: coef holds the running-statistics coefficients of every group
+    return sug_affine_act_groups(z, Co, coef, rows_g, groups, Co, slope, out, ldo, st) == 0 ? SUG_OK : SUG_ERR_ARG;
+  int rpw = 64;                                   // rows per workgroup: >= 1024 workgroups where the layer has them
+  while ((rows_g + rpw - 1) / rpw * groups > 4096) rpw *= 2;
+  hipLaunchKernelGGL(edgeconv_bn_act_kernel, dim3((unsigned)((rows_g + rpw - 1) / rpw), groups), dim3(256),
+                     (size_t)2 * Co * sizeof(float), st, ws, B / groups, Co, groups, gamma, beta, (double)rows_g * k, eps,
+                     momentum, running_mean, running_var, coef, z, rows_g, slope, out, ldo, rpw);
+  SUG_LAUNCH_CHECK("sug_edgeconv_fused_layer_fwd(bn_act)");
+  return SUG_OK;
+}

@@ -98,12 +98,17 @@ class conv_2d(nn.Module):
         else:
             Wcat = ops.edge_weight_split(W)                                 # [2Co, C] = [W1 ; W2-W1]
             self._wcat = (W._version, grad, Wcat) if self.cache_weight_split else None
-        pq = ops.linear_rows(x.reshape(B * N, C), Wcat)
         bias = self.conv[0].bias
-        if bias is not None:                                              # bias rides on the Q half
-            pq = pq + torch.cat((torch.zeros_like(bias), bias))
         bn = self.conv[1]
         ops._count_bn_call(bn)
+        if ops.edgeconv_fused_supported(N, idx.shape[2], C, W.shape[0]):
+            # the GEMM inside the gather kernel: [P|Q] never round-trips HBM (sug_edgeconv_fused_layer_fwd)
+            out, coef = ops.edgeconv_fused(x, Wcat, bias, idx, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                           bn.training, _ACT_SLOPE[self.activation], bn.eps, bn.momentum, out=out)
+            return (out, coef) if return_stats else out
+        pq = ops.linear_rows(x.reshape(B * N, C), Wcat)
+        if bias is not None:                                              # bias rides on the Q half
+            pq = pq + torch.cat((torch.zeros_like(bias), bias))
         out, coef = ops.edgeconv_bn_act_max(pq.view(B, N, -1), idx, bn.weight, bn.bias, bn.running_mean,
                                             bn.running_var, bn.training, _ACT_SLOPE[self.activation],
                                             bn.eps, bn.momentum, out=out)

@@ -317,36 +317,43 @@ class _LinearRows(torch.autograd.Function):
     def backward(ctx, g):
         x, weight = ctx.saved_tensors
         M, N = weight.shape
-        g2 = g.reshape(-1, M)
-        x2 = x.reshape(-1, N)
-        if g2.stride(1) != 1:
-            g2 = g2.contiguous()
-        if x2.stride(1) != 1:
-            x2 = x2.contiguous()
-        R = g2.shape[0]
-        dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            dx = (g2 @ weight).view(x.shape)
-        if ctx.needs_input_grad[1]:
-            if DW_SHAPE_LOG is not None:
-                DW_SHAPE_LOG.append((R, M, N))
-            # (not while a step graph is being captured: the library's split-K solutions for these K = rows shapes
-            # clear their output with a memset, and memset nodes of a replayed hipGraph were not reliably ordered in
-            # front of the accumulating kernels on ROCm 7 -- see sug_mmd_rbf_value -- which showed as NaN weights
-            # after tens to hundreds of replays)
-            lib_ok = DW_FORCE_LIBRARY or ((R, M, N) in DW_LIBRARY_SHAPES and not torch.cuda.is_current_stream_capturing())
-            if M * N > 512 * 512 or lib_ok:
-                dw = g2.t() @ x2            # larger than any encoder layer, or the tuned library GEMM is faster
-            else:
-                dw = torch.empty(M, N, dtype=torch.float32, device=g.device)
-                ws = torch.empty(int(lib().sug_linear_dw_workspace(R, M, N)), dtype=torch.float32, device=g.device)
-                if ctx.has_bias and ctx.needs_input_grad[2]:       # bias gradient from the same pass over g
-                    db = torch.empty(M, dtype=torch.float32, device=g.device)
-                check(lib().sug_linear_dw_bias(_p(g2), g2.stride(0), _p(x2), x2.stride(0), R, M, N, _p(dw), _p(db), _p(ws),
-                                               _st()), 'sug_linear_dw_bias')
-        if ctx.has_bias and ctx.needs_input_grad[2] and db is None:
-            db = colsum(g2)
-        return dx, dw, db
+        dx, dw, db = linear_rows_backward(x.reshape(-1, N), weight, g.reshape(-1, M), ctx.needs_input_grad[0],
+                                          ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2])
+        return (None if dx is None else dx.view(x.shape)), dw, db
+
+
+def linear_rows_backward(x2, weight, g2, need_dx, need_dw, need_db):
+    """Gradients of y = x2 . weight^T (+ b) for rows x2 [R, N], g2 [R, M]: dx by the library GEMM, the weight gradient
+    g^T . x (K = rows, small output) by sug_linear_dw(_bias) -- with the bias gradient from the same pass over g."""
+    M, N = weight.shape
+    if g2.stride(1) != 1:
+        g2 = g2.contiguous()
+    if x2.stride(1) != 1:
+        x2 = x2.contiguous()
+    R = g2.shape[0]
+    dx = dw = db = None
+    if need_dx:
+        dx = g2 @ weight
+    if need_dw:
+        if DW_SHAPE_LOG is not None:
+            DW_SHAPE_LOG.append((R, M, N))
+        # (not while a step graph is being captured: the library's split-K solutions for these K = rows shapes
+        # clear their output with a memset, and memset nodes of a replayed hipGraph were not reliably ordered in
+        # front of the accumulating kernels on ROCm 7 -- see sug_mmd_rbf_value -- which showed as NaN weights
+        # after tens to hundreds of replays)
+        lib_ok = DW_FORCE_LIBRARY or ((R, M, N) in DW_LIBRARY_SHAPES and not torch.cuda.is_current_stream_capturing())
+        if M * N > 512 * 512 or lib_ok:
+            dw = g2.t() @ x2            # larger than any encoder layer, or the tuned library GEMM is faster
+        else:
+            dw = torch.empty(M, N, dtype=torch.float32, device=g2.device)
+            ws = torch.empty(int(lib().sug_linear_dw_workspace(R, M, N)), dtype=torch.float32, device=g2.device)
+            if need_db:       # bias gradient from the same pass over g
+                db = torch.empty(M, dtype=torch.float32, device=g2.device)
+            check(lib().sug_linear_dw_bias(_p(g2), g2.stride(0), _p(x2), x2.stride(0), R, M, N, _p(dw), _p(db), _p(ws),
+                                           _st()), 'sug_linear_dw_bias')
+    if need_db and db is None:
+        db = colsum(g2)
+    return dx, dw, db
 
 
 def linear_rows(x, weight, bias=None):
@@ -839,6 +846,102 @@ def edgeconv_bn_act_max(pq, idx, gamma, beta, running_mean, running_var, trainin
     batch mean, rstd, unbiased batch variance; [G,5,Co] under bn_groups(G > 1))."""
     return _EdgeConv.apply(pq, idx, gamma, beta, running_mean, running_var, training, slope, eps, momentum, BN_GROUPS,
                            None if out is None else [out])
+
+
+# The 1x1 convolution inside the gather kernel (edgeconv_fused.hip): default; SUG_EDGECONV_FUSED=0 selects the
+# library GEMM + edgeconv_bn_act_max path (A/B measurements).
+EDGECONV_FUSED = _os.environ.get('SUG_EDGECONV_FUSED', '1') == '1'
+
+
+def edgeconv_fused_supported(N, k, Cin, Co):
+    return EDGECONV_FUSED and bool(lib().sug_edgeconv_fused_supported(N, k, Cin, Co))
+
+
+class _EdgeConvFused(torch.autograd.Function):
+    """max_k LeakyReLU(BN(W.[x_j - x_i ; x_i])) from the rows x and the split weight [W1 ; W2-W1]: the GEMM, the
+    neighbour gather, the reduction over k and the BatchNorm sums in one kernel, BatchNorm + activation in a second
+    (sug_edgeconv_fused_layer_fwd).  [P|Q] is written only for a backward (sug_edgeconv_layer_bwd reads it)."""
+
+    @staticmethod
+    def forward(ctx, x, wcat, bias, idx, gamma, beta, running_mean, running_var, training, slope, eps, momentum, G,
+                out_holder):
+        _need_gpu(x, wcat, idx, gamma)
+        x3, B, N, C, ld = _rows3(x)
+        Co = wcat.shape[0] // 2
+        idx = _i32(idx).contiguous()
+        k = idx.shape[2]
+        if B % G:
+            raise RuntimeError('edgeconv: %d clouds do not split into %d domain groups' % (B, G))
+        dev = x.device
+        w = wcat.detach().contiguous()
+        b1 = None if bias is None else bias.detach().contiguous()
+        gamma_c, beta_c = gamma.detach().contiguous(), beta.detach().contiguous()
+        need_bwd = any(ctx.needs_input_grad[i] for i in (0, 1, 2, 4, 5))
+        z = torch.empty(B, N, Co, dtype=torch.float32, device=dev)
+        arg = torch.empty(B, N, Co, dtype=torch.uint8, device=dev)
+        s1 = torch.empty(B, N, Co, dtype=torch.float32, device=dev) if need_bwd else None
+        pq = torch.empty(B, N, 2 * Co, dtype=torch.float32, device=dev) if need_bwd else None
+        ws = torch.empty(STATS_BLOCKS * 2 * Co, dtype=torch.float32, device=dev)
+        coef = torch.empty(G, 5, Co, dtype=torch.float32, device=dev)
+        if not training:
+            coef.copy_(eval_coef(gamma_c, beta_c, running_mean, running_var, eps))
+        if out_holder is None:
+            out = torch.empty(B, N, Co, dtype=torch.float32, device=dev)
+        else:
+            out = out_holder[0]
+            if tuple(out.shape) != (B, N, Co) or out.stride(2) != 1 or out.stride(0) != N * out.stride(1) \
+                    or out.dtype != torch.float32 or out.requires_grad:
+                raise RuntimeError('edgeconv: bad destination slice')
+        check(_timed('edgeconv_fused_fwd_C%d_Co%d' % (C, Co), {'B': B, 'N': N, 'k': k, 'Co': Co, 'C': C, 'train': int(need_bwd)},
+                     lambda: lib().sug_edgeconv_fused_layer_fwd(_p(x3), ld, C, _p(w), _p(b1), _p(idx), _p(gamma_c), _p(beta_c),
+                                                                B, N, k, Co, G, 1 if training else 0, eps, momentum,
+                                                                float(slope), _p(running_mean), _p(running_var), _p(z),
+                                                                _p(arg), _p(s1), _p(pq), 2 * Co, _p(coef), _p(out),
+                                                                out.stride(1), _p(ws), _st())),
+              'sug_edgeconv_fused_layer_fwd')
+        if need_bwd:
+            ctx.save_for_backward(x3, w, idx, z, arg, s1, coef, pq)
+            ctx.meta = (B, N, k, C, Co, float(slope), bool(training), G, b1 is not None, tuple(x.shape))
+        coef_out = coef[0] if G == 1 else coef
+        ctx.mark_non_differentiable(coef_out)
+        ctx.set_materialize_grads(False)
+        return out, coef_out
+
+    @staticmethod
+    def backward(ctx, gout, _gcoef):
+        if gout is None:
+            return (None,) * 14
+        x3, w, idx, z, arg, s1, coef, pq = ctx.saved_tensors
+        B, N, k, C, Co, slope, training, G, has_bias, xshape = ctx.meta
+        dev = gout.device
+        gout, _, _, _, ldg = _rows3(gout)                           # a column slice of a wider buffer is fine
+        a = torch.empty(B, N, Co, dtype=torch.float32, device=dev)
+        red = (torch.empty if training else torch.zeros)(G + 1, 2 * Co, dtype=torch.float64, device=dev)
+        ws = torch.empty(STATS_BLOCKS * 2 * Co, dtype=torch.float32, device=dev)
+        off = torch.empty(B, N + 1, dtype=torch.int32, device=dev)
+        ent = torch.empty(B, N * k, dtype=torch.int32, device=dev)
+        dpq = torch.empty(B, N, 2 * Co, dtype=torch.float32, device=dev)
+        rf = torch.empty(2 * Co, dtype=torch.float32, device=dev)
+        check(_timed('edgeconv_layer_bwd_Co%d' % Co, {'B': B, 'N': N, 'k': k, 'Co': Co},
+                     lambda: lib().sug_edgeconv_layer_bwd(_p(gout), ldg, _p(z), _p(arg), _p(s1), _p(pq), 2 * Co, _p(idx),
+                                                          _p(coef), B, N, k, Co, G, 1 if training else 0, slope, _p(a),
+                                                          _p(red), _p(off), _p(ent), _p(dpq), 2 * Co, _p(ws), _p(rf), _st())),
+              'sug_edgeconv_layer_bwd')
+        x2 = x3.reshape(B * N, C) if x3.is_contiguous() else x3.view(B * N, C) if x3.stride(0) == N * x3.stride(1) else x3.reshape(B * N, C)
+        dpq2 = dpq.view(B * N, 2 * Co)
+        dx, dw, _ = linear_rows_backward(x2, w, dpq2, ctx.needs_input_grad[0], ctx.needs_input_grad[1], False)
+        db = None
+        if has_bias and ctx.needs_input_grad[2]:
+            db = colsum(dpq2[:, Co:])                              # the bias rides on the Q half
+        return (None if dx is None else dx.view(xshape)), dw, db, None, rf[Co:], rf[:Co], None, None, None, None, None, \
+            None, None, None
+
+
+def edgeconv_fused(x, wcat, bias, idx, bn_weight, bn_bias, running_mean, running_var, training, slope, eps=1e-5,
+                   momentum=0.1, out=None):
+    """x [B,N,C] rows, wcat [2Co, C] = [W1 ; W2-W1], idx [B,N,k] -> (out [B,N,Co], coef) as edgeconv_bn_act_max."""
+    return _EdgeConvFused.apply(x, wcat, bias, idx, bn_weight, bn_bias, running_mean, running_var, training, slope, eps,
+                                momentum, BN_GROUPS, None if out is None else [out])
 
 
 # ----------------------------------------------------------------------------- per-point MLP + max
