@@ -932,6 +932,10 @@ extern "C" int sug_edgeconv_fwd_bn(const float* pq, int64_t ldpq, const int32_t*
 // EdgeConv forward + BatchNorm coefficients + activation for `groups` domain groups (B/groups clouds each, one
 // BatchNorm call per group) in three launches when the LDS-resident kernel applies to the whole batch: its
 // partial rows are (cloud, part)-major, so each group's rows are contiguous.  Otherwise: group by group.
+int sug_edgeconv_bn_act(const float* ws, int nblk, int Co, int groups, const float* gamma, const float* beta, double count,
+                        float eps, float momentum, float* running_mean, float* running_var, float* coef, const float* z,
+                        int64_t rows_g, float slope, float* out, int64_t ldo, hipStream_t st);
+
 int sug_edgeconv_fwd_bn_act_groups(const float* pq, int64_t ldpq, const int32_t* idx, const float* gamma,
                                    const float* beta, int B, int N, int k, int Co, int groups, float eps, float momentum,
                                    float slope, float* running_mean, float* running_var, float* z, uint8_t* arg,
@@ -947,21 +951,15 @@ int sug_edgeconv_fwd_bn_act_groups(const float* pq, int64_t ldpq, const int32_t*
 #ifdef SUG_EDGECONV_NO_LDS
   const bool one = false;
 #else
-  const bool one = groups > 1 && lds && vec;
+  const bool one = lds && vec;
 #endif
   if (one) {
+    // two launches: gather / reduce with per-(cloud, part) partial rows, then statistics fold + BatchNorm + activation
+    // (edgeconv_fused.hip: every workgroup of the second launch folds its group's partial rows itself)
     int nblk = 0;
     if (int rc = edgeconv_fwd_partials(pq, ldpq, idx, gamma, B, N, k, Co, z, arg, s1, ws, &nblk, stream)) return rc;
-    hipLaunchKernelGGL(stats_finalize_groups_kernel, dim3(sug_divup(Co, 8)), dim3(1024), 0, st, ws, nblk / groups, Co, groups,
-                       gamma, beta, (double)rows * k, eps, momentum, running_mean, running_var, coef, nullptr);
-    SUG_LAUNCH_CHECK("sug_edgeconv_layer_fwd(finalize)");
-    const int64_t total = (int64_t)B * N * (Co / 4);
-    int64_t g = (total + 1023) / 1024;
-    if (g > 8192) g = 8192;
-    hipLaunchKernelGGL(affine_act_vec4_groups_kernel, dim3((int)g), dim3(256), 0, st, z, (int64_t)Co, coef, (int64_t)B * N, rows,
-                       Co, slope, out, ldo);
-    SUG_LAUNCH_CHECK("sug_edgeconv_layer_fwd(act)");
-    return SUG_OK;
+    return sug_edgeconv_bn_act(ws, nblk / groups, Co, groups, gamma, beta, (double)rows * k, eps, momentum, running_mean,
+                               running_var, coef, z, rows, slope, out, ldo, st);
   }
   for (int g = 0; g < groups; ++g) {
     const int64_t r0 = (int64_t)g * rows;

@@ -30,15 +30,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
-constexpr int FT = 512;        // threads per workgroup (8 waves)
 constexpr int SW = 16;         // channels per slice
 constexpr int LP = SW / 4;     // lanes per point in the gather phase
-constexpr int PPP = FT / LP;   // points per pass
 
 // CIN: features per point as the MFMA sees them (4 = xyz padded with a zero feature, else 64 / 128); CR: real
-// feature count = row length of wcat.  KK: neighbours per point.
-template <int CIN, int KK>
-__global__ __launch_bounds__(FT) void edgeconv_fused_fwd_kernel(
+// feature count = row length of wcat.  KK: neighbours per point.  NT: threads per workgroup -- 512 (two workgroups
+// per CU: one's MFMA phase overlaps the other's gather phase) or 1024 (layers with no more workgroups than CUs);
+// either way 16 waves per CU, hence <= 128 registers per lane.
+template <int CIN, int KK, int NT>
+__global__ __launch_bounds__(NT, 4) void edgeconv_fused_fwd_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ wcat, const float* __restrict__ qbias,
     const int32_t* __restrict__ idx, const float* __restrict__ gamma, int B, int N, int Co,
     float* __restrict__ z, uint8_t* __restrict__ arg, float* __restrict__ s1, float* __restrict__ pq_out,
@@ -46,8 +46,10 @@ __global__ __launch_bounds__(FT) void edgeconv_fused_fwd_kernel(
   static_assert(KK % 4 == 0, "neighbour rows are fetched as int4");
   constexpr int CR = CIN == 4 ? 3 : CIN;
   constexpr int HALF = CIN / 2;                    // MFMA k-steps per tile
-  constexpr int KC = HALF < 32 ? HALF : 32;        // k-steps per register chunk of the x operand
+  constexpr int KC = HALF < 32 ? HALF : (CIN == 128 ? 16 : 32);   // k-steps per register chunk of the x operand (two chunks live)
   constexpr int NCH = HALF / KC;
+  constexpr int NW = NT / 64;                      // waves
+  constexpr int PPP = NT / LP;                     // points per pass of the gather phase
   extern __shared__ __attribute__((aligned(16))) float s_lds[];
   float* s_p = s_lds;                              // [N][SW]  sign(gamma) * P slice; later the reduction scratch
   const int nslice = Co / SW;
@@ -85,32 +87,28 @@ __global__ __launch_bounds__(FT) void edgeconv_fused_fwd_kernel(
         areg[4 * g + 0] = w4.x; areg[4 * g + 1] = w4.y; areg[4 * g + 2] = w4.z; areg[4 * g + 3] = w4.w;
       }
     }
-    // epilogue constants of this lane's 16 output channels (P lanes: sign(gamma); Q lanes: the conv bias)
-    float4 eg[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      if (h == 0) {
-        const float4 g4 = ld4(gamma + c0 + 4 * q);
-        eg[q] = make_float4(g4.x >= 0.f ? 1.f : -1.f, g4.y >= 0.f ? 1.f : -1.f, g4.z >= 0.f ? 1.f : -1.f,
-                            g4.w >= 0.f ? 1.f : -1.f);
-      } else {
-        eg[q] = qbias ? ld4(qbias + c0 + 4 * q) : make_float4(0, 0, 0, 0);
-      }
-    }
     const int ntile = (N + 31) >> 5;
-    const int nmine = wv < ntile ? (ntile - wv + 7) >> 3 : 0;      // tiles wv, wv + 8, ...
-    const int nit = nmine * NCH;
-    auto loadB = [&](float (&bv)[KC], int it) {
-      const int tile = wv + 8 * (it / NCH), ch = it % NCH;
-      int r = tile * 32 + jl;
-      r = r < N ? r : N - 1;
+    // the four ds_write_b128 of a P row are issued in a per-lane rotated ORDER (lane j writes quarter (q + (j >> 1)) & 3
+    // in its q-th store): the 8 lanes of a store's lane group (rows 64 B apart: banks 0 / 16 alternate) then cover 8
+    // different bank quads instead of two (4-way conflict); the LDS image itself is the plain [N][16] layout
+    const int rot = (jl >> 1) & 3;
+    // x operand chunks (KC k-steps) are double-buffered: chunk c+1 (of this or of the wave's next tile) is in flight
+    // while chunk c feeds the MFMAs
+    auto loadB = [&](float (&bv)[KC], int tile, int ch) {
+#ifdef SUG_EF_ABL_NOLOADX
+#pragma unroll
+      for (int t = 0; t < KC; ++t) bv[t] = (float)(tile + t);
+      return;
+#endif
+      int r0 = tile * 32 + jl;
+      r0 = r0 < N ? r0 : N - 1;
       if constexpr (CIN == 4) {
-        const float* p = xb + (int64_t)r * ldx;
+        const float* p = xb + (int64_t)r0 * ldx;
         bv[0] = p[2 * h];
         const float y = p[1];
         bv[1] = h ? 0.f : y;
       } else {
-        const float* p = xb + (int64_t)r * ldx + h * HALF + ch * KC;
+        const float* p = xb + (int64_t)r0 * ldx + h * HALF + ch * KC;
 #pragma unroll
         for (int g = 0; g < KC / 4; ++g) {
           const float4 v = ld4(p + 4 * g);
@@ -119,109 +117,172 @@ __global__ __launch_bounds__(FT) void edgeconv_fused_fwd_kernel(
       }
     };
     f32x16 acc;
-    auto compute = [&](const float (&bv)[KC], int it) {
-      const int tile = wv + 8 * (it / NCH), ch = it % NCH;
-      if (ch == 0) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      }
+    auto mma = [&](const float (&bv)[KC], int ch) {
+#ifndef SUG_EF_ABL_NOMFMA          // (-DSUG_EF_ABL_*: timing experiments of tools/bench_edgeconv_fused.py, never in the library)
 #pragma unroll
       for (int t = 0; t < KC; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[ch * KC + t], bv[t], acc, 0, 0, 0);
-      if (ch == NCH - 1) {
-        const int n = tile * 32 + jl;
-        if (n < N) {
-          if (h == 0) {
+#else
+      acc[0] += bv[0] + bv[KC - 1];
+#endif
+    };
+    float bA[KC], bB[KC];
+    if (wv < ntile) loadB(bA, wv, 0);
+    for (int tile = wv; tile < ntile; tile += NW) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const float4 pv = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
-              if (pq_out) st4(pq_out + ((int64_t)b * N + n) * ldpq + c0 + 4 * q, pv);
-              st4(s_p + n * SW + 4 * q, make_float4(pv.x * eg[q].x, pv.y * eg[q].y, pv.z * eg[q].z, pv.w * eg[q].w));
-            }
-          } else {
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const int tnext = tile + NW < ntile ? tile + NW : tile;         // (the last tile re-reads itself: no branch around a load)
+      if constexpr (NCH == 1) {
+        loadB(bB, tnext, 0);
+        mma(bA, 0);
+#pragma unroll
+        for (int t = 0; t < KC; ++t) bA[t] = bB[t];
+      } else {
+        static_assert(NCH % 2 == 0 || NCH == 1, "chunk pairs");
+#pragma unroll
+        for (int ch = 0; ch < NCH; ch += 2) {
+          loadB(bB, tile, ch + 1);
+          mma(bA, ch);
+          if (ch + 2 < NCH) loadB(bA, tile, ch + 2); else loadB(bA, tnext, 0);
+          mma(bB, ch + 1);
+        }
+      }
+      const int n = tile * 32 + jl;
+      if (n < N) {
+        if (h == 0) {
+          if (pq_out) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-              st4(qdst + (int64_t)n * ldq + 4 * q,
-                  make_float4(__fadd_rn(acc[4 * q], eg[q].x), __fadd_rn(acc[4 * q + 1], eg[q].y),
-                              __fadd_rn(acc[4 * q + 2], eg[q].z), __fadd_rn(acc[4 * q + 3], eg[q].w)));
+              st4(pq_out + ((int64_t)b * N + n) * ldpq + c0 + 4 * q, make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]));
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int qq = (q + rot) & 3;
+            float4 pv;
+            pv.x = qq == 0 ? acc[0] : qq == 1 ? acc[4] : qq == 2 ? acc[8] : acc[12];
+            pv.y = qq == 0 ? acc[1] : qq == 1 ? acc[5] : qq == 2 ? acc[9] : acc[13];
+            pv.z = qq == 0 ? acc[2] : qq == 1 ? acc[6] : qq == 2 ? acc[10] : acc[14];
+            pv.w = qq == 0 ? acc[3] : qq == 1 ? acc[7] : qq == 2 ? acc[11] : acc[15];
+            const float4 g4 = ld4(gamma + c0 + 4 * qq);
+            st4(s_p + n * SW + 4 * qq, make_float4(g4.x >= 0.f ? pv.x : -pv.x, g4.y >= 0.f ? pv.y : -pv.y,
+                                                   g4.z >= 0.f ? pv.z : -pv.z, g4.w >= 0.f ? pv.w : -pv.w));
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4 b4 = qbias ? ld4(qbias + c0 + 4 * q) : make_float4(0, 0, 0, 0);
+            st4(qdst + (int64_t)n * ldq + 4 * q,
+                make_float4(__fadd_rn(acc[4 * q], b4.x), __fadd_rn(acc[4 * q + 1], b4.y),
+                            __fadd_rn(acc[4 * q + 2], b4.z), __fadd_rn(acc[4 * q + 3], b4.w)));
           }
         }
       }
-    };
-    float b0[KC], b1[KC];
-    if (nit > 0) loadB(b0, 0);
-    for (int it = 0; it < nit; it += 2) {
-      if (it + 1 < nit) loadB(b1, it + 1);
-      compute(b0, it);
-      if (it + 2 < nit) loadB(b0, it + 2);
-      if (it + 1 < nit) compute(b1, it + 1);
     }
   }
   __syncthreads();          // P slice complete in LDS; the Q rows of every wave are visible (vmcnt(0) + barrier)
 
   // ---------------------------------------------------------------- phase 2: gather, reduce over k
+  // y_j = P[idx_j] + Q (all sign-folded): fp32 addition is monotone, so max_j y_j = (max_j P[idx_j]) + Q exactly and
+  // the running maximum, its (first) position and the sums are taken over the gathered P values alone:
+  // sum y = sum p + k q,  sum y^2 = sum p^2 + 2 q sum p + k q^2  (the sums feed the BatchNorm statistics and s1)
   const int lp = threadIdx.x % LP, slot = threadIdx.x / LP;
   const float4 g4 = ld4(gamma + c0 + lp * 4);
   const float4 sg = make_float4(g4.x >= 0.f ? 1.f : -1.f, g4.y >= 0.f ? 1.f : -1.f, g4.z >= 0.f ? 1.f : -1.f,
                                 g4.w >= 0.f ? 1.f : -1.f);
   float4 a1 = make_float4(0, 0, 0, 0), a2 = make_float4(0, 0, 0, 0);
-  int4 nv[KK / 4], nvn[KK / 4];
-  float4 q = make_float4(0, 0, 0, 0), qn = q;
-  auto fetch = [&](int n, int4 (&iv)[KK / 4], float4& qq) {
-    if (n < N) {
+  constexpr float kf = (float)KK;
+  // (no software prefetch of the next point's neighbour list: with 16 waves per CU the other waves cover the fetch,
+  // and the 24 registers of a second list would not fit the 128-register budget)
+#ifdef SUG_EF_ABL_NOGATHER
+  for (int n = N; n < N; n += PPP) {
+#else
+  for (int n = slot; n < N; n += PPP) {
+#endif
+    int4 nv[KK / 4];
+    float4 q;
+    {
       const int64_t p = (int64_t)b * N + n;
       const int4* ir = reinterpret_cast<const int4*>(idx + p * KK);
 #pragma unroll
-      for (int t = 0; t < KK / 4; ++t) iv[t] = ir[t];
-      qq = ld4(qdst + (int64_t)n * ldq + lp * 4);
-      qq.x *= sg.x; qq.y *= sg.y; qq.z *= sg.z; qq.w *= sg.w;
+      for (int t = 0; t < KK / 4; ++t) nv[t] = ir[t];
+      q = ld4(qdst + (int64_t)n * ldq + lp * 4);
+      q.x *= sg.x; q.y *= sg.y; q.z *= sg.z; q.w *= sg.w;
     }
-  };
-  fetch(slot, nv, q);
-  for (int n = slot; n < N; n += PPP) {
-    fetch(n + PPP, nvn, qn);
     float bx = 0, by = 0, bz = 0, bw = 0;
     int jx = 0, jy = 0, jz = 0, jw = 0;
     float sx = 0, sy = 0, sz = 0, sw = 0, qx = 0, qy = 0, qz = 0, qw = 0;
+    auto gather4 = [&](float4 (&pv)[4], const int4& iv) {
+      const int m4[4] = {iv.x, iv.y, iv.z, iv.w};
 #pragma unroll
-    for (int t = 0; t < KK / 4; ++t) {
-      const int m4[4] = {nv[t].x, nv[t].y, nv[t].z, nv[t].w};
+      for (int u = 0; u < 4; ++u) {
+        const int m = min(max(m4[u], 0), N - 1);                      // clamp to the cloud (v_med3_i32)
+        pv[u] = ld4(s_p + m * SW + lp * 4);
+      }
+    };
+    auto reduce4 = [&](const float4 (&pv)[4], int t) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int j = t * 4 + u;
-        const int m = min(max(m4[u], 0), N - 1);                      // clamp to the cloud (v_med3_i32)
-        const float4 pv = ld4(s_p + m * SW + lp * 4);
-        const float yx = __fadd_rn(pv.x, q.x), yy = __fadd_rn(pv.y, q.y);
-        const float yz = __fadd_rn(pv.z, q.z), yw = __fadd_rn(pv.w, q.w);
-        sx += yx; sy += yy; sz += yz; sw += yw;
-        qx = fmaf(yx, yx, qx); qy = fmaf(yy, yy, qy); qz = fmaf(yz, yz, qz); qw = fmaf(yw, yw, qw);
-        if (j == 0 || yx > bx) { bx = yx; jx = j; }                  // first maximum wins, as torch.max
-        if (j == 0 || yy > by) { by = yy; jy = j; }
-        if (j == 0 || yz > bz) { bz = yz; jz = j; }
-        if (j == 0 || yw > bw) { bw = yw; jw = j; }
+        sx += pv[u].x; sy += pv[u].y; sz += pv[u].z; sw += pv[u].w;
+        qx = fmaf(pv[u].x, pv[u].x, qx); qy = fmaf(pv[u].y, pv[u].y, qy);
+        qz = fmaf(pv[u].z, pv[u].z, qz); qw = fmaf(pv[u].w, pv[u].w, qw);
+        if (j == 0 || pv[u].x > bx) { bx = pv[u].x; jx = j; }          // first maximum wins, as torch.max
+        if (j == 0 || pv[u].y > by) { by = pv[u].y; jy = j; }
+        if (j == 0 || pv[u].z > bz) { bz = pv[u].z; jz = j; }
+        if (j == 0 || pv[u].w > bw) { bw = pv[u].w; jw = j; }
       }
+    };
+    // software pipeline over batches of 4 neighbours: the LDS reads of batch t+1 are issued before the arithmetic of
+    // batch t (two batches = 32 registers live; the scheduling barriers keep the compiler from hoisting all 20 reads)
+    float4 pa[4], pb[4];
+    gather4(pa, nv[0]);
+#pragma unroll
+    for (int t = 0; t < KK / 4; t += 2) {
+      if (t + 1 < KK / 4) gather4(pb, nv[t + 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      reduce4(pa, t);
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + 2 < KK / 4) gather4(pa, nv[t + 2]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + 1 < KK / 4) reduce4(pb, t + 1);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    bx *= sg.x; by *= sg.y; bz *= sg.z; bw *= sg.w;                   // back to the true sign
-    sx *= sg.x; sy *= sg.y; sz *= sg.z; sw *= sg.w;
+    // + Q, back to the true sign
+    const float zx = __fadd_rn(bx, q.x) * sg.x, zy = __fadd_rn(by, q.y) * sg.y;
+    const float zz = __fadd_rn(bz, q.z) * sg.z, zw = __fadd_rn(bw, q.w) * sg.w;
+    const float yx = fmaf(kf, q.x, sx), yy = fmaf(kf, q.y, sy), yz = fmaf(kf, q.z, sz), yw = fmaf(kf, q.w, sw);   // sum y'
+    qx = fmaf(q.x, yx + sx, qx); qy = fmaf(q.y, yy + sy, qy);          // sum y'^2 = sum p^2 + q (2 sum p + k q)
+    qz = fmaf(q.z, yz + sz, qz); qw = fmaf(q.w, yw + sw, qw);
     const int64_t o = ((int64_t)b * N + n) * Co + c0 + lp * 4;
-    st4(z + o, make_float4(bx, by, bz, bw));                          // (overwrites this point's parked Q quarter)
+    st4(z + o, make_float4(zx, zy, zz, zw));                          // (overwrites this point's parked Q quarter)
     *reinterpret_cast<uint32_t*>(arg + o) =
         (uint32_t)jx | ((uint32_t)jy << 8) | ((uint32_t)jz << 16) | ((uint32_t)jw << 24);
-    if (s1) st4(s1 + o, make_float4(sx, sy, sz, sw));
-    a1.x += sx; a1.y += sy; a1.z += sz; a1.w += sw;
+    const float4 sy4 = make_float4(yx * sg.x, yy * sg.y, yz * sg.z, yw * sg.w);
+    if (s1) st4(s1 + o, sy4);
+    a1.x += sy4.x; a1.y += sy4.y; a1.z += sy4.z; a1.w += sy4.w;
     a2.x += qx; a2.y += qy; a2.z += qz; a2.w += qw;
-#pragma unroll
-    for (int t = 0; t < KK / 4; ++t) nv[t] = nvn[t];
-    q = qn;
   }
-  // fixed-order reduction over the point slots (fp64), one partial row per cloud; the scratch reuses the P image
+  // fixed-order reduction over the point slots (fp64), one partial row per cloud; the scratch reuses the P image:
+  // 2*SW columns x PPP slots, folded by 16 threads per column (slots t, t+16, ...) and then by one
   __syncthreads();
   float* s_red = s_lds;                            // [PPP][2*SW]
   st4(s_red + slot * 2 * SW + lp * 4, a1);
   st4(s_red + slot * 2 * SW + SW + lp * 4, a2);
   __syncthreads();
+  double part = 0.0;
+  {
+    const int col = threadIdx.x & (2 * SW - 1), tl = (threadIdx.x >> 5) & 15;
+    if (threadIdx.x < 2 * SW * 16) {
+      for (int t = tl; t < PPP; t += 16) part += (double)s_red[t * 2 * SW + col];
+    }
+  }
+  __syncthreads();
+  double* s_d = reinterpret_cast<double*>(s_lds);  // [16][2*SW]
+  if (threadIdx.x < 2 * SW * 16) s_d[threadIdx.x] = part;
+  __syncthreads();
   if (threadIdx.x < 2 * SW) {
     double acc = 0.0;
-    for (int t = 0; t < PPP; ++t) acc += (double)s_red[t * 2 * SW + threadIdx.x];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc += s_d[t * 2 * SW + threadIdx.x];
     const int col = threadIdx.x < SW ? c0 + threadIdx.x : Co + c0 + (threadIdx.x - SW);
     ws[(size_t)b * 2 * Co + col] = (float)acc;
   }
@@ -313,26 +374,55 @@ __global__ __launch_bounds__(256) void edgeconv_bn_act_kernel(
   }
 }
 
+template <int CIN, int NT>
+int launch_fused_nt(const float* x, int64_t ldx, const float* wcat, const float* qbias, const int32_t* idx,
+                    const float* gamma, int B, int N, int Co, float* z, uint8_t* arg, float* s1, float* pq_out,
+                    int64_t ldpq, float* ws, hipStream_t st) {
+  const size_t plds = (size_t)N * SW * sizeof(float);
+  const size_t rlds = (size_t)(NT / LP) * 2 * SW * sizeof(float);
+  const size_t sh = plds > rlds ? plds : rlds;
+  static SugLdsOptIn note;
+  if (int rc = sug_allow_dynamic_lds(note, &edgeconv_fused_fwd_kernel<CIN, 20, NT>, 150 * 1024, "sug_edgeconv_fused_layer_fwd"))
+    return rc;
+  hipLaunchKernelGGL((edgeconv_fused_fwd_kernel<CIN, 20, NT>), dim3(B * (Co / SW)), dim3(NT), sh, st, x, ldx, wcat, qbias, idx,
+                     gamma, B, N, Co, z, arg, s1, pq_out, ldpq, ws);
+  SUG_LAUNCH_CHECK("sug_edgeconv_fused_layer_fwd");
+  return SUG_OK;
+}
+
 template <int CIN>
 int launch_fused(const float* x, int64_t ldx, const float* wcat, const float* qbias, const int32_t* idx,
                  const float* gamma, int B, int N, int Co, float* z, uint8_t* arg, float* s1, float* pq_out,
                  int64_t ldpq, float* ws, hipStream_t st) {
-  const size_t plds = (size_t)N * SW * sizeof(float);
-  const size_t rlds = (size_t)PPP * 2 * SW * sizeof(float);
-  const size_t sh = plds > rlds ? plds : rlds;
-  static SugLdsOptIn note;
-  if (int rc = sug_allow_dynamic_lds(note, &edgeconv_fused_fwd_kernel<CIN, 20>, 150 * 1024, "sug_edgeconv_fused_layer_fwd"))
-    return rc;
-  hipLaunchKernelGGL((edgeconv_fused_fwd_kernel<CIN, 20>), dim3(B * (Co / SW)), dim3(FT), sh, st, x, ldx, wcat, qbias, idx,
-                     gamma, B, N, Co, z, arg, s1, pq_out, ldpq, ws);
-  SUG_LAUNCH_CHECK("sug_edgeconv_fused_layer_fwd");
-  return SUG_OK;
+  // no more workgroups than CUs (or a P image beyond half the LDS): one 16-wave workgroup per CU; otherwise two
+  // 8-wave workgroups per CU, whose phases overlap
+  const bool big = (int64_t)B * (Co / SW) <= 256 || (size_t)N * SW * sizeof(float) > 80 * 1024;
+#ifdef SUG_EF_FORCE_NT
+  return launch_fused_nt<CIN, SUG_EF_FORCE_NT>(x, ldx, wcat, qbias, idx, gamma, B, N, Co, z, arg, s1, pq_out, ldpq, ws, st);
+#endif
+  if (big) return launch_fused_nt<CIN, 1024>(x, ldx, wcat, qbias, idx, gamma, B, N, Co, z, arg, s1, pq_out, ldpq, ws, st);
+  return launch_fused_nt<CIN, 512>(x, ldx, wcat, qbias, idx, gamma, B, N, Co, z, arg, s1, pq_out, ldpq, ws, st);
 }
 
 }  // namespace
 
 int sug_affine_act_groups(const float* z, int64_t ldz, const float* coef, int64_t rows, int groups, int C, float slope,
                           float* out, int64_t ldo, hipStream_t st);
+
+// Statistics fold + BatchNorm + LeakyReLU of an EdgeConv layer in ONE launch (edgeconv_bn_act_kernel), shared by the
+// fused layer below and by the library-GEMM path (edgeconv.hip): ws = `groups` x nblk partial rows [2Co] (group-major),
+// z [groups*rows_g, Co] dense, count = samples per channel and group.
+int sug_edgeconv_bn_act(const float* ws, int nblk, int Co, int groups, const float* gamma, const float* beta, double count,
+                        float eps, float momentum, float* running_mean, float* running_var, float* coef, const float* z,
+                        int64_t rows_g, float slope, float* out, int64_t ldo, hipStream_t st) {
+  int rpw = 64;                                   // rows per workgroup: >= 1024 workgroups where the layer has them
+  while ((rows_g + rpw - 1) / rpw * groups > 4096) rpw *= 2;
+  hipLaunchKernelGGL(edgeconv_bn_act_kernel, dim3((unsigned)((rows_g + rpw - 1) / rpw), groups), dim3(256),
+                     (size_t)2 * Co * sizeof(float), st, ws, nblk, Co, groups, gamma, beta, count, eps, momentum,
+                     running_mean, running_var, coef, z, rows_g, slope, out, ldo, rpw);
+  SUG_LAUNCH_CHECK("sug_edgeconv_bn_act");
+  return SUG_OK;
+}
 
 extern "C" int sug_edgeconv_fused_supported(int N, int k, int Cin, int Co) {
   return k == 20 && (Cin == 3 || Cin == 64 || Cin == 128) && Co % 16 == 0 && Co >= 16 && Co <= 1024 && N >= 32 &&
@@ -365,13 +455,11 @@ extern "C" int sug_edgeconv_fused_layer_fwd(const float* x, int64_t ldx, int Cin
     rc = launch_fused<128>(x, ldx, wcat, qbias, idx, gamma, B, N, Co, z, arg, s1, pq_out, ldpq, ws, st);
   if (rc != SUG_OK) return rc;
   const int64_t rows_g = (int64_t)(B / groups) * N;
+#ifdef SUG_EF_ABL_NOACT
+  return SUG_OK;
+#endif
   if (!training)               // eval mode: coef holds the running-statistics coefficients of every group
     return sug_affine_act_groups(z, Co, coef, rows_g, groups, Co, slope, out, ldo, st) == 0 ? SUG_OK : SUG_ERR_ARG;
-  int rpw = 64;                                   // rows per workgroup: >= 1024 workgroups where the layer has them
-  while ((rows_g + rpw - 1) / rpw * groups > 4096) rpw *= 2;
-  hipLaunchKernelGGL(edgeconv_bn_act_kernel, dim3((unsigned)((rows_g + rpw - 1) / rpw), groups), dim3(256),
-                     (size_t)2 * Co * sizeof(float), st, ws, B / groups, Co, groups, gamma, beta, (double)rows_g * k, eps,
-                     momentum, running_mean, running_var, coef, z, rows_g, slope, out, ldo, rpw);
-  SUG_LAUNCH_CHECK("sug_edgeconv_fused_layer_fwd(bn_act)");
-  return SUG_OK;
+  return sug_edgeconv_bn_act(ws, B / groups, Co, groups, gamma, beta, (double)rows_g * k, eps, momentum, running_mean,
+                             running_var, coef, z, rows_g, slope, out, ldo, st);
 }

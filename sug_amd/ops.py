@@ -853,8 +853,15 @@ def edgeconv_bn_act_max(pq, idx, gamma, beta, running_mean, running_var, trainin
 EDGECONV_FUSED = _os.environ.get('SUG_EDGECONV_FUSED', '1') == '1'
 
 
+# Widest input the fused layer takes by default.  A workgroup = (cloud, 16-channel slice) streams the cloud's x rows
+# through L2 once per slice; at Cin = 128 / Co = 256 (DGCNN conv4: 16 slices x 512 KB per cloud) those re-reads cost
+# more than the [P|Q] round trip of the library-GEMM path (tools/bench_edgeconv_fused.py: 208 vs ~190 us per 64 clouds),
+# at Cin <= 64 the fused layer is level or ahead.  SUG_EDGECONV_FUSED_MAXC=128 fuses every layer.
+EDGECONV_FUSED_MAXC = int(_os.environ.get('SUG_EDGECONV_FUSED_MAXC', '64'))
+
+
 def edgeconv_fused_supported(N, k, Cin, Co):
-    return EDGECONV_FUSED and bool(lib().sug_edgeconv_fused_supported(N, k, Cin, Co))
+    return EDGECONV_FUSED and Cin <= EDGECONV_FUSED_MAXC and bool(lib().sug_edgeconv_fused_supported(N, k, Cin, Co))
 
 
 class _EdgeConvFused(torch.autograd.Function):

@@ -298,8 +298,8 @@ def test_edgeconv_fused_matches_gemm_path(C, Co, N, B, G):
         m = conv_2d(2 * C, Co, 1, activation='leakyrelu', bias=True)
         m.load_state_dict(O.fill_params({kk: tuple(v.shape) for kk, v in m.state_dict().items()}, 9))
         m = m.cuda().train()
-        keep = ops.EDGECONV_FUSED
-        ops.EDGECONV_FUSED = fused
+        keep, keepc = ops.EDGECONV_FUSED, ops.EDGECONV_FUSED_MAXC
+        ops.EDGECONV_FUSED, ops.EDGECONV_FUSED_MAXC = fused, 128          # (the default fuses Cin <= 64 only)
         try:
             assert bool(ops.edgeconv_fused_supported(N, k, C, Co)) == fused
             xi = x.clone().requires_grad_(True)
@@ -309,7 +309,7 @@ def test_edgeconv_fused_matches_gemm_path(C, Co, N, B, G):
             assert y.data_ptr() == wide[:, :, 32:32 + Co].data_ptr()
             (y * probe).sum().backward()
         finally:
-            ops.EDGECONV_FUSED = keep
+            ops.EDGECONV_FUSED, ops.EDGECONV_FUSED_MAXC = keep, keepc
         assert float(wide[:, :, :32].abs().max()) == 0 and float(wide[:, :, 32 + Co:].abs().max()) == 0
         res.append(dict(y=y.detach().clone(), coef=coef.clone(), gx=xi.grad.clone(), gw=m.conv[0].weight.grad.clone(),
                         gb=m.conv[0].bias.grad.clone(), gg=m.conv[1].weight.grad.clone(), gbeta=m.conv[1].bias.grad.clone(),
