@@ -54,6 +54,15 @@ def kernel_model(name, shape):
     if name.startswith('knn'):
         C = shape['C']
         return {'bytes': B * (4 * C * N + 4 * N * k), 'flops': B * N * N * (2 * C + 3)}
+    if name.startswith('edgeconv_fused_fwd'):       # fused layer call (2 launches): SURVEY 8d's fused-layer bytes
+        C, Co = shape['C'], shape['Co']              # x, idx in; activations out; + arg-max bytes when a backward follows
+        return {'bytes': B * N * (4 * C + 4 * Co + 4 * k + (Co if shape.get('train') else 0)),
+                'flops': B * N * (2 * C * 2 * Co + 6 * k * Co)}
+    if name.startswith('ptran_'):                   # k-expanded [B*n*k, d] operands, e bytes per element
+        R, d, e = B * N * k, shape['d'], shape['e']
+        nops = {'ptran_pos1_fwd': 1, 'ptran_qk_fwd': 2, 'ptran_attn_fwd': 2, 'ptran_attn_bwd': 4, 'ptran_qk_bwd': 2,
+                'ptran_relu_bwd': 2, 'ptran_pos1_bwd': 1}.get(name.rsplit('_n', 1)[0], 1)
+        return {'bytes': nops * R * d * e, 'flops': 0}
     if name.startswith(('edgeconv_fwd', 'edgeconv_layer_fwd')):     # layer call: + stats fold + affine pass
         Co = shape['Co']            # read PQ (8Co) + idx (4k); write z (4Co) + arg (Co) + s1 (4Co)
         return {'bytes': B * N * (8 * Co + 4 * k + 9 * Co), 'flops': B * N * k * Co * 6}
@@ -71,6 +80,112 @@ def kernel_model(name, shape):
 BENCH_METHODS = {'GEO_MMD': [{'NAME': 'SOFT_MMD', 'LABEL_SCALE': 50, 'GEO_WEIGHTS': 'mean2one', 'GEO_SCALE': 1}],
                  'SEM_MMD': [{'NAME': 'SOFT_MMD', 'LABEL_SCALE': 5, 'SEM_WEIGHTS': 'mean2one', 'LABEL_WEIGHT': 0.5,
                               'SEM_SCALE': 1}]}
+
+
+KERNEL_SOURCES = {'knn': ('knn_pc.hip', 'mfma_tile.h', 'common.h'), 'edgeconv_fused': ('edgeconv_fused.hip', 'common.h'),
+                  'edgeconv': ('edgeconv.hip', 'common.h'), 'pointmlp': ('pointmlp.hip', 'mfma_tile.h', 'common.h'),
+                  'ptran': ('ptran.hip', 'common.h')}
+
+
+def kernel_source_hash(name):
+    """sha256 (12 hex digits) of the sources of the kernel family `name` belongs to: the PMC traffic file of a kernel
+    carries this hash in its name (tools/pmc_traffic.py), so numbers of an older kernel version are never reported."""
+    import hashlib
+    fam = max((f for f in KERNEL_SOURCES if name.startswith(f)), key=len, default=None)
+    if fam is None:
+        return None
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES[fam]:
+        with open(os.path.join(ROOT, 'sug_amd', 'csrc', f), 'rb') as fh:
+            h.update(fh.read())
+    return fam + '_' + h.hexdigest()[:12]
+
+
+def pmc_traffic(name, shape):
+    """HBM bytes per launch of kernel `name` from the committed PMC passes, or None when there is no file for the
+    CURRENT sources of that kernel or the shape differs."""
+    tag = kernel_source_hash(name)
+    if tag is None:
+        return None
+    try:
+        rec = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic_%s.json' % tag))).get(name)
+    except (OSError, ValueError):
+        return None
+    if rec and all(rec.get(k) == shape.get(k) for k in ('B', 'N', 'k')):
+        return rec
+    return None
+
+
+def kernel_table(profs):
+    """{name: [(ev0, ev1, shape), ...]} -> {name: launches, avg / total ms, GB/s, TFLOP/s, bound, frac}."""
+    kern = {}
+    for name, recs in profs.items():
+        ms = [a.elapsed_time(b) for a, b, _ in recs]
+        mdl = kernel_model(name, recs[0][2])
+        avg = sum(ms) / len(ms)
+        gbps = mdl['bytes'] / avg / 1e6 if avg > 0 else 0.0
+        tfl = mdl['flops'] / avg / 1e9 if avg > 0 else 0.0
+        cb = mdl['flops'] / max(mdl['bytes'], 1) > FP32_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS
+        kern[name] = {'launches': len(ms), 'avg_ms': avg, 'total_ms': sum(ms), 'GBps': gbps, 'TFLOPs': tfl,
+                      'bytes': mdl['bytes'], 'flops': mdl['flops'], 'bound': 'mfma' if cb else 'hbm',
+                      'frac': tfl / FP32_PEAK_TFLOPS if cb else gbps / HBM_PEAK_GBS}
+    return kern
+
+
+def other_workload(model_name, B, N, fp16, dev, steps=10, warmup=3, profile_steps=3):
+    """One more BASELINE configuration in the same process: `steps` hipGraph-replayed SUG steps after `warmup`,
+    then a few eager steps with kernel events for the dominant hand-written kernel."""
+    from sug_amd import ops
+    from sug_amd.model import Ptran_transformer as PT
+    from sug_amd.model.Model import Net_MDA
+    from sug_amd.train_step import SUGStep
+    keep = (PT.GEMM_DTYPE, PT.PROJ_16BIT)
+    try:
+        if fp16:
+            PT.GEMM_DTYPE, PT.PROJ_16BIT = torch.float16, True
+        torch.manual_seed(666)
+        model = Net_MDA(model_name).to(dev).train()
+        tr = SUGStep(model, lr=1e-3, weight_decay=5e-5, use_graph=True, methods=BENCH_METHODS)
+        batch = synth(B, N, 666, dev)
+        torch.manual_seed(666)
+        for _ in range(max(warmup, 3)):
+            tr.step(*batch)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            losses = tr.step(*batch)
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / steps
+        vals = [None if l is None else float(l) for l in losses]
+        tr.use_graph = False
+        tr.fused_heads = False
+        tr.step(*batch)
+        torch.cuda.synchronize()
+        keep_prof = (ops.PROFILE, ops.PROFILE_ONLY)
+        ops.PROFILE_ONLY, ops.PROFILE = {'edgeconv', 'pointmlp', 'knn', 'ptran'}, {}
+        for _ in range(profile_steps):
+            tr.step(*batch)
+        torch.cuda.synchronize()
+        prof, (ops.PROFILE, ops.PROFILE_ONLY) = ops.PROFILE, keep_prof
+        kern = kernel_table(prof)
+        out = {'workload': '%s, N=%d, batch=%d per domain, MSA+SDA losses on' % (BACKBONE.get(model_name, model_name), N, B)
+                           + (', fp16 transformer linears' if fp16 else ''),
+               'dtype': 'f16' if fp16 else 'f32', 'ms_per_step': ms, 'clouds_per_sec': 2 * B / (ms * 1e-3), 'steps': steps,
+               'warmup': max(warmup, 3), 'launch': 'hipGraph replay of the whole step', 'losses': vals}
+        if kern:
+            dom = max(kern, key=lambda n: kern[n]['total_ms'])
+            kd = kern[dom]
+            out['dominant_kernel'] = {'kernel': dom, 'bound': kd['bound'], 'frac': round(kd['frac'], 4),
+                                      'avg_launch_ms': round(kd['avg_ms'], 5),
+                                      'ms_per_step': round(kd['total_ms'] / profile_steps, 4),
+                                      'unit': 'TFLOP/s' if kd['bound'] == 'mfma' else 'GB/s',
+                                      'achieved': round(kd['TFLOPs'] if kd['bound'] == 'mfma' else kd['GBps'], 2)}
+        return out
+    finally:
+        PT.GEMM_DTYPE, PT.PROJ_16BIT = keep
+        tr = model = None
+        gc.collect()
+        torch.cuda.empty_cache()
 
 
 def cpu_baseline(B, N, steps=1):
@@ -141,6 +256,8 @@ def main():
     ap.add_argument('--caller-steps', type=int, default=10,
                     help='extra timed steps in the unchanged-caller form (four separate model(...) calls, no sharing); 0 = skip')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-other-workloads', action='store_true',
+                    help='skip the extra configurations timed after the headline region (BASELINE configs 1, 3, 5 -> config.other_workloads)')
     ap.add_argument('--fp16', action='store_true',
                     help='Point Transformer only (BASELINE config 5): k-expanded attention tensors and their 512x512 linears in '
                          'fp16 (MFMA, fp32 accumulation); default fp32 = the reference arithmetic')
@@ -299,39 +416,22 @@ def main():
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    share_prefix_on, pair_domains_on = trainer.share_prefix, trainer.pair_domains
     if rank == 0:
         clouds = world * 2 * B * args.steps
         value = clouds / dt
         # ---- per-kernel live timings (events on the launch stream) -> roofline of the dominant one
-        kern = {}
         timed_names = set(prof)
         allprof = dict(extra_prof)
         allprof.update(prof)
-        for name, recs in list(prof.items()) + list(extra_prof.items()):
-            ms = [a.elapsed_time(b) for a, b, _ in recs]
-            shape = recs[0][2]
-            mdl = kernel_model(name, shape)
-            avg = sum(ms) / len(ms)
-            gbps = mdl['bytes'] / avg / 1e6 if avg > 0 else 0.0
-            tfl = mdl['flops'] / avg / 1e9 if avg > 0 else 0.0
-            cb = mdl['flops'] / max(mdl['bytes'], 1) > FP32_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS
-            kern[name] = {'launches': len(ms), 'avg_ms': avg, 'total_ms': sum(ms), 'GBps': gbps, 'TFLOPs': tfl,
-                          'bytes': mdl['bytes'], 'bound': 'mfma' if cb else 'hbm',
-                          'frac': tfl / FP32_PEAK_TFLOPS if cb else gbps / HBM_PEAK_GBS}
+        kern = kernel_table(allprof)
         roofline = None
         if kern:
             fam = [n for n in kern if n.startswith(tuple(timed_family))]
             cands = timed_names or fam or set(kern)
-            top = max(kern[n]['total_ms'] for n in cands)
-            # the two feature-space kNN instances share the step almost evenly (3 x C=64 against 2 x C=128): among
-            # kernels within 5 % of the largest summed time the one with the most algorithmic work per step is named,
-            # so that the line does not flip from run to run (every kernel's figures are under `kernels` regardless)
-            near = [n for n in cands if kern[n]['total_ms'] >= 0.95 * top]
-            dom = max(near, key=lambda n: (kernel_model(n, allprof[n][0][2])['flops'] * kern[n]['launches'], kern[n]['total_ms']))
+            dom = max(cands, key=lambda n: kern[n]['total_ms'])            # strictly the largest summed time
             kd = kern[dom]
-            ai = kernel_model(dom, allprof[dom][0][2])
-            compute_bound = ai['flops'] / max(ai['bytes'], 1) > FP32_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS
-            if compute_bound:
+            if kd['bound'] == 'mfma':
                 roofline = {'kernel': dom, 'bound': 'mfma', 'achieved': kd['TFLOPs'], 'peak': FP32_PEAK_TFLOPS,
                             'unit': 'TFLOP/s', 'frac': kd['TFLOPs'] / FP32_PEAK_TFLOPS, 'traffic': None,
                             'note': 'fp32 kernel; peak = fp32 vector/MFMA rate; HBM GB/s at algorithmic bytes: %.1f' % kd['GBps']}
@@ -339,18 +439,35 @@ def main():
                 roofline = {'kernel': dom, 'bound': 'hbm', 'achieved': kd['GBps'], 'peak': HBM_PEAK_GBS,
                             'unit': 'GB/s', 'frac': kd['GBps'] / HBM_PEAK_GBS, 'traffic': None}
             roofline['avg_launch_ms'] = kd['avg_ms']
-            # HBM bytes per launch from the committed PMC passes (not collectable inside this
-            # process): only for the shape they were taken on
-            try:
-                pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles',
-                                                  'r02_pmc_traffic.json'))).get(dom)
-                shp = allprof[dom][0][2]
-                if pmc and all(pmc[k] == shp[k] for k in ('B', 'N', 'k')):
-                    roofline['traffic'] = pmc['traffic_bytes']
-                    roofline['traffic_note'] = 'bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE; ' \
-                                               'algorithmic %d' % ai['bytes']
-            except (OSError, ValueError, KeyError):
-                pass
+            # time-weighted fraction over the whole kernel family of the named kernel (e.g. kNN at C = 3, 64, 128)
+            famname = dom.split('_')[0]
+            members = [n for n in kern if n.split('_')[0] == famname and kern[n]['bound'] == kd['bound']]
+            tt = sum(kern[n]['total_ms'] for n in members)
+            if tt > 0:
+                work = sum((kern[n]['flops'] if kd['bound'] == 'mfma' else kern[n]['bytes']) * kern[n]['launches'] for n in members)
+                rate = work / tt / (1e9 if kd['bound'] == 'mfma' else 1e6)
+                roofline['family'] = {'kernels': sorted(members), 'achieved': rate,
+                                      'frac': rate / (FP32_PEAK_TFLOPS if kd['bound'] == 'mfma' else HBM_PEAK_GBS)}
+            # HBM bytes per launch from the committed PMC passes of THIS kernel version (file name = source hash;
+            # tools/pmc_traffic.py); not collectable inside this process
+            rec = pmc_traffic(dom, allprof[dom][0][2])
+            if rec:
+                roofline['traffic'] = rec['traffic_bytes']
+                roofline['traffic_note'] = 'bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, profiles/pmc_traffic_%s.json; algorithmic %d' % (kernel_source_hash(dom), kd['bytes'])
+            else:
+                roofline['traffic_note'] = 'no PMC passes on file for this kernel version (profiles/pmc_traffic_%s.json)' % kernel_source_hash(dom)
+        others = None
+        if world == 1 and not args.plain and not args.no_other_workloads and args.model == 'DGCNN':
+            # the other BASELINE configurations, driver-timed in the same line (configs 1, 3, 5 and N = 2048)
+            trainer = model = None
+            gc.collect()
+            torch.cuda.empty_cache()
+            others = []
+            for nm, b_, n_, f16 in (('Pointnet', 8, 1024, False), ('Pointnet2', 64, 2048, False), ('PTran', 16, 2048, True)):
+                try:
+                    others.append(other_workload(nm, b_, n_, f16, dev))
+                except RuntimeError as e:
+                    others.append({'workload': '%s N=%d batch=%d' % (nm, n_, b_), 'error': str(e).splitlines()[0][:200]})
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cps, secs = cpu_baseline(args.cpu_batch, N, args.cpu_steps)
@@ -368,15 +485,17 @@ def main():
                           'global_batch': world * B, 'parallelism': 'dp%d' % world,
                           'launch': 'hipGraph replay of the whole step' if graph_mode else 'eager',
                           'eager_ms_per_step': eager_ms,
-                          'share_prefix': trainer.share_prefix, 'pair_domains': trainer.pair_domains,
+                          'share_prefix': share_prefix_on, 'pair_domains': pair_domains_on,
                           'tuned_gemms': tuned, 'geo_weights': 'mean2one', 'sem_weights': 'mean2one',
                           'weight_gradients': ('own split-K kernels (no library split-K, hence no memset nodes, inside the captured graph)'
                                                if graph_mode else 'own kernels, tuned library GEMMs for the listed shapes'),
                           'unchanged_caller_ms_per_step': caller_ms,
+                          'clouds_per_step': world * 2 * B,
+                          'other_workloads': others,
                           **({'fp16_linears': 'k-expanded and per-point 512-wide linears of the transformer blocks'}
                              if (args.fp16 and args.model == 'PTran') else {})},
                'roofline': roofline, 'cpu_baseline': cpu, 'losses': loss_vals,
-               'kernels': {k: {kk: (round(vv, 5) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in kern.items()}}
+               'kernels': {k: {kk: (round(vv, 5) if isinstance(vv, float) else vv) for kk, vv in v.items() if kk != 'flops'} for k, v in kern.items()}}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -325,7 +325,8 @@ int sug_edgeconv_layer_fwd(const float* pq, int64_t ldpq, const int32_t* idx, co
  * launches: MFMA + gather + BatchNorm partial rows, then statistics fold + BatchNorm + LeakyReLU (the fold runs in
  * every workgroup of the second launch; coef [groups,5,Co] and the running buffers are written by one of them).
  * Requires k == 20, Co % 16 == 0, N*64 bytes of LDS (N <= 2400): sug_edgeconv_fused_supported.
- * ws: SUG_STATS_BLOCKS*2*Co floats.  training = 0: coef is an input (running-statistics coefficients). */
+ * ws: SUG_STATS_BLOCKS*2*Co floats.  training = 0: coef is an input (running-statistics coefficients).
+ * arg, s1 and pq_out serve the backward only and may be NULL (a forward without autograd writes z and out alone). */
 int sug_edgeconv_fused_supported(int N, int k, int Cin, int Co);
 int sug_edgeconv_fused_layer_fwd(const float* x, int64_t ldx, int Cin, const float* wcat, const float* qbias,
                                  const int32_t* idx, const float* gamma, const float* beta, int B, int N, int k,

@@ -37,7 +37,10 @@ constexpr int LP = SW / 4;     // lanes per point in the gather phase
 // feature count = row length of wcat.  KK: neighbours per point.  NT: threads per workgroup -- 512 (two workgroups
 // per CU: one's MFMA phase overlaps the other's gather phase) or 1024 (layers with no more workgroups than CUs);
 // either way 16 waves per CU, hence <= 128 registers per lane.
-template <int CIN, int KK, int NT>
+// QLDS: the Q slice waits in LDS next to the P image (2 x N x 64 bytes: one workgroup per CU) instead of in the z
+// buffer -- parked in global memory it costs its bytes twice in HBM-side traffic (PMC: written back before z
+// overwrites it, fetched again by the gather phase), which is what the fusion is there to avoid.
+template <int CIN, int KK, int NT, bool QLDS>
 __global__ __launch_bounds__(NT, 4) void edgeconv_fused_fwd_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ wcat, const float* __restrict__ qbias,
     const int32_t* __restrict__ idx, const float* __restrict__ gamma, int B, int N, int Co,
@@ -52,6 +55,7 @@ __global__ __launch_bounds__(NT, 4) void edgeconv_fused_fwd_kernel(
   constexpr int PPP = NT / LP;                     // points per pass of the gather phase
   extern __shared__ __attribute__((aligned(16))) float s_lds[];
   float* s_p = s_lds;                              // [N][SW]  sign(gamma) * P slice; later the reduction scratch
+  float* s_q = s_lds + (size_t)N * SW;             // [N][SW]  Q slice (QLDS)
   const int nslice = Co / SW;
   int b, sl;
   if ((B & 7) == 0) {                              // the slices of a cloud share an XCD (its L2 holds x once)
@@ -169,10 +173,16 @@ __global__ __launch_bounds__(NT, 4) void edgeconv_fused_fwd_kernel(
         } else {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const float4 b4 = qbias ? ld4(qbias + c0 + 4 * q) : make_float4(0, 0, 0, 0);
-            st4(qdst + (int64_t)n * ldq + 4 * q,
-                make_float4(__fadd_rn(acc[4 * q], b4.x), __fadd_rn(acc[4 * q + 1], b4.y),
-                            __fadd_rn(acc[4 * q + 2], b4.z), __fadd_rn(acc[4 * q + 3], b4.w)));
+            const int qq = QLDS ? (q + rot) & 3 : q;
+            float4 qv;
+            qv.x = qq == 0 ? acc[0] : qq == 1 ? acc[4] : qq == 2 ? acc[8] : acc[12];
+            qv.y = qq == 0 ? acc[1] : qq == 1 ? acc[5] : qq == 2 ? acc[9] : acc[13];
+            qv.z = qq == 0 ? acc[2] : qq == 1 ? acc[6] : qq == 2 ? acc[10] : acc[14];
+            qv.w = qq == 0 ? acc[3] : qq == 1 ? acc[7] : qq == 2 ? acc[11] : acc[15];
+            const float4 b4 = qbias ? ld4(qbias + c0 + 4 * qq) : make_float4(0, 0, 0, 0);
+            qv = make_float4(__fadd_rn(qv.x, b4.x), __fadd_rn(qv.y, b4.y), __fadd_rn(qv.z, b4.z), __fadd_rn(qv.w, b4.w));
+            if (QLDS) st4(s_q + n * SW + 4 * qq, qv);
+            if (!QLDS || pq_out) st4(qdst + (int64_t)n * ldq + 4 * qq, qv);
           }
         }
       }
@@ -204,7 +214,7 @@ __global__ __launch_bounds__(NT, 4) void edgeconv_fused_fwd_kernel(
       const int4* ir = reinterpret_cast<const int4*>(idx + p * KK);
 #pragma unroll
       for (int t = 0; t < KK / 4; ++t) nv[t] = ir[t];
-      q = ld4(qdst + (int64_t)n * ldq + lp * 4);
+      q = QLDS ? ld4(s_q + n * SW + lp * 4) : ld4(qdst + (int64_t)n * ldq + lp * 4);
       q.x *= sg.x; q.y *= sg.y; q.z *= sg.z; q.w *= sg.w;
     }
     float bx = 0, by = 0, bz = 0, bw = 0;
@@ -253,9 +263,16 @@ __global__ __launch_bounds__(NT, 4) void edgeconv_fused_fwd_kernel(
     qx = fmaf(q.x, yx + sx, qx); qy = fmaf(q.y, yy + sy, qy);          // sum y'^2 = sum p^2 + q (2 sum p + k q)
     qz = fmaf(q.z, yz + sz, qz); qw = fmaf(q.w, yw + sw, qw);
     const int64_t o = ((int64_t)b * N + n) * Co + c0 + lp * 4;
-    st4(z + o, make_float4(zx, zy, zz, zw));                          // (overwrites this point's parked Q quarter)
-    *reinterpret_cast<uint32_t*>(arg + o) =
-        (uint32_t)jx | ((uint32_t)jy << 8) | ((uint32_t)jz << 16) | ((uint32_t)jw << 24);
+#ifndef SUG_EF_ABL_NOZ
+    st4(z + o, make_float4(zx, zy, zz, zw));                          // (overwrites this point's parked Q quarter, if any)
+#else
+    if (zx == 123.456f) st4(z + o, make_float4(zx, zy, zz, zw));
+#endif
+#ifndef SUG_EF_ABL_NOARG
+    if (arg)
+      *reinterpret_cast<uint32_t*>(arg + o) =
+          (uint32_t)jx | ((uint32_t)jy << 8) | ((uint32_t)jz << 16) | ((uint32_t)jw << 24);
+#endif
     const float4 sy4 = make_float4(yx * sg.x, yy * sg.y, yz * sg.z, yw * sg.w);
     if (s1) st4(s1 + o, sy4);
     a1.x += sy4.x; a1.y += sy4.y; a1.z += sy4.z; a1.w += sy4.w;
@@ -374,18 +391,18 @@ __global__ __launch_bounds__(256) void edgeconv_bn_act_kernel(
   }
 }
 
-template <int CIN, int NT>
+template <int CIN, int NT, bool QLDS>
 int launch_fused_nt(const float* x, int64_t ldx, const float* wcat, const float* qbias, const int32_t* idx,
                     const float* gamma, int B, int N, int Co, float* z, uint8_t* arg, float* s1, float* pq_out,
                     int64_t ldpq, float* ws, hipStream_t st) {
-  const size_t plds = (size_t)N * SW * sizeof(float);
+  const size_t plds = (size_t)N * SW * sizeof(float) * (QLDS ? 2 : 1);
   const size_t rlds = (size_t)(NT / LP) * 2 * SW * sizeof(float);
   const size_t sh = plds > rlds ? plds : rlds;
   static SugLdsOptIn note;
-  if (int rc = sug_allow_dynamic_lds(note, &edgeconv_fused_fwd_kernel<CIN, 20, NT>, 150 * 1024, "sug_edgeconv_fused_layer_fwd"))
+  if (int rc = sug_allow_dynamic_lds(note, &edgeconv_fused_fwd_kernel<CIN, 20, NT, QLDS>, 160 * 1024, "sug_edgeconv_fused_layer_fwd"))
     return rc;
-  hipLaunchKernelGGL((edgeconv_fused_fwd_kernel<CIN, 20, NT>), dim3(B * (Co / SW)), dim3(NT), sh, st, x, ldx, wcat, qbias, idx,
-                     gamma, B, N, Co, z, arg, s1, pq_out, ldpq, ws);
+  hipLaunchKernelGGL((edgeconv_fused_fwd_kernel<CIN, 20, NT, QLDS>), dim3(B * (Co / SW)), dim3(NT), sh, st, x, ldx, wcat, qbias,
+                     idx, gamma, B, N, Co, z, arg, s1, pq_out, ldpq, ws);
   SUG_LAUNCH_CHECK("sug_edgeconv_fused_layer_fwd");
   return SUG_OK;
 }
@@ -394,14 +411,13 @@ template <int CIN>
 int launch_fused(const float* x, int64_t ldx, const float* wcat, const float* qbias, const int32_t* idx,
                  const float* gamma, int B, int N, int Co, float* z, uint8_t* arg, float* s1, float* pq_out,
                  int64_t ldpq, float* ws, hipStream_t st) {
-  // no more workgroups than CUs (or a P image beyond half the LDS): one 16-wave workgroup per CU; otherwise two
-  // 8-wave workgroups per CU, whose phases overlap
-  const bool big = (int64_t)B * (Co / SW) <= 256 || (size_t)N * SW * sizeof(float) > 80 * 1024;
-#ifdef SUG_EF_FORCE_NT
-  return launch_fused_nt<CIN, SUG_EF_FORCE_NT>(x, ldx, wcat, qbias, idx, gamma, B, N, Co, z, arg, s1, pq_out, ldpq, ws, st);
+  // P and Q slices both in LDS (one 16-wave workgroup per CU) while they fit; larger clouds park Q in the z buffer
+  const bool qlds = (size_t)N * SW * sizeof(float) * 2 <= 160 * 1024;
+#ifdef SUG_EF_ABL_QGLOBAL
+  return launch_fused_nt<CIN, 512, false>(x, ldx, wcat, qbias, idx, gamma, B, N, Co, z, arg, s1, pq_out, ldpq, ws, st);
 #endif
-  if (big) return launch_fused_nt<CIN, 1024>(x, ldx, wcat, qbias, idx, gamma, B, N, Co, z, arg, s1, pq_out, ldpq, ws, st);
-  return launch_fused_nt<CIN, 512>(x, ldx, wcat, qbias, idx, gamma, B, N, Co, z, arg, s1, pq_out, ldpq, ws, st);
+  if (qlds) return launch_fused_nt<CIN, 1024, true>(x, ldx, wcat, qbias, idx, gamma, B, N, Co, z, arg, s1, pq_out, ldpq, ws, st);
+  return launch_fused_nt<CIN, 1024, false>(x, ldx, wcat, qbias, idx, gamma, B, N, Co, z, arg, s1, pq_out, ldpq, ws, st);
 }
 
 }  // namespace
@@ -426,7 +442,7 @@ int sug_edgeconv_bn_act(const float* ws, int nblk, int Co, int groups, const flo
 
 extern "C" int sug_edgeconv_fused_supported(int N, int k, int Cin, int Co) {
   return k == 20 && (Cin == 3 || Cin == 64 || Cin == 128) && Co % 16 == 0 && Co >= 16 && Co <= 1024 && N >= 32 &&
-         (size_t)N * SW * 4 <= 150 * 1024;
+         (size_t)N * SW * 4 <= 160 * 1024;
 }
 
 extern "C" int sug_edgeconv_fused_layer_fwd(const float* x, int64_t ldx, int Cin, const float* wcat, const float* qbias,
@@ -435,13 +451,13 @@ extern "C" int sug_edgeconv_fused_layer_fwd(const float* x, int64_t ldx, int Cin
                                             float slope, float* running_mean, float* running_var, float* z,
                                             uint8_t* arg, float* s1, float* pq_out, int64_t ldpq, float* coef,
                                             float* out, int64_t ldo, float* ws, void* stream) {
-  SUG_REQUIRE(x && wcat && idx && gamma && beta && z && arg && coef && out && ws, "sug_edgeconv_fused_layer_fwd: null pointer");
+  SUG_REQUIRE(x && wcat && idx && gamma && beta && z && coef && out && ws, "sug_edgeconv_fused_layer_fwd: null pointer");
   SUG_REQUIRE(B > 0 && groups >= 1 && B % groups == 0, "sug_edgeconv_fused_layer_fwd: B=%d does not split into %d groups", B, groups);
   SUG_REQUIRE(sug_edgeconv_fused_supported(N, k, Cin, Co), "sug_edgeconv_fused_layer_fwd: unsupported shape N=%d k=%d Cin=%d Co=%d", N, k, Cin, Co);
   SUG_REQUIRE(B <= SUG_STATS_ROWS, "sug_edgeconv_fused_layer_fwd: B=%d exceeds the statistics workspace", B);
   SUG_REQUIRE(ldx >= Cin && (Cin == 3 || (ldx % 4 == 0 && ((uintptr_t)x % 16) == 0)), "sug_edgeconv_fused_layer_fwd: x rows must be 16-byte aligned");
   SUG_REQUIRE(((uintptr_t)wcat % 16) == 0 && ((uintptr_t)gamma % 16) == 0 && ((uintptr_t)z % 16) == 0 && ((uintptr_t)idx % 16) == 0 &&
-                  ((uintptr_t)arg % 4) == 0 && (!s1 || ((uintptr_t)s1 % 16) == 0) && (!qbias || ((uintptr_t)qbias % 16) == 0) &&
+                  (!arg || ((uintptr_t)arg % 4) == 0) && (!s1 || ((uintptr_t)s1 % 16) == 0) && (!qbias || ((uintptr_t)qbias % 16) == 0) &&
                   ((uintptr_t)out % 16) == 0 && ldo % 4 == 0 && ldo >= Co,
               "sug_edgeconv_fused_layer_fwd: pointers must be 16-byte aligned");
   SUG_REQUIRE(!pq_out || (ldpq >= 2 * Co && ldpq % 4 == 0 && ((uintptr_t)pq_out % 16) == 0), "sug_edgeconv_fused_layer_fwd: bad [P|Q] buffer");

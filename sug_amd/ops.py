@@ -773,7 +773,8 @@ class _EdgeConv(torch.autograd.Function):
     """BN(train or eval) + LeakyReLU + max over k of y = P[idx] + Q, see include/sug_amd.h."""
 
     @staticmethod
-    def forward(ctx, pq, idx, gamma, beta, running_mean, running_var, training, slope, eps, momentum, G, out_holder):
+    def forward(ctx, pq, idx, gamma, beta, running_mean, running_var, training, slope, eps, momentum, G, out_holder,
+                grad_on=True):
         _need_gpu(pq, idx, gamma)
         pq, B, N, C2, ld = _rows3(pq)
         Co = C2 // 2
@@ -783,7 +784,9 @@ class _EdgeConv(torch.autograd.Function):
             raise RuntimeError('edgeconv: %d clouds do not split into %d domain groups' % (B, G))
         dev = pq.device
         gamma_c, beta_c = gamma.detach().contiguous(), beta.detach().contiguous()
-        need_bwd = any(ctx.needs_input_grad[i] for i in (0, 2, 3))
+        # (needs_input_grad reports requires_grad of the inputs even under torch.no_grad(): the caller passes the grad
+        # mode, or the no-grad passes of a step would write s1 -- 4*Co bytes per point -- for a backward that never runs)
+        need_bwd = grad_on and any(ctx.needs_input_grad[i] for i in (0, 2, 3))
         z = torch.empty(B, N, Co, dtype=torch.float32, device=dev)
         arg = torch.empty(B, N, Co, dtype=torch.uint8, device=dev)
         s1 = torch.empty(B, N, Co, dtype=torch.float32, device=dev) if need_bwd else None
@@ -821,7 +824,7 @@ class _EdgeConv(torch.autograd.Function):
         pq, idx, z, arg, s1, coef = ctx.saved_tensors
         B, N, k, Co, ld, slope, training, G = ctx.meta
         if gout is None:
-            return (None,) * 12
+            return (None,) * 13
         dev = gout.device
         gout, _, _, _, ldg = _rows3(gout)                           # a column slice of a wider buffer is fine
         a = torch.empty(B, N, Co, dtype=torch.float32, device=dev)
@@ -837,7 +840,7 @@ class _EdgeConv(torch.autograd.Function):
                                                           _p(coef), B, N, k, Co, G, 1 if training else 0, slope, _p(a),
                                                           _p(red), _p(off), _p(ent), _p(dpq), 2 * Co, _p(ws), _p(rf), _st())),
               'sug_edgeconv_layer_bwd')
-        return dpq, None, rf[Co:], rf[:Co], None, None, None, None, None, None, None, None
+        return dpq, None, rf[Co:], rf[:Co], None, None, None, None, None, None, None, None, None
 
 
 def edgeconv_bn_act_max(pq, idx, gamma, beta, running_mean, running_var, training, slope, eps=1e-5, momentum=0.1,
@@ -845,7 +848,7 @@ def edgeconv_bn_act_max(pq, idx, gamma, beta, running_mean, running_var, trainin
     """pq [B,N,2*Co] = x.[W1;W2-W1]^T, idx [B,N,k] -> (out [B,N,Co], coef [5,Co] = scale, shift,
     batch mean, rstd, unbiased batch variance; [G,5,Co] under bn_groups(G > 1))."""
     return _EdgeConv.apply(pq, idx, gamma, beta, running_mean, running_var, training, slope, eps, momentum, BN_GROUPS,
-                           None if out is None else [out])
+                           None if out is None else [out], torch.is_grad_enabled())
 
 
 # The 1x1 convolution inside the gather kernel (edgeconv_fused.hip): default; SUG_EDGECONV_FUSED=0 selects the
@@ -871,7 +874,7 @@ class _EdgeConvFused(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, wcat, bias, idx, gamma, beta, running_mean, running_var, training, slope, eps, momentum, G,
-                out_holder):
+                out_holder, grad_on=True):
         _need_gpu(x, wcat, idx, gamma)
         x3, B, N, C, ld = _rows3(x)
         Co = wcat.shape[0] // 2
@@ -883,9 +886,10 @@ class _EdgeConvFused(torch.autograd.Function):
         w = wcat.detach().contiguous()
         b1 = None if bias is None else bias.detach().contiguous()
         gamma_c, beta_c = gamma.detach().contiguous(), beta.detach().contiguous()
-        need_bwd = any(ctx.needs_input_grad[i] for i in (0, 1, 2, 4, 5))
+        # (needs_input_grad ignores torch.no_grad(): the caller passes the grad mode -- see _EdgeConv)
+        need_bwd = grad_on and any(ctx.needs_input_grad[i] for i in (0, 1, 2, 4, 5))
         z = torch.empty(B, N, Co, dtype=torch.float32, device=dev)
-        arg = torch.empty(B, N, Co, dtype=torch.uint8, device=dev)
+        arg = torch.empty(B, N, Co, dtype=torch.uint8, device=dev) if need_bwd else None
         s1 = torch.empty(B, N, Co, dtype=torch.float32, device=dev) if need_bwd else None
         pq = torch.empty(B, N, 2 * Co, dtype=torch.float32, device=dev) if need_bwd else None
         ws = torch.empty(STATS_BLOCKS * 2 * Co, dtype=torch.float32, device=dev)
@@ -917,7 +921,7 @@ class _EdgeConvFused(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout, _gcoef):
         if gout is None:
-            return (None,) * 14
+            return (None,) * 15
         x3, w, idx, z, arg, s1, coef, pq = ctx.saved_tensors
         B, N, k, C, Co, slope, training, G, has_bias, xshape = ctx.meta
         dev = gout.device
@@ -941,14 +945,14 @@ class _EdgeConvFused(torch.autograd.Function):
         if has_bias and ctx.needs_input_grad[2]:
             db = colsum(dpq2[:, Co:])                              # the bias rides on the Q half
         return (None if dx is None else dx.view(xshape)), dw, db, None, rf[Co:], rf[:Co], None, None, None, None, None, \
-            None, None, None
+            None, None, None, None
 
 
 def edgeconv_fused(x, wcat, bias, idx, bn_weight, bn_bias, running_mean, running_var, training, slope, eps=1e-5,
                    momentum=0.1, out=None):
     """x [B,N,C] rows, wcat [2Co, C] = [W1 ; W2-W1], idx [B,N,k] -> (out [B,N,Co], coef) as edgeconv_bn_act_max."""
     return _EdgeConvFused.apply(x, wcat, bias, idx, bn_weight, bn_bias, running_mean, running_var, training, slope, eps,
-                                momentum, BN_GROUPS, None if out is None else [out])
+                                momentum, BN_GROUPS, None if out is None else [out], torch.is_grad_enabled())
 
 
 # ----------------------------------------------------------------------------- per-point MLP + max
@@ -1183,14 +1187,16 @@ class _PTranAttention(torch.autograd.Function):
         check(L_.sug_ptran_pos1_fwd(_p(xyz), _p(nbr), _p(w1c), _p(b1c), B, n, k, d, code, _p(T0), _st()), 'sug_ptran_pos1_fwd')
         delta = torch.addmm(wl[1], T0, wl[0].t())
         U = torch.empty(R, d, dtype=lo, device=dev)
-        check(L_.sug_ptran_qk_fwd(_p(q), _p(kf), _p(delta), _p(nbr), B, n, k, d, code, _p(U), _st()), 'sug_ptran_qk_fwd')
+        shp = {'B': B, 'N': n, 'k': k, 'd': d, 'e': 4 if code == 0 else 2}
+        check(_timed('ptran_qk_fwd_n%d' % n, shp, lambda: L_.sug_ptran_qk_fwd(_p(q), _p(kf), _p(delta), _p(nbr), B, n, k, d, code, _p(U), _st())),
+              'sug_ptran_qk_fwd')
         T1 = torch._addmm_activation(wl[3], U, wl[2].t())          # bias + ReLU in the library GEMM's epilogue
         Lg = torch.addmm(wl[5], T1, wl[4].t())
         mixed = torch.empty(B, n, d, dtype=torch.float32, device=dev)
         mx, sm = torch.empty_like(mixed), torch.empty_like(mixed)
         scale = 1.0 / (d ** 0.5)
-        check(L_.sug_ptran_attn_fwd(_p(Lg), _p(delta), _p(vf), _p(nbr), B, n, k, d, code, scale, _p(mixed), _p(mx), _p(sm),
-                                    _st()), 'sug_ptran_attn_fwd')
+        check(_timed('ptran_attn_fwd_n%d' % n, shp, lambda: L_.sug_ptran_attn_fwd(_p(Lg), _p(delta), _p(vf), _p(nbr), B, n, k, d, code, scale,
+                                                                          _p(mixed), _p(mx), _p(sm), _st())), 'sug_ptran_attn_fwd')
         ctx.save_for_backward(xyz, nbr, vf, w1c, b1c, wl[0], wl[2], wl[4], T0, delta, U, T1, Lg, mx, sm, mixed)
         ctx.meta = (B, n, k, d, code, scale)
         return mixed
@@ -1210,8 +1216,10 @@ class _PTranAttention(torch.autograd.Function):
         R = B * n * k
         cws = torch.empty(L_.sug_ptran_colsum_workspace(R), dtype=f32, device=dev)
         dbg2, dbg1, db2 = (torch.empty(d, dtype=f32, device=dev) for _ in range(3))
-        check(L_.sug_ptran_attn_bwd(_p(g), _p(mixed), _p(Lg), _p(delta), _p(vf), _p(nbr), _p(mx), _p(sm), _p(off), _p(ent), B,
-                                    n, k, d, code, scale, _p(dL), _p(da), _p(dv), _p(dbg2), _p(cws), _st()),
+        shp = {'B': B, 'N': n, 'k': k, 'd': d, 'e': 4 if code == 0 else 2}
+        check(_timed('ptran_attn_bwd_n%d' % n, shp, lambda: L_.sug_ptran_attn_bwd(_p(g), _p(mixed), _p(Lg), _p(delta), _p(vf), _p(nbr), _p(mx),
+                                                                          _p(sm), _p(off), _p(ent), B, n, k, d, code, scale, _p(dL),
+                                                                          _p(da), _p(dv), _p(dbg2), _p(cws), _st())),
               'sug_ptran_attn_bwd')
 
         dwg2 = _dweight(dL, T1)
@@ -1220,8 +1228,8 @@ class _PTranAttention(torch.autograd.Function):
         dwg1 = _dweight(dT1, U)
         dU = dT1 @ wg1l
         dq, dk = torch.empty_like(dv), torch.empty_like(dv)
-        check(L_.sug_ptran_qk_bwd(_p(dU), _p(da), _p(off), _p(ent), B, n, k, d, code, _p(dq), _p(dk), _p(db2), _p(cws),
-                                  _st()), 'sug_ptran_qk_bwd')
+        check(_timed('ptran_qk_bwd_n%d' % n, shp, lambda: L_.sug_ptran_qk_bwd(_p(dU), _p(da), _p(off), _p(ent), B, n, k, d, code, _p(dq), _p(dk),
+                                                                      _p(db2), _p(cws), _st())), 'sug_ptran_qk_bwd')
         ddelta = da                                            # = dU + da
         dw2 = _dweight(ddelta, T0)
         dT0 = ddelta @ w2l

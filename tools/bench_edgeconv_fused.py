@@ -38,7 +38,13 @@ def time_layer(L, C, Co, train, iters=20, B=64, N=1024, k=20):
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
+    fresh = os.environ.get('EF_FRESH') == '1'
+
     def call():
+        nonlocal z, arg, out
+        if fresh:           # new output buffers per launch, as the autograd op allocates them
+            z, out = torch.empty(B, N, Co, device=dev), torch.empty(B, N, Co, device=dev)
+            arg = torch.empty(B, N, Co, device=dev, dtype=torch.uint8)
         rc = L.sug_edgeconv_fused_layer_fwd(p(x), C, C, p(w), None, p(idx), p(gamma), p(beta), B, N, k, Co, 2, 1, 1e-5, 0.1, 0.01,
                                             p(rm), p(rv), p(z), p(arg), p(s1), p(pq), 2 * Co, p(coef), p(out), Co, p(ws), st)
         assert rc == 0, rc
@@ -62,6 +68,11 @@ if __name__ == '__main__':
                 ('neither, no x loads', ['-DSUG_EF_ABL_NOACT', '-DSUG_EF_ABL_NOGATHER', '-DSUG_EF_ABL_NOMFMA', '-DSUG_EF_ABL_NOLOADX']),
                 ('no x loads', ['-DSUG_EF_ABL_NOACT', '-DSUG_EF_ABL_NOLOADX'])] + \
                [(t, d.split()) for t, d in (a.split('=', 1) for a in sys.argv[1:])]
+    only = os.environ.get('EF_ONLY')           # one variant, layer 2 shape, few launches: for a rocprofv3 --pmc pass
+    if only:
+        L = build('only', only.split())
+        print(time_layer(L, 64, 64, 0, iters=5))
+        sys.exit(0)
     libs = [(t, build(t.replace(' ', '_').replace(',', ''), d)) for t, d in variants]
     for train in (0, 1):
         for C, Co in ((3, 64), (64, 64), (64, 128), (128, 256)):

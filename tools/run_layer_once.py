@@ -1,5 +1,5 @@
 """A few launches of one hot kernel at the C2 paired shape (64 clouds x 1024 points, k = 20) for rocprofv3 passes.
-usage: python tools/run_layer_once.py knn C | edgeconv C Co | pointmlp"""
+usage: python tools/run_layer_once.py knn C | edgeconv C Co | edgeconv_fwd C Co | pointmlp"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -23,6 +23,14 @@ elif what == 'edgeconv':
         for _ in range(3):
             y = m.edge_rows(x, idx)
             y.square().sum().backward()
+elif what == 'edgeconv_fwd':          # forward only, no autograd: the fused layer without the [P|Q] side output
+    C, Co = int(sys.argv[2]), int(sys.argv[3])
+    x = torch.randn(B, N, C, device='cuda') * 0.3 + torch.randn(B, 1, C, device='cuda')
+    idx = ops.knn(x, 20)
+    m = conv_2d(2 * C, Co, 1, activation='leakyrelu', bias=False).cuda().train()
+    with torch.no_grad(), ops.bn_groups(2):
+        for _ in range(5):
+            m.edge_rows(x, idx)
 else:
     x = torch.randn(B * N, 128, device='cuda', requires_grad=True)
     W = (torch.randn(1024, 128, device='cuda') / 11).requires_grad_(True)
