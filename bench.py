@@ -265,6 +265,9 @@ def main():
                     help='launch every kernel of the timed steps from Python instead of replaying a captured hipGraph '
                          '(the default on one GPU: an eager step is host-bound on this path -- ~450 launches in ~6.5 ms -- '
                          'and a single host hiccup inside a 20-step window moves the result by several per cent)')
+    ap.add_argument('--segmented', action='store_true',
+                    help='one GPU: run the multi-rank launch form (5 graph segments + 4 RCCL collectives on a 1-rank group) -- a '
+                         'rehearsal of what --gpus N > 1 executes')
     ap.add_argument('--plain', action='store_true', help='only warm-up + timed steps (for rocprofv3 kernel traces): no extra passes')
     ap.add_argument('--eager-steps', type=int, default=10,
                     help='graph mode: extra eager steps after the timed region (per-kernel HIP-event timings, eager ms/step)')
@@ -296,6 +299,11 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     dev = torch.device('cuda', local)
+    if world == 1 and args.segmented:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        torch.cuda.set_device(local)
+        dist.init_process_group(os.environ.get('SUG_BENCH_BACKEND', 'nccl'), rank=0, world_size=1, device_id=dev)
 
     from sug_amd import ops, _lib
     from sug_amd.model.Model import Net_MDA
@@ -315,11 +323,11 @@ def main():
     if world > 1:                                       # same initial weights on every rank
         for t in list(model.parameters()) + list(model.buffers()):
             dist.broadcast(t.data, 0)
-    want_graph = world == 1 and not args.eager
+    want_graph = not args.eager
 
     def make_trainer(use_graph):
         return SUGStep(model, lr=1e-3, weight_decay=5e-5, share_prefix=not args.no_share_prefix, use_graph=use_graph,
-                       pair_domains=not args.no_pair, methods=BENCH_METHODS)
+                       pair_domains=not args.no_pair, methods=BENCH_METHODS, force_segmented=args.segmented)
 
     trainer = make_trainer(want_graph)
     B, N = args.batch, args.npoints
@@ -368,7 +376,7 @@ def main():
     loss_vals = [None if l is None else float(l) for l in losses]
     prof, ops.PROFILE = ({} if graph_mode else ops.PROFILE), None
     eager_ms = None
-    if args.plain:
+    if args.plain or ((world > 1 or args.segmented) and graph_mode):        # (multi-rank: nothing but the timed region)
         extra_prof = {}
     elif graph_mode:
         # eager steps of the same trainer: per-kernel event timings of every hand-written family + eager ms/step
@@ -396,7 +404,7 @@ def main():
     # calls per step, nothing shared between them (the headline uses the exact restructurings of
     # paired domains + shared prefix).
     caller_ms = None
-    if args.caller_steps > 0 and not args.plain and (trainer.pair_domains or trainer.share_prefix):
+    if args.caller_steps > 0 and not args.plain and world == 1 and not args.segmented and (trainer.pair_domains or trainer.share_prefix):
         keep = (trainer.pair_domains, trainer.share_prefix)
         trainer.pair_domains = trainer.share_prefix = False
         if hasattr(model.g, 'share_prefix'):
@@ -457,7 +465,7 @@ def main():
             else:
                 roofline['traffic_note'] = 'no PMC passes on file for this kernel version (profiles/pmc_traffic_%s.json)' % kernel_source_hash(dom)
         others = None
-        if world == 1 and not args.plain and not args.no_other_workloads and args.model == 'DGCNN':
+        if world == 1 and not args.plain and not args.segmented and not args.no_other_workloads and args.model == 'DGCNN':
             # the other BASELINE configurations, driver-timed in the same line (configs 1, 3, 5 and N = 2048)
             trainer = model = None
             gc.collect()
@@ -483,7 +491,9 @@ def main():
                'config': {'workload': '%s, N=%d, batch=%d per domain per GPU, MSA+SDA losses on '
                                       '(2 sem + 2 node forwards, 3 soft-MMD, backward, 3 Adam)' % (BACKBONE.get(args.model, args.model), N, B),
                           'global_batch': world * B, 'parallelism': 'dp%d' % world,
-                          'launch': 'hipGraph replay of the whole step' if graph_mode else 'eager',
+                          'launch': ('segmented hipGraph (5 captured segments around the all-gather, the 9-double all-reduce and the two '
+                                     'gradient-bucket all-reduces, bucket 1 in flight under the encoder backward)' if (graph_mode and (world > 1 or args.segmented)) else
+                                     'hipGraph replay of the whole step' if graph_mode else 'eager'),
                           'eager_ms_per_step': eager_ms,
                           'share_prefix': share_prefix_on, 'pair_domains': pair_domains_on,
                           'tuned_gemms': tuned, 'geo_weights': 'mean2one', 'sem_weights': 'mean2one',
@@ -497,7 +507,7 @@ def main():
                'roofline': roofline, 'cpu_baseline': cpu, 'losses': loss_vals,
                'kernels': {k: {kk: (round(vv, 5) if isinstance(vv, float) else vv) for kk, vv in v.items() if kk != 'flops'} for k, v in kern.items()}}
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or args.segmented:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -414,6 +414,9 @@ class Net_MDA(nn.Module):
                 x, feat_ori, _ = self.g(x_pair, node=True, feat_grad=False)     # only the node features are used
             else:
                 x, feat_ori, _ = self.g(x_pair, node=True)
+        cuts = getattr(self, '_cuts', None)
+        if cuts is not None:            # SUGStep's two-phase backward cuts the graph at the encoder's outputs
+            cuts.append(feat_ori if node_adaptation else x)
         halves = lambda t: t.reshape(2, B, -1).unbind(0)      # backward: one stack, no zero fills
         if node_adaptation:
             f_s, f_t = halves(feat_ori.contiguous())

@@ -1384,6 +1384,49 @@ def mix_rbf_mmd2_rows_sharded(Zloc, Zall, mloc, M, row0, sample_weights=None, si
     return _MixRbfMMD2Sharded.apply(Zloc, Zall, mloc, M, row0, sample_weights, tuple(sigmas), world, group)
 
 
+def mmd_rows_local_sums(Zall, M, row0, mloc, sample_weights, sums_out, need_wt=True, sigmas=SIGMA_LIST):
+    """First half of mix_rbf_mmd2_rows_sharded for a step whose collectives sit BETWEEN captured graph segments: this
+    rank's row block of the kernel matrix of the gathered batch -> its three partial sums accumulated into `sums_out`
+    (fp64 [3], zeroed by the caller) and the derivative block wt [2*mloc, 2M]; no collective here."""
+    _need_gpu(Zall)
+    Za = Zall if (Zall.stride(1) == 1 and Zall.stride(0) >= Zall.shape[1]) else Zall.contiguous()
+    D = Za.shape[1]
+    ng = _neg_gammas(sigmas, Za.device)
+    wt = torch.empty(2 * mloc, 2 * M, dtype=torch.float32, device=Za.device) if need_wt else None
+    wc = sample_weights.detach().reshape(-1).to(device=Za.device, dtype=torch.float32).contiguous() \
+        if sample_weights is not None else None
+    check(lib().sug_mmd_rbf_rows(_p(Za), Za.stride(0), M, D, _p(wc), _p(ng), len(sigmas), row0, mloc, _p(sums_out), _p(wt),
+                                 _st()), 'sug_mmd_rbf_rows')
+    return Za, wt
+
+
+class _MMDFromReducedSums(torch.autograd.Function):
+    """Second half: the MMD^2 value from the all-reduced sums; the gradient of this rank's rows comes from its own row
+    block (sug_mmd_rbf_rows_bwd), scaled by the world size (the gradient averaging divides by it again)."""
+
+    @staticmethod
+    def forward(ctx, Zloc, sums, Za, wt, mloc, M, row0, world):
+        ctx.save_for_backward(Za, wt)
+        ctx.meta = (mloc, M, row0, world)
+        mm = float(M) * float(M)
+        return ((sums[0] + sums[1] - 2.0 * sums[2]) / mm).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        Za, wt = ctx.saved_tensors
+        mloc, M, row0, world = ctx.meta
+        D = Za.shape[1]
+        gs = g.detach().to(device=Za.device, dtype=torch.float32).reshape(1)
+        dZ = torch.empty(2 * mloc, D, dtype=torch.float32, device=Za.device)
+        check(lib().sug_mmd_rbf_rows_bwd(_p(Za), Za.stride(0), _p(wt), M, D, row0, mloc, _p(gs), float(world), _p(dZ), D,
+                                         _st()), 'sug_mmd_rbf_rows_bwd')
+        return dZ, None, None, None, None, None, None, None
+
+
+def mmd_from_reduced_sums(Zloc, sums, Za, wt, mloc, M, row0, world):
+    return _MMDFromReducedSums.apply(Zloc, sums, Za, wt, mloc, M, row0, world)
+
+
 class _AssembleZ(torch.autograd.Function):
     """[feat_s ; feat_t | one-hot(label) * scale] of soft_mmd (model/mmd.py:56-66) in one launch instead of
     scatter + three cats + a mul; the gradient of the feature block is handed back as two row-slice views."""

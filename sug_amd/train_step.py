@@ -238,7 +238,8 @@ class _StartFeeder:
 
 class SUGStep:
     def __init__(self, model, lr=1e-3, weight_decay=5e-5, lr_scaler=1.0, methods=None, criterion=None,
-                 global_mmd=True, fused_adam=None, share_prefix=True, use_graph=False, pair_domains=True):
+                 global_mmd=True, fused_adam=None, share_prefix=True, use_graph=False, pair_domains=True,
+                 force_segmented=False):
         self.model = model
         self.base_lr, self.lr_scaler = float(lr), float(lr_scaler)
         # source and target batch go through the encoder as one 2B-cloud batch with per-domain
@@ -257,9 +258,12 @@ class SUGStep:
             self.methods.update(methods)
         self.criterion = criterion if criterion is not None else nn.CrossEntropyLoss()
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-        self.global_mmd = global_mmd and self.world > 1
+        # force_segmented: the multi-rank launch form (graph segments + collectives) even on ONE rank of an initialised
+        # process group -- a one-GPU rehearsal of the RCCL calls between graph replays (bench.py --segmented)
+        force_segmented = bool(force_segmented) and dist.is_available() and dist.is_initialized()
+        self.global_mmd = global_mmd and (self.world > 1 or force_segmented)
         self.reducer = None
-        if self.world > 1:
+        if self.world > 1 and not use_graph:     # eager multi-rank steps: bucketed all-reduce from autograd hooks
             early = [p for m in (model.c1, model.c2, model.attention_s, model.attention_t) for p in m.parameters()]
             self.reducer = GradReducer([early, list(model.g.parameters())], self.world)
         # fused_adam: None/True -> sug_amd.optim.Adam (one launch per optimizer) on a HIP device;
@@ -273,7 +277,9 @@ class SUGStep:
         # the default.  History: an early version of the step faulted inside a torch scatter kernel on
         # its second replay; not reproduced since the pooling tail moved into bn_act_pool (3000 clean
         # replays, tools/graph_soak.py).  Single-GPU only.
-        self.use_graph = bool(use_graph) and self.world == 1 and next(model.parameters()).is_cuda
+        self.use_graph = bool(use_graph) and next(model.parameters()).is_cuda
+        # more than one rank: the step is captured as FIVE graph segments around its four collectives (_segmented_step)
+        self.segmented = self.use_graph and (self.world > 1 or force_segmented)
         self._graphs = None
         self.max_graphs = 4                             # captured steps kept (each owns a private memory pool)
         # SUG_GRAPH_GUARD=1 restores the historical guard (one eager op between two replays)
@@ -414,6 +420,8 @@ class SUGStep:
         In graph mode the returned tensors are static buffers overwritten by the next step."""
         if self.use_graph:
             return self._graph_step(data, label, data_t, label_t, epoch)
+        if self.world > 1 and os.environ.get('SUG_SEGMENTED_EAGER') == '1':
+            return self._run_segments(self._segments(data, label, data_t, label_t, epoch), {})
         return self._eager_step(data, label, data_t, label_t, epoch)
 
     def _opts(self):
@@ -454,9 +462,14 @@ class SUGStep:
             if hasattr(o, 'refresh_device_scalars'):
                 o.refresh_device_scalars()
         st = self._graphs.get(key)
-        if st is not None and st['graph'] is not None and st['gens'] != self._plan_generations():
+        if st is not None and st.get('gens') is not None and st['gens'] != self._plan_generations():
             del self._graphs[key]                           # raw pointers into a freed Adam plan: never replay
             st = None
+        if self.segmented:
+            if st is None:
+                while len(self._graphs) >= self.max_graphs:
+                    self._graphs.pop(next(iter(self._graphs)))
+            return self._segmented_step(st, key, data, label, data_t, label_t, epoch)
         if st is None:
             while len(self._graphs) >= self.max_graphs:
                 self._graphs.pop(next(iter(self._graphs)))  # dicts keep insertion order; a hit re-inserts (below)
@@ -500,6 +513,260 @@ class SUGStep:
         st['graph'].replay()
         return st['out']
 
+    # ------------------------------------------------------------------ multi-rank step in graph segments
+    def _seg_check(self, data, data_t, mmd_on):
+        M = self.methods
+        geo, sem = M['GEO_MMD'][0], M['SEM_MMD'][0]
+        ok = self.pair_domains and data.shape == data_t.shape and self.model.training and M['ADV_WEIGHT'] <= 0 and \
+            M['TARGET_LOSS'] <= 0
+        if mmd_on and M['MMD_WEIGHT'] > 0:
+            ok = ok and self.global_mmd and geo['NAME'] == 'SOFT_MMD' and sem['NAME'] == 'SOFT_MMD' and sem['SEM_SCALE'] > 0
+        if not ok:
+            raise RuntimeError('SUGStep(use_graph=True) on %d ranks captures the step in segments around its collectives; '
+                               'that form covers paired domains + global soft MMD (or MMD off) with ADV_WEIGHT = '
+                               'TARGET_LOSS = 0 -- use use_graph=False for other METHODS' % self.world)
+
+    def _segments(self, data, label, data_t, label_t, epoch):
+        """The step of a batch-sharded run as five device segments (closures over a state dict S) with the four
+        collectives BETWEEN them, so that each segment can be captured into a hipGraph and the collectives stay
+        eager RCCL calls (no collective inside a capture):
+            A  both paired encoder passes, heads, CE loss; everything the global MMD needs from the other ranks packed
+               column-wise into one [m_local, W] buffer                         -> all-gather (values)
+            B  SDA weights of the gathered batch, label-augmented operands, this rank's row block of the three kernel
+               matrices -> 9 partial sums                                        -> all-reduce (9 doubles)
+            C1 the three MMD values, total loss, backward of everything above the encoder (heads, attention layers): their
+               gradients packed into flat bucket 1                               -> all-reduce (async: runs under C2)
+            C2 the encoder's backward from the gradients at its outputs, bucket 2 -> wait for bucket 1, all-reduce
+            D  / world, gradients as views of the flat buffers, three Adam updates.
+        Same arithmetic as the eager multi-rank step (train_dg.py:216-217, :357-368 is the reference's seam); what
+        changes is the launch: five replays + four collectives per step instead of ~350 launches from Python."""
+        M_ = self.methods
+        mmd_on = epoch >= M_['PURE_CLS_EPOCH'] and M_['MMD_WEIGHT'] > 0
+        self._seg_check(data, data_t, mmd_on)
+        model, world, rank = self.model, self.world, dist.get_rank()
+        geo, sem = M_['GEO_MMD'][0], M_['SEM_MMD'][0]
+        mloc = label.shape[0]
+        gloo_gpu = dist.get_backend() == 'gloo'
+
+        def seg_a(S):
+            from .model import Ptran_transformer as _PT
+            ops.W16_CACHE = ops.w16_prefill(getattr(self, '_w16_plan', None) or []) if _PT.GEMM_DTYPE is not None else None
+            fused_before, ops.FUSED_HEADS = ops.FUSED_HEADS, (self.fused_heads or ops.FUSED_HEADS)
+            try:
+                model._cuts = S['cuts'] = []
+                pair = torch.cat((data, data_t), dim=0)
+                (p_s1, p_s2, f_s1, f_s2), (p_t1, p_t2, f_t1, f_t2) = model.forward_pair(pair)
+                S['loss_cls'] = (0.5 * M_['SRC_LOSS_WEIGHT'] * M_['CLS_WEIGHT']) * (self.criterion(p_s1, label) +
+                                                                                   self.criterion(p_s2, label))
+                if mmd_on:
+                    node_s, node_t = model.forward_pair(pair, node_adaptation=True)
+                    S['loc'] = (node_s, node_t, f_s1, f_t1, f_s2, f_t2)
+                    vals = [label, label_t, node_s.detach(), node_t.detach(), f_s1.detach(), f_t1.detach(), f_s2.detach(),
+                            f_t2.detach(), p_s1.detach(), p_t1.detach(), p_s2.detach(), p_t2.detach()]
+                    if geo.get('GEO_WEIGHTS'):
+                        vals.append(mmd.chamfer_distances(data, data_t).reshape(-1, 1))
+                    cols, meta = [], []
+                    for t in vals:
+                        t2 = t.reshape(t.shape[0], -1)
+                        meta.append((t2.shape[1], t.dtype, tuple(t.shape[1:])))
+                        cols.append(t2 if t2.dtype == torch.float32 else t2.to(torch.float32))
+                    S['meta'] = meta
+                    S['packed'] = torch.cat(cols, dim=1)
+            finally:
+                model._cuts = None
+                ops.FUSED_HEADS = fused_before
+                if ops.W16_CACHE is not None:
+                    self._w16_plan = ops.w16_plan(ops.W16_CACHE)
+                ops.W16_CACHE = None
+
+        def col_gather(S):
+            if not mmd_on:
+                return
+            G = S['static']['G']
+            if gloo_gpu:                                  # rehearsal backend: gathers device tensors as a list
+                dist.all_gather(list(G.chunk(world, dim=0)), S['packed'])
+            else:
+                dist.all_gather_into_tensor(G, S['packed'])
+
+        def seg_b(S):
+            if not mmd_on:
+                return
+            G, off, g = S['static']['G'], 0, []
+            for w, dt, tail in S['meta']:
+                t = G[:, off:off + w]
+                off += w
+                if dt != torch.float32:
+                    t = t.round().to(dt)
+                g.append(t.reshape((G.shape[0],) + tail))
+            label_g, label_tg, fn_s, fn_t, g_s1, g_t1, g_s2, g_t2, g_p1s, g_p1t, g_p2s, g_p2t = g[:12]
+            node_s, node_t, f_s1, f_t1, f_s2, f_t2 = S['loc']
+            M_all, row0 = label_g.shape[0], rank * mloc
+            sums = S['static']['sums']
+            sums.fill_(0.0)                               # (a fill kernel: no memset node in the captured segment)
+            terms = []
+            w_geo = mmd.distance2weights(g[12].reshape(-1), geo['GEO_WEIGHTS']).reshape(1, -1) if geo.get('GEO_WEIGHTS') else None
+            specs = [(node_s, node_t, fn_s, fn_t, float(geo['LABEL_SCALE']), w_geo)]
+            for fs, ft, gs, gt, gps, gpt in ((f_s1, f_t1, g_s1, g_t1, g_p1s, g_p1t), (f_s2, f_t2, g_s2, g_t2, g_p2s, g_p2t)):
+                w = mmd.prob_weights_soft(gps, gpt, label_g, label_tg, sem['LABEL_WEIGHT'], sem['SEM_WEIGHTS']) \
+                    if sem.get('SEM_WEIGHTS') else None
+                specs.append((fs, ft, gs, gt, float(sem['LABEL_SCALE']), w))
+            for i, (fs, ft, gs, gt, lsc, w) in enumerate(specs):
+                Zloc = ops.mmd_assemble(fs, ft, label, label_t, lsc)
+                Zall = ops.mmd_assemble(gs.detach(), gt.detach(), label_g, label_tg, lsc)
+                Za, wt = ops.mmd_rows_local_sums(Zall, M_all, row0, mloc, w, sums[i])
+                terms.append((Zloc, Za, wt))
+            S['terms'], S['M_all'], S['row0'] = terms, M_all, row0
+
+        def sum_reduce(S):
+            if mmd_on:
+                dist.all_reduce(S['static']['sums'])
+
+        def _pack(ps, key, S):
+            if key not in S['static']:
+                S['static'][key] = torch.empty(sum(p.numel() for p in ps), dtype=torch.float32, device=data.device)
+            return S['static'][key]
+
+        def seg_c1(S):
+            """MMD values, total loss, backward of everything ABOVE the encoder: heads, attention layers, losses.  Their
+            gradients (38 of DGCNN's 46 MB) go into flat bucket 1, whose all-reduce then runs under segment C2."""
+            loss_cls, loss_geo, loss_sem = S['loss_cls'], None, None
+            loss = loss_cls
+            if mmd_on:
+                sums = S['static']['sums']
+                v = [ops.mmd_from_reduced_sums(Zloc, sums[i], Za, wt, mloc, S['M_all'], S['row0'], world)
+                     for i, (Zloc, Za, wt) in enumerate(S['terms'])]
+                loss_geo = (M_['MMD_WEIGHT'] * geo['GEO_SCALE']) * v[0]
+                loss_sem = (0.5 * M_['MMD_WEIGHT'] * sem['SEM_SCALE']) * (v[1] + v[2])
+                loss = loss + loss_geo + loss_sem
+            cuts = [t for t in S['cuts'] if t is not None and t.requires_grad]
+            st_ = S['static']
+            early = st_.get('early')
+            if early is None:                             # (planning step) the parameters above the cut
+                early = [p for m in (model.c1, model.c2, model.attention_s, model.attention_t) for p in m.parameters()
+                         if p.requires_grad]
+            grads = torch.autograd.grad(loss, early + cuts, allow_unused=True)
+            ge, gc = grads[:len(early)], grads[len(early):]
+            if 'early' not in st_:
+                keep = [i for i, g in enumerate(ge) if g is not None]
+                st_['early'] = [early[i] for i in keep]
+                ge = [ge[i] for i in keep]
+            S['cut_grads'] = [(t, g) for t, g in zip(cuts, gc) if g is not None]
+            torch.cat([g.reshape(-1) for g in ge], out=_pack(st_['early'], 'flat1', S))
+            S['out'] = (loss_cls.detach(), None if loss_geo is None else loss_geo.detach(),
+                        None if loss_sem is None else loss_sem.detach())
+
+        def grad_reduce1(S):
+            S['work'] = dist.all_reduce(S['static']['flat1'], async_op=True)      # in flight under segment C2
+
+        def seg_c2(S):
+            """The encoder's backward from the gradients at the cut; its parameter gradients -> flat bucket 2."""
+            cg = S['cut_grads']
+            torch.autograd.backward([t for t, _ in cg], [g for _, g in cg])
+            if self.share_prefix:
+                model.g.clear_prefix_cache()
+            for m in self._split_layers:
+                m._wcat = None
+            st_ = S['static']
+            if 'late' not in st_:
+                st_['late'] = [p for p in model.g.parameters() if p.grad is not None]
+            torch.cat([p.grad.reshape(-1) for p in st_['late']], out=_pack(st_['late'], 'flat2', S))
+
+        def grad_reduce2(S):
+            w = S.pop('work', None)
+            if w is not None:
+                w.wait()
+            dist.all_reduce(S['static']['flat2'])
+
+        def seg_d(S):
+            st_ = S['static']
+            for ps, flat in ((st_['early'], st_['flat1']), (st_['late'], st_['flat2'])):
+                flat.div_(world)
+                off = 0
+                for p in ps:                              # the averaged gradients stay in the flat buffers
+                    n = p.numel()
+                    p.grad = flat[off:off + n].view_as(p)
+                    off += n
+            self.optimizer_dis.step()
+            self.optimizer_g.step()
+            self.optimizer_c.step()
+            self.optimizer_g.zero_grad()
+            self.optimizer_c.zero_grad()
+            self.optimizer_dis.zero_grad()
+
+        return {'device': (seg_a, seg_b, seg_c1, seg_c2, seg_d), 'collective': (col_gather, sum_reduce, grad_reduce1, grad_reduce2),
+                'mloc': mloc,
+                'mmd_on': mmd_on, 'device_of': data.device}
+
+    def _seg_static(self, S, segs):
+        """Buffers the collectives read / write: allocated once per configuration, OUTSIDE any graph pool."""
+        st = S.setdefault('static', {})
+        if segs['mmd_on'] and 'sums' not in st:
+            st['sums'] = torch.zeros(3, 3, dtype=torch.float64, device=segs['device_of'])
+        return st
+
+    def _run_segments(self, segs, S):
+        """Uncaptured execution: segment, collective, segment, ...  (the planning step of graph mode; with
+        SUG_SEGMENTED_EAGER=1 every step -- the segmented formulation without graphs)."""
+        self._seg_static(S, segs)
+        dev, col = segs['device'], segs['collective']
+        for i, fn in enumerate(dev):
+            fn(S)
+            if i == 0 and segs['mmd_on'] and 'G' not in S['static']:
+                S['static']['G'] = torch.empty(self.world * segs['mloc'], S['packed'].shape[1], dtype=torch.float32,
+                                               device=segs['device_of'])
+            if i < len(col):
+                col[i](S)
+        return S['out']
+
+    def _segmented_step(self, st, key, data, label, data_t, label_t, epoch):
+        """Graph mode on more than one rank: plan (uncaptured), capture the segments into hipGraphs that share one memory
+        pool, then per step: replay A, all-gather, replay B, all-reduce, replay C1, all-reduce (async), replay C2, all-reduce, replay D."""
+        if st is None:
+            st = {'feeder': _StartFeeder(data.device), 'graphs': None, 'gens': None, 'S': {}}
+            self._graphs[key] = st
+            ops.START_PROVIDER = st['feeder'].record
+            try:
+                out = self._run_segments(self._segments(data, label, data_t, label_t, epoch), st['S'])
+            finally:
+                ops.START_PROVIDER = None
+            st['feeder'].build()
+            st['S'] = {'static': st['S']['static']}         # keep only the collective buffers
+            return out
+        self._graphs[key] = self._graphs.pop(key)
+        if st['graphs'] is None:
+            st['in'] = [t.clone() for t in (data, label, data_t, label_t)]
+            for o in self._opts():
+                o.zero_grad(set_to_none=True)
+            st['feeder'].cursor = 0
+            segs = self._segments(*st['in'], epoch)
+            S = st['S']
+            graphs, pool = [], None
+            ops.START_PROVIDER = st['feeder'].provide
+            try:
+                for fn in segs['device']:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, pool=pool):
+                        fn(S)
+                    pool = g.pool() if pool is None else pool
+                    graphs.append(g)
+            finally:
+                ops.START_PROVIDER = None
+            st['graphs'], st['segs'], st['out'] = graphs, segs, S['out']
+            st['gens'] = self._plan_generations()
+            # autograd objects of the capture are no longer needed: the graphs own the memory
+            for k in ('loc', 'terms', 'loss_cls', 'cuts', 'cut_grads'):
+                S.pop(k, None)
+        for dst, src in zip(st['in'], (data, label, data_t, label_t)):
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src, non_blocking=True)
+        st['feeder'].refill()
+        S, col = st['S'], st['segs']['collective']
+        for g, c in zip(st['graphs'], col + (None,)):
+            g.replay()
+            if c is not None:
+                c(S)
+        return st['out']
+
     def _eager_step(self, data, label, data_t, label_t, epoch=0):
         mmd_on = epoch >= self.methods['PURE_CLS_EPOCH']
         from .model import Ptran_transformer as _PT
@@ -519,6 +786,9 @@ class SUGStep:
             loss = loss + loss_geo
         if loss_sem is not None:
             loss = loss + loss_sem
+        if self.world > 1 and self.reducer is None:      # a graph-mode trainer switched to eager launches
+            early = [p for m in (self.model.c1, self.model.c2, self.model.attention_s, self.model.attention_t) for p in m.parameters()]
+            self.reducer = GradReducer([early, list(self.model.g.parameters())], self.world)
         if self.reducer is not None:
             self.reducer.begin(mmd_on)
         loss.backward()

@@ -47,7 +47,7 @@ def _data(B, N, seed):
     return data, lab, data_t, lab_t
 
 
-def _worker(rank, world, port, backend, q):
+def _worker(rank, world, port, backend, q, mode='eager', steps=2):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       HSA_ENABLE_IPC_MODE_LEGACY='0')
@@ -64,24 +64,28 @@ def _worker(rank, world, port, backend, q):
     lo, hi = rank * B // world, (rank + 1) * B // world
     shard = [t[lo:hi].to(dev) for t in (data, lab, data_t, lab_t)]
     net = _make(3).to(dev).train()
-    tr = SUGStep(net, global_mmd=True)
+    if mode == 'segmented_eager':
+        os.environ['SUG_SEGMENTED_EAGER'] = '1'    # the segment / collective sequence of graph mode, uncaptured
+    tr = SUGStep(net, global_mmd=True, use_graph=(mode == 'segmented_graph'))
     torch.manual_seed(100 + rank)                  # FPS start draws, per rank (train_dg.py:78)
     out = []
-    for _ in range(2):
+    for _ in range(steps):
         out.append([float(v) for v in tr.step(*shard)])
+    if mode == 'segmented_graph':
+        assert tr.segmented and len(tr._graphs) == 1 and len(next(iter(tr._graphs.values()))['graphs']) == 5
     chk = torch.stack([p.detach().double().sum() for p in net.parameters()]).cpu()
     q.put((rank, out, chk.numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def _run(backend):
+def _run(backend, mode='eager', steps=2):
     import torch.multiprocessing as mp
     world = 2
     port = _free_port()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, backend, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, backend, q, mode, steps)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
@@ -131,6 +135,80 @@ def _check(res):
 
 def test_two_rank_step_gloo_on_one_gpu():
     _check(_run('gloo'))
+
+
+def _segmented(backend):
+    """Graph mode on two ranks = five captured segments around the four collectives (SUGStep._segments): the
+    uncaptured segment sequence and the captured one follow the eager multi-rank step (bucketed all-reduce from
+    autograd hooks) -- first step to rounding, later steps within the trajectory noise of two eager runs -- and the
+    replicas stay identical."""
+    runs = {m: _run(backend, m, steps=5) for m in ('eager', 'segmented_eager', 'segmented_graph')}
+    for m, res in runs.items():
+        (_, out0, chk0), (_, out1, chk1) = res
+        assert abs(chk0 - chk1).max() <= 1e-6 * max(1.0, abs(chk0).max()), '%s: parameters diverged between ranks' % m
+        for s in range(5):
+            for t in (1, 2):                      # the global MMD terms are identical on both ranks
+                assert abs(out0[s][t] - out1[s][t]) <= 1e-6 * max(1.0, abs(out0[s][t])), (m, out0, out1)
+    ref = runs['eager']
+    for m in ('segmented_eager', 'segmented_graph'):
+        for r in range(2):
+            for a, b in zip(ref[r][1][0], runs[m][r][1][0]):
+                assert abs(a - b) <= 1e-5 * max(1.0, abs(a)), (m, ref[r][1], runs[m][r][1])
+            for sa, sb in zip(ref[r][1], runs[m][r][1]):
+                for a, b in zip(sa, sb):
+                    assert abs(a - b) <= 2e-2 * max(1.0, abs(a)), (m, ref[r][1], runs[m][r][1])
+    print({m: res[0][1] for m, res in runs.items()})
+
+
+def test_two_rank_segmented_graph_gloo_on_one_gpu():
+    _segmented('gloo')
+
+
+def test_two_rank_segmented_graph_rccl():
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs 2 HIP devices (RCCL over xGMI)')
+    _segmented('nccl')
+
+
+def _worker_one_rank_rccl(port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    import torch.distributed as dist
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(dev)
+    from sug_amd.train_step import SUGStep
+    shard = [t.to(dev) for t in _data(4, 1024, 5)]
+    out = {}
+    for mode in ('whole', 'segmented'):
+        if mode == 'segmented':
+            dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+        tr = SUGStep(_make(3).to(dev).train(), use_graph=True, force_segmented=(mode == 'segmented'))
+        assert tr.segmented == (mode == 'segmented')
+        torch.manual_seed(100)
+        out[mode] = [[float(v) for v in tr.step(*shard)] for _ in range(5)]
+    q.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_segmented_graph_over_rccl_on_one_rank():
+    """The multi-rank launch form -- five graph replays with RCCL collectives between them -- on a one-rank RCCL
+    group: this is the only way the 1-GPU box can execute RCCL calls between hipGraph replays (all-gather of values,
+    fp64 all-reduce, async all-reduce under a replay, wait).  Losses follow the whole-step graph of the same trainer."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_one_rank_rccl, args=(_free_port(), q))
+    p.start()
+    out = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    print(out)
+    for a, b in zip(out['whole'][0], out['segmented'][0]):
+        assert abs(a - b) <= 1e-5 * max(1.0, abs(a)), out
+    for sa, sb in zip(out['whole'], out['segmented']):
+        for a, b in zip(sa, sb):
+            assert abs(a - b) <= 2e-2 * max(1.0, abs(a)), out
 
 
 def test_two_rank_step_rccl():
