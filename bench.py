@@ -408,7 +408,7 @@ def main():
         keep = (trainer.pair_domains, trainer.share_prefix)
         trainer.pair_domains = trainer.share_prefix = False
         if hasattr(model.g, 'share_prefix'):
-            model.g.share_prefix = False
+            model.g.share_prefix = 'auto'          # what a plain Net_MDA(...) does by itself (liveness-checked reuse)
         for m_ in trainer._split_layers:
             m_.cache_weight_split = False
         for _ in range(3):

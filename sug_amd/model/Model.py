@@ -20,6 +20,33 @@ from .Ptran_transformer import TransformerBlock
 K = 20      # model/Model.py:52
 
 
+class _PrefixEntry:
+    """Cached result of an encoder prefix (DGCNN: kNN + conv1, kNN + conv2; Point Transformer: fc1 + transformer1) that a
+    second forward on the SAME batch with the SAME weights may reuse.  `alive` turns False as soon as a backward pass
+    reaches the cached tensors: their autograd graph is consumed then, and a later forward must recompute."""
+
+    def __init__(self, tensors, extra=None):
+        self.tensors, self.extra = tensors, extra
+        # the hook must not reference this entry (entry -> tensor -> grad_fn -> hook -> entry would be a cycle, and the
+        # cached tensors -- graph-pool memory under hipGraph capture -- would wait for the cyclic collector)
+        self._flag = flag = [True]
+        last = tensors[-1]
+        if last.requires_grad:
+            last.register_hook(lambda grad, f=flag: f.__setitem__(0, False))
+
+    @property
+    def alive(self):
+        return self._flag[0]
+
+
+def _sharing_on(flag, training):
+    """share_prefix: True (SUGStep: one backward over all passes of a step), False, or 'auto' (default): share while it
+    is provably the same computation -- same input tensor and version, same parameter versions, training mode, and the
+    earlier pass's graph not yet consumed by a backward (what train_dg_single_gpu.py:260-335 does: four forwards, one
+    backward)."""
+    return bool(flag) and training
+
+
 class CALayer(nn.Module):
     """Channel attention on the flattened node features (model/Model.py:16-34)."""
 
@@ -82,7 +109,7 @@ class DGCNN(nn.Module):
         # in both passes (train-mode BN uses batch statistics, no dropout, deterministic
         # kernels), so the second pass reuses it and only replays the BN running-stat update.
         # Requires a single backward over both passes (the graph of the prefix is shared).
-        self.share_prefix = False
+        self.share_prefix = 'auto'
         self._prefix_cache = {}
 
     def clear_prefix_cache(self):
@@ -91,14 +118,15 @@ class DGCNN(nn.Module):
     def _prefix(self, x, loc, nb, out1=None):
         """kNN + conv1, kNN + conv2.  out1: where conv1's activations should be written (a column
         slice of the conv5 input buffer); a cache hit returns the tensors of the earlier pass instead."""
-        if not (self.share_prefix and self.training):
+        if not _sharing_on(self.share_prefix, self.training):
             x1 = self.conv1.edge_rows(loc, nb(loc, 0), out=out1)
             return x1, self.conv2.edge_rows(x1, nb(x1, 1))
         ver = sum(p._version for m in (self.conv1, self.conv2) for p in m.parameters())
         key = (x.data_ptr(), x._version, tuple(x.shape), torch.is_grad_enabled(), ver, ops.BN_GROUPS)
         hit = self._prefix_cache.get(key)
-        if hit is not None:
-            x1, x2, st1, st2 = hit
+        if hit is not None and hit.alive:
+            x1, x2 = hit.tensors
+            st1, st2 = hit.extra
             self.conv1.replay_bn_update(st1)
             self.conv2.replay_bn_update(st2)
             return x1, x2
@@ -106,7 +134,7 @@ class DGCNN(nn.Module):
         x2, st2 = self.conv2.edge_rows(x1, nb(x1, 1), return_stats=True)
         if len(self._prefix_cache) >= 4:            # a step has two inputs; never grow unbounded
             self._prefix_cache.clear()
-        self._prefix_cache[key] = (x1, x2, st1, st2)
+        self._prefix_cache[key] = _PrefixEntry((x1, x2), (st1, st2))
         return x1, x2
 
     def forward(self, x, node=False, knn_idx=None, feat_grad=True):
@@ -246,7 +274,7 @@ class PTran_g(nn.Module):
         # resolution, before any farthest-point sampling, have no BatchNorm and no dropout -- the semantic
         # and the node pass of one step compute them on identical inputs with identical weights, so the
         # second pass reuses the first one's result (one backward over both passes).
-        self.share_prefix = False
+        self.share_prefix = 'auto'
         self._prefix_cache = {}
 
     def clear_prefix_cache(self):
@@ -259,16 +287,16 @@ class PTran_g(nn.Module):
         return ops.linear_rows(h, self.fc1[2].weight, self.fc1[2].bias)
 
     def _prefix(self, x, x_, xyz):
-        if not (self.share_prefix and self.training):
+        if not _sharing_on(self.share_prefix, self.training):
             return self.transformer1(xyz, self._lift(x_))[0]
         ver = sum(p._version for m in (self.fc1, self.transformer1) for p in m.parameters())
         key = (x.data_ptr(), x._version, tuple(x.shape), torch.is_grad_enabled(), ver)
         hit = self._prefix_cache.get(key)
-        if hit is None:
+        if hit is None or not hit.alive:
             if len(self._prefix_cache) >= 4:
                 self._prefix_cache.clear()
-            hit = self._prefix_cache[key] = self.transformer1(xyz, self._lift(x_))[0]
-        return hit
+            hit = self._prefix_cache[key] = _PrefixEntry((self.transformer1(xyz, self._lift(x_))[0],))
+        return hit.tensors[0]
 
     def fps_plan(self, N):
         """Point counts of the farthest_point_sample calls of one forward, in call order."""

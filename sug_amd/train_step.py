@@ -247,7 +247,7 @@ class SUGStep:
         self.pair_domains = bool(pair_domains) and hasattr(model, 'forward_pair')
         # one backward over all four forwards of a step -> the encoder may share the stage in
         # front of the SA-node module between the semantic and node pass of a batch (exact)
-        self.share_prefix = share_prefix and hasattr(model.g, 'share_prefix')
+        self.share_prefix = bool(share_prefix) and hasattr(model.g, 'share_prefix')
         if hasattr(model.g, 'share_prefix'):
             model.g.share_prefix = self.share_prefix
         self._split_layers = [m for m in model.modules() if hasattr(m, 'cache_weight_split')]

@@ -330,3 +330,63 @@ def test_training_step_issues_no_device_memsets(model_name):
     assert names, 'the profiler saw no kernels'
     bad = [n for n in names if 'emset' in n or 'fillBuffer' in n]
     assert not bad, bad[:5]
+
+
+def test_automatic_prefix_sharing_is_exact_and_safe():
+    """A plain Net_MDA (share_prefix = 'auto', no SUGStep): the four forwards of train_dg_single_gpu.py:260-310 followed
+    by ONE backward reuse the kNN + conv1 + conv2 stage of each batch -- same losses / gradients / BatchNorm buffers as
+    with sharing off.  And it is safe outside that pattern: once a backward has consumed the cached graph, the next
+    forward on the same input recomputes (no 'backward through the graph a second time')."""
+    from sug_amd import ops
+    from sug_amd.model.Model import Net_MDA
+    from sug_amd.model import mmd
+    G = load_golden('step_dgcnn.npz')
+    seed = G['seed']
+    data, data_t = G['data'].cuda(), G['data_t'].cuda()
+    lab, lab_t = G['label'].cuda(), G['label_t'].cuda()
+    cfg = {'NAME': 'SOFT_MMD', 'LABEL_SCALE': 50, 'GEO_SCALE': 1}
+    res, calls = [], []
+    real_knn = ops.knn
+    for mode in (False, 'auto'):
+        net = Net_MDA('DGCNN')
+        net.load_state_dict(O.fill_params({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed))
+        for m in net.modules():
+            if isinstance(m, torch.nn.Dropout2d):
+                m.p = 0.0
+        net = net.cuda().train()
+        assert net.g.share_prefix == 'auto'
+        net.g.share_prefix = mode
+        n = [0]
+
+        def spy(f, k):
+            n[0] += 1
+            return real_knn(f, k)
+        ops.knn = spy
+        try:
+            torch.manual_seed(seed)
+            ys = net(data, semantic_adaption=True)
+            yt = net(data_t, semantic_adaption=True)
+            fs = net(data, node_adaptation_s=True)
+            ft = net(data_t, node_adaptation_t=True)
+            loss = torch.nn.functional.cross_entropy(ys[0], lab) + mmd.mmd_cal(lab, fs, lab_t, ft, cfg) + \
+                mmd.mmd_cal(lab, ys[2], lab_t, yt[2], cfg)
+            loss.backward()
+            calls.append(n[0])
+            res.append((float(loss), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None},
+                        {k: v.clone() for k, v in net.state_dict().items() if 'running' in k}))
+            if mode == 'auto':
+                # the cached graph is consumed: a further forward + backward on the same input must still work
+                n[0] = 0
+                y2 = net(data, semantic_adaption=True)
+                y2[0].sum().backward()
+                assert n[0] == 4, 'after a backward the prefix must be recomputed (%d kNN calls)' % n[0]
+        finally:
+            ops.knn = real_knn
+    assert calls == [16, 12], calls                       # 4 passes x 4 graphs; the node passes reuse 2 each
+    assert res[0][0] == res[1][0]
+    gmax = max(float(g.abs().max()) for g in res[0][1].values())
+    assert res[0][1].keys() == res[1][1].keys()
+    for k in res[0][1]:
+        torch.testing.assert_close(res[1][1][k], res[0][1][k], rtol=1e-4, atol=3e-6 * gmax)
+    for k in res[0][2]:
+        assert torch.equal(res[0][2][k], res[1][2][k]), k
