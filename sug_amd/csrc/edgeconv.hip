@@ -125,7 +125,7 @@ template <int SW, int KK>
 __global__ __launch_bounds__(256) void edgeconv_fwd_lds_kernel(
     const float* __restrict__ pq, int64_t ldpq, const int32_t* __restrict__ idx,
     const float* __restrict__ gamma, int B, int N, int Co, int psplit,
-    float* __restrict__ z, uint8_t* __restrict__ arg, float* __restrict__ s1, float* __restrict__ ws) {
+    float* __restrict__ z, uint8_t* __restrict__ arg, float* __restrict__ s1, float* __restrict__ ws, int Bg) {
   static_assert(KK % 4 == 0, "neighbour rows are fetched as int4");
   extern __shared__ __attribute__((aligned(16))) float s_lds[];
   float* s_p = s_lds;                          // [N][SW]
@@ -161,6 +161,17 @@ __global__ __launch_bounds__(256) void edgeconv_fwd_lds_kernel(
   const float4 sg = make_float4(g4.x >= 0.f ? 1.f : -1.f, g4.y >= 0.f ? 1.f : -1.f, g4.z >= 0.f ? 1.f : -1.f,
                                 g4.w >= 0.f ? 1.f : -1.f);
   float4 a1 = make_float4(0, 0, 0, 0), a2 = make_float4(0, 0, 0, 0);
+  // BatchNorm sums about a pivot (common.h; Bg > 0): y of point 0 / its first neighbour slot taken as point 0 of the
+  // first cloud of this cloud's domain group, p = P[b0,0] + Q[b0,0] (sign-folded like y'); the group's partial rows
+  // share it, the first cloud's workgroups publish it for the fold.  The stored maxima z and s1 = sum_j y stay unshifted.
+  float4 pv4 = make_float4(0, 0, 0, 0);
+  if (Bg > 0) {
+    const float* p0 = pq + (int64_t)(b / Bg) * Bg * N * ldpq;
+    const float4 a = ld4(p0 + c0 + lp * 4), c = ld4(p0 + Co + c0 + lp * 4);
+    pv4 = make_float4(__fadd_rn(a.x, c.x), __fadd_rn(a.y, c.y), __fadd_rn(a.z, c.z), __fadd_rn(a.w, c.w));
+    if (b % Bg == 0 && part == 0 && slot == 0) st4(ws + SUG_PIVOT_OFFSET(Co) + (size_t)(b / Bg) * Co + c0 + lp * 4, pv4);
+    pv4.x *= sg.x; pv4.y *= sg.y; pv4.z *= sg.z; pv4.w *= sg.w;
+  }
   const int n_per = (N + psplit - 1) / psplit;
   const int n_begin = part * n_per, n_end = (n_begin + n_per < N) ? n_begin + n_per : N;
   // the neighbour list and the Q row of the NEXT point are fetched (global) while the current point
@@ -195,7 +206,8 @@ __global__ __launch_bounds__(256) void edgeconv_fwd_lds_kernel(
         const float yx = __fadd_rn(pv.x, q.x), yy = __fadd_rn(pv.y, q.y);
         const float yz = __fadd_rn(pv.z, q.z), yw = __fadd_rn(pv.w, q.w);
         sx += yx; sy += yy; sz += yz; sw += yw;
-        qx = fmaf(yx, yx, qx); qy = fmaf(yy, yy, qy); qz = fmaf(yz, yz, qz); qw = fmaf(yw, yw, qw);
+        const float dx = yx - pv4.x, dy = yy - pv4.y, dz = yz - pv4.z, dw = yw - pv4.w;
+        qx = fmaf(dx, dx, qx); qy = fmaf(dy, dy, qy); qz = fmaf(dz, dz, qz); qw = fmaf(dw, dw, qw);
         if (j == 0 || yx > bx) { bx = yx; jx = j; }                  // first maximum wins, as torch.max
         if (j == 0 || yy > by) { by = yy; jy = j; }
         if (j == 0 || yz > bz) { bz = yz; jz = j; }
@@ -210,7 +222,9 @@ __global__ __launch_bounds__(256) void edgeconv_fwd_lds_kernel(
     *reinterpret_cast<uint32_t*>(arg + o) =
         (uint32_t)jx | ((uint32_t)jy << 8) | ((uint32_t)jz << 16) | ((uint32_t)jw << 24);
     if (s1) st4(s1 + o, make_float4(sx, sy, sz, sw));
-    a1.x += sx; a1.y += sy; a1.z += sz; a1.w += sw;
+    constexpr float kf = (float)KK;                                   // sum_j (y - p) = sum_j y - k p  (true sign)
+    a1.x += fmaf(-kf, pv4.x * sg.x, sx); a1.y += fmaf(-kf, pv4.y * sg.y, sy);
+    a1.z += fmaf(-kf, pv4.z * sg.z, sz); a1.w += fmaf(-kf, pv4.w * sg.w, sw);
     a2.x += qx; a2.y += qy; a2.z += qz; a2.w += qw;
 #pragma unroll
     for (int t = 0; t < KK / 4; ++t) nv[t] = nvn[t];
@@ -847,9 +861,11 @@ int sug_stats_finalize(const float* ws, int nblk, int C, const float* gamma, con
 }
 
 // producer only: per-workgroup partial rows in ws, their number in *nblk
+// Bg > 0: sums about the pivot of each domain group of Bg clouds (LDS-resident kernel only; the caller folds with
+// sug_edgeconv_bn_act, which reads the pivot rows); Bg = 0: plain sums
 static int edgeconv_fwd_partials(const float* pq, int64_t ldpq, const int32_t* idx, const float* gamma, int B, int N,
                                  int k, int Co, float* z, uint8_t* arg, float* s1, float* ws, int* nblk,
-                                 void* stream) {
+                                 void* stream, int Bg = 0) {
   SUG_REQUIRE(pq && idx && gamma && z && arg && ws, "sug_edgeconv_fwd: null pointer");
   SUG_REQUIRE(B > 0 && N > 0 && k > 0 && k <= 255, "sug_edgeconv_fwd: bad shape B=%d N=%d k=%d", B, N, k);
   SUG_REQUIRE(Co > 0 && Co % 4 == 0 && Co <= 1024, "sug_edgeconv_fwd: Co=%d must be a multiple of 4, <= 1024", Co);
@@ -870,7 +886,7 @@ static int edgeconv_fwd_partials(const float* pq, int64_t ldpq, const int32_t* i
     if (int rc = sug_allow_dynamic_lds(note, &edgeconv_fwd_lds_kernel<16, 20>, 150 * 1024, "sug_edgeconv_fwd(lds)")) return rc;
     const int grid = ((B & 7) == 0 ? B : B) * nslice * psplit;
     hipLaunchKernelGGL((edgeconv_fwd_lds_kernel<16, 20>), dim3(grid), dim3(256), sh, st_, pq, ldpq, idx, gamma, B, N, Co,
-                       psplit, z, arg, s1, ws);
+                       psplit, z, arg, s1, ws, Bg);
     SUG_LAUNCH_CHECK("sug_edgeconv_fwd(lds)");
     *nblk = B * psplit;
     return SUG_OK;
@@ -957,7 +973,7 @@ int sug_edgeconv_fwd_bn_act_groups(const float* pq, int64_t ldpq, const int32_t*
     // two launches: gather / reduce with per-(cloud, part) partial rows, then statistics fold + BatchNorm + activation
     // (edgeconv_fused.hip: every workgroup of the second launch folds its group's partial rows itself)
     int nblk = 0;
-    if (int rc = edgeconv_fwd_partials(pq, ldpq, idx, gamma, B, N, k, Co, z, arg, s1, ws, &nblk, stream)) return rc;
+    if (int rc = edgeconv_fwd_partials(pq, ldpq, idx, gamma, B, N, k, Co, z, arg, s1, ws, &nblk, stream, Bg)) return rc;
     return sug_edgeconv_bn_act(ws, nblk / groups, Co, groups, gamma, beta, (double)rows * k, eps, momentum, running_mean,
                                running_var, coef, z, rows, slope, out, ldo, st);
   }

@@ -43,7 +43,7 @@ constexpr int LP = SW / 4;     // lanes per point in the gather phase
 template <int CIN, int KK, int NT, bool QLDS>
 __global__ __launch_bounds__(NT, 4) void edgeconv_fused_fwd_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ wcat, const float* __restrict__ qbias,
-    const int32_t* __restrict__ idx, const float* __restrict__ gamma, int B, int N, int Co,
+    const int32_t* __restrict__ idx, const float* __restrict__ gamma, int B, int N, int Co, int Bg,
     float* __restrict__ z, uint8_t* __restrict__ arg, float* __restrict__ s1, float* __restrict__ pq_out,
     int64_t ldpq, float* __restrict__ ws) {
   static_assert(KK % 4 == 0, "neighbour rows are fetched as int4");
@@ -74,6 +74,20 @@ __global__ __launch_bounds__(NT, 4) void edgeconv_fused_fwd_kernel(
   float* qdst = pq_out ? pq_out + (int64_t)b * N * ldpq + Co + c0 : z + (int64_t)b * N * Co + c0;
   const int64_t ldq = pq_out ? ldpq : (int64_t)Co;
 
+  // BatchNorm sums are taken about a PIVOT (common.h): y of point 0 / neighbour slot "point 0" of the first cloud of this
+  // cloud's domain group, p = P[b0,0] + Q[b0,0], split as pP + pQ.  Every workgroup forms the pivot of its 16 channels
+  // itself -- the same 2 x 16 ascending fma chains over the features everywhere, hence the same bits -- so that the
+  // partial rows of a group share it; the workgroups of the group's first cloud publish it for the fold.
+  float* s_piv = reinterpret_cast<float*>(s_lds) + (size_t)N * SW * (QLDS ? 2 : 1);          // [2*SW]: pP | pQ (true sign)
+  if (threadIdx.x < 2 * SW) {
+    const int hh = threadIdx.x >> 4, r = threadIdx.x & 15;
+    const float* wr = wcat + (int64_t)(hh * Co + c0 + r) * CR;
+    const float* x0 = x + (int64_t)(b / Bg) * Bg * N * ldx;
+    float d = 0.f;
+    for (int t = 0; t < CR; ++t) d = fmaf(wr[t], x0[t], d);
+    if (hh == 1 && qbias) d = __fadd_rn(d, qbias[c0 + r]);
+    s_piv[threadIdx.x] = d;
+  }
   // ---------------------------------------------------------------- phase 1: [P ; Q] slice by MFMA
   {
     // A operand: weight row of A-row jl, features h*HALF + t (CIN = 4: features 2h + t, the 4th is zero)
@@ -189,6 +203,8 @@ __global__ __launch_bounds__(NT, 4) void edgeconv_fused_fwd_kernel(
     }
   }
   __syncthreads();          // P slice complete in LDS; the Q rows of every wave are visible (vmcnt(0) + barrier)
+  if (b % Bg == 0 && threadIdx.x < SW)
+    ws[SUG_PIVOT_OFFSET(Co) + (size_t)(b / Bg) * Co + c0 + threadIdx.x] = __fadd_rn(s_piv[threadIdx.x], s_piv[SW + threadIdx.x]);
 
   // ---------------------------------------------------------------- phase 2: gather, reduce over k
   // y_j = P[idx_j] + Q (all sign-folded): fp32 addition is monotone, so max_j y_j = (max_j P[idx_j]) + Q exactly and
@@ -200,6 +216,10 @@ __global__ __launch_bounds__(NT, 4) void edgeconv_fused_fwd_kernel(
                                 g4.w >= 0.f ? 1.f : -1.f);
   float4 a1 = make_float4(0, 0, 0, 0), a2 = make_float4(0, 0, 0, 0);
   constexpr float kf = (float)KK;
+  // pivot parts of this lane's 4 channels, sign-folded like the LDS image
+  const float4 pp = make_float4(s_piv[lp * 4 + 0] * sg.x, s_piv[lp * 4 + 1] * sg.y, s_piv[lp * 4 + 2] * sg.z, s_piv[lp * 4 + 3] * sg.w);
+  const float4 pq4 = make_float4(s_piv[SW + lp * 4 + 0] * sg.x, s_piv[SW + lp * 4 + 1] * sg.y, s_piv[SW + lp * 4 + 2] * sg.z,
+                                 s_piv[SW + lp * 4 + 3] * sg.w);
   // (no software prefetch of the next point's neighbour list: with 16 waves per CU the other waves cover the fetch,
   // and the 24 registers of a second list would not fit the 128-register budget)
 #ifdef SUG_EF_ABL_NOGATHER
@@ -232,9 +252,9 @@ __global__ __launch_bounds__(NT, 4) void edgeconv_fused_fwd_kernel(
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int j = t * 4 + u;
-        sx += pv[u].x; sy += pv[u].y; sz += pv[u].z; sw += pv[u].w;
-        qx = fmaf(pv[u].x, pv[u].x, qx); qy = fmaf(pv[u].y, pv[u].y, qy);
-        qz = fmaf(pv[u].z, pv[u].z, qz); qw = fmaf(pv[u].w, pv[u].w, qw);
+        const float dx = pv[u].x - pp.x, dy = pv[u].y - pp.y, dz = pv[u].z - pp.z, dw = pv[u].w - pp.w;   // about the pivot
+        sx += dx; sy += dy; sz += dz; sw += dw;
+        qx = fmaf(dx, dx, qx); qy = fmaf(dy, dy, qy); qz = fmaf(dz, dz, qz); qw = fmaf(dw, dw, qw);
         if (j == 0 || pv[u].x > bx) { bx = pv[u].x; jx = j; }          // first maximum wins, as torch.max
         if (j == 0 || pv[u].y > by) { by = pv[u].y; jy = j; }
         if (j == 0 || pv[u].z > bz) { bz = pv[u].z; jz = j; }
@@ -259,9 +279,11 @@ __global__ __launch_bounds__(NT, 4) void edgeconv_fused_fwd_kernel(
     // + Q, back to the true sign
     const float zx = __fadd_rn(bx, q.x) * sg.x, zy = __fadd_rn(by, q.y) * sg.y;
     const float zz = __fadd_rn(bz, q.z) * sg.z, zw = __fadd_rn(bw, q.w) * sg.w;
-    const float yx = fmaf(kf, q.x, sx), yy = fmaf(kf, q.y, sy), yz = fmaf(kf, q.z, sz), yw = fmaf(kf, q.w, sw);   // sum y'
-    qx = fmaf(q.x, yx + sx, qx); qy = fmaf(q.y, yy + sy, qy);          // sum y'^2 = sum p^2 + q (2 sum p + k q)
-    qz = fmaf(q.z, yz + sz, qz); qw = fmaf(q.w, yw + sw, qw);
+    // y' - p' = (P' - pP') + (Q' - pQ') = d + e:  sum = sd + k e,  sum of squares = sum d^2 + e (2 sd + k e)
+    const float ex = q.x - pq4.x, ey = q.y - pq4.y, ez = q.z - pq4.z, ew = q.w - pq4.w;
+    const float yx = fmaf(kf, ex, sx), yy = fmaf(kf, ey, sy), yz = fmaf(kf, ez, sz), yw = fmaf(kf, ew, sw);
+    qx = fmaf(ex, yx + sx, qx); qy = fmaf(ey, yy + sy, qy);
+    qz = fmaf(ez, yz + sz, qz); qw = fmaf(ew, yw + sw, qw);
     const int64_t o = ((int64_t)b * N + n) * Co + c0 + lp * 4;
 #ifndef SUG_EF_ABL_NOZ
     st4(z + o, make_float4(zx, zy, zz, zw));                          // (overwrites this point's parked Q quarter, if any)
@@ -273,8 +295,10 @@ __global__ __launch_bounds__(NT, 4) void edgeconv_fused_fwd_kernel(
       *reinterpret_cast<uint32_t*>(arg + o) =
           (uint32_t)jx | ((uint32_t)jy << 8) | ((uint32_t)jz << 16) | ((uint32_t)jw << 24);
 #endif
-    const float4 sy4 = make_float4(yx * sg.x, yy * sg.y, yz * sg.z, yw * sg.w);
-    if (s1) st4(s1 + o, sy4);
+    const float4 sy4 = make_float4(yx * sg.x, yy * sg.y, yz * sg.z, yw * sg.w);          // sum_j (y - p), true sign
+    // s1 = sum_j y (unshifted: the backward's dQ formula wants it) = sum_j (y - p) + k p
+    if (s1) st4(s1 + o, make_float4(fmaf(kf, pp.x + pq4.x, yx) * sg.x, fmaf(kf, pp.y + pq4.y, yy) * sg.y,
+                                    fmaf(kf, pp.z + pq4.z, yz) * sg.z, fmaf(kf, pp.w + pq4.w, yw) * sg.w));
     a1.x += sy4.x; a1.y += sy4.y; a1.z += sy4.z; a1.w += sy4.w;
     a2.x += qx; a2.y += qy; a2.z += qz; a2.w += qw;
   }
@@ -314,7 +338,7 @@ __global__ __launch_bounds__(256) void edgeconv_bn_act_kernel(
     const float* __restrict__ ws, int nblk, int Co, int groups, const float* __restrict__ gamma,
     const float* __restrict__ beta, double count, float eps, float momentum, float* __restrict__ rmean,
     float* __restrict__ rvar, float* __restrict__ coef, const float* __restrict__ z, int64_t rows_g, float slope,
-    float* __restrict__ out, int64_t ldo, int rows_per_wg) {
+    float* __restrict__ out, int64_t ldo, int rows_per_wg, const float* __restrict__ pivot) {
   extern __shared__ __attribute__((aligned(16))) float s_c[];      // scale [Co] | shift [Co]
   const int g = blockIdx.y;
   const bool writer = blockIdx.x == 0 && blockIdx.y == 0;
@@ -326,9 +350,10 @@ __global__ __launch_bounds__(256) void edgeconv_bn_act_kernel(
       s += (double)w[(size_t)r * 2 * Co + c];
       q += (double)w[(size_t)r * 2 * Co + Co + c];
     }
-    mean = s / count;
-    var = q / count - mean * mean;
+    const double m1 = s / count;                     // mean of (y - pivot)
+    var = q / count - m1 * m1;
     if (var < 0) var = 0;
+    mean = (pivot ? (double)pivot[(size_t)gg * Co + c] : 0.0) + m1;
   };
   for (int c = threadIdx.x; c < Co; c += 256) {
     double mean, var;
@@ -393,31 +418,31 @@ __global__ __launch_bounds__(256) void edgeconv_bn_act_kernel(
 
 template <int CIN, int NT, bool QLDS>
 int launch_fused_nt(const float* x, int64_t ldx, const float* wcat, const float* qbias, const int32_t* idx,
-                    const float* gamma, int B, int N, int Co, float* z, uint8_t* arg, float* s1, float* pq_out,
+                    const float* gamma, int B, int N, int Co, int Bg, float* z, uint8_t* arg, float* s1, float* pq_out,
                     int64_t ldpq, float* ws, hipStream_t st) {
-  const size_t plds = (size_t)N * SW * sizeof(float) * (QLDS ? 2 : 1);
+  const size_t plds = (size_t)N * SW * sizeof(float) * (QLDS ? 2 : 1) + 2 * SW * sizeof(float);      // P (| Q) image + pivot row
   const size_t rlds = (size_t)(NT / LP) * 2 * SW * sizeof(float);
   const size_t sh = plds > rlds ? plds : rlds;
   static SugLdsOptIn note;
   if (int rc = sug_allow_dynamic_lds(note, &edgeconv_fused_fwd_kernel<CIN, 20, NT, QLDS>, 160 * 1024, "sug_edgeconv_fused_layer_fwd"))
     return rc;
   hipLaunchKernelGGL((edgeconv_fused_fwd_kernel<CIN, 20, NT, QLDS>), dim3(B * (Co / SW)), dim3(NT), sh, st, x, ldx, wcat, qbias,
-                     idx, gamma, B, N, Co, z, arg, s1, pq_out, ldpq, ws);
+                     idx, gamma, B, N, Co, Bg, z, arg, s1, pq_out, ldpq, ws);
   SUG_LAUNCH_CHECK("sug_edgeconv_fused_layer_fwd");
   return SUG_OK;
 }
 
 template <int CIN>
 int launch_fused(const float* x, int64_t ldx, const float* wcat, const float* qbias, const int32_t* idx,
-                 const float* gamma, int B, int N, int Co, float* z, uint8_t* arg, float* s1, float* pq_out,
+                 const float* gamma, int B, int N, int Co, int Bg, float* z, uint8_t* arg, float* s1, float* pq_out,
                  int64_t ldpq, float* ws, hipStream_t st) {
   // P and Q slices both in LDS (one 16-wave workgroup per CU) while they fit; larger clouds park Q in the z buffer
-  const bool qlds = (size_t)N * SW * sizeof(float) * 2 <= 160 * 1024;
+  const bool qlds = (size_t)N * SW * sizeof(float) * 2 + 2 * SW * sizeof(float) <= 160 * 1024;
 #ifdef SUG_EF_ABL_QGLOBAL
-  return launch_fused_nt<CIN, 512, false>(x, ldx, wcat, qbias, idx, gamma, B, N, Co, z, arg, s1, pq_out, ldpq, ws, st);
+  return launch_fused_nt<CIN, 512, false>(x, ldx, wcat, qbias, idx, gamma, B, N, Co, Bg, z, arg, s1, pq_out, ldpq, ws, st);
 #endif
-  if (qlds) return launch_fused_nt<CIN, 1024, true>(x, ldx, wcat, qbias, idx, gamma, B, N, Co, z, arg, s1, pq_out, ldpq, ws, st);
-  return launch_fused_nt<CIN, 1024, false>(x, ldx, wcat, qbias, idx, gamma, B, N, Co, z, arg, s1, pq_out, ldpq, ws, st);
+  if (qlds) return launch_fused_nt<CIN, 1024, true>(x, ldx, wcat, qbias, idx, gamma, B, N, Co, Bg, z, arg, s1, pq_out, ldpq, ws, st);
+  return launch_fused_nt<CIN, 1024, false>(x, ldx, wcat, qbias, idx, gamma, B, N, Co, Bg, z, arg, s1, pq_out, ldpq, ws, st);
 }
 
 }  // namespace
@@ -431,18 +456,20 @@ int sug_affine_act_groups(const float* z, int64_t ldz, const float* coef, int64_
 int sug_edgeconv_bn_act(const float* ws, int nblk, int Co, int groups, const float* gamma, const float* beta, double count,
                         float eps, float momentum, float* running_mean, float* running_var, float* coef, const float* z,
                         int64_t rows_g, float slope, float* out, int64_t ldo, hipStream_t st) {
+  // the partial rows are sums about the pivot row the producers published behind them (common.h)
+  const float* pivot = ws + SUG_PIVOT_OFFSET(Co);
   int rpw = 64;                                   // rows per workgroup: >= 1024 workgroups where the layer has them
   while ((rows_g + rpw - 1) / rpw * groups > 4096) rpw *= 2;
   hipLaunchKernelGGL(edgeconv_bn_act_kernel, dim3((unsigned)((rows_g + rpw - 1) / rpw), groups), dim3(256),
                      (size_t)2 * Co * sizeof(float), st, ws, nblk, Co, groups, gamma, beta, count, eps, momentum,
-                     running_mean, running_var, coef, z, rows_g, slope, out, ldo, rpw);
+                     running_mean, running_var, coef, z, rows_g, slope, out, ldo, rpw, pivot);
   SUG_LAUNCH_CHECK("sug_edgeconv_bn_act");
   return SUG_OK;
 }
 
 extern "C" int sug_edgeconv_fused_supported(int N, int k, int Cin, int Co) {
   return k == 20 && (Cin == 3 || Cin == 64 || Cin == 128) && Co % 16 == 0 && Co >= 16 && Co <= 1024 && N >= 32 &&
-         (size_t)N * SW * 4 <= 160 * 1024;
+         (size_t)N * SW * 4 + 2 * SW * 4 <= 160 * 1024;
 }
 
 extern "C" int sug_edgeconv_fused_layer_fwd(const float* x, int64_t ldx, int Cin, const float* wcat, const float* qbias,
@@ -464,11 +491,11 @@ extern "C" int sug_edgeconv_fused_layer_fwd(const float* x, int64_t ldx, int Cin
   hipStream_t st = (hipStream_t)stream;
   int rc;
   if (Cin == 3)
-    rc = launch_fused<4>(x, ldx, wcat, qbias, idx, gamma, B, N, Co, z, arg, s1, pq_out, ldpq, ws, st);
+    rc = launch_fused<4>(x, ldx, wcat, qbias, idx, gamma, B, N, Co, B / groups, z, arg, s1, pq_out, ldpq, ws, st);
   else if (Cin == 64)
-    rc = launch_fused<64>(x, ldx, wcat, qbias, idx, gamma, B, N, Co, z, arg, s1, pq_out, ldpq, ws, st);
+    rc = launch_fused<64>(x, ldx, wcat, qbias, idx, gamma, B, N, Co, B / groups, z, arg, s1, pq_out, ldpq, ws, st);
   else
-    rc = launch_fused<128>(x, ldx, wcat, qbias, idx, gamma, B, N, Co, z, arg, s1, pq_out, ldpq, ws, st);
+    rc = launch_fused<128>(x, ldx, wcat, qbias, idx, gamma, B, N, Co, B / groups, z, arg, s1, pq_out, ldpq, ws, st);
   if (rc != SUG_OK) return rc;
   const int64_t rows_g = (int64_t)(B / groups) * N;
 #ifdef SUG_EF_ABL_NOACT

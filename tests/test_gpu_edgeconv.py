@@ -324,3 +324,40 @@ def test_edgeconv_fused_matches_gemm_path(C, Co, N, B, G):
         assert rel < 1e-4, (key, rel)
     # a conv bias in front of train-mode BatchNorm has zero gradient: both paths return rounding noise only
     assert float(b['gb'].abs().max()) <= 1e-3 * float(b['gw'].abs().max()) + 1e-5
+
+
+@pytest.mark.parametrize('C,Co', [(64, 64), (128, 256)])
+def test_edgeconv_large_offset(C, Co):
+    """EdgeConv BatchNorm statistics when the mean of y = W.[x_j - x_i ; x_i] dwarfs its spread (y ~ 100 +- 0.05): the
+    sums inside the gather kernels (the fused layer for C = 64, the library-GEMM path for C = 128) are taken about a
+    pivot, so the normalised activations match an fp64 evaluation of the layer."""
+    from sug_amd import ops
+    from sug_amd.model.model_utils import conv_2d
+    B, N, k = 4, 256, 20
+    g = torch.Generator().manual_seed(C + Co)
+    x = (5.0 + 0.01 * torch.randn(B, N, C, generator=g)).cuda()
+    idx = torch.randint(0, N, (B, N, k), generator=g, dtype=torch.int32).cuda()
+    m = conv_2d(2 * C, Co, 1, activation='leakyrelu', bias=False).cuda().train()
+    with torch.no_grad():
+        w = torch.randn(Co, 2 * C, generator=g) * 0.3
+        w[:, C:] += 20.0 / C                                   # the x_i half: W2 . x_i ~ 100
+        m.conv[0].weight.copy_(w.view(Co, 2 * C, 1, 1).cuda())
+        gam = 1 + 0.3 * torch.randn(Co, generator=g)
+        gam[::3] = -gam[::3]
+        m.conv[1].weight.copy_(gam.cuda())
+    with ops.bn_groups(2), torch.no_grad():
+        out = m.edge_rows(x, idx)
+    xd, wd = x.double(), m.conv[0].weight.view(Co, 2 * C).double()
+    bi = torch.arange(B, device='cuda').view(B, 1, 1)
+    nbr = xd[bi, idx.long()]                                                          # [B,N,k,C]
+    y = torch.cat((nbr - xd.unsqueeze(2), xd.unsqueeze(2).expand_as(nbr)), -1) @ wd.t()   # [B,N,k,Co]
+    assert float(y.mean().abs()) > 50 and float(y.std(dim=(0, 1, 2)).mean()) < 1.0
+    refs = []
+    for yg in y.chunk(2, dim=0):
+        mu, var = yg.mean((0, 1, 2)), yg.var((0, 1, 2), unbiased=False)
+        u = (yg - mu) / torch.sqrt(var + m.conv[1].eps) * m.conv[1].weight.double() + m.conv[1].bias.double()
+        refs.append(torch.nn.functional.leaky_relu(u, 0.01).max(dim=2)[0])
+    ref = torch.cat(refs).float()
+    err = float((out - ref).abs().max())
+    print('max deviation from the fp64 layer: %.3e' % err)
+    assert err < 5e-3, err                  # input rounding: ulp(100) = 7.6e-6 against a spread of ~0.05
