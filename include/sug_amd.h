@@ -205,6 +205,9 @@ int sug_edgeconv_bwd_scatter(const float* a, const uint8_t* arg, const float* s1
 int64_t sug_linear_dw_workspace(int64_t R, int M, int N);
 int sug_linear_dw(const float* g, int64_t ldg, const float* x, int64_t ldx, int64_t R, int M, int N,
                   float* dw, float* ws, void* stream);
+/* Ordered fold of nchunk split-K partials part[nchunk][MN] -> dw[MN] (fp64 accumulation in a fixed order; no atomics,
+ * no memset): the second half of sug_linear_dw, for partials a batched library GEMM over row chunks produced. */
+int sug_linear_dw_fold(const float* part, int nchunk, int64_t MN, float* dw, void* stream);
 /* The same launch also forms the bias gradient db[M] = column sums of g (the Conv bias, nn.Conv2d(bias=True) of
  * model/pointnet2_utils.py:172 and the nn.Linear biases of model/Ptran_transformer.py:17-33) from the g elements
  * it already holds, instead of a second pass over g.  db == NULL: sug_linear_dw. */

@@ -76,6 +76,7 @@ SIGNATURES = {
     'sug_adam_step': [_vp, _vp, _vp, _i32, _vp, _f64, _f64, _f64, _f64, _f64, _f64, _f64, _vp],
     'sug_adam_step_capturable': [_vp, _vp, _vp, _i32, _vp, _f64, _f64, _f64, _f64, _f64, _vp, _vp, _vp, _vp],
     'sug_linear_dw': [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp],
+    'sug_linear_dw_fold': [_vp, _i32, _i64, _vp, _vp],
     'sug_sa_first_fwd': [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp],
     'sug_sa_first_bwd': [_vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                          _vp, _vp, _vp],

@@ -291,3 +291,13 @@ extern "C" int sug_linear_dw(const float* g, int64_t ldg, const float* x, int64_
                              int N, float* dw, float* ws, void* stream) {
   return sug_linear_dw_bias(g, ldg, x, ldx, R, M, N, dw, nullptr, ws, stream);
 }
+
+// Ordered fold of `nchunk` partial outputs part[nchunk][MN] (fp64 accumulation, fixed order, no atomics, no memset):
+// the second half of sug_linear_dw, exposed for split-K partials that a batched library GEMM produced.
+extern "C" int sug_linear_dw_fold(const float* part, int nchunk, int64_t MN, float* dw, void* stream) {
+  SUG_REQUIRE(part && dw && nchunk > 0 && MN > 0, "sug_linear_dw_fold: bad argument");
+  hipLaunchKernelGGL(linear_dw_reduce_kernel, dim3(sug_divup(MN, 16)), dim3(256), 0, (hipStream_t)stream, part, nchunk, MN,
+                     MN, dw, (float*)nullptr);
+  SUG_LAUNCH_CHECK("sug_linear_dw_fold");
+  return SUG_OK;
+}

@@ -322,6 +322,21 @@ class _LinearRows(torch.autograd.Function):
         return (None if dx is None else dx.view(x.shape)), dw, db
 
 
+DW_BMM = _os.environ.get('SUG_DW_BMM', '1') == '1'
+
+
+def _dw_bmm_chunks(R, M, N, g2, x2):
+    """Row chunks for the batched-GEMM form of a weight gradient (0 = use sug_linear_dw): outputs >= 128 x 128 (or
+    256 x 64), dense operands, chunks of ~4096 rows (8 .. 64 chunks)."""
+    if not DW_BMM or M * N < 128 * 128 or min(M, N) < 64 or g2.stride(0) != M or x2.stride(0) != N or \
+            g2.stride(1) != 1 or x2.stride(1) != 1:
+        return 0
+    S = 64
+    while S > 8 and R // S < 4096:
+        S //= 2
+    return S if (R % S == 0 and R // S >= 1024) else 0
+
+
 def linear_rows_backward(x2, weight, g2, need_dx, need_dw, need_db):
     """Gradients of y = x2 . weight^T (+ b) for rows x2 [R, N], g2 [R, M]: dx by the library GEMM, the weight gradient
     g^T . x (K = rows, small output) by sug_linear_dw(_bias) -- with the bias gradient from the same pass over g."""
@@ -342,8 +357,26 @@ def linear_rows_backward(x2, weight, g2, need_dx, need_dw, need_db):
         # front of the accumulating kernels on ROCm 7 -- see sug_mmd_rbf_value -- which showed as NaN weights
         # after tens to hundreds of replays)
         lib_ok = DW_FORCE_LIBRARY or ((R, M, N) in DW_LIBRARY_SHAPES and not torch.cuda.is_current_stream_capturing())
+        S = _dw_bmm_chunks(R, M, N, g2, x2) if not need_db else 0
         if M * N > 512 * 512 or lib_ok:
             dw = g2.t() @ x2            # larger than any encoder layer, or the tuned library GEMM is faster
+        elif S:
+            # outputs of 128 x 128 and more: the library's GEMM kernels beat the one-wave MFMA tiles of sug_linear_dw
+            # (512 x 512 at 65536 rows: 240 vs 335 us) once K = rows is split by BATCHING over row chunks -- no split-K
+            # solution, hence no memset node -- and the partials are folded by sug_linear_dw's ordered reduce
+            # (outside TunableOp: its look-up of a shape that is not in the recorded table ends in a hipBLASLt call that
+            # is not permitted while a stream is capturing; the default heuristic's batched kernel is)
+            import torch.cuda.tunable as _tn
+            tuned = _tn.is_enabled()
+            if tuned:
+                _tn.enable(False)
+            try:
+                part = torch.bmm(g2.view(S, R // S, M).transpose(1, 2), x2.view(S, R // S, N))
+            finally:
+                if tuned:
+                    _tn.enable(True)
+            dw = torch.empty(M, N, dtype=torch.float32, device=g2.device)
+            check(lib().sug_linear_dw_fold(_p(part), S, M * N, _p(dw), _st()), 'sug_linear_dw_fold')
         else:
             dw = torch.empty(M, N, dtype=torch.float32, device=g2.device)
             ws = torch.empty(int(lib().sug_linear_dw_workspace(R, M, N)), dtype=torch.float32, device=g2.device)

@@ -35,6 +35,11 @@ for R, M, N in ((65536, 3, 64), (65536, 64, 64), (65536, 64, 128), (65536, 128, 
     ws = torch.empty(int(L.sug_linear_dw_workspace(R, M, N)), device='cuda')
     us = t(lambda: L.sug_linear_dw_bias(g.data_ptr(), M, x.data_ptr(), N, R, M, N, dw.data_ptr(), db.data_ptr(), ws.data_ptr(), ops._st()))
     lib_us = t(lambda: torch.mm(g.t(), x))
+    bmm = {}
+    if M * N >= 128 * 128:
+        for S in (8, 16, 32, 64):       # batched library GEMM over row chunks = split-K without a memset, + ordered sum
+            if R % S == 0:
+                bmm[S] = t(lambda: torch.bmm(g.view(S, R // S, M).transpose(1, 2), x.view(S, R // S, N)).sum(0))
     ref = (g.double().t() @ x.double()).float()
     err = float((dw - ref).abs().max() / ref.abs().max())
-    print('R=%8d M=%4d N=%4d  %7.1f us  %6.1f TFLOP/s  %5.2f TB/s  rel err %.1e   library %7.1f us' % (R, M, N, us, 2.0 * R * M * N / us / 1e6, 4.0 * R * (M + N) / us / 1e6, err, lib_us))
+    print('R=%8d M=%4d N=%4d  %7.1f us  %6.1f TFLOP/s  %5.2f TB/s  rel err %.1e   library %7.1f us  bmm+sum %s' % (R, M, N, us, 2.0 * R * M * N / us / 1e6, 4.0 * R * (M + N) / us / 1e6, err, lib_us, {k: round(v, 1) for k, v in bmm.items()}))
