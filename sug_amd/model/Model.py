@@ -414,8 +414,8 @@ class Net_MDA(nn.Module):
             x = grad_reverse(x, constant)
         if not semantic_adaption:
             return self.c1(x, adapt=False), self.c2(x, adapt=False)
-        y1, sem_feature1 = self.c1(x, adapt=True)
-        y2, sem_feature2 = self.c2(x, adapt=True)
+        (y1, sem_feature1), (y2, sem_feature2) = ops.run_parallel([lambda: self.c1(x, adapt=True),
+                                                                    lambda: self.c2(x, adapt=True)])
         return y1, y2, sem_feature1, sem_feature2
 
     def forward_pair(self, x_pair, node_adaptation=False):
@@ -448,8 +448,7 @@ class Net_MDA(nn.Module):
         halves = lambda t: t.reshape(2, B, -1).unbind(0)      # backward: one stack, no zero fills
         if node_adaptation:
             f_s, f_t = halves(feat_ori.contiguous())
-            return self.attention_s(f_s), self.attention_t(f_t)
-        y1, f1 = self.c1(x, adapt=True)
-        y2, f2 = self.c2(x, adapt=True)
+            return tuple(ops.run_parallel([lambda: self.attention_s(f_s), lambda: self.attention_t(f_t)]))
+        (y1, f1), (y2, f2) = ops.run_parallel([lambda: self.c1(x, adapt=True), lambda: self.c2(x, adapt=True)])
         (y1s, y1t), (y2s, y2t), (f1s, f1t), (f2s, f2t) = halves(y1), halves(y2), halves(f1), halves(f2)
         return (y1s, y2s, f1s, f2s), (y1t, y2t, f1t, f2t)

@@ -27,6 +27,39 @@ PROFILE_ONLY = None
 START_PROVIDER = None
 
 
+# Independent branches of a step (the two classifier heads, the two attention layers, the three MMD terms) are chains of
+# small kernels -- 5-15 us each, launch-latency bound.  Inside a captured hipGraph they can run side by side: with
+# PARALLEL_BRANCHES on (SUGStep switches it on for its own forwards when it replays the step from a graph), run_parallel
+# forks the branches onto side streams and joins them; autograd runs each branch's backward on the stream of its
+# forward, so the backward branches overlap too.  Launched eagerly from Python the extra event records only cost host
+# time, hence off by default.  (Measured on ROCm 7.2 / MI355X: also under graph replay it is a loss -- 5.35 vs 5.26 ms per
+# DGCNN step -- a cross-stream edge of a hipGraph costs more than the kernels it overlaps; SUG_PARALLEL_BRANCHES=1 opts in.)
+PARALLEL_BRANCHES = False
+_SIDE_STREAMS = {}
+
+
+def run_parallel(fns):
+    """[f() for f in fns], the calls after the first on side streams forked from / joined to the current stream."""
+    if not PARALLEL_BRANCHES or len(fns) < 2 or not torch.cuda.is_available():
+        return [f() for f in fns]
+    main = torch.cuda.current_stream()
+    dev = main.device_index
+    sides = []
+    for i in range(1, len(fns)):
+        st = _SIDE_STREAMS.get((dev, i))
+        if st is None:
+            st = _SIDE_STREAMS[(dev, i)] = torch.cuda.Stream(device=dev)
+        st.wait_stream(main)                  # fork point: before any branch is enqueued
+        sides.append(st)
+    outs = [fns[0]()]
+    for f, st in zip(fns[1:], sides):
+        with torch.cuda.stream(st):
+            outs.append(f())
+    for st in sides:
+        main.wait_stream(st)                  # join
+    return outs
+
+
 # Domain groups of a batch: with BN_GROUPS = G the batch dimension holds G equal contiguous parts
 # (Net_MDA.forward_pair: source clouds then target clouds) that the reference sends through the
 # network in G separate forward calls.  Everything per-cloud / per-row is oblivious to that; the

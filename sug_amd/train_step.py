@@ -290,6 +290,10 @@ class SUGStep:
         # fused small ops (LayerNorm heads) pay off once the host no longer launches; scoped to this trainer's
         # forwards (set and restored around self.losses())
         self.fused_heads = self.use_graph
+        # opt-in (SUG_PARALLEL_BRANCHES=1): independent small-kernel chains (heads, attention layers, MMD terms) on forked
+        # streams inside the captured graph.  Measured SLOWER on ROCm 7.2 / MI355X (5.35 vs 5.26 ms per step: a cross-stream
+        # edge of a hipGraph costs more than the ~5 us kernels it lets overlap), hence off.
+        self.parallel_branches = self.use_graph and os.environ.get('SUG_PARALLEL_BRANCHES', '0') == '1'
         if self.use_graph:
             if own_adam:
                 kw['graph_capturable'] = True           # step count / bias corrections / lr on the device
@@ -406,12 +410,16 @@ class SUGStep:
             return (loss_cls,) + self._global_soft_mmd(data, label, data_t, label_t, feat_node_s, feat_node_t,
                                                         (sem_s1, sem_t1, pred_s1, pred_t1),
                                                         (sem_s2, sem_t2, pred_s2, pred_t2))
-        loss_geo = M['MMD_WEIGHT'] * geo['GEO_SCALE'] * self._mmd(label, feat_node_s, label_t, feat_node_t, geo, data, data_t)
+        # the three MMD terms are independent chains of small kernels: side by side under graph replay (ops.run_parallel)
+        terms = [lambda: self._mmd(label, feat_node_s, label_t, feat_node_t, geo, data, data_t)]
+        if sem['SEM_SCALE'] > 0:
+            terms += [lambda: self._mmd(label, sem_s1, label_t, sem_t1, sem, pred_s1, pred_t1),
+                      lambda: self._mmd(label, sem_s2, label_t, sem_t2, sem, pred_s2, pred_t2)]
+        vals = ops.run_parallel(terms)
+        loss_geo = M['MMD_WEIGHT'] * geo['GEO_SCALE'] * vals[0]
         loss_sem = None
         if sem['SEM_SCALE'] > 0:
-            l1 = self._mmd(label, sem_s1, label_t, sem_t1, sem, pred_s1, pred_t1)
-            l2 = self._mmd(label, sem_s2, label_t, sem_t2, sem, pred_s2, pred_t2)
-            loss_sem = (0.5 * M['MMD_WEIGHT'] * sem['SEM_SCALE']) * (l1 + l2)
+            loss_sem = (0.5 * M['MMD_WEIGHT'] * sem['SEM_SCALE']) * (vals[1] + vals[2])
         return loss_cls, loss_geo, loss_sem
 
     # ------------------------------------------------------------------ step
@@ -552,6 +560,7 @@ class SUGStep:
             from .model import Ptran_transformer as _PT
             ops.W16_CACHE = ops.w16_prefill(getattr(self, '_w16_plan', None) or []) if _PT.GEMM_DTYPE is not None else None
             fused_before, ops.FUSED_HEADS = ops.FUSED_HEADS, (self.fused_heads or ops.FUSED_HEADS)
+            par_before, ops.PARALLEL_BRANCHES = ops.PARALLEL_BRANCHES, (self.parallel_branches or ops.PARALLEL_BRANCHES)
             try:
                 model._cuts = S['cuts'] = []
                 pair = torch.cat((data, data_t), dim=0)
@@ -575,6 +584,7 @@ class SUGStep:
             finally:
                 model._cuts = None
                 ops.FUSED_HEADS = fused_before
+                ops.PARALLEL_BRANCHES = par_before
                 if ops.W16_CACHE is not None:
                     self._w16_plan = ops.w16_plan(ops.W16_CACHE)
                 ops.W16_CACHE = None
@@ -774,10 +784,12 @@ class SUGStep:
         # multi-tensor copy into the first step's buffers
         ops.W16_CACHE = ops.w16_prefill(getattr(self, '_w16_plan', None) or []) if _PT.GEMM_DTYPE is not None else None
         fused_before, ops.FUSED_HEADS = ops.FUSED_HEADS, (self.fused_heads or ops.FUSED_HEADS)
+        par_before, ops.PARALLEL_BRANCHES = ops.PARALLEL_BRANCHES, (self.parallel_branches or ops.PARALLEL_BRANCHES)
         try:
             loss_cls, loss_geo, loss_sem = self.losses(data, label, data_t, label_t, mmd_on)
         finally:
             ops.FUSED_HEADS = fused_before
+            ops.PARALLEL_BRANCHES = par_before
             if ops.W16_CACHE is not None:
                 self._w16_plan = ops.w16_plan(ops.W16_CACHE)
             ops.W16_CACHE = None
