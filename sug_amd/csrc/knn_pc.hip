@@ -27,8 +27,8 @@
 //              give the lists of the exact consumer bit for bit (tests/golden/knn_pc_hashes.json).
 // One barrier per tile hands tile t's scores to the consumers while the producers work on tile
 // t+1.  No candidate ring, no compaction, no merge.
-// LDS: tiles 3 x 32 x (C+4) + score tiles 2 x 4 x 64 x 36 floats = 100 / 125 KB (C = 64 / 128).
-// Workgroup = 256 queries of one cloud; the 4 workgroups of a 1024-point cloud share an XCD (one L2).
+// LDS: tiles 3 x 32 x (C+4) + score tiles 2 x PW x 64 x 36 floats = 100 / 125 KB (C = 64 / 128, PW = 4) or 63 KB (C = 64, PW = 2).
+// Workgroup = 64 PW queries of one cloud; the workgroups of a cloud share an XCD (one L2).
 //
 // FLOPs N^2*(2C+3) per cloud on the matrix pipe (157 TFLOP/s); algorithmic bytes 4*C*N + 4*N*k.
 #include <float.h>
@@ -99,17 +99,22 @@ __device__ __forceinline__ float exact_norm(const float* __restrict__ r) {
   }
 }
 
-template <int CP, int K>
-__global__ __launch_bounds__(512, 2) void knn_pc_kernel(const float* __restrict__ x, int64_t ldx, int B, int N,
-                                                        int k, int32_t* __restrict__ idx, int force) {
+// PW: producer waves = consumer waves per workgroup.  PW = 4 (product): 256 queries, 512 threads, one workgroup per CU
+// (100 / 125 KB of LDS).  PW = 2 (A/B knob, measured slower): 128 queries, 256 threads, 63 KB of LDS at C <= 64 -- two
+// workgroups per CU with independent barrier phases.
+template <int CP, int K, int PW>
+__global__ __launch_bounds__(128 * PW, 2) void knn_pc_kernel(const float* __restrict__ x, int64_t ldx, int B, int N,
+                                                             int k, int32_t* __restrict__ idx, int force) {
   constexpr int RS = CP + 4;
   constexpr int HALF = CP / 2;
+  constexpr int NTP = 64 * PW;                                          // producer threads
+  constexpr int QB = 64 * PW;                                           // queries per workgroup
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* s_tile = reinterpret_cast<float*>(smem);                       // [3][TJ][RS]
   float* s_norm = s_tile + 3 * TJ * RS;                                 // [3][TJ] (+pad)
-  float* s_score = s_norm + 4 * TJ;                                     // [2][4][64][SROW]
+  float* s_score = s_norm + 4 * TJ;                                     // [2][PW][64][SROW]
 
-  const int nq = (N + 255) / 256;
+  const int nq = (N + QB - 1) / QB;
   int b, qb;
   if ((B & 7) == 0) {                        // a cloud's query blocks share an XCD (its L2 holds the cloud once)
     const int grp = blockIdx.x / (8 * nq), rem = blockIdx.x % (8 * nq);
@@ -120,30 +125,30 @@ __global__ __launch_bounds__(512, 2) void knn_pc_kernel(const float* __restrict_
     qb = blockIdx.x % nq;
   }
   const float* xb = x + (int64_t)b * N * ldx;
-  const bool producer = threadIdx.x < 256;
-  const int lane = threadIdx.x & 63, wv = (threadIdx.x >> 6) & 3;       // wv: producer / consumer pair index
+  const bool producer = threadIdx.x < NTP;
+  const int lane = threadIdx.x & 63, wv = (threadIdx.x >> 6) & (PW - 1);   // wv: producer / consumer pair index
   const int qj = lane & 31, h = lane >> 5;
-  const int q0 = qb * 256;
+  const int q0 = qb * QB;
 
   const int ntile = (N + TJ - 1) / TJ;
   auto tbuf = [&](int t) { return s_tile + (t % 3) * TJ * RS; };
   auto nbuf = [&](int t) { return s_norm + (t % 3) * TJ; };
 
   // The two roles are separate code paths (disjoint register sets); both execute the same sequence
-  // of workgroup barriers: 17 in the query staging, 2 in the pipeline fill, one per tile.
+  // of workgroup barriers: 4 PW + 1 in the query staging, 2 in the pipeline fill, one per tile.
   if (producer) {
-    // ---- query operands, staged through the tile buffers: 8 tiles of 32 query rows.  They are scaled by -2 (exact):
+    // ---- query operands, staged through the tile buffers: 2 PW tiles of 32 query rows.  They are scaled by -2 (exact):
     // the chains then deliver inner = -2<x_i,x_j> itself, bit for bit fl(-2 * dot), and the consumers save the
     // multiplication per candidate
     float bq0[HALF], bq1[HALF];
     {
-      TileRegs<CP> tq[2];                        // the next query tile's loads fly under this one's staging
-      tile_load<CP>(tq[0], xb, ldx, N, q0);
+      TileRegs<CP, NTP> tq[2];                   // the next query tile's loads fly under this one's staging
+      tile_load<CP, NTP>(tq[0], xb, ldx, N, q0);
 #pragma unroll
-      for (int w = 0; w < 8; ++w) {
+      for (int w = 0; w < 2 * PW; ++w) {
         __syncthreads();
-        if (w + 1 < 8) tile_load<CP>(tq[(w + 1) & 1], xb, ldx, N, q0 + (w + 1) * TJ);
-        tile_store<CP, true>(tq[w & 1], s_tile, s_norm, N, q0 + w * TJ);
+        if (w + 1 < 2 * PW) tile_load<CP, NTP>(tq[(w + 1) & 1], xb, ldx, N, q0 + (w + 1) * TJ);
+        tile_store<CP, true, NTP>(tq[w & 1], s_tile, s_norm, N, q0 + w * TJ);
         __syncthreads();
         if ((w >> 1) == wv) {
           const float* qrow = s_tile + qj * RS + h * HALF;
@@ -195,7 +200,7 @@ __global__ __launch_bounds__(512, 2) void knn_pc_kernel(const float* __restrict_
 #endif
       }
       // S^T tile: lane = query column, registers 4g..4g+3 = candidate rows 8g + 4h .. +3: one b128 per g
-      float* d0 = s_score + ((buf * 4 + wv) * 64 + qj) * SROW + 4 * h;
+      float* d0 = s_score + ((buf * PW + wv) * 64 + qj) * SROW + 4 * h;
       float* d1 = d0 + 32 * SROW;
 #pragma unroll
       for (int g = 0; g < 4; ++g)
@@ -207,28 +212,28 @@ __global__ __launch_bounds__(512, 2) void knn_pc_kernel(const float* __restrict_
 
     // pipeline: iteration t = scores of tile t+1 (consumers are on tile t); registers of tile t+2 -> LDS;
     // the global loads of tile t+3 are in flight for a whole iteration
-    TileRegs<CP> tr;
-    tile_load<CP>(tr, xb, ldx, N, 0);
-    tile_store<CP, true>(tr, tbuf(0), nbuf(0), N, 0);
-    if (ntile > 1) tile_load<CP>(tr, xb, ldx, N, TJ);
+    TileRegs<CP, NTP> tr;
+    tile_load<CP, NTP>(tr, xb, ldx, N, 0);
+    tile_store<CP, true, NTP>(tr, tbuf(0), nbuf(0), N, 0);
+    if (ntile > 1) tile_load<CP, NTP>(tr, xb, ldx, N, TJ);
     __syncthreads();
     produce(0, 0);
-    if (ntile > 1) tile_store<CP, true>(tr, tbuf(1), nbuf(1), N, TJ);
-    if (ntile > 2) tile_load<CP>(tr, xb, ldx, N, 2 * TJ);
+    if (ntile > 1) tile_store<CP, true, NTP>(tr, tbuf(1), nbuf(1), N, TJ);
+    if (ntile > 2) tile_load<CP, NTP>(tr, xb, ldx, N, 2 * TJ);
     __syncthreads();
     for (int t = 0; t < ntile; ++t) {
 #ifdef SUG_KNN_SERIAL
       // experiment (tools/bench_knn_pc.py): the MFMA chain of tile t+1 only after the selection of tile t instead of
       // next to it -- the two share the SIMD's FMA lanes, but alternating them measured 7 us slower (138 vs 131 at C=64)
-      if (t + 2 < ntile) tile_store<CP, true>(tr, tbuf(t + 2), nbuf(t + 2), N, (t + 2) * TJ);
-      if (t + 3 < ntile) tile_load<CP>(tr, xb, ldx, N, (t + 3) * TJ);
+      if (t + 2 < ntile) tile_store<CP, true, NTP>(tr, tbuf(t + 2), nbuf(t + 2), N, (t + 2) * TJ);
+      if (t + 3 < ntile) tile_load<CP, NTP>(tr, xb, ldx, N, (t + 3) * TJ);
       __syncthreads();
       if (t + 1 < ntile) produce(t + 1, (t + 1) & 1);
       __syncthreads();
 #else
       if (t + 1 < ntile) produce(t + 1, (t + 1) & 1);
-      if (t + 2 < ntile) tile_store<CP, true>(tr, tbuf(t + 2), nbuf(t + 2), N, (t + 2) * TJ);
-      if (t + 3 < ntile) tile_load<CP>(tr, xb, ldx, N, (t + 3) * TJ);
+      if (t + 2 < ntile) tile_store<CP, true, NTP>(tr, tbuf(t + 2), nbuf(t + 2), N, (t + 2) * TJ);
+      if (t + 3 < ntile) tile_load<CP, NTP>(tr, xb, ldx, N, (t + 3) * TJ);
       __syncthreads();
 #endif
     }
@@ -237,7 +242,7 @@ __global__ __launch_bounds__(512, 2) void knn_pc_kernel(const float* __restrict_
     // ---- consumer: lane = one query; |x_i|^2 from the staged query tiles
     float ni = 0.f;
 #pragma unroll
-    for (int w = 0; w < 8; ++w) {
+    for (int w = 0; w < 2 * PW; ++w) {
       __syncthreads();
       __syncthreads();
       if ((w >> 1) == wv && h == (w & 1)) ni = s_norm[qj];
@@ -270,7 +275,7 @@ __global__ __launch_bounds__(512, 2) void knn_pc_kernel(const float* __restrict_
       __syncthreads();
       continue;
 #endif
-      const float* srow = s_score + (((t & 1) * 4 + wv) * 64 + lane) * SROW;
+      const float* srow = s_score + (((t & 1) * PW + wv) * 64 + lane) * SROW;
       const float* nrm = nbuf(t);
       // pass 1: which of the 32 candidates can still enter (thr: from the (K+2)-th key as of the previous tile:
       // stale by at most one tile, never too high; rows past N score -inf and never pass).  Candidate c -> bit 31-c.
@@ -390,8 +395,8 @@ __global__ __launch_bounds__(512, 2) void knn_pc_kernel(const float* __restrict_
     }
     if (__ballot(amb) != 0ull) {
       // scratch: this wave's two score rows blocks (no other wave touches them; the producers are done)
-      int* s_keys = reinterpret_cast<int*>(s_score + ((0 * 4 + wv) * 64) * SROW);       // [64][KP]
-      float* s_fv = s_score + ((1 * 4 + wv) * 64) * SROW;                                // [K][64]
+      int* s_keys = reinterpret_cast<int*>(s_score + ((0 * PW + wv) * 64) * SROW);      // [64][KP]
+      float* s_fv = s_score + ((1 * PW + wv) * 64) * SROW;                               // [K][64]
 #pragma unroll
       for (int t = 0; t < KP; ++t) s_keys[lane * KP + t] = L[t];
       // (a) exact re-rank of the K+2 candidates of one query at a time: lane u = candidate u
@@ -447,17 +452,28 @@ __global__ __launch_bounds__(512, 2) void knn_pc_kernel(const float* __restrict_
   }
 }
 
-template <int CP, int K>
-int launch_pc(const float* x, int64_t ldx, int B, int N, int k, int32_t* idx, hipStream_t st) {
+template <int CP, int K, int PW>
+int launch_pc_pw(const float* x, int64_t ldx, int B, int N, int k, int32_t* idx, hipStream_t st) {
   constexpr int RS = CP + 4;
-  const size_t sh = (size_t)(3 * TJ * RS + 4 * TJ + 2 * 4 * 64 * SROW) * sizeof(float);
+  const size_t sh = (size_t)(3 * TJ * RS + 4 * TJ + 2 * PW * 64 * SROW) * sizeof(float);
   static SugLdsOptIn note;
-  if (int rc = sug_allow_dynamic_lds(note, &knn_pc_kernel<CP, K>, (int)sh, "sug_knn(mfma, producer/consumer)")) return rc;
-  dim3 grid(sug_divup(N, 256) * B);
+  if (int rc = sug_allow_dynamic_lds(note, &knn_pc_kernel<CP, K, PW>, (int)sh, "sug_knn(mfma, producer/consumer)")) return rc;
+  dim3 grid(sug_divup(N, 64 * PW) * B);
   const char* fe = getenv("SUG_KNN_FORCE");      // test knob: 1 = exact re-rank for every query, 2 = exact rescan
-  hipLaunchKernelGGL((knn_pc_kernel<CP, K>), grid, dim3(512), sh, st, x, ldx, B, N, k, idx, fe ? atoi(fe) : 0);
+  hipLaunchKernelGGL((knn_pc_kernel<CP, K, PW>), grid, dim3(128 * PW), sh, st, x, ldx, B, N, k, idx, fe ? atoi(fe) : 0);
   SUG_LAUNCH_CHECK("sug_knn(mfma, producer/consumer)");
   return SUG_OK;
+}
+
+template <int CP, int K>
+int launch_pc(const float* x, int64_t ldx, int B, int N, int k, int32_t* idx, hipStream_t st) {
+  // 256-query workgroups (PW = 4, one per CU) are the product form.  SUG_KNN_PW=2 selects 128-query workgroups (two per CU
+  // at C <= 64) for A/B timing (tools/bench_knn_pw.py): measured SLOWER -- 157 vs 133 us at C = 64, 77 vs 71 at C = 3 (every
+  // workgroup stages all candidate tiles, so two per CU double that work and halve the waves behind each barrier).
+  static const int forced = getenv("SUG_KNN_PW") ? atoi(getenv("SUG_KNN_PW")) : 0;
+  const bool two = forced == 2;
+  if (two) return launch_pc_pw<CP, K, 2>(x, ldx, B, N, k, idx, st);
+  return launch_pc_pw<CP, K, 4>(x, ldx, B, N, k, idx, st);
 }
 
 template <int K>

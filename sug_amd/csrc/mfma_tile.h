@@ -16,15 +16,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int TJ = 32;   // rows per tile = MFMA M
 
 // Global -> register half of the staging (so the loads fly under the previous tile's MFMAs).
-template <int CP>
+// NT: threads that stage a tile together (256, or 128 for the two-wave producers of knn_pc_kernel's 128-query form)
+template <int CP, int NT = 256>
 struct TileRegs {
-  static constexpr int NV = (CP == 4) ? 1 : (CP / 64);   // (row, 8-feature chunk) items per thread
+  static constexpr int NV = (CP == 4) ? 1 : (4 * CP / NT);   // (row, 8-feature chunk) items per thread
   float4 lo[NV], hi[NV];
 };
 
-// rows [row0, row0+32) of xb (row stride ldx); rows >= N read as zero.  256 threads.
-template <int CP>
-__device__ __forceinline__ void tile_load(TileRegs<CP>& t, const float* __restrict__ xb, int64_t ldx,
+// rows [row0, row0+32) of xb (row stride ldx); rows >= N read as zero.  NT threads.
+template <int CP, int NT = 256>
+__device__ __forceinline__ void tile_load(TileRegs<CP, NT>& t, const float* __restrict__ xb, int64_t ldx,
                                           int N, int row0) {
   // The loads carry no guards (a guarded load compiles to a branch and the wait counters around it collapse to
   // vmcnt(0), which would serialise a prefetch with the loads before it): rows past N read row N-1 and are zeroed
@@ -38,8 +39,8 @@ __device__ __forceinline__ void tile_load(TileRegs<CP>& t, const float* __restri
   } else {
     constexpr int CH = CP / 8;                 // chunks per row
 #pragma unroll
-    for (int u = 0; u < TileRegs<CP>::NV; ++u) {
-      const int item = (int)threadIdx.x + u * 256;
+    for (int u = 0; u < TileRegs<CP, NT>::NV; ++u) {
+      const int item = (int)threadIdx.x + u * NT;
       const int r = row0 + item / CH, c8 = item % CH;
       const bool ok = r < N;
       const float4* p = reinterpret_cast<const float4*>(xb + (int64_t)(ok ? r : N - 1) * ldx + c8 * 8);
@@ -51,8 +52,8 @@ __device__ __forceinline__ void tile_load(TileRegs<CP>& t, const float* __restri
 }
 
 // Register -> LDS half: de-interleave; with NORM also the row norms |x_j|^2 (rows >= N: +inf).
-template <int CP, bool NORM = true>
-__device__ __forceinline__ void tile_store(const TileRegs<CP>& t, float* __restrict__ s_tile,
+template <int CP, bool NORM = true, int NT = 256>
+__device__ __forceinline__ void tile_store(const TileRegs<CP, NT>& t, float* __restrict__ s_tile,
                                            float* __restrict__ s_norm, int N, int row0) {
   constexpr int RS = CP + 4;
   if constexpr (CP == 4) {
@@ -68,8 +69,8 @@ __device__ __forceinline__ void tile_store(const TileRegs<CP>& t, float* __restr
     constexpr int CH = CP / 8;
     constexpr int HALF = CP / 2;
 #pragma unroll
-    for (int u = 0; u < TileRegs<CP>::NV; ++u) {
-      const int item = (int)threadIdx.x + u * 256;
+    for (int u = 0; u < TileRegs<CP, NT>::NV; ++u) {
+      const int item = (int)threadIdx.x + u * NT;
       const int r = item / CH, c8 = item % CH;
       const float4 a = t.lo[u], b = t.hi[u];
       float* d = s_tile + r * RS;
