@@ -750,17 +750,33 @@ class SUGStep:
             st['feeder'].cursor = 0
             segs = self._segments(*st['in'], epoch)
             S = st['S']
-            graphs, pool = [], None
+            graphs, pool, err = [], None, None
             ops.START_PROVIDER = st['feeder'].provide
             try:
                 for fn in segs['device']:
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, pool=pool):
+                    # thread_local: the process group's watchdog thread queries events of finished collectives while
+                    # we capture; in the default (global) mode such a call from ANOTHER thread invalidates the capture
+                    with torch.cuda.graph(g, pool=pool, capture_error_mode='thread_local'):
                         fn(S)
                     pool = g.pool() if pool is None else pool
                     graphs.append(g)
+            except RuntimeError as e:                      # (reported below, after every rank has been heard)
+                err = e
             finally:
                 ops.START_PROVIDER = None
+            # the ranks must agree before the first replay: a rank whose capture failed would otherwise meet the others'
+            # all-gather with a different collective.  One flag all-reduce per capture (not per step).
+            ok = torch.tensor([0.0 if err is not None else 1.0], device=data.device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if float(ok.item()) < 1.0:
+                self._graphs.pop(key, None)
+                for o in self._opts():                    # gradients of the aborted capture point into its discarded pool
+                    o.zero_grad(set_to_none=True)
+                if self.share_prefix:
+                    self.model.g.clear_prefix_cache()
+                raise RuntimeError('segmented hipGraph capture failed on %s: %s' % (
+                    'this rank' if err is not None else 'another rank', str(err).splitlines()[0] if err is not None else ''))
             st['graphs'], st['segs'], st['out'] = graphs, segs, S['out']
             st['gens'] = self._plan_generations()
             # autograd objects of the capture are no longer needed: the graphs own the memory
