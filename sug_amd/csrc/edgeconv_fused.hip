@@ -34,14 +34,15 @@ constexpr int SW = 16;         // channels per slice
 constexpr int LP = SW / 4;     // lanes per point in the gather phase
 
 // CIN: features per point as the MFMA sees them (4 = xyz padded with a zero feature, else 64 / 128); CR: real
-// feature count = row length of wcat.  KK: neighbours per point.  NT: threads per workgroup -- 512 (two workgroups
-// per CU: one's MFMA phase overlaps the other's gather phase) or 1024 (layers with no more workgroups than CUs);
-// either way 16 waves per CU, hence <= 128 registers per lane.
+// feature count = row length of wcat.  KK: neighbours per point.  NT: threads per workgroup.  The product form is ONE
+// 512-thread workgroup per CU (P and Q images: 128 KB of LDS) with up to 256 registers per lane: with the pivot of the
+// BatchNorm sums in registers the 1024-thread form (128 registers) spilled into scratch memory (PMC: +30 % HBM-side
+// traffic), and 16 waves per CU had measured no faster than 8 (phases add up either way).
 // QLDS: the Q slice waits in LDS next to the P image (2 x N x 64 bytes: one workgroup per CU) instead of in the z
 // buffer -- parked in global memory it costs its bytes twice in HBM-side traffic (PMC: written back before z
 // overwrites it, fetched again by the gather phase), which is what the fusion is there to avoid.
 template <int CIN, int KK, int NT, bool QLDS>
-__global__ __launch_bounds__(NT, 4) void edgeconv_fused_fwd_kernel(
+__global__ __launch_bounds__(NT, NT / 256) void edgeconv_fused_fwd_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ wcat, const float* __restrict__ qbias,
     const int32_t* __restrict__ idx, const float* __restrict__ gamma, int B, int N, int Co, int Bg,
     float* __restrict__ z, uint8_t* __restrict__ arg, float* __restrict__ s1, float* __restrict__ pq_out,
@@ -261,19 +262,14 @@ __global__ __launch_bounds__(NT, 4) void edgeconv_fused_fwd_kernel(
         if (j == 0 || pv[u].w > bw) { bw = pv[u].w; jw = j; }
       }
     };
-    // software pipeline over batches of 4 neighbours: the LDS reads of batch t+1 are issued before the arithmetic of
-    // batch t (two batches = 32 registers live; the scheduling barriers keep the compiler from hoisting all 20 reads)
-    float4 pa[4], pb[4];
-    gather4(pa, nv[0]);
+    // batches of 4 neighbours: 4 LDS reads in flight, then their arithmetic (16 waves per CU cover the read latency; a
+    // second register set for a software pipeline does not fit the 128-register budget next to the pivot -- it spilled)
+    float4 pa[4];
 #pragma unroll
-    for (int t = 0; t < KK / 4; t += 2) {
-      if (t + 1 < KK / 4) gather4(pb, nv[t + 1]);
+    for (int t = 0; t < KK / 4; ++t) {
+      gather4(pa, nv[t]);
       __builtin_amdgcn_sched_barrier(0);
       reduce4(pa, t);
-      __builtin_amdgcn_sched_barrier(0);
-      if (t + 2 < KK / 4) gather4(pa, nv[t + 2]);
-      __builtin_amdgcn_sched_barrier(0);
-      if (t + 1 < KK / 4) reduce4(pb, t + 1);
       __builtin_amdgcn_sched_barrier(0);
     }
     // + Q, back to the true sign
@@ -441,8 +437,8 @@ int launch_fused(const float* x, int64_t ldx, const float* wcat, const float* qb
 #ifdef SUG_EF_ABL_QGLOBAL
   return launch_fused_nt<CIN, 512, false>(x, ldx, wcat, qbias, idx, gamma, B, N, Co, Bg, z, arg, s1, pq_out, ldpq, ws, st);
 #endif
-  if (qlds) return launch_fused_nt<CIN, 1024, true>(x, ldx, wcat, qbias, idx, gamma, B, N, Co, Bg, z, arg, s1, pq_out, ldpq, ws, st);
-  return launch_fused_nt<CIN, 1024, false>(x, ldx, wcat, qbias, idx, gamma, B, N, Co, Bg, z, arg, s1, pq_out, ldpq, ws, st);
+  if (qlds) return launch_fused_nt<CIN, 512, true>(x, ldx, wcat, qbias, idx, gamma, B, N, Co, Bg, z, arg, s1, pq_out, ldpq, ws, st);
+  return launch_fused_nt<CIN, 512, false>(x, ldx, wcat, qbias, idx, gamma, B, N, Co, Bg, z, arg, s1, pq_out, ldpq, ws, st);
 }
 
 }  // namespace
