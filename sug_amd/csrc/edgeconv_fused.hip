@@ -15,9 +15,8 @@
 // MFMA orientation (M = channels, N = points): lane l holds D[i][j] for column j = l & 31 (a point) and rows
 // i = (r & 3) + 8 (r >> 2) + 4 (l >> 5), r = 0..15.  Weight row of A-row i: P channel r' for (i >> 2) & 1 == 0,
 // Q channel r' otherwise, r' = (i & 3) + 4 (i >> 3): lanes 0..31 then hold P[j][c0 .. c0+15], lanes 32..63
-// Q[j][c0 .. c0+15] -- one 64-byte row each.  k order: lane half h takes features h*C/2 + t at step t, so a lane
-// reads its x row as contiguous float4s (the sum over k is a reordered fma chain: results equal a GEMM's to fp32
-// rounding, not bit for bit).
+// Q[j][c0 .. c0+15] -- one 64-byte row each.  k order: step t takes features 2t (lanes 0-31) and 2t+1 (lanes 32-63): an
+// ascending fma chain from zero, bit for bit a plain dot product's.
 //
 // Per cloud and layer (fp32): x once per slice through L2 (HBM: once), idx, z / arg / s1 once.  FLOPs 2*N*C*2Co on
 // the fp32 matrix pipe + 6*N*k*Co VALU.
@@ -91,19 +90,24 @@ __global__ __launch_bounds__(NT, NT / 256) void edgeconv_fused_fwd_kernel(
   }
   // ---------------------------------------------------------------- phase 1: [P ; Q] slice by MFMA
   {
-    // A operand: weight row of A-row jl, features h*HALF + t (CIN = 4: features 2h + t, the 4th is zero)
+    // A operand: weight row of A-row jl.  k order: MFMA step t multiplies feature 2t in lanes 0-31 and feature 2t+1 in
+    // lanes 32-63, and the instruction adds the two products in that order: the accumulator runs through the features in
+    // ASCENDING order from zero -- a plain dot product's fma chain (with it the free-running forward reproduces the
+    // reference run's neighbour lists, tests/test_gpu_model.py::test_dgcnn_parity_free_running; halves-of-the-row order
+    // flipped 4 near-tie rows of 6144 there)
     const int arow = ((jl >> 2) & 1) * Co + c0 + (jl & 3) + 4 * (jl >> 3);
     float areg[HALF];
     if constexpr (CIN == 4) {
       const float* wr = wcat + (int64_t)arow * CR;
-      areg[0] = wr[2 * h];
-      areg[1] = h ? 0.f : wr[1];
+      areg[0] = wr[h];
+      areg[1] = h ? 0.f : wr[2];
     } else {
-      const float* wr = wcat + (int64_t)arow * CR + h * HALF;
+      const float* wr = wcat + (int64_t)arow * CR;
 #pragma unroll
       for (int g = 0; g < HALF / 4; ++g) {
-        const float4 w4 = ld4(wr + 4 * g);
-        areg[4 * g + 0] = w4.x; areg[4 * g + 1] = w4.y; areg[4 * g + 2] = w4.z; areg[4 * g + 3] = w4.w;
+        const float4 a = ld4(wr + 8 * g), c = ld4(wr + 8 * g + 4);
+        areg[4 * g + 0] = h ? a.y : a.x; areg[4 * g + 1] = h ? a.w : a.z;
+        areg[4 * g + 2] = h ? c.y : c.x; areg[4 * g + 3] = h ? c.w : c.z;
       }
     }
     const int ntile = (N + 31) >> 5;
@@ -123,23 +127,41 @@ __global__ __launch_bounds__(NT, NT / 256) void edgeconv_fused_fwd_kernel(
       r0 = r0 < N ? r0 : N - 1;
       if constexpr (CIN == 4) {
         const float* p = xb + (int64_t)r0 * ldx;
-        bv[0] = p[2 * h];
-        const float y = p[1];
-        bv[1] = h ? 0.f : y;
+        bv[0] = p[h];
+        const float zc = p[2];
+        bv[1] = h ? 0.f : zc;
       } else {
-        const float* p = xb + (int64_t)r0 * ldx + h * HALF + ch * KC;
+        // chunk ch = features [2 KC ch, 2 KC (ch + 1)) of the row; this lane half loads its contiguous KC of them (the
+        // halves trade registers in mma(): a lane never loads a feature it does not multiply)
+        const float* p = xb + (int64_t)r0 * ldx + ch * 2 * KC + h * KC;
 #pragma unroll
         for (int g = 0; g < KC / 4; ++g) {
-          const float4 v = ld4(p + 4 * g);
-          bv[4 * g + 0] = v.x; bv[4 * g + 1] = v.y; bv[4 * g + 2] = v.z; bv[4 * g + 3] = v.w;
+          const float4 a = ld4(p + 4 * g);
+          bv[4 * g + 0] = a.x; bv[4 * g + 1] = a.y; bv[4 * g + 2] = a.z; bv[4 * g + 3] = a.w;
         }
       }
     };
     f32x16 acc;
-    auto mma = [&](const float (&bv)[KC], int ch) {
+    auto mma = [&](float (&bv)[KC], int ch) {
 #ifndef SUG_EF_ABL_NOMFMA          // (-DSUG_EF_ABL_*: timing experiments of tools/bench_edgeconv_fused.py, never in the library)
+      if constexpr (CIN == 4) {
 #pragma unroll
-      for (int t = 0; t < KC; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[ch * KC + t], bv[t], acc, 0, 0, 0);
+        for (int t = 0; t < KC; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[t], bv[t], acc, 0, 0, 0);
+      } else {
+        // registers (e, e+1) hold chunk features (e, e+1) in lanes 0-31 and (KC+e, KC+e+1) in lanes 32-63;
+        // v_permlane32_swap trades the upper half of the first with the lower half of the second: register e then holds
+        // features (e | e+1) and register e+1 features (KC+e | KC+e+1) -- consecutive pairs, in place
+#pragma unroll
+        for (int e = 0; e < KC; e += 2) {
+          const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(bv[e]), __float_as_uint(bv[e + 1]), false, false);
+          bv[e] = __uint_as_float(r[0]); bv[e + 1] = __uint_as_float(r[1]);
+        }
+#pragma unroll
+        for (int s = 0; s < KC; ++s) {          // step s: chunk features (2s, 2s+1)
+          const int r = s < KC / 2 ? 2 * s : 2 * (s - KC / 2) + 1;
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[ch * KC + s], bv[r], acc, 0, 0, 0);
+        }
+      }
 #else
       acc[0] += bv[0] + bv[KC - 1];
 #endif

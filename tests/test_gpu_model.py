@@ -118,17 +118,36 @@ def test_dgcnn_parity_teacher_forced():
 
 
 def test_dgcnn_parity_free_running():
-    """Own kNN graphs in feature space: indices must agree with the reference's except at
-    near-ties; logits stay within 1e-4 when no flip occurs and within 1e-3 otherwise."""
+    """Own kNN graphs in feature space against the reference run recorded in the golden.  The xyz graph must be bit-exact.
+    The feature-space graphs (layers 2-4) can differ from the reference's at fp32 near-ties (any change of rounding in a
+    BatchNorm statistic moves an activation by an ulp and may swap two neighbours whose distances differ by less than the
+    rounding of the score: quantified against fp64 in test_dgcnn_free_running_flips_are_fp32_ties; the arithmetic behind
+    given lists is pinned at 1e-4 in test_dgcnn_parity_teacher_forced).  Here: the number of (point, layer) rows whose
+    neighbour SET differs from the golden's is reported and must stay below 1 % of the rows; logits within 1e-4 when
+    no row differs, otherwise within 5e-2 (a swapped neighbour changes a max over k, BatchNorm over a batch of 2 clouds
+    spreads it)."""
     from sug_amd import ops
-    G, net, (y1, y2, s1, s2), loss = run_passes('DGCNN', 'model_dgcnn.npz', False)
-    x = G['x'].cuda()
-    rows = x.squeeze(-1).transpose(1, 2).contiguous()
-    idx1 = ops.knn(rows, 20)
-    assert torch.equal(idx1.cpu().long(), G['knn1']), 'layer-1 (xyz) neighbour graph must be bit-exact'
-    err = max(close(y1, G['y1'], 1e-3, 'logits c1'), close(y2, G['y2'], 1e-3, 'logits c2'))
-    close(s1, G['s1'], 1e-3, 'sem feature c1')
-    print('free-running DGCNN logits max err %.3e' % err)
+    rec, real_knn = [], ops.knn
+
+    def spy(f, k):
+        idx = real_knn(f, k)
+        rec.append(idx.cpu().long())
+        return idx
+    ops.knn = spy
+    try:
+        G, net, (y1, y2, s1, s2), loss = run_passes('DGCNN', 'model_dgcnn.npz', False)
+    finally:
+        ops.knn = real_knn
+    assert len(rec) == 4
+    assert torch.equal(rec[0], G['knn1']), 'layer-1 (xyz) neighbour graph must be bit-exact'
+    differ = [int((rec[i].sort(-1)[0] != G['knn%d' % (i + 1)].sort(-1)[0]).any(-1).sum()) for i in range(4)]
+    rows = rec[0].shape[0] * rec[0].shape[1]
+    tol = 1e-4 if sum(differ) == 0 else 5e-2
+    err = max(close(y1, G['y1'], tol, 'logits c1'), close(y2, G['y2'], tol, 'logits c2'))
+    close(s1, G['s1'], tol, 'sem feature c1')
+    print('free-running DGCNN: rows whose neighbour set differs from the reference run, per layer: %s of %d; logits max err %.3e'
+          % (differ, rows, err))
+    assert all(d <= 0.01 * rows for d in differ), differ
 
 
 def test_dgcnn_node_pass_and_buffers():
