@@ -135,34 +135,46 @@ __global__ __launch_bounds__(128 * PW, 2) void knn_pc_kernel(const float* __rest
   auto nbuf = [&](int t) { return s_norm + (t % 3) * TJ; };
 
   // The two roles are separate code paths (disjoint register sets); both execute the same sequence
-  // of workgroup barriers: 4 PW + 1 in the query staging, 2 in the pipeline fill, one per tile.
+  // of workgroup barriers: 2 in the pipeline fill, one per tile.
   if (producer) {
-    // ---- query operands, staged through the tile buffers: 2 PW tiles of 32 query rows.  They are scaled by -2 (exact):
-    // the chains then deliver inner = -2<x_i,x_j> itself, bit for bit fl(-2 * dot), and the consumers save the
-    // multiplication per candidate
+    // ---- query operands (B operand of both column blocks, whole kernel in registers), straight from global memory: lane
+    // (qj, h) loads the contiguous half [h HALF, h HALF + HALF) of its two query rows; v_permlane32_swap then trades
+    // registers between the lane halves: register pair (e, e+1) = features (e, e+1 | HALF+e, HALF+e+1) becomes
+    // (e | e+1) and (HALF+e | HALF+e+1), i.e. register breg(s) holds features (2s | 2s+1) = the k pair of MFMA step s --
+    // the same operands the de-interleaved LDS image of mfma_tile.h gives the A side.  They are scaled by -2 (exact): the
+    // chains then deliver inner = -2<x_i,x_j> itself, bit for bit fl(-2 * dot), and the consumers save the
+    // multiplication per candidate.  (Until round 3 the query tiles were staged through the tile buffers: 4 PW + 1
+    // barriers and 2 PW dependent load -> store -> read steps, 10 us of the kernel.)
+    TileRegs<CP, NTP> tr;
+    tile_load<CP, NTP>(tr, xb, ldx, N, 0);       // candidate tile 0: in flight under the query loads
     float bq0[HALF], bq1[HALF];
     {
-      TileRegs<CP, NTP> tq[2];                   // the next query tile's loads fly under this one's staging
-      tile_load<CP, NTP>(tq[0], xb, ldx, N, q0);
+      const int r0 = min(q0 + wv * 64 + qj, N - 1), r1 = min(q0 + wv * 64 + 32 + qj, N - 1);   // (rows past N: results unused)
+      const float* p0 = xb + (int64_t)r0 * ldx;
+      const float* p1 = xb + (int64_t)r1 * ldx;
+      if constexpr (CP == 4) {
+        const float x0 = p0[0], y0 = p0[1], z0 = p0[2], x1 = p1[0], y1 = p1[1], z1 = p1[2];
+        bq0[0] = -2.f * (h ? y0 : x0); bq0[1] = h ? 0.f : -2.f * z0;
+        bq1[0] = -2.f * (h ? y1 : x1); bq1[1] = h ? 0.f : -2.f * z1;
+      } else {
 #pragma unroll
-      for (int w = 0; w < 2 * PW; ++w) {
-        __syncthreads();
-        if (w + 1 < 2 * PW) tile_load<CP, NTP>(tq[(w + 1) & 1], xb, ldx, N, q0 + (w + 1) * TJ);
-        tile_store<CP, true, NTP>(tq[w & 1], s_tile, s_norm, N, q0 + w * TJ);
-        __syncthreads();
-        if ((w >> 1) == wv) {
-          const float* qrow = s_tile + qj * RS + h * HALF;
-          if (w & 1) {
+        for (int g = 0; g < HALF / 4; ++g) {
+          const float4 a = *reinterpret_cast<const float4*>(p0 + h * HALF + 4 * g);
+          const float4 c = *reinterpret_cast<const float4*>(p1 + h * HALF + 4 * g);
+          bq0[4 * g] = -2.f * a.x; bq0[4 * g + 1] = -2.f * a.y; bq0[4 * g + 2] = -2.f * a.z; bq0[4 * g + 3] = -2.f * a.w;
+          bq1[4 * g] = -2.f * c.x; bq1[4 * g + 1] = -2.f * c.y; bq1[4 * g + 2] = -2.f * c.z; bq1[4 * g + 3] = -2.f * c.w;
+        }
 #pragma unroll
-            for (int e = 0; e < HALF; ++e) bq1[e] = -2.f * qrow[e];
-          } else {
-#pragma unroll
-            for (int e = 0; e < HALF; ++e) bq0[e] = -2.f * qrow[e];
-          }
+        for (int e = 0; e < HALF; e += 2) {
+          const auto u = __builtin_amdgcn_permlane32_swap(__float_as_uint(bq0[e]), __float_as_uint(bq0[e + 1]), false, false);
+          bq0[e] = __uint_as_float(u[0]); bq0[e + 1] = __uint_as_float(u[1]);
+          const auto v = __builtin_amdgcn_permlane32_swap(__float_as_uint(bq1[e]), __float_as_uint(bq1[e + 1]), false, false);
+          bq1[e] = __uint_as_float(v[0]); bq1[e + 1] = __uint_as_float(v[1]);
         }
       }
     }
-    __syncthreads();
+    // register of k-step s
+    auto breg = [](int s2) constexpr { return CP == 4 ? s2 : (s2 < HALF / 2 ? 2 * s2 : 2 * (s2 - HALF / 2) + 1); };
 
     // scores of candidate tile t for this wave's 64 queries -> score buffer `buf`
     auto produce = [&](int t, int buf) {
@@ -187,21 +199,29 @@ __global__ __launch_bounds__(128 * PW, 2) void knn_pc_kernel(const float* __rest
 #else
 #pragma unroll
         for (int g = 0; g < HALF / 4; ++g) {
+#ifdef SUG_KNN_ABL_NOAREAD
+          const float4 a4 = make_float4(bq0[g], bq1[g], bq0[g + 1], bq1[g + 1]);
+#else
           const float4 a4 = *reinterpret_cast<const float4*>(arow + 4 * g);
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, bq0[4 * g + 0], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, bq1[4 * g + 0], acc1, 0, 0, 0);
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, bq0[4 * g + 1], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, bq1[4 * g + 1], acc1, 0, 0, 0);
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, bq0[4 * g + 2], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, bq1[4 * g + 2], acc1, 0, 0, 0);
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, bq0[4 * g + 3], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, bq1[4 * g + 3], acc1, 0, 0, 0);
+#endif
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, bq0[breg(4 * g + 0)], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, bq1[breg(4 * g + 0)], acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, bq0[breg(4 * g + 1)], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, bq1[breg(4 * g + 1)], acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, bq0[breg(4 * g + 2)], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, bq1[breg(4 * g + 2)], acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, bq0[breg(4 * g + 3)], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, bq1[breg(4 * g + 3)], acc1, 0, 0, 0);
         }
 #endif
       }
       // S^T tile: lane = query column, registers 4g..4g+3 = candidate rows 8g + 4h .. +3: one b128 per g
       float* d0 = s_score + ((buf * PW + wv) * 64 + qj) * SROW + 4 * h;
       float* d1 = d0 + 32 * SROW;
+#ifdef SUG_KNN_ABL_NOSCOREWRITE
+      if (acc0[0] + acc1[0] + acc0[15] + acc1[15] == 12345.f) d0[0] = 1.f;
+      return;
+#endif
 #pragma unroll
       for (int g = 0; g < 4; ++g)
         *reinterpret_cast<float4*>(d0 + 8 * g) = make_float4(acc0[4 * g], acc0[4 * g + 1], acc0[4 * g + 2], acc0[4 * g + 3]);
@@ -212,8 +232,6 @@ __global__ __launch_bounds__(128 * PW, 2) void knn_pc_kernel(const float* __rest
 
     // pipeline: iteration t = scores of tile t+1 (consumers are on tile t); registers of tile t+2 -> LDS;
     // the global loads of tile t+3 are in flight for a whole iteration
-    TileRegs<CP, NTP> tr;
-    tile_load<CP, NTP>(tr, xb, ldx, N, 0);
     tile_store<CP, true, NTP>(tr, tbuf(0), nbuf(0), N, 0);
     if (ntile > 1) tile_load<CP, NTP>(tr, xb, ldx, N, TJ);
     __syncthreads();
@@ -232,22 +250,19 @@ __global__ __launch_bounds__(128 * PW, 2) void knn_pc_kernel(const float* __rest
       __syncthreads();
 #else
       if (t + 1 < ntile) produce(t + 1, (t + 1) & 1);
+#ifndef SUG_KNN_ABL_NOSTAGE
       if (t + 2 < ntile) tile_store<CP, true, NTP>(tr, tbuf(t + 2), nbuf(t + 2), N, (t + 2) * TJ);
       if (t + 3 < ntile) tile_load<CP, NTP>(tr, xb, ldx, N, (t + 3) * TJ);
+#endif
+#ifndef SUG_KNN_ABL_NOBARRIER
       __syncthreads();
+#endif
 #endif
     }
   } else {
     __builtin_amdgcn_s_setprio(1);     // the selection waves are the second-dispatched half of the workgroup: static priority (-5 us at C=3)
-    // ---- consumer: lane = one query; |x_i|^2 from the staged query tiles
-    float ni = 0.f;
-#pragma unroll
-    for (int w = 0; w < 2 * PW; ++w) {
-      __syncthreads();
-      __syncthreads();
-      if ((w >> 1) == wv && h == (w & 1)) ni = s_norm[qj];
-    }
-    __syncthreads();
+    // ---- consumer: lane = one query; |x_i|^2 in the rounding order of tile_store's norms (exact_norm)
+    const float ni = exact_norm<CP>(xb + (int64_t)min(q0 + wv * 64 + lane, N - 1) * ldx);
 
     constexpr int KP = K + 2;
     constexpr int EMPTY = 0x7fffffff;          // never-filled slot
@@ -272,7 +287,9 @@ __global__ __launch_bounds__(128 * PW, 2) void knn_pc_kernel(const float* __rest
     __syncthreads();                            // tile 0 scored
     for (int t = 0; t < ntile; ++t) {
 #ifdef SUG_KNN_ABL_NOCONS
+#ifndef SUG_KNN_ABL_NOBARRIER
       __syncthreads();
+#endif
       continue;
 #endif
       const float* srow = s_score + (((t & 1) * PW + wv) * 64 + lane) * SROW;

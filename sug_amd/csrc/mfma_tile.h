@@ -23,30 +23,27 @@ struct TileRegs {
   float4 lo[NV], hi[NV];
 };
 
-// rows [row0, row0+32) of xb (row stride ldx); rows >= N read as zero.  NT threads.
+// rows [row0, row0+32) of xb (row stride ldx); rows >= N read row N-1 (their norm is stored as +inf by tile_store: such a
+// candidate never scores, and the scores of such a query are never used).  NT threads.
 template <int CP, int NT = 256>
 __device__ __forceinline__ void tile_load(TileRegs<CP, NT>& t, const float* __restrict__ xb, int64_t ldx,
                                           int N, int row0) {
-  // The loads carry no guards (a guarded load compiles to a branch and the wait counters around it collapse to
-  // vmcnt(0), which would serialise a prefetch with the loads before it): rows past N read row N-1 and are zeroed
-  // by a select.
+  // The loads carry no guards and their values no select on r < N: with `ok ? loaded : 0` the compiler sinks the load
+  // into a branch on ok and waits for it on the spot (s_waitcnt vmcnt(0) right behind the global_load) -- the prefetch
+  // of tile t+3 then cost its full latency in every iteration of knn_pc_kernel (10-13 us per launch until round 3).
   if constexpr (CP == 4) {
-    const int r = row0 + (int)(threadIdx.x & (TJ - 1));
-    const bool ok = r < N;
-    const float* p = xb + (int64_t)(ok ? r : N - 1) * ldx;
-    const float x = p[0], y = p[1], z = p[2];
-    t.lo[0] = make_float4(ok ? x : 0.f, ok ? y : 0.f, ok ? z : 0.f, 0.f);
+    const int r = min(row0 + (int)(threadIdx.x & (TJ - 1)), N - 1);
+    const float* p = xb + (int64_t)r * ldx;
+    t.lo[0] = make_float4(p[0], p[1], p[2], 0.f);
   } else {
     constexpr int CH = CP / 8;                 // chunks per row
 #pragma unroll
     for (int u = 0; u < TileRegs<CP, NT>::NV; ++u) {
       const int item = (int)threadIdx.x + u * NT;
-      const int r = row0 + item / CH, c8 = item % CH;
-      const bool ok = r < N;
-      const float4* p = reinterpret_cast<const float4*>(xb + (int64_t)(ok ? r : N - 1) * ldx + c8 * 8);
-      const float4 a = p[0], b = p[1];
-      t.lo[u] = ok ? a : make_float4(0, 0, 0, 0);
-      t.hi[u] = ok ? b : make_float4(0, 0, 0, 0);
+      const int r = min(row0 + item / CH, N - 1), c8 = item % CH;
+      const float4* p = reinterpret_cast<const float4*>(xb + (int64_t)r * ldx + c8 * 8);
+      t.lo[u] = p[0];
+      t.hi[u] = p[1];
     }
   }
 }

@@ -38,6 +38,14 @@ if __name__ == '__main__':
     variants = [('product', []), ('serial', ['-DSUG_KNN_SERIAL']), ('no insertion', ['-DSUG_KNN_ABL_NOINSERT']), ('no consumer', ['-DSUG_KNN_ABL_NOCONS']),
                 ('no MFMA', ['-DSUG_KNN_ABL_NOMFMA']), ('no MFMA, no consumer', ['-DSUG_KNN_ABL_NOMFMA', '-DSUG_KNN_ABL_NOCONS']),
                 ('no MFMA, no insertion', ['-DSUG_KNN_ABL_NOMFMA', '-DSUG_KNN_ABL_NOINSERT'])]
+    if len(sys.argv) > 1 and sys.argv[1] == 'producer':       # the producer side alone, piece by piece
+        NC = ['-DSUG_KNN_ABL_NOCONS']
+        variants = [('no consumer', NC), ('+ no score writes', NC + ['-DSUG_KNN_ABL_NOSCOREWRITE']),
+                    ('+ no staging', NC + ['-DSUG_KNN_ABL_NOSCOREWRITE', '-DSUG_KNN_ABL_NOSTAGE']),
+                    ('+ no A reads', NC + ['-DSUG_KNN_ABL_NOSCOREWRITE', '-DSUG_KNN_ABL_NOSTAGE', '-DSUG_KNN_ABL_NOAREAD']),
+                    ('+ no barrier', NC + ['-DSUG_KNN_ABL_NOSCOREWRITE', '-DSUG_KNN_ABL_NOSTAGE', '-DSUG_KNN_ABL_NOAREAD', '-DSUG_KNN_ABL_NOBARRIER']),
+                    ('no barrier only', NC + ['-DSUG_KNN_ABL_NOBARRIER']), ('no A reads only', NC + ['-DSUG_KNN_ABL_NOAREAD']),
+                    ('no staging only', NC + ['-DSUG_KNN_ABL_NOSTAGE'])]
     libs = [(t, build(t.replace(' ', '_').replace(',', ''), d)) for t, d in variants]
     for C in (3, 64, 128):
         x = torch.randn(64, 1024, C, device='cuda')
