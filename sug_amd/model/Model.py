@@ -412,11 +412,17 @@ class Net_MDA(nn.Module):
             return self.attention_t(feat_ori.contiguous().view(batch_size, -1))
         if adaptation:
             x = grad_reverse(x, constant)
+        (y1, sem_feature1), (y2, sem_feature2) = self._heads(x)
         if not semantic_adaption:
-            return self.c1(x, adapt=False), self.c2(x, adapt=False)
-        (y1, sem_feature1), (y2, sem_feature2) = ops.run_parallel([lambda: self.c1(x, adapt=True),
-                                                                    lambda: self.c2(x, adapt=True)])
+            return y1, y2
         return y1, y2, sem_feature1, sem_feature2
+
+    def _heads(self, x):
+        """[(logits, mid feature)] of c1 and c2 on the pooled feature x: one launch per layer for both heads
+        (ops.heads_fused, sug_head_linear_*) where the shapes allow, the module path otherwise."""
+        if ops.heads_fused_supported((self.c1, self.c2), x):
+            return ops.heads_fused((self.c1, self.c2), x)
+        return ops.run_parallel([lambda: self.c1(x, adapt=True), lambda: self.c2(x, adapt=True)])
 
     def forward_pair(self, x_pair, node_adaptation=False):
         """Both domains in one encoder pass (not in the reference; used by SUGStep).
@@ -449,6 +455,6 @@ class Net_MDA(nn.Module):
         if node_adaptation:
             f_s, f_t = halves(feat_ori.contiguous())
             return tuple(ops.run_parallel([lambda: self.attention_s(f_s), lambda: self.attention_t(f_t)]))
-        (y1, f1), (y2, f2) = ops.run_parallel([lambda: self.c1(x, adapt=True), lambda: self.c2(x, adapt=True)])
+        (y1, f1), (y2, f2) = self._heads(x)
         (y1s, y1t), (y2s, y2t), (f1s, f1t), (f2s, f2t) = halves(y1), halves(y2), halves(f1), halves(f2)
         return (y1s, y2s, f1s, f2s), (y1t, y2t, f1t, f2t)

@@ -702,6 +702,161 @@ def ln_act(x, ln, slope):
     return _LNAct.apply(x, ln.weight, ln.bias, ln.eps, slope)
 
 
+# ---- classifier heads (Pointnet_c) in six launches ------------------------------------------------------------------
+HEADS_FUSED = _os.environ.get('SUG_HEADS_FUSED', '1') != '0'       # A/B knob: 0 = library GEMMs + LayerNorm / dropout ops
+
+
+def _ptrs(ts):
+    """host array of device pointers (None -> null) for the per-head operands of sug_head_linear_*"""
+    return (ctypes.c_void_p * len(ts))(*[None if t is None else t.data_ptr() for t in ts])
+
+
+def heads_fused_supported(heads, x):
+    """Can Pointnet_c heads `heads` (1 or 2, same architecture, same input x [M, K]) run through sug_head_linear_*?"""
+    if not (HEADS_FUSED and 1 <= len(heads) <= 2 and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2):
+        return False
+    M, K = x.shape
+    L = lib()
+    h0 = heads[0]
+    for hd in heads:
+        if hd.PTran != h0.PTran or hd.training != h0.training or hd.dropout1.p != h0.dropout1.p or hd.dropout2.p != h0.dropout2.p:
+            return False
+        layers = ([] if hd.PTran else [hd.mlp1]) + [hd.mlp2]
+        for fc in layers:
+            if len(fc.fc) != 3 or not ln_act_supported(x, fc.fc[1]) or fc.fc[1].eps != h0.mlp2.fc[1].eps:
+                return False
+        if type(hd.mlp2.ac) is not type(h0.mlp2.ac) or (not hd.PTran and type(hd.mlp1.ac) is not type(hd.mlp2.ac)):
+            return False
+        for lin in [fc.fc[0] for fc in layers] + [hd.mlp3]:
+            if lin.weight.dtype != torch.float32 or not lin.weight.is_cuda:
+                return False
+        if hd.mlp3.weight.shape != h0.mlp3.weight.shape or hd.mlp2.fc[0].weight.shape != h0.mlp2.fc[0].weight.shape:
+            return False
+    dims = [K] + ([] if h0.PTran else [h0.mlp1.fc[0].out_features]) + [h0.mlp2.fc[0].out_features, h0.mlp3.out_features]
+    first = (h0.mlp2 if h0.PTran else h0.mlp1).fc[0]
+    if first.in_features != K or h0.mlp3.in_features != dims[-2] or (not h0.PTran and h0.mlp2.fc[0].in_features != dims[1]):
+        return False
+    nl = len(dims) - 1
+    for i in range(nl):
+        pro, epi = int(i > 0), int(i < nl - 1)
+        if not L.sug_head_linear_supported(M, dims[i], dims[i + 1], pro, epi):
+            return False
+    return True
+
+
+class _HeadsFused(torch.autograd.Function):
+    """Pointnet_c heads (model/Model.py:412-449) on one input: per layer ONE launch for all heads, the LayerNorm /
+    activation / dropout between two Linear layers applied to the next layer's operand as it is loaded
+    (sug_head_linear_fwd), and one launch per layer in the backward (sug_head_linear_bwd).  Arguments after the
+    scalars: per head (W1, b1, g1, be1, W2, b2, g2, be2, W3, b3) -- the first four None for the two-layer (Point
+    Transformer) head.  Returns per head (logits, mid feature)."""
+
+    @staticmethod
+    def forward(ctx, x, training, p1, p2, slope, eps, nheads, *params):
+        _need_gpu(x)
+        assert len(params) == 10 * nheads
+        P = [[None if t is None else t.detach().contiguous() for t in params[10 * h:10 * h + 10]] for h in range(nheads)]
+        three = P[0][0] is not None
+        x2 = x.detach().contiguous()
+        M, K = x2.shape
+        dev = x.device
+        N1 = P[0][0].shape[0] if three else 0
+        N2, NC = P[0][4].shape[0], P[0][8].shape[0]
+        drop1, drop2 = training and three and p1 > 0, training and p2 > 0
+        # one launch of uniform randoms for every dropout of every head: [head][M][N1 | N2]
+        # (flat: [head][M][N1] blocks, then [head][M][N2] blocks -- every operand a contiguous view)
+        u = torch.rand(nheads * M * (N1 + N2), dtype=torch.float32, device=dev) if (drop1 or drop2) else None
+        u1 = [u[h * M * N1:(h + 1) * M * N1].view(M, N1) if drop1 else None for h in range(nheads)] if three else None
+        o2 = nheads * M * N1
+        u2 = [u[o2 + h * M * N2:o2 + (h + 1) * M * N2].view(M, N2) if drop2 else None for h in range(nheads)]
+        H = range(nheads)
+        L = lib()
+        col = lambda i: [P[h][i] for h in H]
+        new = lambda n: [torch.empty(M, n, dtype=torch.float32, device=dev) for _ in H]
+        z1 = st1 = None
+        if three:
+            z1, st1 = new(N1), new(2)
+            check(L.sug_head_linear_fwd(nheads, _ptrs([x2] * nheads), K, _ptrs(col(0)), _ptrs(col(1)), _ptrs(z1), None, None, None,
+                                        None, None, M, K, N1, 0, slope, eps, 0.0, _st()), 'sug_head_linear_fwd')
+        z2, st2, mid, logits = new(N2), new(2), new(N2), new(NC)
+        if three:
+            check(L.sug_head_linear_fwd(nheads, _ptrs(z1), N1, _ptrs(col(4)), _ptrs(col(5)), _ptrs(z2), _ptrs(col(2)), _ptrs(col(3)),
+                                        _ptrs(u1), _ptrs(st1), None, M, N1, N2, 1, slope, eps, p1 if drop1 else 0.0, _st()),
+                  'sug_head_linear_fwd')
+        else:
+            check(L.sug_head_linear_fwd(nheads, _ptrs([x2] * nheads), K, _ptrs(col(4)), _ptrs(col(5)), _ptrs(z2), None, None, None,
+                                        None, None, M, K, N2, 0, slope, eps, 0.0, _st()), 'sug_head_linear_fwd')
+        check(L.sug_head_linear_fwd(nheads, _ptrs(z2), N2, _ptrs(col(8)), _ptrs(col(9)), _ptrs(logits), _ptrs(col(6)), _ptrs(col(7)),
+                                    _ptrs(u2), _ptrs(st2), _ptrs(mid), M, N2, NC, 1, slope, eps, p2 if drop2 else 0.0, _st()),
+              'sug_head_linear_fwd')
+        ctx.P, ctx.act = P, (x2, z1, st1, z2, st2, u1, u2)
+        ctx.meta = (three, M, K, N1, N2, NC, float(slope), float(eps), float(p1 if drop1 else 0.0), float(p2 if drop2 else 0.0),
+                    nheads, tuple(x.shape))
+        ctx.need_dx = ctx.needs_input_grad[0]
+        out = []
+        for h in H:
+            out += [logits[h], mid[h]]
+        return tuple(out)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        three, M, K, N1, N2, NC, slope, eps, p1, p2, nheads, xshape = ctx.meta
+        P = ctx.P
+        x2, z1, st1, z2, st2, u1, u2 = ctx.act
+        dev = x2.device
+        H = range(nheads)
+        L = lib()
+        col = lambda i: [P[h][i] for h in H]
+        zeros = lambda n: torch.zeros(M, n, dtype=torch.float32, device=dev)
+        gl = [gs[2 * h].contiguous() if gs[2 * h] is not None else zeros(NC) for h in H]
+        gm = [None if gs[2 * h + 1] is None else gs[2 * h + 1].contiguous() for h in H]
+        like = lambda i: [None if P[h][i] is None else torch.empty_like(P[h][i]) for h in H]
+        new = lambda n: [torch.empty(M, n, dtype=torch.float32, device=dev) for _ in H]
+        grads = [like(i) for i in range(10)]
+        # layer 3: logits = Dropout(act(LN(z2))) . W3^T + b3
+        da2 = new(N2)
+        check(L.sug_head_linear_bwd(nheads, 0, _ptrs(gl), NC, None, None, None, None, None, None, _ptrs(z2), N2, _ptrs(st2),
+                                    _ptrs(col(6)), _ptrs(col(7)), _ptrs(u2), _ptrs(col(8)), _ptrs(grads[8]), _ptrs(grads[9]), None, None,
+                                    _ptrs(da2), N2, M, N2, NC, 0, 1, slope, eps, 0.0, p2, _st()), 'sug_head_linear_bwd')
+        dx = torch.empty(M, K, dtype=torch.float32, device=dev) if ctx.need_dx else None
+        if three:
+            da1 = new(N1)
+            check(L.sug_head_linear_bwd(nheads, 0, _ptrs(da2), N2, _ptrs(z2), _ptrs(st2), _ptrs(col(6)), _ptrs(col(7)), _ptrs(u2),
+                                        _ptrs(gm), _ptrs(z1), N1, _ptrs(st1), _ptrs(col(2)), _ptrs(col(3)), _ptrs(u1), _ptrs(col(4)),
+                                        _ptrs(grads[4]), _ptrs(grads[5]), _ptrs(grads[6]), _ptrs(grads[7]), _ptrs(da1), N1, M, N1, N2,
+                                        1, 1, slope, eps, p2, p1, _st()), 'sug_head_linear_bwd')
+            check(L.sug_head_linear_bwd(nheads, 1, _ptrs(da1), N1, _ptrs(z1), _ptrs(st1), _ptrs(col(2)), _ptrs(col(3)), _ptrs(u1),
+                                        None, _ptrs([x2] * nheads), K, None, None, None, None, _ptrs(col(0)), _ptrs(grads[0]),
+                                        _ptrs(grads[1]), _ptrs(grads[2]), _ptrs(grads[3]), _ptrs([dx] + [None] * (nheads - 1)), K,
+                                        M, K, N1, 1, 0, slope, eps, p1, 0.0, _st()), 'sug_head_linear_bwd')
+        else:
+            check(L.sug_head_linear_bwd(nheads, 1, _ptrs(da2), N2, _ptrs(z2), _ptrs(st2), _ptrs(col(6)), _ptrs(col(7)), _ptrs(u2),
+                                        _ptrs(gm), _ptrs([x2] * nheads), K, None, None, None, None, _ptrs(col(4)), _ptrs(grads[4]),
+                                        _ptrs(grads[5]), _ptrs(grads[6]), _ptrs(grads[7]), _ptrs([dx] + [None] * (nheads - 1)), K,
+                                        M, K, N2, 1, 0, slope, eps, p2, 0.0, _st()), 'sug_head_linear_bwd')
+        flat = []
+        for h in H:
+            flat += [grads[i][h] for i in range(10)]
+        return (None if dx is None else dx.view(xshape), None, None, None, None, None, None) + tuple(flat)
+
+
+def heads_fused(heads, x):
+    """[(logits, mid feature) per head] of Pointnet_c heads on the pooled feature x [M, K] (see _HeadsFused)."""
+    h0 = heads[0]
+    act = h0.mlp2.ac
+    slope = 0.0 if isinstance(act, torch.nn.ReLU) else float(act.negative_slope)
+    params = []
+    for hd in heads:
+        if hd.PTran:
+            params += [None, None, None, None]
+        else:
+            params += [hd.mlp1.fc[0].weight, hd.mlp1.fc[0].bias, hd.mlp1.fc[1].weight, hd.mlp1.fc[1].bias]
+        params += [hd.mlp2.fc[0].weight, hd.mlp2.fc[0].bias, hd.mlp2.fc[1].weight, hd.mlp2.fc[1].bias, hd.mlp3.weight, hd.mlp3.bias]
+    out = _HeadsFused.apply(x, h0.training, float(h0.dropout1.p), float(h0.dropout2.p), slope, float(h0.mlp2.fc[1].eps),
+                            len(heads), *params)
+    return [(out[2 * i], out[2 * i + 1]) for i in range(len(heads))]
+
+
 # num_batches_tracked increments: one tiny launch per BatchNorm call unless deferred; inside a
 # `deferred_bn_counts()` block they are collected and applied with one foreach add at the end.
 _PENDING_COUNTS = None
