@@ -105,6 +105,10 @@ int sug_knn_query_direct(const float* xyz, const float* query, int B, int N, int
 int sug_three_nn(const float* query, const float* cand, int B, int N, int S,
                  int32_t* idx3, float* dist3, void* stream);
 
+/* dst[r][0..C) = src[r][0..C), r < rows, row strides lds / ldd in floats (C, lds, ldd multiples of 4; 16-byte aligned):
+ * a dense tensor into a column slice of a wider row buffer (the torch.cat of DGCNN.forward, model/Model.py:111) or back. */
+int sug_copy_rows2d(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t rows, int C, void* stream);
+
 /* ---- row gather / scatter (index_points) ------------------------------------
  * replaces index_points(), model/point_utils.py:60-83,
  * model/pointnet2_utils.py:41-57 and gather_points/group_points wrappers
@@ -230,33 +234,36 @@ int sug_gate_bwd(const float* g, const float* x, const float* z, int64_t n, floa
  * Pointnet_c (model/Model.py:412-449): fc_layer(1024, 512) -> Dropout -> fc_layer(512, 256) [= mid feature] -> Dropout ->
  * Linear(256, num_class), fc_layer = Linear -> LayerNorm -> LeakyReLU(0.2) / ReLU (model/model_utils.py:35-57); Net_MDA
  * runs two such heads (c1, c2) on the same pooled feature.  All per-head operands are HOST arrays of `heads` device
- * pointers (entries / whole arrays may be null where noted).
+ * pointers (entries / whole arrays may be null where noted).  Every sum runs in a fixed order.  8 launches replace the
+ * ~47 library / elementwise launches of the two heads per training step.
  *
  * sug_head_linear_fwd: z[h] [M, No] = pro(in[h]) . W[h]^T + bias[h].  pro != 0: in[h] is the PREVIOUS layer's
  *   pre-LayerNorm output and pro(v) = Dropout(act(LayerNorm(v; gamma[h], beta[h]))), dropout from uniform randoms u[h]
  *   [M, K] (keep when u >= p_drop, scale 1/(1-p_drop); u null: no dropout); side outputs stats[h] [M, 2] = mean | rstd of
  *   the rows of in[h] and act[h] [M, K] = the activation before the dropout (null: not written).
- *   K % 64 == 0 (pro: K % 256 == 0, K <= 1024), No <= 512, M <= 128 (sug_head_linear_supported).
- * sug_head_linear_bwd: gup[h] [M, No] (row stride ldg) is the gradient of this layer's output -- of z itself (epi == 0) or
- *   (epi != 0) of Dropout(act(LayerNorm(z))) with the layer's z / stats / gamma / beta / u and gextra[h] = an additional
- *   gradient of the activation BEFORE the dropout (the mid feature's; may be null).  Writes dW[h] [No, K], db[h] [No]
- *   (null: none), dgamma[h] / dbeta[h] [No] (epi) and the input gradient [M, K] (row stride ldda): da[h] per head, or
- *   with sum_da != 0 the sum over the heads into da[0] (the heads share their input).  The layer input is in[h] itself
- *   (pro == 0) or pro(in[h]) recomputed from stats_in / gamma_in / beta_in / u_in (dropout probability p_drop_in; p_drop is
- *   the one behind this layer's LayerNorm).  No <= 32, 256 or 512.
- *   Every sum runs in a fixed order.  Replaces ~47 library / elementwise launches per step by 6. */
+ *   K % 256 == 0 (pro: K <= 1024), No <= 32 or 256 or 512, M <= 128 (sug_head_linear_supported).
+ * sug_head_ln_bwd: dz[h] [M, No] = gradient of a layer's Linear output z[h] from gup[h] [M, No] (row stride ldg) = the
+ *   gradient of Dropout(act(LayerNorm(z))), plus gextra[h] = a gradient of the activation BEFORE the dropout (the mid
+ *   feature's; may be null); also dgamma[h], dbeta[h] [No] and db[h] [No] = the column sums of dz (null: none).
+ *   No = 256 or 512.
+ * sug_head_linear_bwd: from dz[h] [M, No] (row stride ldg): dW[h] [No, K] = dz^T . a, db[h] [No] = column sums of dz
+ *   (null: none) and the input gradient dz . W[h] [M, K] (row stride ldda): da[h] per head, or with sum_da != 0 the sum
+ *   over the heads into da[0] (the heads share their input).  The layer input a is in[h] itself (pro == 0) or
+ *   pro(in[h]) recomputed from stats_in / gamma_in / beta_in / u_in (dropout probability p_drop_in). */
 int sug_head_linear_supported(int M, int K, int No, int pro, int epi);
 int sug_head_linear_fwd(int heads, const float* const* in, int64_t ldin, const float* const* W, const float* const* bias,
                         float* const* z, const float* const* gamma, const float* const* beta, const float* const* u,
                         float* const* stats, float* const* act, int M, int K, int No, int pro, float slope, float eps,
                         float p_drop, void* stream);
-int sug_head_linear_bwd(int heads, int sum_da, const float* const* gup, int64_t ldg, const float* const* z,
-                        const float* const* stats, const float* const* gamma, const float* const* beta,
-                        const float* const* u, const float* const* gextra, const float* const* in, int64_t ldin,
+int sug_head_ln_bwd(int heads, const float* const* gup, int64_t ldg, const float* const* z, const float* const* stats,
+                    const float* const* gamma, const float* const* beta, const float* const* u,
+                    const float* const* gextra, float* const* dz, float* const* dgamma, float* const* dbeta,
+                    float* const* db, int M, int No, float slope, float p_drop, void* stream);
+int sug_head_linear_bwd(int heads, int sum_da, const float* const* dz, int64_t ldg, const float* const* in, int64_t ldin,
                         const float* const* stats_in, const float* const* gamma_in, const float* const* beta_in,
                         const float* const* u_in, const float* const* W, float* const* dW, float* const* db,
-                        float* const* dgamma, float* const* dbeta, float* const* da, int64_t ldda, int M, int K, int No,
-                        int epi, int pro, float slope, float eps, float p_drop, float p_drop_in, void* stream);
+                        float* const* da, int64_t ldda, int M, int K, int No, int pro, float slope, float p_drop_in,
+                        void* stream);
 
 /* ---- LayerNorm + (Leaky)ReLU of the FC heads ---------------------------------------------------
  * fc_layer (model/model_utils.py:35-57: nn.Linear -> nn.LayerNorm -> LeakyReLU(0.2) / ReLU) behind the Linear:

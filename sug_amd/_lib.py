@@ -84,8 +84,9 @@ SIGNATURES = {
     'sug_pointmlp_max_bwd_dwfix': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
     'sug_head_linear_supported': [_i32, _i32, _i32, _i32, _i32],
     'sug_head_linear_fwd': [_i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _vp],
-    'sug_head_linear_bwd': [_i32, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64,
-                            _i32, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _vp],
+    'sug_head_ln_bwd': [_i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _f32, _vp],
+    'sug_head_linear_bwd': [_i32, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _f32, _f32, _vp],
+    'sug_copy_rows2d': [_vp, _i64, _vp, _i64, _i64, _i32, _vp],
     'sug_ln_act_fwd': [_vp, _vp, _vp, _i32, _i32, _f32, _f32, _vp, _vp, _vp],
     'sug_ln_act_bwd': [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp],
     'sug_interp3_cat_bwd_lists': [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp],

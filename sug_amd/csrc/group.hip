@@ -88,6 +88,18 @@ inline int ew_grid(int64_t total) {
   return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
 }
 
+// dst[r][0..C) = src[r][0..C) for R rows with row strides lds / ldd (floats), C % 4 == 0: a column slice of a wide row
+// buffer from a dense tensor or the other way round (torch's strided copy runs this at ~1 TB/s: 30 us for 16.8 MB)
+__global__ __launch_bounds__(256) void copy_rows2d_kernel(const float* __restrict__ src, int64_t lds, float* __restrict__ dst,
+                                                          int64_t ldd, int64_t R, int C4) {
+  const int64_t total = R * C4;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t r = e / C4;
+    const int c = (int)(e - r * C4) * 4;
+    *reinterpret_cast<float4*>(dst + r * ldd + c) = *reinterpret_cast<const float4*>(src + r * lds + c);
+  }
+}
+
 }  // namespace
 
 extern "C" int sug_gather_rows(const float* feat, int64_t ldf, const int32_t* idx, int B, int N, int S,
@@ -131,5 +143,16 @@ extern "C" int sug_group_max_bwd(const float* g, const int32_t* arg, int B, int 
   hipLaunchKernelGGL(group_max_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, g,
                      arg, N, S, C, total, dfeat, ldf);
   SUG_LAUNCH_CHECK("sug_group_max_bwd");
+  return SUG_OK;
+}
+
+extern "C" int sug_copy_rows2d(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t rows, int C, void* stream) {
+  SUG_REQUIRE(src && dst && rows > 0 && C > 0 && C % 4 == 0 && lds >= C && ldd >= C && lds % 4 == 0 && ldd % 4 == 0,
+              "sug_copy_rows2d: bad shape rows=%lld C=%d lds=%lld ldd=%lld", (long long)rows, C, (long long)lds, (long long)ldd);
+  SUG_REQUIRE(((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0, "sug_copy_rows2d: operands must be 16-byte aligned");
+  const int64_t total = rows * (C / 4);
+  const int grid = (int)(total / 256 + 1 < 8192 ? total / 256 + 1 : 8192);
+  hipLaunchKernelGGL(copy_rows2d_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, lds, dst, ldd, rows, C / 4);
+  SUG_LAUNCH_CHECK("sug_copy_rows2d");
   return SUG_OK;
 }

@@ -747,7 +747,8 @@ def heads_fused_supported(heads, x):
 class _HeadsFused(torch.autograd.Function):
     """Pointnet_c heads (model/Model.py:412-449) on one input: per layer ONE launch for all heads, the LayerNorm /
     activation / dropout between two Linear layers applied to the next layer's operand as it is loaded
-    (sug_head_linear_fwd), and one launch per layer in the backward (sug_head_linear_bwd).  Arguments after the
+    (sug_head_linear_fwd); in the backward one launch per Linear layer (sug_head_linear_bwd) and one per LayerNorm
+    (sug_head_ln_bwd).  Arguments after the
     scalars: per head (W1, b1, g1, be1, W2, b2, g2, be2, W3, b3) -- the first four None for the two-layer (Point
     Transformer) head.  Returns per head (logits, mid feature)."""
 
@@ -814,26 +815,27 @@ class _HeadsFused(torch.autograd.Function):
         new = lambda n: [torch.empty(M, n, dtype=torch.float32, device=dev) for _ in H]
         grads = [like(i) for i in range(10)]
         # layer 3: logits = Dropout(act(LN(z2))) . W3^T + b3
-        da2 = new(N2)
-        check(L.sug_head_linear_bwd(nheads, 0, _ptrs(gl), NC, None, None, None, None, None, None, _ptrs(z2), N2, _ptrs(st2),
-                                    _ptrs(col(6)), _ptrs(col(7)), _ptrs(u2), _ptrs(col(8)), _ptrs(grads[8]), _ptrs(grads[9]), None, None,
-                                    _ptrs(da2), N2, M, N2, NC, 0, 1, slope, eps, 0.0, p2, _st()), 'sug_head_linear_bwd')
+        da2, dz2 = new(N2), new(N2)
+        check(L.sug_head_linear_bwd(nheads, 0, _ptrs(gl), NC, _ptrs(z2), N2, _ptrs(st2), _ptrs(col(6)), _ptrs(col(7)), _ptrs(u2),
+                                    _ptrs(col(8)), _ptrs(grads[8]), _ptrs(grads[9]), _ptrs(da2), N2, M, N2, NC, 1, slope, p2, _st()),
+              'sug_head_linear_bwd')
+        check(L.sug_head_ln_bwd(nheads, _ptrs(da2), N2, _ptrs(z2), _ptrs(st2), _ptrs(col(6)), _ptrs(col(7)), _ptrs(u2), _ptrs(gm),
+                                _ptrs(dz2), _ptrs(grads[6]), _ptrs(grads[7]), _ptrs(grads[5]), M, N2, slope, p2, _st()), 'sug_head_ln_bwd')
         dx = torch.empty(M, K, dtype=torch.float32, device=dev) if ctx.need_dx else None
+        dxs = _ptrs([dx] + [None] * (nheads - 1))
         if three:
-            da1 = new(N1)
-            check(L.sug_head_linear_bwd(nheads, 0, _ptrs(da2), N2, _ptrs(z2), _ptrs(st2), _ptrs(col(6)), _ptrs(col(7)), _ptrs(u2),
-                                        _ptrs(gm), _ptrs(z1), N1, _ptrs(st1), _ptrs(col(2)), _ptrs(col(3)), _ptrs(u1), _ptrs(col(4)),
-                                        _ptrs(grads[4]), _ptrs(grads[5]), _ptrs(grads[6]), _ptrs(grads[7]), _ptrs(da1), N1, M, N1, N2,
-                                        1, 1, slope, eps, p2, p1, _st()), 'sug_head_linear_bwd')
-            check(L.sug_head_linear_bwd(nheads, 1, _ptrs(da1), N1, _ptrs(z1), _ptrs(st1), _ptrs(col(2)), _ptrs(col(3)), _ptrs(u1),
-                                        None, _ptrs([x2] * nheads), K, None, None, None, None, _ptrs(col(0)), _ptrs(grads[0]),
-                                        _ptrs(grads[1]), _ptrs(grads[2]), _ptrs(grads[3]), _ptrs([dx] + [None] * (nheads - 1)), K,
-                                        M, K, N1, 1, 0, slope, eps, p1, 0.0, _st()), 'sug_head_linear_bwd')
+            da1, dz1 = new(N1), new(N1)
+            check(L.sug_head_linear_bwd(nheads, 0, _ptrs(dz2), N2, _ptrs(z1), N1, _ptrs(st1), _ptrs(col(2)), _ptrs(col(3)), _ptrs(u1),
+                                        _ptrs(col(4)), _ptrs(grads[4]), None, _ptrs(da1), N1, M, N1, N2, 1, slope, p1, _st()),
+                  'sug_head_linear_bwd')
+            check(L.sug_head_ln_bwd(nheads, _ptrs(da1), N1, _ptrs(z1), _ptrs(st1), _ptrs(col(2)), _ptrs(col(3)), _ptrs(u1), None,
+                                    _ptrs(dz1), _ptrs(grads[2]), _ptrs(grads[3]), _ptrs(grads[1]), M, N1, slope, p1, _st()),
+                  'sug_head_ln_bwd')
+            check(L.sug_head_linear_bwd(nheads, 1, _ptrs(dz1), N1, _ptrs([x2] * nheads), K, None, None, None, None, _ptrs(col(0)),
+                                        _ptrs(grads[0]), None, dxs, K, M, K, N1, 0, slope, 0.0, _st()), 'sug_head_linear_bwd')
         else:
-            check(L.sug_head_linear_bwd(nheads, 1, _ptrs(da2), N2, _ptrs(z2), _ptrs(st2), _ptrs(col(6)), _ptrs(col(7)), _ptrs(u2),
-                                        _ptrs(gm), _ptrs([x2] * nheads), K, None, None, None, None, _ptrs(col(4)), _ptrs(grads[4]),
-                                        _ptrs(grads[5]), _ptrs(grads[6]), _ptrs(grads[7]), _ptrs([dx] + [None] * (nheads - 1)), K,
-                                        M, K, N2, 1, 0, slope, eps, p2, 0.0, _st()), 'sug_head_linear_bwd')
+            check(L.sug_head_linear_bwd(nheads, 1, _ptrs(dz2), N2, _ptrs([x2] * nheads), K, None, None, None, None, _ptrs(col(4)),
+                                        _ptrs(grads[4]), None, dxs, K, M, K, N2, 0, slope, 0.0, _st()), 'sug_head_linear_bwd')
         flat = []
         for h in H:
             flat += [grads[i][h] for i in range(10)]
@@ -1487,9 +1489,17 @@ class _AssembleRows(torch.autograd.Function):
             if not (t.data_ptr() == dst.data_ptr() and t.stride() == dst.stride() and t.shape == dst.shape):
                 # copy through an alias with its own version counter: an in-place op on a view of `buf`
                 # would invalidate (for autograd) the slices the producers already returned
-                alias = torch.empty(0, dtype=buf.dtype, device=buf.device).set_(
-                    buf.untyped_storage(), dst.storage_offset(), dst.shape, dst.stride())
-                alias.copy_(t)
+                t2 = t.detach()
+                rows = t2.numel() // max(w, 1)
+                if t2.is_cuda and t2.dtype == torch.float32 and t2.is_contiguous() and w % 4 == 0 and dst.stride(-1) == 1 \
+                        and all(dst.stride(d) == dst.stride(d + 1) * dst.shape[d + 1] for d in range(dst.dim() - 2)) \
+                        and dst.stride(-2) % 4 == 0 and t2.data_ptr() % 16 == 0 and dst.data_ptr() % 16 == 0:
+                    # own float4 copy: torch's strided copy kernel takes 30 us for a 16.8 MB part
+                    check(lib().sug_copy_rows2d(_p(t2), w, _p(dst), dst.stride(-2), rows, w, _st()), 'sug_copy_rows2d')
+                else:
+                    alias = torch.empty(0, dtype=buf.dtype, device=buf.device).set_(
+                        buf.untyped_storage(), dst.storage_offset(), dst.shape, dst.stride())
+                    alias.copy_(t)
             widths.append(w)
             off += w
         if off != buf.shape[-1]:
