@@ -229,6 +229,15 @@ int sug_colsum(const void* x, int64_t ld, int64_t rows, int C, int dtype, float 
  * output of the second 1x1 conv; backward dx = g * sigmoid(z) + g, dz = g * x * sigmoid'(z). */
 int sug_gate_fwd(const float* x, const float* z, int64_t n, float* out, void* stream);
 int sug_gate_bwd(const float* g, const float* x, const float* z, int64_t n, float* dx, float* dz, void* stream);
+/* The gate followed by CALayer's BatchNorm1d (model/Model.py:442-449: attention_s / attention_t on [M, 4096] node
+ * features, M = the clouds of one domain): out = BN(x * sigmoid(z) + x), train mode = batch statistics over the M rows
+ * (two-pass) with the running buffers updated (null: not tracked), eval mode = running statistics; stat [2, C] = mean |
+ * invstd for the backward, which returns dx, dz of the gate and dgamma, dbeta [C].  One launch each way. */
+int sug_gate_bn_fwd(const float* x, const float* z, int M, int C, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, int training, float eps, float momentum, float* out,
+                    float* stat, void* stream);
+int sug_gate_bn_bwd(const float* g, const float* x, const float* z, int M, int C, const float* gamma, const float* stat,
+                    int training, float* dx, float* dz, float* dgamma, float* dbeta, void* stream);
 
 /* ---- Classifier heads: Linear layers with M <= 128 rows, one launch per layer for up to two heads ----------------
  * Pointnet_c (model/Model.py:412-449): fc_layer(1024, 512) -> Dropout -> fc_layer(512, 256) [= mid feature] -> Dropout ->

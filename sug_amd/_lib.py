@@ -86,6 +86,8 @@ SIGNATURES = {
     'sug_head_linear_fwd': [_i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _vp],
     'sug_head_ln_bwd': [_i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _f32, _vp],
     'sug_head_linear_bwd': [_i32, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _f32, _f32, _vp],
+    'sug_gate_bn_fwd': [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _vp, _vp, _vp],
+    'sug_gate_bn_bwd': [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
     'sug_copy_rows2d': [_vp, _i64, _vp, _i64, _i64, _i32, _vp],
     'sug_ln_act_fwd': [_vp, _vp, _vp, _i32, _i32, _f32, _f32, _vp, _vp, _vp],
     'sug_ln_act_bwd': [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp],

@@ -65,8 +65,9 @@ class CALayer(nn.Module):
         c0, c2 = self.conv_du[0], self.conv_du[2]
         y = F.relu(F.linear(v, c0.weight.view(c0.weight.shape[0], -1), c0.bias))
         z = F.linear(y, c2.weight.view(c2.weight.shape[0], -1), c2.bias)
-        # torch's BatchNorm1d here: statistics over the B samples only (B = 2..32), where its two-pass
-        # variance is better conditioned than the sum / sum-of-squares form of the rows kernels
+        if ops.gate_bn_supported(v, self.bn):
+            # gate + BatchNorm1d over the B samples in one launch (two-pass statistics, as torch's kernel)
+            return ops.gate_bn(v, z, self.bn)
         return self.bn(ops.gate(v, z))                                      # v * sigmoid(z) + v
 
 

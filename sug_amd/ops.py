@@ -1747,6 +1747,54 @@ def gate(x, z):
     return _Gate.apply(x, z)
 
 
+class _GateBN(torch.autograd.Function):
+    """BatchNorm1d(x * sigmoid(z) + x) over the M rows of x, z [M, C] -- the tail of CALayer (sug_gate_bn_fwd / _bwd):
+    one launch each way instead of the gate + torch's three BatchNorm launches (and its 32 us backward reduce)."""
+
+    @staticmethod
+    def forward(ctx, x, z, gamma, beta, running_mean, running_var, training, eps, momentum):
+        _need_gpu(x, z, gamma)
+        x, z = x.contiguous(), z.contiguous()
+        M, C = x.shape
+        g, b = gamma.detach().contiguous(), beta.detach().contiguous()
+        out = torch.empty_like(x)
+        stat = torch.empty(2, C, dtype=torch.float32, device=x.device)
+        check(lib().sug_gate_bn_fwd(_p(x), _p(z), M, C, _p(g), _p(b), _p(running_mean), _p(running_var), 1 if training else 0,
+                                    float(eps), float(momentum), _p(out), _p(stat), _st()), 'sug_gate_bn_fwd')
+        ctx.save_for_backward(x, z, g, stat)
+        ctx.training = bool(training)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, z, g, stat = ctx.saved_tensors
+        M, C = x.shape
+        gout = gout.contiguous()
+        dx, dz = torch.empty_like(x), torch.empty_like(x)
+        dgb = torch.empty(2, C, dtype=torch.float32, device=x.device)
+        check(lib().sug_gate_bn_bwd(_p(gout), _p(x), _p(z), M, C, _p(g), _p(stat), 1 if ctx.training else 0, _p(dx), _p(dz),
+                                    _p(dgb[0]), _p(dgb[1]), _st()), 'sug_gate_bn_bwd')
+        return dx, dz, dgb[0], dgb[1], None, None, None, None, None
+
+
+def gate_bn_supported(x, bn):
+    return GATE_BN_FUSED and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] <= 1024 and bn.affine and \
+        (bn.training or bn.track_running_stats) and bn.momentum is not None and BN_GROUPS == 1
+
+
+def gate_bn(x, z, bn):
+    """bn(x * sigmoid(z) + x) for an nn.BatchNorm1d over [M, C] rows (CALayer, model/Model.py:28-34)."""
+    if x.dtype != torch.float32 or z.dtype != torch.float32 or x.shape != z.shape:
+        raise RuntimeError('sug_amd.ops.gate_bn: two fp32 tensors of one shape')
+    _count_bn_call(bn)
+    track = bn.track_running_stats
+    return _GateBN.apply(x, z, bn.weight, bn.bias, bn.running_mean if track else None, bn.running_var if track else None,
+                         bn.training or not track, bn.eps, bn.momentum)
+
+
+GATE_BN_FUSED = _os.environ.get('SUG_GATE_BN_FUSED', '1') != '0'
+
+
 class _EdgeWeightSplit(torch.autograd.Function):
     """W [Co, 2C] -> [W1 ; W2 - W1] [2Co, C], the EdgeConv GEMM operand (one launch forward, one backward:
     dW = [gP - gQ | gQ])."""

@@ -136,3 +136,37 @@ def test_heads_fused_unsupported_shapes_take_the_module_path():
     assert not ops.heads_fused_supported(hs, torch.zeros(8, 1024, device='cuda', dtype=torch.float16))
     hs[1].dropout2.p = 0.1                                                                  # heads must agree on their dropout
     assert not ops.heads_fused_supported(hs, torch.zeros(8, 1024, device='cuda'))
+
+
+@pytest.mark.parametrize('M', [2, 32, 100])
+@pytest.mark.parametrize('mode', ['train', 'eval'])
+def test_gate_bn_matches_gate_then_batchnorm(M, mode):
+    """CALayer's tail BN(x * sigmoid(z) + x) in one launch (sug_gate_bn_fwd / _bwd) against ops.gate + nn.BatchNorm1d:
+    output, the four gradients and the running buffers, train and eval mode, with a large common offset in x (the
+    two-pass statistics must not care)."""
+    from sug_amd import ops
+    C = 4096
+    g = torch.Generator().manual_seed(M)
+    # (two rows: x_hat = +-1 whatever the data, and a common offset only adds rounding noise to the tiny difference
+    # both implementations divide by -- keep that case centred)
+    x = (torch.randn(M, C, generator=g) * 0.5 + (30.0 if M > 2 else 0.0)).cuda().requires_grad_(True)
+    z = torch.randn(M, C, generator=g).cuda().requires_grad_(True)
+    probe = torch.randn(M, C, generator=g).cuda()
+    res = []
+    for fused in (False, True):
+        bn = torch.nn.BatchNorm1d(C).cuda()
+        torch.manual_seed(3)
+        bn.weight.data.copy_(torch.rand(C) + 0.5)
+        bn.bias.data.copy_(torch.rand(C) - 0.5)
+        bn.running_mean.copy_(torch.full((C,), 29.0))
+        bn.running_var.copy_(torch.full((C,), 2.0))
+        bn.train(mode == 'train')
+        assert ops.gate_bn_supported(x, bn)
+        out = ops.gate_bn(x, z, bn) if fused else bn(ops.gate(x, z))
+        grads = torch.autograd.grad((out * probe).sum(), [x, z, bn.weight, bn.bias])
+        res.append([out.detach()] + list(grads) + [bn.running_mean.clone(), bn.running_var.clone(), bn.num_batches_tracked.clone()])
+    names = ['out', 'dx', 'dz', 'dgamma', 'dbeta', 'running_mean', 'running_var']
+    for n, a, b in zip(names, res[1], res[0]):
+        scale = float(b.abs().max()) + 1e-12
+        assert float((a - b).abs().max()) / scale <= 5e-5, (n, float((a - b).abs().max()), scale)
+    assert int(res[1][-1]) == int(res[0][-1])
