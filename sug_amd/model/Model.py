@@ -221,13 +221,43 @@ class Pointnet_g(nn.Module):
         self.conv4 = conv_2d(128, 128, 1)
         self.conv5 = conv_2d(128, 1024, 1)
         self.bn1 = nn.BatchNorm1d(1024)
+        # Common-subexpression sharing as for DGCNN: both T-Nets, conv1 and conv2 run in front of the SA-node module
+        # (the first farthest-point draw), so the semantic and the node pass of a step compute them on identical inputs
+        # with identical weights; the second pass reuses the result and replays the BatchNorm running-statistics
+        # updates (ops.record_bn_stats / replay_bn_stats).  One backward over both passes.
+        self.share_prefix = 'auto'
+        self._prefix_cache = {}
+
+    def clear_prefix_cache(self):
+        self._prefix_cache = {}
+
+    def _prefix_modules(self):
+        return (self.trans_net1, self.conv1, self.conv2, self.trans_net2)
+
+    def _prefix(self, x, loc):
+        def run():
+            y = torch.bmm(loc, self.trans_net1.rows(loc))
+            y = self.conv2.rows(self.conv1.rows(y))
+            return torch.bmm(y, self.trans_net2.rows(y))
+        if not (_sharing_on(self.share_prefix, self.training) and x.is_cuda):
+            return run()
+        ver = sum(p._version for mod in self._prefix_modules() for p in mod.parameters())
+        key = (x.data_ptr(), x._version, tuple(x.shape), torch.is_grad_enabled(), ver, ops.BN_GROUPS)
+        hit = self._prefix_cache.get(key)
+        if hit is not None and hit.alive:
+            ops.replay_bn_stats(hit.extra)
+            return hit.tensors[0]
+        with ops.record_bn_stats() as rec:
+            y = run()
+        if len(self._prefix_cache) >= 4:
+            self._prefix_cache.clear()
+        self._prefix_cache[key] = _PrefixEntry((y,), rec)
+        return y
 
     def forward(self, x, node=False, feat_grad=True):
         """feat_grad=False: node-adaptation pass, the stage behind the SA-node module runs without autograd."""
         loc = x.squeeze(-1).transpose(1, 2).contiguous()              # [B,N,3]
-        y = torch.bmm(loc, self.trans_net1.rows(loc))
-        y = self.conv2.rows(self.conv1.rows(y))
-        y = torch.bmm(y, self.trans_net2.rows(y))
+        y = self._prefix(x, loc)
         y, node_fea, node_off = self.conv3.rows(y, loc)
         with torch.set_grad_enabled(torch.is_grad_enabled() and feat_grad):
             y = bn_module(self.bn1, self.conv5.rows_max(self.conv4.rows(y)))

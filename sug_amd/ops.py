@@ -572,6 +572,8 @@ class _BNActRows(torch.autograd.Function):
         check(lib().sug_bn_act_rows_fwd(_p(y2), C, rows, C, G, _p(g), _p(b), 1 if training else 0, eps, momentum,
                                         float(slope), _p(running_mean), _p(running_var), _p(coef), _p(out), C,
                                         _p(stats), _p(ws), _st()), 'sug_bn_act_rows_fwd')
+        global _LAST_COEF
+        _LAST_COEF = coef
         if any(ctx.needs_input_grad[i] for i in (0, 1, 2)):
             ctx.save_for_backward(y2, coef)
             ctx.meta = (rows, C, float(slope), bool(training), tuple(y.shape), G)
@@ -893,6 +895,33 @@ def _count_bn_call(bn, n=None):
             bn.num_batches_tracked.add_(n)
 
 
+# A shared prefix (DGCNN / Point Transformer / PointNet encoders: the part of the semantic and of the node pass of a step that
+# is the same computation) is run once; the second pass only REPLAYS the running-statistics updates of its BatchNorm layers.
+# `with record_bn_stats() as rec:` collects (module, batch-statistics coefficients) of every train-mode BatchNorm op inside.
+BN_RECORD = None
+_LAST_COEF = None
+
+
+@contextlib.contextmanager
+def record_bn_stats():
+    global BN_RECORD
+    prev, BN_RECORD = BN_RECORD, []
+    try:
+        yield BN_RECORD
+    finally:
+        BN_RECORD = prev
+
+
+def _record_bn(bn):
+    if BN_RECORD is not None and bn.training and bn.track_running_stats:
+        BN_RECORD.append((bn, _LAST_COEF))
+
+
+def replay_bn_stats(rec):
+    for bn, coef in rec:
+        bn_replay(bn, coef)
+
+
 def bn_replay(bn, coef):
     """Running-statistics update of len(coef) more train-mode forwards with known batch statistics
     (coef [5,C] or [G,5,C] from a BN op), in order (sug_bn_replay)."""
@@ -907,8 +936,10 @@ def bn_replay(bn, coef):
 def bn_act_rows(y, bn, slope):
     """bn: an nn.BatchNorm{1,2}d module whose parameters / running buffers are used."""
     _count_bn_call(bn)
-    return _BNActRows.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, slope, bn.eps,
-                            bn.momentum, BN_GROUPS)
+    out = _BNActRows.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, slope, bn.eps,
+                           bn.momentum, BN_GROUPS)
+    _record_bn(bn)
+    return out
 
 
 class _BNActPool(torch.autograd.Function):
@@ -1219,6 +1250,8 @@ class _PointMLPMax(torch.autograd.Function):
                                                               float(slope), _p(running_mean), _p(running_var), _p(zext),
                                                               _p(arg), _p(coef), _p(out), Co, _p(ws), _st())),
               'sug_pointmlp_max_layer_fwd')
+        global _LAST_COEF
+        _LAST_COEF = coef
         if any(ctx.needs_input_grad[i] for i in (0, 1, 2, 3, 4)):
             ctx.save_for_backward(x2, w2, b1, zext, arg, coef)
             ctx.meta = (rows, K, Co, seg, G, float(slope), bool(training), tuple(x.shape), tuple(weight.shape))
@@ -1284,8 +1317,10 @@ def pointmlp_max(x, weight, bias, bn, slope, seg):
     """x [..., K] rows (segments of `seg` consecutive rows), weight [Co, K(,1,1)], bn an nn.BatchNorm
     module -> [rows/seg, Co] = max over each segment of LeakyReLU_slope(bn(x.W^T + b))."""
     _count_bn_call(bn)
-    return _PointMLPMax.apply(x, weight, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training,
-                              slope, bn.eps, bn.momentum, seg, BN_GROUPS)
+    out = _PointMLPMax.apply(x, weight, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training,
+                             slope, bn.eps, bn.momentum, seg, BN_GROUPS)
+    _record_bn(bn)
+    return out
 
 
 # Step-scoped cache of 16-bit copies of weights / biases (opt-in: SUGStep sets a dict before the forwards of a step and

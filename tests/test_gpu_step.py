@@ -87,10 +87,11 @@ def test_two_training_steps_match_reference():
     print('worst checksum deviation / allowance vs oracle = %.3f' % worst)
 
 
-@pytest.mark.parametrize('model_name', ['DGCNN', 'PTran'])
+@pytest.mark.parametrize('model_name', ['DGCNN', 'PTran', 'Pointnet'])
 def test_prefix_sharing_is_exact(model_name):
     """SUGStep(share_prefix=True) (the semantic and node pass of a batch share the stage in front of the
-    first random sampling: kNN+conv1/conv2 for DGCNN, fc1 + transformer1 for the Point Transformer)
+    first random sampling: kNN+conv1/conv2 for DGCNN, fc1 + transformer1 for the Point Transformer, both T-Nets +
+    conv1/conv2 for PointNet)
     gives bit-identical losses and BN buffers, and the same gradients, as four independent passes."""
     from sug_amd.model.Model import Net_MDA
     from sug_amd.train_step import SUGStep
