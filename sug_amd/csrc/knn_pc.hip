@@ -177,7 +177,7 @@ __global__ __launch_bounds__(128 * PW, 2) void knn_pc_kernel(const float* __rest
     auto breg = [](int s2) constexpr { return CP == 4 ? s2 : (s2 < HALF / 2 ? 2 * s2 : 2 * (s2 - HALF / 2) + 1); };
 
     // scores of candidate tile t for this wave's 64 queries -> score buffer `buf`
-    auto produce = [&](int t, int buf) {
+    auto produce = [&](int t, int buf, auto&& mid) {
       const float* arow = tbuf(t) + qj * RS + h * HALF;
       f32x16 acc0, acc1;
 #pragma unroll
@@ -193,12 +193,15 @@ __global__ __launch_bounds__(128 * PW, 2) void knn_pc_kernel(const float* __rest
         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.x, bq1[0], acc1, 0, 0, 0);
         acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.y, bq0[1], acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.y, bq1[1], acc1, 0, 0, 0);
+        mid();
       } else {
 #ifdef SUG_KNN_ABL_NOMFMA
         acc0[0] = arow[0]; acc1[0] = bq0[0] + bq1[0];
+        mid();
 #else
 #pragma unroll
         for (int g = 0; g < HALF / 4; ++g) {
+          if (g == HALF / 8) mid();             // (empty in the product: see SUG_KNN_STAGE_MID below)
 #ifdef SUG_KNN_ABL_NOAREAD
           const float4 a4 = make_float4(bq0[g], bq1[g], bq0[g + 1], bq1[g + 1]);
 #else
@@ -235,7 +238,7 @@ __global__ __launch_bounds__(128 * PW, 2) void knn_pc_kernel(const float* __rest
     tile_store<CP, true, NTP>(tr, tbuf(0), nbuf(0), N, 0);
     if (ntile > 1) tile_load<CP, NTP>(tr, xb, ldx, N, TJ);
     __syncthreads();
-    produce(0, 0);
+    produce(0, 0, [] {});
     if (ntile > 1) tile_store<CP, true, NTP>(tr, tbuf(1), nbuf(1), N, TJ);
     if (ntile > 2) tile_load<CP, NTP>(tr, xb, ldx, N, 2 * TJ);
     __syncthreads();
@@ -246,13 +249,21 @@ __global__ __launch_bounds__(128 * PW, 2) void knn_pc_kernel(const float* __rest
       if (t + 2 < ntile) tile_store<CP, true, NTP>(tr, tbuf(t + 2), nbuf(t + 2), N, (t + 2) * TJ);
       if (t + 3 < ntile) tile_load<CP, NTP>(tr, xb, ldx, N, (t + 3) * TJ);
       __syncthreads();
-      if (t + 1 < ntile) produce(t + 1, (t + 1) & 1);
+      if (t + 1 < ntile) produce(t + 1, (t + 1) & 1, [] {});
       __syncthreads();
 #else
-      if (t + 1 < ntile) produce(t + 1, (t + 1) & 1);
+      auto stage = [&] {
 #ifndef SUG_KNN_ABL_NOSTAGE
-      if (t + 2 < ntile) tile_store<CP, true, NTP>(tr, tbuf(t + 2), nbuf(t + 2), N, (t + 2) * TJ);
-      if (t + 3 < ntile) tile_load<CP, NTP>(tr, xb, ldx, N, (t + 3) * TJ);
+        if (t + 2 < ntile) tile_store<CP, true, NTP>(tr, tbuf(t + 2), nbuf(t + 2), N, (t + 2) * TJ);
+        if (t + 3 < ntile) tile_load<CP, NTP>(tr, xb, ldx, N, (t + 3) * TJ);
+#endif
+      };
+#ifdef SUG_KNN_STAGE_MID                        // (A/B, tools/bench_knn_pc.py: the staging in the middle of the chain instead
+      // of behind it measured 2-5 us SLOWER -- VALU between dependent MFMAs costs more than the idle tail)
+      if (t + 1 < ntile) produce(t + 1, (t + 1) & 1, stage); else stage();
+#else
+      if (t + 1 < ntile) produce(t + 1, (t + 1) & 1, [] {});
+      stage();
 #endif
 #ifndef SUG_KNN_ABL_NOBARRIER
       __syncthreads();

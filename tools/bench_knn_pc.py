@@ -35,7 +35,7 @@ def time_knn(L, x, k, iters=20):
 
 if __name__ == '__main__':
     torch.manual_seed(0)
-    variants = [('product', []), ('serial', ['-DSUG_KNN_SERIAL']), ('no insertion', ['-DSUG_KNN_ABL_NOINSERT']), ('no consumer', ['-DSUG_KNN_ABL_NOCONS']),
+    variants = [('product', []), ('staging inside the chain', ['-DSUG_KNN_STAGE_MID']), ('serial', ['-DSUG_KNN_SERIAL']), ('no insertion', ['-DSUG_KNN_ABL_NOINSERT']), ('no consumer', ['-DSUG_KNN_ABL_NOCONS']),
                 ('no MFMA', ['-DSUG_KNN_ABL_NOMFMA']), ('no MFMA, no consumer', ['-DSUG_KNN_ABL_NOMFMA', '-DSUG_KNN_ABL_NOCONS']),
                 ('no MFMA, no insertion', ['-DSUG_KNN_ABL_NOMFMA', '-DSUG_KNN_ABL_NOINSERT'])]
     if len(sys.argv) > 1 and sys.argv[1] == 'producer':       # the producer side alone, piece by piece
