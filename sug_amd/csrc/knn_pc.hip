@@ -259,7 +259,7 @@ __global__ __launch_bounds__(128 * PW, 2) void knn_pc_kernel(const float* __rest
 #endif
       };
 #ifdef SUG_KNN_STAGE_MID                        // (A/B, tools/bench_knn_pc.py: the staging in the middle of the chain instead
-      // of behind it measured 2-5 us SLOWER -- VALU between dependent MFMAs costs more than the idle tail)
+      // of behind it measured within 1 % -- VALU between dependent MFMAs costs about what the idle tail does)
       if (t + 1 < ntile) produce(t + 1, (t + 1) & 1, stage); else stage();
 #else
       if (t + 1 < ntile) produce(t + 1, (t + 1) & 1, [] {});
@@ -330,15 +330,25 @@ __global__ __launch_bounds__(128 * PW, 2) void knn_pc_kernel(const float* __rest
         inv_scale = R / (float)FXMAX;
         if (!(scale < FLT_MAX) || !(inv_scale > 0.f)) { scale = 1.f; inv_scale = 1.f; }
       } else {
+        // score >= thr, conservatively, in two instructions per candidate: with u = fl(-nj - inner) (the score's own first
+        // rounding) the score is fl(u - ni), so score >= thr implies u >= thr + ni - ulp: compare u with
+        // thr2 = fl(thr + ni) - 2.4e-7 (|thr| + |ni|) through the sign bit of fl(u - thr2) (a difference has the sign of the
+        // exact one; u = -inf for rows past N gives -inf: rejected), shifted into the mask by v_alignbit.  A candidate
+        // that passes here and not the exact test only costs an insertion that leaves the list unchanged.
+        const float thr2 = thr == -FLT_MAX ? -FLT_MAX : __fsub_rn(__fadd_rn(thr, ni), 2.4e-7f * (fabsf(thr) + fabsf(ni)));
+        unsigned int rej = 0u;
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
           const float4 s4 = *reinterpret_cast<const float4*>(srow + 4 * g);
           const float4 n4 = *reinterpret_cast<const float4*>(nrm + 4 * g);
-          mask = mask + mask + (score(s4.x, n4.x) >= thr ? 1u : 0u);
-          mask = mask + mask + (score(s4.y, n4.y) >= thr ? 1u : 0u);
-          mask = mask + mask + (score(s4.z, n4.z) >= thr ? 1u : 0u);
-          mask = mask + mask + (score(s4.w, n4.w) >= thr ? 1u : 0u);
+          const float wx = __fsub_rn(__fsub_rn(-n4.x, s4.x), thr2), wy = __fsub_rn(__fsub_rn(-n4.y, s4.y), thr2);
+          const float wz = __fsub_rn(__fsub_rn(-n4.z, s4.z), thr2), ww = __fsub_rn(__fsub_rn(-n4.w, s4.w), thr2);
+          rej = __builtin_amdgcn_alignbit(rej, __float_as_uint(wx), 31);
+          rej = __builtin_amdgcn_alignbit(rej, __float_as_uint(wy), 31);
+          rej = __builtin_amdgcn_alignbit(rej, __float_as_uint(wz), 31);
+          rej = __builtin_amdgcn_alignbit(rej, __float_as_uint(ww), 31);
         }
+        mask = ~rej;
       }
       // pass 2: the marked candidates in ascending index order, one per lane per iteration (all lanes in
       // lockstep); iterations = the largest number of marked candidates of any lane: a wave-wide maximum built

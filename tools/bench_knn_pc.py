@@ -46,7 +46,16 @@ if __name__ == '__main__':
                     ('+ no barrier', NC + ['-DSUG_KNN_ABL_NOSCOREWRITE', '-DSUG_KNN_ABL_NOSTAGE', '-DSUG_KNN_ABL_NOAREAD', '-DSUG_KNN_ABL_NOBARRIER']),
                     ('no barrier only', NC + ['-DSUG_KNN_ABL_NOBARRIER']), ('no A reads only', NC + ['-DSUG_KNN_ABL_NOAREAD']),
                     ('no staging only', NC + ['-DSUG_KNN_ABL_NOSTAGE'])]
-    libs = [(t, build(t.replace(' ', '_').replace(',', ''), d)) for t, d in variants]
+    if len(sys.argv) > 1 and sys.argv[1] == 'ab':             # careful A/B of two builds: interleaved rounds, median and minimum
+        variants = [('product', []), ('staging inside the chain', ['-DSUG_KNN_STAGE_MID'])]
+    libs = [(t, build(t.replace(' ', '_').replace(',', '').replace('+', 'p'), d)) for t, d in variants]
     for C in (3, 64, 128):
         x = torch.randn(64, 1024, C, device='cuda')
-        print('C=%3d  ' % C + '  '.join('%s %6.1f' % (t, time_knn(L, x, 20)) for t, L in libs))
+        if len(sys.argv) > 1 and sys.argv[1] == 'ab':
+            res = {t: [] for t, _ in libs}
+            for _ in range(9):
+                for t, L in libs:
+                    res[t].append(time_knn(L, x, 20, 50))
+            print('C=%3d  ' % C + '  '.join('%s median %6.1f min %6.1f' % (t, sorted(v)[len(v) // 2], min(v)) for t, v in res.items()))
+        else:
+            print('C=%3d  ' % C + '  '.join('%s %6.1f' % (t, time_knn(L, x, 20)) for t, L in libs))
