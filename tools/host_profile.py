@@ -6,6 +6,11 @@ from sug_amd.model.Model import Net_MDA
 from sug_amd.train_step import SUGStep
 dev = torch.device('cuda')
 tr = SUGStep(Net_MDA('DGCNN').to(dev).train())
+if len(sys.argv) > 1 and sys.argv[1] == 'caller':          # the unchanged-caller form bench.py times: four separate model(...) calls
+    tr.pair_domains = tr.share_prefix = False
+    tr.model.g.share_prefix = 'auto'
+    for m_ in tr._split_layers:
+        m_.cache_weight_split = False
 data = synth(32, 1024, 666, dev)
 for _ in range(3):
     tr.step(*data)
