@@ -100,7 +100,7 @@ __device__ __forceinline__ float exact_norm(const float* __restrict__ r) {
 }
 
 // PW: producer waves = consumer waves per workgroup.  PW = 4 (product): 256 queries, 512 threads, one workgroup per CU
-// (100 / 125 KB of LDS).  PW = 2 (A/B knob, measured slower): 128 queries, 256 threads, 63 KB of LDS at C <= 64 -- two
+// (100 / 125 KB of LDS).  PW = 2 (small batches: see launch_pc): 128 queries, 256 threads, 63 KB of LDS at C <= 64 -- two
 // workgroups per CU with independent barrier phases.
 template <int CP, int K, int PW>
 __global__ __launch_bounds__(128 * PW, 2) void knn_pc_kernel(const float* __restrict__ x, int64_t ldx, int B, int N,
@@ -505,11 +505,23 @@ int launch_pc_pw(const float* x, int64_t ldx, int B, int N, int k, int32_t* idx,
 
 template <int CP, int K>
 int launch_pc(const float* x, int64_t ldx, int B, int N, int k, int32_t* idx, hipStream_t st) {
-  // 256-query workgroups (PW = 4, one per CU) are the product form.  SUG_KNN_PW=2 selects 128-query workgroups (two per CU
-  // at C <= 64) for A/B timing (tools/bench_knn_pw.py): measured SLOWER -- 157 vs 133 us at C = 64, 77 vs 71 at C = 3 (every
-  // workgroup stages all candidate tiles, so two per CU double that work and halve the waves behind each barrier).
+  // 256-query workgroups (PW = 4, one per CU) when they fill the chip; 128-query workgroups (PW = 2; two per CU at C <= 64) when
+  // the 256-query grid would leave half of the CUs idle -- 32 clouds of 1024 points are 128 workgroups on 256 CUs.  Measured
+  // (tools/bench_knn_pw.py, us per launch at C = 3 / 64 / 128): 32 clouds PW = 4: 61 / 119 / 181, PW = 2: 55 / 92 / 157;
+  // 64 clouds PW = 4: 71 / 133 / 190, PW = 2: 77 / 157 / -- (every workgroup stages all candidate tiles, so two per CU
+  // double that work and halve the waves behind each barrier).  Same lists either way.  SUG_KNN_PW=2|4 forces a form.
   static const int forced = getenv("SUG_KNN_PW") ? atoi(getenv("SUG_KNN_PW")) : 0;
-  const bool two = forced == 2;
+  static std::atomic<int> cus[SUG_MAX_DEVICES];
+  int ncu = 256, dev = 0;
+  if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < SUG_MAX_DEVICES) {
+    ncu = cus[dev].load(std::memory_order_relaxed);
+    if (ncu == 0) {
+      if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+      cus[dev].store(ncu, std::memory_order_relaxed);
+    }
+  }
+  const int64_t grid4 = (int64_t)B * sug_divup(N, 256);
+  const bool two = forced == 2 || (forced != 4 && 2 * grid4 <= ncu);
   if (two) return launch_pc_pw<CP, K, 2>(x, ldx, B, N, k, idx, st);
   return launch_pc_pw<CP, K, 4>(x, ldx, B, N, k, idx, st);
 }

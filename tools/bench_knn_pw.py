@@ -1,5 +1,5 @@
 """knn_pc_kernel: 256-query workgroups (one per CU) against 128-query workgroups (two per CU), us per launch at the C2 shapes.
-The form is chosen per process (SUG_KNN_PW is read once), so each form runs in a child process.  usage: python tools/bench_knn_pw.py"""
+The form is chosen per process (SUG_KNN_PW is read once), so each form runs in a child process.  usage: python tools/bench_knn_pw.py [CLOUDS]"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = '''
@@ -8,7 +8,7 @@ sys.path.insert(0, %r)
 from sug_amd import ops
 torch.manual_seed(0)
 for C in (3, 64, 128):
-    x = torch.randn(64, 1024, C, device='cuda')
+    x = torch.randn(int(sys.argv[1]) if len(sys.argv) > 1 else 64, 1024, C, device="cuda")
     for _ in range(3): ops.knn(x, 20)
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
@@ -18,4 +18,4 @@ for C in (3, 64, 128):
 ''' % ROOT
 for pw in ('4', '2'):
     print('SUG_KNN_PW=' + pw, flush=True)
-    subprocess.run([sys.executable, '-c', CHILD], env=dict(os.environ, SUG_KNN_PW=pw), check=True)
+    subprocess.run([sys.executable, '-c', CHILD] + sys.argv[1:2], env=dict(os.environ, SUG_KNN_PW=pw), check=True)
