@@ -792,7 +792,13 @@ class _HeadsFused(torch.autograd.Function):
         check(L.sug_head_linear_fwd(nheads, _ptrs(z2), N2, _ptrs(col(8)), _ptrs(col(9)), _ptrs(logits), _ptrs(col(6)), _ptrs(col(7)),
                                     _ptrs(u2), _ptrs(st2), _ptrs(mid), M, N2, NC, 1, slope, eps, p2 if drop2 else 0.0, _st()),
               'sug_head_linear_fwd')
-        ctx.P, ctx.act = P, (x2, z1, st1, z2, st2, u1, u2)
+        # saved through autograd (version checks, freed with the graph): parameters, then per head z1 st1 z2 st2 u1 u2, then x
+        flatP = [t for h in H for t in P[h]]
+        acts = []
+        for h in H:
+            acts += [z1[h] if three else None, st1[h] if three else None, z2[h], st2[h],
+                     u1[h] if (three and u1 is not None) else None, u2[h]]
+        ctx.save_for_backward(*flatP, *acts, x2)
         ctx.meta = (three, M, K, N1, N2, NC, float(slope), float(eps), float(p1 if drop1 else 0.0), float(p2 if drop2 else 0.0),
                     nheads, tuple(x.shape))
         ctx.need_dx = ctx.needs_input_grad[0]
@@ -804,10 +810,13 @@ class _HeadsFused(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *gs):
         three, M, K, N1, N2, NC, slope, eps, p1, p2, nheads, xshape = ctx.meta
-        P = ctx.P
-        x2, z1, st1, z2, st2, u1, u2 = ctx.act
-        dev = x2.device
+        saved = ctx.saved_tensors
         H = range(nheads)
+        P = [list(saved[10 * h:10 * h + 10]) for h in H]
+        acts = saved[10 * nheads:10 * nheads + 6 * nheads]
+        x2 = saved[-1]
+        z1, st1, z2, st2, u1, u2 = ([acts[6 * h + i] for h in H] for i in range(6))
+        dev = x2.device
         L = lib()
         col = lambda i: [P[h][i] for h in H]
         zeros = lambda n: torch.zeros(M, n, dtype=torch.float32, device=dev)
