@@ -1,4 +1,4 @@
-"""The classifier heads in six launches (sug_head_linear_fwd / _bwd, ops.heads_fused) against the module path they
+"""The classifier heads in eight launches (sug_head_linear_fwd / sug_head_ln_bwd / sug_head_linear_bwd, ops.heads_fused) against the module path they
 replace -- Pointnet_c, model/Model.py:412-449: Linear -> LayerNorm -> act -> Dropout -> Linear -> LayerNorm -> act
 (mid feature) -> Dropout -> Linear -- for the three head flavours (DGCNN: LeakyReLU + bias; PointNet / PointNet++: ReLU,
 first Linear without bias; Point Transformer: two layers), one and two heads per launch, row counts on both sides of the
