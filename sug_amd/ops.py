@@ -647,8 +647,11 @@ class _SAFirstLayer(torch.autograd.Function):
         return dP, dQ, None, rf[C:], rf[:C], None, None, None, None, None, None
 
 
+SA_FIRST = _os.environ.get('SUG_SA_FIRST', '1') != '0'          # 0: grouped tensor + GEMM (the reference's arithmetic) instead
+
+
 def sa_first_layer_supported(C):
-    return C in (64, 128)
+    return SA_FIRST and C in (64, 128)
 
 
 def sa_first_layer(P, Q, idx, bn):
@@ -1219,8 +1222,11 @@ def edgeconv_fused(x, wcat, bias, idx, bn_weight, bn_bias, running_mean, running
 
 
 # ----------------------------------------------------------------------------- per-point MLP + max
+POINTMLP_MAX = _os.environ.get('SUG_POINTMLP_MAX', '1') != '0'    # 0: library GEMM + BatchNorm rows kernels + torch.max instead
+
+
 def pointmlp_max_supported(K, Co, seg):
-    return K in (64, 128) and Co % 128 == 0 and seg >= 32 and seg % 32 == 0
+    return POINTMLP_MAX and K in (64, 128) and Co % 128 == 0 and seg >= 32 and seg % 32 == 0
 
 
 class _PointMLPMax(torch.autograd.Function):

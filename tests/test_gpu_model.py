@@ -1,6 +1,7 @@
 """GPU parity of the full encoders + heads behind Net_MDA.forward against golden outputs of
 the reference (tests/golden/model_*.npz; weights by the shared deterministic fill, dropout
 disabled, BatchNorm in train mode).  Bar: fp32 logits / features within 1e-4 (north star)."""
+import os
 import pytest
 import torch
 
@@ -224,10 +225,13 @@ def test_gradient_error_is_fp32_rounding_of_the_reference_arithmetic(name):
     rounding amplified through arg-max / ReLU-kink near-ties, and the HIP path deviates by the same order -- over all
     parameters, relative L2 error vs fp64 of the HIP gradients <= 3 x that of the fp32 oracle (+1e-5) for PointNet and DGCNN
     (measured: 5.5e-4 vs 5.9e-4 and 1.6e-5 vs 1.4e-5), and no single significant parameter tensor off by more than 10 x
-    its fp32-oracle error (+1e-4).  PointNet++ is the exception and is pinned as measured: 4.2e-3 against 7.4e-4 -- the
-    set-abstraction conv weights are off by ~0.5 % of their own norm where the fp32 reference is off by ~0.1 % (the fused
-    MLP + max layer's rank-K BatchNorm backward subtracts statistics terms formed from uncentred fp32 sums; a known
-    precision limit), bounded here at 1e-2."""
+    its fp32-oracle error (+1e-4).  PointNet++ is pinned as measured, 4.2e-3 against 7.4e-4: its gradients are the worst
+    conditioned of the four (three nested max-pools): tests/diagnostics/diag_sa3.py evaluates the SAME fp64 arithmetic of the
+    group-all layer once on the HIP path's inputs and once on the fp64 oracle's (relative difference 1.3e-6: rounding) and gets
+    weight gradients 1.2e-3 apart -- a handful of the 4096 max-pool winners have a runner-up within 1e-5 -- while the HIP
+    backward of that layer agrees with the fp64 arithmetic ON ITS OWN INPUTS to 1e-6, as do the FPS / ball-query index sets
+    with both oracles (diag_pn2_groups.py).  Neither the fused first layer (SUG_SA_FIRST=0) nor the fused last layer
+    (SUG_POINTMLP_MAX=0) changes the figure.  Bounded here at 1e-2."""
     from sug_amd.model.Model import Net_MDA
     seed = 5
     shapes = {k: tuple(v.shape) for k, v in Net_MDA(name).state_dict().items()}
@@ -273,6 +277,11 @@ def test_gradient_error_is_fp32_rounding_of_the_reference_arithmetic(name):
     e_ref = sum(float((g32[k] - g64[k]).norm()) ** 2 for k in keys) ** 0.5 / tot
     print('%s: relative L2 gradient error vs the fp64 oracle: HIP %.3e, fp32 oracle %.3e' % (name, e_gpu, e_ref))
     top = sorted(keys, key=lambda k: -float((got[k] - g64[k]).norm()))[:6]
+    if os.environ.get('SUG_GRADERR_ALL'):          # diagnostic: every parameter, error relative to its OWN norm
+        for k in keys:
+            n = float(g64[k].norm()) + 1e-30
+            print('   %-40s own-relative error HIP %.2e  fp32 oracle %.2e  (norm / total %.1e)' % (
+                k, float((got[k] - g64[k]).norm()) / n, float((g32[k] - g64[k]).norm()) / n, n / tot))
     print('   largest contributions (|err| / total |g|, HIP | fp32 oracle | own norm / total):',
           [(k, '%.1e' % (float((got[k] - g64[k]).norm()) / tot), '%.1e' % (float((g32[k] - g64[k]).norm()) / tot),
             '%.1e' % (float(g64[k].norm()) / tot)) for k in top])
