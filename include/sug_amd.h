@@ -43,7 +43,9 @@ extern "C" {
 #define SUG_STATS_BLOCKS 1024
 
 const char* sug_last_error(void);
-/* ABI version of the loaded library (bumped when a signature changes). */
+/* ABI version of the loaded library (bumped when a signature changes; 3: sug_adam_step_capturable gained lr_dev,
+ * round-3 entry points).  A binding checks sug_abi_version() == SUG_ABI_VERSION of the header it was written against. */
+#define SUG_ABI_VERSION 3
 int sug_abi_version(void);
 
 /* ---- kNN graph ----------------------------------------------------------

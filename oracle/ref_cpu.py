@@ -456,6 +456,35 @@ def pointnet_cls(p, x, training=True, drop_p=0.0):
     return F.linear(y, p['mlp3.weight'], p['mlp3.bias'])
 
 
+def pointnet2_cls(p, x, training=True, starts=(None, None), drop_p=0.0):
+    """Pointnet2_cls.forward, model/model_pointnet.py:74-90 (train_source.py:76-77): three SA layers, then
+    Linear -> BatchNorm1d -> ReLU -> Dropout twice, Linear.  x [B,3,N,1] -> logits [B,10]."""
+    xyz = x.squeeze(-1)
+    B = xyz.shape[0]
+    l1_xyz, l1_pts = set_abstraction(p, 'sa1.', xyz, None, 512, 0.2, 32, training=training, start=starts[0])
+    l2_xyz, l2_pts = set_abstraction(p, 'sa2.', l1_xyz, l1_pts, 128, 0.4, 64, training=training, start=starts[1])
+    _, l3_pts = set_abstraction(p, 'sa3.', l2_xyz, l2_pts, None, None, None, group_all=True, training=training)
+    y = l3_pts.view(B, 1024)
+    y = F.dropout(F.relu(_bn(p, 'bn1.', F.linear(y, p['fc1.weight'], p['fc1.bias']), training)), drop_p, training)
+    y = F.dropout(F.relu(_bn(p, 'bn2.', F.linear(y, p['fc2.weight'], p['fc2.bias']), training)), drop_p, training)
+    return F.linear(y, p['fc3.weight'], p['fc3.bias'])
+
+
+def dgcnn_cls(p, x, training=True, drop_p=0.0, k=20, knn_override=None):
+    """model_pointnet.DGCNN.forward, model/model_pointnet.py:115-161: four EdgeConv layers WITHOUT the SA-node module
+    (x2 feeds conv3 directly), conv5 + bn5 + leaky_relu(0.2), max | avg pool, Pointnet_c(dgcnn_flag=True).
+    x [B,3,N,1] -> (logits [B,10], (x1, x2, x3, x4))."""
+    ko = knn_override or [None] * 4
+    x1 = conv_bn_act(p, 'conv1.', graph_feature(x, k, ko[0]), 'leakyrelu', training).max(dim=-1)[0]
+    x2 = conv_bn_act(p, 'conv2.', graph_feature(x1, k, ko[1]), 'leakyrelu', training).max(dim=-1)[0]
+    x3 = conv_bn_act(p, 'conv3.', graph_feature(x2, k, ko[2]), 'leakyrelu', training).max(dim=-1)[0]
+    x4 = conv_bn_act(p, 'conv4.', graph_feature(x3, k, ko[3]), 'leakyrelu', training).max(dim=-1)[0]
+    x5 = F.conv1d(torch.cat((x1, x2, x3, x4), dim=1), p['conv5.weight'])
+    x5 = F.leaky_relu(_bn(p, 'bn5.', x5, training), 0.2)
+    feat = torch.cat((x5.max(dim=-1)[0], x5.mean(dim=-1)), 1)
+    return pointnet_c(p, 'classifier.', feat, True, False, drop_p, training), (x1, x2, x3, x4)
+
+
 # --------------------------------------------------------------------------
 # MMD alignment loss (model/mmd.py)
 # --------------------------------------------------------------------------

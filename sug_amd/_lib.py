@@ -142,7 +142,7 @@ def lib():
         L.sug_last_error.argtypes = []
         L.sug_abi_version.restype = ctypes.c_int
         L.sug_abi_version.argtypes = []
-        if L.sug_abi_version() != 2:
+        if L.sug_abi_version() != 3:
             raise RuntimeError('sug_amd: ABI version mismatch, rebuild libsug_amd.so')
         _lib = L
     return _lib

@@ -13,4 +13,4 @@ void sug_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* sug_last_error(void) { return g_err; }
-extern "C" int sug_abi_version(void) { return 2; }
+extern "C" int sug_abi_version(void) { return SUG_ABI_VERSION; }

@@ -958,6 +958,7 @@ int sug_edgeconv_fwd_bn_act_groups(const float* pq, int64_t ldpq, const int32_t*
                                    float* s1, float* coef, float* out, int64_t ldo, float* ws, void* stream) {
   SUG_REQUIRE(beta && coef && out, "sug_edgeconv_layer_fwd: null pointer");
   SUG_REQUIRE(groups >= 1 && B % groups == 0, "sug_edgeconv_layer_fwd: B=%d does not split into %d groups", B, groups);
+  SUG_REQUIRE(groups <= 16, "sug_edgeconv_layer_fwd: %d groups, the workspace reserves pivot rows for 16", groups);
   hipStream_t st = (hipStream_t)stream;
   const int Bg = B / groups;
   const int64_t rows = (int64_t)Bg * N;

@@ -498,6 +498,7 @@ extern "C" int sug_edgeconv_fused_layer_fwd(const float* x, int64_t ldx, int Cin
                                             float* out, int64_t ldo, float* ws, void* stream) {
   SUG_REQUIRE(x && wcat && idx && gamma && beta && z && coef && out && ws, "sug_edgeconv_fused_layer_fwd: null pointer");
   SUG_REQUIRE(B > 0 && groups >= 1 && B % groups == 0, "sug_edgeconv_fused_layer_fwd: B=%d does not split into %d groups", B, groups);
+  SUG_REQUIRE(groups <= 16, "sug_edgeconv_fused_layer_fwd: %d groups, the workspace reserves pivot rows for 16", groups);
   SUG_REQUIRE(sug_edgeconv_fused_supported(N, k, Cin, Co), "sug_edgeconv_fused_layer_fwd: unsupported shape N=%d k=%d Cin=%d Co=%d", N, k, Cin, Co);
   SUG_REQUIRE(B <= SUG_STATS_ROWS, "sug_edgeconv_fused_layer_fwd: B=%d exceeds the statistics workspace", B);
   SUG_REQUIRE(ldx >= Cin && (Cin == 3 || (ldx % 4 == 0 && ((uintptr_t)x % 16) == 0)), "sug_edgeconv_fused_layer_fwd: x rows must be 16-byte aligned");

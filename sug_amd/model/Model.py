@@ -7,6 +7,8 @@ work unchanged.  Inside, the encoders run on point-major rows [B,N,C] and call t
 kernels (sug_amd.ops); inputs and outputs keep the reference layout ([B,3,N,1] in,
 [B,1024] / [B,64,64,1] out).  KPConv / PointNet++-MSG are out of scope.
 """
+import weakref
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -25,8 +27,12 @@ class _PrefixEntry:
     second forward on the SAME batch with the SAME weights may reuse.  `alive` turns False as soon as a backward pass
     reaches the cached tensors: their autograd graph is consumed then, and a later forward must recompute."""
 
-    def __init__(self, tensors, extra=None):
+    def __init__(self, tensors, extra=None, source=None):
         self.tensors, self.extra = tensors, extra
+        # identity of the input batch: (data_ptr, _version, shape) alone is NOT tensor identity -- the caching allocator
+        # hands a freed batch's address to the next one with _version 0 again (ADVICE r3) -- so a hit also requires the
+        # very same tensor object; a weak reference, the entry must not keep the batch alive
+        self._source = weakref.ref(source) if source is not None else None
         # the hook must not reference this entry (entry -> tensor -> grad_fn -> hook -> entry would be a cycle, and the
         # cached tensors -- graph-pool memory under hipGraph capture -- would wait for the cyclic collector)
         self._flag = flag = [True]
@@ -38,10 +44,15 @@ class _PrefixEntry:
     def alive(self):
         return self._flag[0]
 
+    def serves(self, x):
+        """True if this entry was computed from the tensor object `x` and its autograd graph is still unconsumed."""
+        return self._flag[0] and self._source is not None and self._source() is x
+
 
 def _sharing_on(flag, training):
     """share_prefix: True (SUGStep: one backward over all passes of a step), False, or 'auto' (default): share while it
-    is provably the same computation -- same input tensor and version, same parameter versions, training mode, and the
+    is provably the same computation -- the SAME input tensor object (weak reference) at the same version, same parameter
+    versions, training mode, and the
     earlier pass's graph not yet consumed by a backward (what train_dg_single_gpu.py:260-335 does: four forwards, one
     backward)."""
     return bool(flag) and training
@@ -125,7 +136,7 @@ class DGCNN(nn.Module):
         ver = sum(p._version for m in (self.conv1, self.conv2) for p in m.parameters())
         key = (x.data_ptr(), x._version, tuple(x.shape), torch.is_grad_enabled(), ver, ops.BN_GROUPS)
         hit = self._prefix_cache.get(key)
-        if hit is not None and hit.alive:
+        if hit is not None and hit.serves(x):
             x1, x2 = hit.tensors
             st1, st2 = hit.extra
             self.conv1.replay_bn_update(st1)
@@ -135,7 +146,7 @@ class DGCNN(nn.Module):
         x2, st2 = self.conv2.edge_rows(x1, nb(x1, 1), return_stats=True)
         if len(self._prefix_cache) >= 4:            # a step has two inputs; never grow unbounded
             self._prefix_cache.clear()
-        self._prefix_cache[key] = _PrefixEntry((x1, x2), (st1, st2))
+        self._prefix_cache[key] = _PrefixEntry((x1, x2), (st1, st2), source=x)
         return x1, x2
 
     def forward(self, x, node=False, knn_idx=None, feat_grad=True):
@@ -244,14 +255,14 @@ class Pointnet_g(nn.Module):
         ver = sum(p._version for mod in self._prefix_modules() for p in mod.parameters())
         key = (x.data_ptr(), x._version, tuple(x.shape), torch.is_grad_enabled(), ver, ops.BN_GROUPS)
         hit = self._prefix_cache.get(key)
-        if hit is not None and hit.alive:
+        if hit is not None and hit.serves(x):
             ops.replay_bn_stats(hit.extra)
             return hit.tensors[0]
         with ops.record_bn_stats() as rec:
             y = run()
         if len(self._prefix_cache) >= 4:
             self._prefix_cache.clear()
-        self._prefix_cache[key] = _PrefixEntry((y,), rec)
+        self._prefix_cache[key] = _PrefixEntry((y,), rec, source=x)
         return y
 
     def forward(self, x, node=False, feat_grad=True):
@@ -323,10 +334,10 @@ class PTran_g(nn.Module):
         ver = sum(p._version for m in (self.fc1, self.transformer1) for p in m.parameters())
         key = (x.data_ptr(), x._version, tuple(x.shape), torch.is_grad_enabled(), ver)
         hit = self._prefix_cache.get(key)
-        if hit is None or not hit.alive:
+        if hit is None or not hit.serves(x):
             if len(self._prefix_cache) >= 4:
                 self._prefix_cache.clear()
-            hit = self._prefix_cache[key] = _PrefixEntry((self.transformer1(xyz, self._lift(x_))[0],))
+            hit = self._prefix_cache[key] = _PrefixEntry((self.transformer1(xyz, self._lift(x_))[0],), source=x)
         return hit.tensors[0]
 
     def fps_plan(self, N):

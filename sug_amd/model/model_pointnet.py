@@ -1,8 +1,11 @@
-"""Source-only classifiers used by train_source.py (mirror of model/model_pointnet.py:5-90)."""
+"""Source-only classifiers used by train_source.py (mirror of model/model_pointnet.py:5-161; train_source.py:5,76-77
+imports Pointnet_cls, Pointnet2_cls and DGCNN from here)."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import ops
+from .Model import Pointnet_c
 from .model_utils import conv_2d, fc_layer, transform_net
 from .pointnet2_utils import PointNetSetAbstraction
 
@@ -70,3 +73,41 @@ class Pointnet2_cls(nn.Module):
         x = self.drop1(F.relu(self.bn1(self.fc1(x))))
         x = self.drop2(F.relu(self.bn2(self.fc2(x))))
         return self.fc3(x)
+
+
+K = 20      # model/model_pointnet.py:92
+
+
+class DGCNN(nn.Module):
+    """Source-only DGCNN classifier (model/model_pointnet.py:93-161): four EdgeConv layers (no SA-node module: x2 feeds
+    conv3 directly), conv5 + bn5 + leaky_relu(0.2), max | avg pool, Pointnet_c(dgcnn_flag=True).  Same parameter names
+    as the reference (`input_transform_net` is constructed and unused there too)."""
+
+    def __init__(self):
+        super(DGCNN, self).__init__()
+        self.k = K
+        self.input_transform_net = transform_net(6, 3)
+        self.conv1 = conv_2d(6, 64, kernel=1, bias=False, activation='leakyrelu')
+        self.conv2 = conv_2d(64 * 2, 64, kernel=1, bias=False, activation='leakyrelu')
+        self.conv3 = conv_2d(64 * 2, 128, kernel=1, bias=False, activation='leakyrelu')
+        self.conv4 = conv_2d(128 * 2, 256, kernel=1, bias=False, activation='leakyrelu')
+        num_f_prev = 64 + 64 + 128 + 256
+        self.bn5 = nn.BatchNorm1d(512)
+        self.conv5 = nn.Conv1d(num_f_prev, 512, kernel_size=1, bias=False)
+        self.classifier = Pointnet_c(dgcnn_flag=True)
+
+    def forward(self, x, node=False, knn_idx=None):
+        """x [B,3,N,1] -> logits [B,10].  `knn_idx` (4 tensors [B,N,k]) overrides the neighbour graphs (tests)."""
+        B, N = x.size(0), x.size(2)
+        loc = x.squeeze(-1).transpose(1, 2).contiguous()              # [B,N,3] rows
+        gi = knn_idx or [None] * 4
+        nb = lambda f, i: gi[i] if gi[i] is not None else ops.knn(f, self.k)
+        # the EdgeConv layers write straight into the column slices of conv5's input (no torch.cat)
+        cat_in = torch.empty(B, N, 512, dtype=torch.float32, device=x.device)
+        x1 = self.conv1.edge_rows(loc, nb(loc, 0), out=cat_in[:, :, 0:64])
+        x2 = self.conv2.edge_rows(x1, nb(x1, 1), out=cat_in[:, :, 64:128])
+        x3 = self.conv3.edge_rows(x2, nb(x2, 2), out=cat_in[:, :, 128:256])
+        x4 = self.conv4.edge_rows(x3, nb(x3, 3), out=cat_in[:, :, 256:512])
+        x5 = ops.linear_rows(ops.assemble_rows(cat_in, (x1, x2, x3, x4)), self.conv5.weight.squeeze(-1))
+        feat = torch.cat(ops.bn_act_pool(x5, self.bn5, 0.2), 1)       # bn5 -> leaky_relu(0.2) -> max | avg pool
+        return self.classifier(feat)

@@ -271,17 +271,17 @@ class SUGStep:
         kw = {}
         on_gpu = next(model.parameters()).is_cuda
         own_adam = on_gpu and (fused_adam is None or fused_adam)
-        # hipGraph mode (opt-in): the whole step (forwards, losses, backward, 3 Adam updates) is
-        # captured once and replayed, FPS start indices fed through a static buffer.  Replay time
-        # equals the GPU-bound eager time (the step is GPU-bound on the boxes measured), so eager stays
-        # the default.  History: an early version of the step faulted inside a torch scatter kernel on
-        # its second replay; not reproduced since the pooling tail moved into bn_act_pool (3000 clean
-        # replays, tools/graph_soak.py).  Single-GPU only.
+        # hipGraph mode: the whole step (forwards, losses, backward, 3 Adam updates) is captured once and replayed, FPS
+        # start indices fed through a static buffer.  One rank: one graph per configuration key;
+        # more ranks: five captured segments around the four collectives (_segmented_step).
         self.use_graph = bool(use_graph) and next(model.parameters()).is_cuda
         # more than one rank: the step is captured as FIVE graph segments around its four collectives (_segmented_step)
         self.segmented = self.use_graph and (self.world > 1 or force_segmented)
         self._graphs = None
         self.max_graphs = 4                             # captured steps kept (each owns a private memory pool)
+        # segmented steps: {collective name: [(event before, event after), ...]} when a dict is assigned (bench.py
+        # --gpus N reads it for config.collectives); None = no events
+        self.collective_events = None
         # SUG_GRAPH_GUARD=1 restores the historical guard (one eager op between two replays)
         self._tick = torch.zeros(1, device=next(model.parameters()).device) \
             if (self.use_graph and os.environ.get('SUG_GRAPH_GUARD') == '1') else None
@@ -666,6 +666,9 @@ class SUGStep:
                         None if loss_sem is None else loss_sem.detach())
 
         def grad_reduce1(S):
+            if self.collective_events is not None:
+                S['ev_b1'] = torch.cuda.Event(enable_timing=True)
+                S['ev_b1'].record()
             S['work'] = dist.all_reduce(S['static']['flat1'], async_op=True)      # in flight under segment C2
 
         def seg_c2(S):
@@ -683,9 +686,21 @@ class SUGStep:
 
         def grad_reduce2(S):
             w = S.pop('work', None)
+            ev = self.collective_events
+            if ev is not None:
+                e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+                e0.record()                               # segment C2 (the encoder's backward) has finished here
             if w is not None:
-                w.wait()
+                w.wait()                                  # the compute stream waits for bucket 1
+            if ev is not None:
+                e1.record()                               # e0 -> e1: the part of bucket 1 that C2 did not hide
             dist.all_reduce(S['static']['flat2'])
+            if ev is not None:
+                e2.record()
+                ev.setdefault('bucket1_exposed', []).append((e0, e1))
+                ev.setdefault('bucket2_all_reduce', []).append((e1, e2))
+                if 'ev_b1' in S:                          # launch -> done, i.e. bucket 1 AND whatever of C2 ran beside it
+                    ev.setdefault('bucket1_launch_to_done', []).append((S.pop('ev_b1'), e1))
 
         def seg_d(S):
             st_ = S['static']
@@ -787,11 +802,34 @@ class SUGStep:
                 dst.copy_(src, non_blocking=True)
         st['feeder'].refill()
         S, col = st['S'], st['segs']['collective']
-        for g, c in zip(st['graphs'], col + (None,)):
+        ev = self.collective_events
+        for i, (g, c) in enumerate(zip(st['graphs'], col + (None,))):
             g.replay()
             if c is not None:
-                c(S)
+                if ev is not None and i < 2:              # all-gather, 9-double all-reduce: synchronous, bracketed here
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    c(S)
+                    e1.record()
+                    ev.setdefault(('all_gather_packed', 'sums_all_reduce')[i], []).append((e0, e1))
+                else:
+                    c(S)
         return st['out']
+
+    def collective_summary(self):
+        """Mean milliseconds per step of every collective recorded in `collective_events` (events on the compute stream:
+        a synchronous collective makes that stream wait for the communication stream, so the pair brackets it), and the
+        message sizes.  bucket1_exposed = the wait for bucket 1 AFTER the encoder backward it runs under."""
+        ev = self.collective_events or {}
+        torch.cuda.synchronize()
+        out = {k: round(sum(a.elapsed_time(b) for a, b in v) / max(len(v), 1), 4) for k, v in ev.items()}
+        sizes = {}
+        for st in (self._graphs or {}).values():
+            stat = (st.get('S') or {}).get('static') or {}
+            for name, key in (('all_gather_packed', 'G'), ('sums_all_reduce', 'sums'), ('bucket1', 'flat1'), ('bucket2', 'flat2')):
+                if key in stat:
+                    sizes[name] = stat[key].numel() * stat[key].element_size()
+        return {'ms': out, 'bytes': sizes}
 
     def _eager_step(self, data, label, data_t, label_t, epoch=0):
         mmd_on = epoch >= self.methods['PURE_CLS_EPOCH']

@@ -337,6 +337,74 @@ def gen_pointnet_cls():
     save('pointnet_cls.npz', x=x, label=lab, y=y, loss=loss, seed=seed)
 
 
+def _cls_record(net, y, lab):
+    """CE loss + backward of a source-only classifier; gradient norms / probe dots / BatchNorm buffer sums."""
+    loss = torch.nn.functional.cross_entropy(y, lab)
+    net.zero_grad()
+    loss.backward()
+    gnames, gnorm, gdot = [], [], []
+    for k, v in net.named_parameters():
+        if v.grad is None:
+            continue
+        gnames.append(k)
+        gnorm.append(v.grad.norm().item())
+        gdot.append((v.grad * _probe(v.shape, 'g' + k)).sum().item())
+    sd = net.state_dict()
+    bn_names = [k for k in sd if k.endswith('running_mean') or k.endswith('running_var')]
+    return dict(loss=loss, grad_names=np.array(gnames), grad_norm=np.array(gnorm, dtype=np.float64),
+                grad_dot=np.array(gdot, dtype=np.float64), bn_names=np.array(bn_names),
+                bn_sum=np.array([sd[k].double().sum().item() for k in bn_names]))
+
+
+def gen_pointnet2_cls():
+    """train_source.py:76-77 with Model Pointnet2: model_pointnet.Pointnet2_cls forward + CE loss + backward
+    (B=4 so that the BatchNorm1d heads see more than a sign pattern; N=2048 as in BASELINE config 3)."""
+    seed, B, N = 33, 4, 2048
+    g = torch.Generator().manual_seed(seed)
+    x = O.synth_clouds(B, N, g)
+    lab = torch.randint(0, 10, (B,), generator=g)
+    net = r_mp.Pointnet2_cls()
+    p0 = _load(net, seed)
+    _no_dropout(net)
+    net.train()
+    torch.manual_seed(seed + 1)
+    y = net(x)
+    rec = _cls_record(net, y, lab)
+    torch.manual_seed(seed + 1)
+    starts = torch.stack([torch.randint(0, r, (B,)) for r in (N, 512)])
+    p = O.as_params(p0)
+    o = O.pointnet2_cls(p, x, True, (starts[0], starts[1]))
+    same(o, y, 'pointnet2_cls', 2e-6)
+    torch.nn.functional.cross_entropy(o, lab).backward()
+    for k, gn in zip(rec['grad_names'], rec['grad_norm']):
+        assert abs(p[k].grad.norm().item() - gn) <= 2e-4 * max(1.0, gn), (k, p[k].grad.norm().item(), gn)
+    save('pointnet2_cls.npz', x=x, label=lab, y=y, seed=seed, start0=starts, **rec)
+
+
+def gen_dgcnn_cls():
+    """train_source.py:76-77 with Model DGCNN: model_pointnet.DGCNN forward + CE loss + backward, plus the four
+    neighbour lists of the run (teacher forcing / free-running comparison)."""
+    seed, B, N = 34, 2, 1024
+    g = torch.Generator().manual_seed(seed)
+    x = O.synth_clouds(B, N, g)
+    lab = torch.randint(0, 10, (B,), generator=g)
+    net = r_mp.DGCNN()
+    p0 = _load(net, seed)
+    _no_dropout(net)
+    net.train()
+    y = net(x)
+    rec = _cls_record(net, y, lab)
+    p = O.as_params(p0)
+    o, (x1, x2, x3, x4) = O.dgcnn_cls(p, x, True)
+    same(o, y, 'dgcnn_cls', 2e-6)
+    torch.nn.functional.cross_entropy(o, lab).backward()
+    for k, gn in zip(rec['grad_names'], rec['grad_norm']):
+        assert abs(p[k].grad.norm().item() - gn) <= 2e-4 * max(1.0, gn), (k, p[k].grad.norm().item(), gn)
+    with torch.no_grad():
+        knn = [r_mu.knn(t.detach(), 20) for t in (x.squeeze(-1), x1, x2, x3)]
+    save('dgcnn_cls.npz', x=x, label=lab, y=y, seed=seed, knn1=knn[0], knn2=knn[1], knn3=knn[2], knn4=knn[3], **rec)
+
+
 def gen_focal():
     """focal_loss (model/model_utils.py:131-176, the CLS_LOSS: FocalLoss criterion of
     train_dg_single_gpu.py:167,176): first call of a fresh module, uniform and per-class alpha."""
@@ -455,9 +523,55 @@ def gen_step():
          p_abs=np.array([sd[k].double().abs().sum().item() for k in names]))
 
 
+def gen_step_seeds():
+    """The two-step run of gen_step for 8 more seeds (data = O.synth_clouds from the seed, so the fixture holds only the
+    reference's six loss values per seed): how far apart are the reference's own second-step losses on two CPUs, next
+    to how far the HIP path is from the oracle on the same machine (tests/test_gpu_step.py)."""
+    B, N = 4, 1024
+    LR, WD = 1e-3, 5e-5
+    geo = {'NAME': 'SOFT_MMD', 'LABEL_SCALE': 50, 'GEO_SCALE': 1}
+    sem = {'NAME': 'SOFT_MMD', 'LABEL_SCALE': 5, 'SEM_WEIGHTS': 'none', 'LABEL_WEIGHT': 0.5, 'SEM_SCALE': 1}
+    seeds = [701 + i for i in range(8)]
+    all_losses = []
+    for seed in seeds:
+        g = torch.Generator().manual_seed(seed)
+        data, data_t = O.synth_clouds(B, N, g), O.synth_clouds(B, N, g)
+        lab, lab_t = torch.randint(0, 10, (B,), generator=g), torch.randint(0, 10, (B,), generator=g)
+        net = r_M.Net_MDA('DGCNN')
+        _load(net, seed)
+        _no_dropout(net)
+        net.train()
+        params = [{'params': v} for k, v in net.g.named_parameters() if 'pred_offset' not in k]
+        opt_g = torch.optim.Adam(params, lr=LR, weight_decay=WD)
+        opt_c = torch.optim.Adam([{'params': net.c1.parameters()}, {'params': net.c2.parameters()}], lr=LR, weight_decay=WD)
+        opt_d = torch.optim.Adam([{'params': net.g.parameters()}, {'params': net.attention_s.parameters()},
+                                  {'params': net.attention_t.parameters()}], lr=LR, weight_decay=WD)
+        crit = torch.nn.CrossEntropyLoss()
+        losses = []
+        torch.manual_seed(seed)
+        for step in range(2):
+            ps1, ps2, fs1, fs2 = net(data, semantic_adaption=True)
+            pt1, pt2, ft1, ft2 = net(data_t, semantic_adaption=True)
+            loss_cls = 0.5 * crit(ps1, lab) + 0.5 * crit(ps2, lab)
+            node_s = net(data, node_adaptation_s=True)
+            node_t = net(data_t, node_adaptation_t=True)
+            l_geo = r_mmd.mmd_cal(lab, node_s, lab_t, node_t, geo, data_s=data, data_t=data_t)
+            l1 = r_mmd.mmd_cal(lab, fs1, lab_t, ft1, sem, data_s=ps1, data_t=pt1)
+            l2 = r_mmd.mmd_cal(lab, fs2, lab_t, ft2, sem, data_s=ps2, data_t=pt2)
+            loss = loss_cls + l_geo + (0.5 * l1 + 0.5 * l2)
+            loss.backward()
+            opt_d.step(); opt_g.step(); opt_c.step()
+            opt_g.zero_grad(); opt_c.zero_grad(); opt_d.zero_grad()
+            losses.append([loss_cls.item(), l_geo.item(), (0.5 * l1 + 0.5 * l2).item()])
+        print('seed', seed, losses)
+        all_losses.append(losses)
+    save('step_dgcnn_seeds.npz', seeds=np.array(seeds, dtype=np.int32), losses=np.array(all_losses, dtype=np.float64),
+         B=np.int32(B), N=np.int32(N))
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['ops', 'mmd', 'pointnet_cls', 'dgcnn', 'pointnet', 'pointnet2', 'ptran', 'step', 'focal', 'ptran2048',
-                             'pointnet2_b4']
+                             'pointnet2_b4', 'pointnet2_cls', 'dgcnn_cls', 'step_seeds']
     if 'ops' in which:
         gen_ops()
     if 'mmd' in which:
@@ -480,3 +594,9 @@ if __name__ == '__main__':
         gen_model('Pointnet2', 4, 2048, 16, 'model_pointnet2_b4.npz')
     if 'step' in which:
         gen_step()
+    if 'step_seeds' in which:
+        gen_step_seeds()
+    if 'pointnet2_cls' in which:
+        gen_pointnet2_cls()
+    if 'dgcnn_cls' in which:
+        gen_dgcnn_cls()

@@ -124,9 +124,9 @@ def test_dgcnn_parity_free_running():
     BatchNorm statistic moves an activation by an ulp and may swap two neighbours whose distances differ by less than the
     rounding of the score: quantified against fp64 in test_dgcnn_free_running_flips_are_fp32_ties; the arithmetic behind
     given lists is pinned at 1e-4 in test_dgcnn_parity_teacher_forced).  Here: the number of (point, layer) rows whose
-    neighbour SET differs from the golden's is reported and must stay below 1 % of the rows; logits within 1e-4 when
-    no row differs, otherwise within 5e-2 (a swapped neighbour changes a max over k, BatchNorm over a batch of 2 clouds
-    spreads it)."""
+    neighbour SET differs from the golden's must be ZERO on this fixture (it is, with the ascending-feature MFMA chain of
+    the fused EdgeConv layer) and the logits hold the north star's 1e-4.  The flip analysis for inputs where near-ties do
+    flip lives in tests/test_gpu_fullsize.py."""
     from sug_amd import ops
     rec, real_knn = [], ops.knn
 
@@ -143,12 +143,13 @@ def test_dgcnn_parity_free_running():
     assert torch.equal(rec[0], G['knn1']), 'layer-1 (xyz) neighbour graph must be bit-exact'
     differ = [int((rec[i].sort(-1)[0] != G['knn%d' % (i + 1)].sort(-1)[0]).any(-1).sum()) for i in range(4)]
     rows = rec[0].shape[0] * rec[0].shape[1]
-    tol = 1e-4 if sum(differ) == 0 else 5e-2
+    print('free-running DGCNN: rows whose neighbour set differs from the reference run, per layer: %s of %d' % (differ, rows))
+    assert sum(differ) == 0, differ
+    tol = 1e-4
     err = max(close(y1, G['y1'], tol, 'logits c1'), close(y2, G['y2'], tol, 'logits c2'))
     close(s1, G['s1'], tol, 'sem feature c1')
-    print('free-running DGCNN: rows whose neighbour set differs from the reference run, per layer: %s of %d; logits max err %.3e'
-          % (differ, rows, err))
-    assert all(d <= 0.01 * rows for d in differ), differ
+    close(s2, G['s2'], tol, 'sem feature c2')
+    print('free-running DGCNN: logits max err %.3e' % err)
 
 
 def test_dgcnn_node_pass_and_buffers():
@@ -180,6 +181,72 @@ def test_pointnet_cls_config1():
     close(y, G['y'], 1e-4, 'logits')
     loss = torch.nn.functional.cross_entropy(y, G['label'].cuda())
     assert abs(loss.item() - float(G['loss'])) < 1e-4
+
+
+def _cls_net(cls, G):
+    from sug_amd.model import model_pointnet as MP
+    net = getattr(MP, cls)()
+    net.load_state_dict(O.fill_params({k: tuple(v.shape) for k, v in net.state_dict().items()}, G['seed']))
+    for m in net.modules():
+        if isinstance(m, (torch.nn.Dropout, torch.nn.Dropout2d)):
+            m.p = 0.0
+    return net.cuda().train()
+
+
+def _cls_check(net, G, y, tol, grad_tol, dot_tol=None):
+    close(y, G['y'], tol, 'logits')
+    loss = torch.nn.functional.cross_entropy(y, G['label'].cuda())
+    assert abs(loss.item() - float(G['loss'])) <= tol * max(1.0, abs(float(G['loss']))), (loss.item(), float(G['loss']))
+    loss.backward()
+    check_grads(net, G, grad_tol, dot_tol=dot_tol)
+    sd = net.state_dict()
+    for k, v in zip(G['bn_names'], G['bn_sum'].tolist()):
+        got = sd[k].double().sum().item()
+        assert abs(got - v) <= 2e-4 * max(1.0, abs(v)), 'BN buffer %s: %.8g vs %.8g' % (k, got, v)
+
+
+def test_pointnet2_cls_source_only():
+    """train_source.py:76-77 with Model Pointnet2: model_pointnet.Pointnet2_cls (model/model_pointnet.py:58-90) against the
+    reference run of tests/golden/pointnet2_cls.npz -- logits, CE loss, gradients, BatchNorm buffers."""
+    G = load_golden('pointnet2_cls.npz')
+    net = _cls_net('Pointnet2_cls', G)
+    torch.manual_seed(G['seed'] + 1)
+    y = net(G['x'].cuda())
+    _cls_check(net, G, y, 1e-4, 2e-2, dot_tol=5e-2)
+
+
+def test_dgcnn_cls_source_only_teacher_forced():
+    """model_pointnet.DGCNN (model/model_pointnet.py:93-161) with the reference run's neighbour graphs."""
+    G = load_golden('dgcnn_cls.npz')
+    net = _cls_net('DGCNN', G)
+    forced = [G['knn%d' % i].to(torch.int32).cuda() for i in (1, 2, 3, 4)]
+    y = net(G['x'].cuda(), knn_idx=forced)
+    _cls_check(net, G, y, 1e-4, 2e-3)
+
+
+def test_dgcnn_cls_source_only_free_running():
+    """The same with its own kNN graphs: on this fixture every neighbour list must equal the reference run's, and the
+    logits hold 1e-4."""
+    from sug_amd import ops
+    G = load_golden('dgcnn_cls.npz')
+    net = _cls_net('DGCNN', G)
+    rec, real_knn = [], ops.knn
+
+    def spy(f, k):
+        idx = real_knn(f, k)
+        rec.append(idx.cpu().long())
+        return idx
+    ops.knn = spy
+    try:
+        y = net(G['x'].cuda())
+    finally:
+        ops.knn = real_knn
+    assert len(rec) == 4
+    assert torch.equal(rec[0], G['knn1']), 'layer-1 (xyz) neighbour graph must be bit-exact'
+    differ = [int((rec[i].sort(-1)[0] != G['knn%d' % (i + 1)].sort(-1)[0]).any(-1).sum()) for i in range(4)]
+    print('free-running model_pointnet.DGCNN: rows whose neighbour set differs from the reference run: %s' % differ)
+    assert sum(differ) == 0, differ
+    _cls_check(net, G, y, 1e-4, 2e-3)
 
 
 @pytest.mark.parametrize('dtype,tol,proj16', [(torch.float16, 3e-3, False), (torch.bfloat16, 3e-2, False),
@@ -218,33 +285,21 @@ def test_ptran_reduced_precision_mode_deviation(dtype, tol, proj16):
     assert g is not None and bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0
 
 
-@pytest.mark.parametrize('name', ['Pointnet', 'DGCNN', 'Pointnet2'])
-def test_gradient_error_is_fp32_rounding_of_the_reference_arithmetic(name):
-    """What the loose gradient tolerances of the parity tests stand for (VERDICT r2 weak 2): the same network evaluated by
-    the oracle in fp64 is the noise-free gradient; the oracle in fp32 (= the reference's arithmetic) deviates from it by
-    rounding amplified through arg-max / ReLU-kink near-ties, and the HIP path deviates by the same order -- over all
-    parameters, relative L2 error vs fp64 of the HIP gradients <= 3 x that of the fp32 oracle (+1e-5) for PointNet and DGCNN
-    (measured: 5.5e-4 vs 5.9e-4 and 1.6e-5 vs 1.4e-5), and no single significant parameter tensor off by more than 10 x
-    its fp32-oracle error (+1e-4).  PointNet++ is pinned as measured, 4.2e-3 against 7.4e-4: its gradients are the worst
-    conditioned of the four (three nested max-pools): tests/diagnostics/diag_sa3.py evaluates the SAME fp64 arithmetic of the
-    group-all layer once on the HIP path's inputs and once on the fp64 oracle's (relative difference 1.3e-6: rounding) and gets
-    weight gradients 1.2e-3 apart -- a handful of the 4096 max-pool winners have a runner-up within 1e-5 -- while the HIP
-    backward of that layer agrees with the fp64 arithmetic ON ITS OWN INPUTS to 1e-6, as do the FPS / ball-query index sets
-    with both oracles (diag_pn2_groups.py).  Neither the fused first layer (SUG_SA_FIRST=0) nor the fused last layer
-    (SUG_POINTMLP_MAX=0) changes the figure.  Bounded here at 1e-2."""
+def _gradient_errors(name, seed, data_seed, B=4, verbose=True):
+    """Relative L2 error over all parameters of the HIP gradients and of the fp32 oracle's, both against the fp64 oracle
+    (same network, same inputs, same FPS starts; DGCNN: all three on the HIP path's neighbour graphs)."""
     from sug_amd.model.Model import Net_MDA
-    seed = 5
+    from sug_amd import ops
     shapes = {k: tuple(v.shape) for k, v in Net_MDA(name).state_dict().items()}
     fill = O.fill_params(shapes, seed)
-    g = torch.Generator().manual_seed(3)
-    x = O.synth_clouds(4, 2048 if name == 'Pointnet2' else 1024, g)
-    w1, w2 = probe((4, 10), 'w1'), probe((4, 256), 'w2')
+    g = torch.Generator().manual_seed(data_seed)
+    x = O.synth_clouds(B, 2048 if name == 'Pointnet2' else 1024, g)
+    w1, w2 = probe((B, 10), 'w1'), probe((B, 256), 'w2')
 
     def loss_of(y1, y2, s1, s2, dev=None):
         a, b = (w1, w2) if dev is None else (w1.to(dev), w2.to(dev))
         return (y1 * a.to(y1.dtype)).sum() + (y2 * a.to(y1.dtype)).sum() + (s1 * b.to(y1.dtype)).sum() + (s2 * b.to(y1.dtype)).sum()
 
-    from sug_amd import ops
     net = build(name, seed)
     rec, real_knn = [], ops.knn
 
@@ -275,7 +330,22 @@ def test_gradient_error_is_fp32_rounding_of_the_reference_arithmetic(name):
     tot = sum(float(g64[k].norm()) ** 2 for k in keys) ** 0.5
     e_gpu = sum(float((got[k] - g64[k]).norm()) ** 2 for k in keys) ** 0.5 / tot
     e_ref = sum(float((g32[k] - g64[k]).norm()) ** 2 for k in keys) ** 0.5 / tot
-    print('%s: relative L2 gradient error vs the fp64 oracle: HIP %.3e, fp32 oracle %.3e' % (name, e_gpu, e_ref))
+    if verbose:
+        print('%s seed %d: relative L2 gradient error vs the fp64 oracle: HIP %.3e, fp32 oracle %.3e' % (name, seed, e_gpu, e_ref))
+    return e_gpu, e_ref, got, g32, g64, keys, tot
+
+
+@pytest.mark.parametrize('name', ['Pointnet', 'DGCNN', 'Pointnet2'])
+def test_gradient_error_is_fp32_rounding_of_the_reference_arithmetic(name):
+    """What the loose gradient tolerances of the parity tests stand for (VERDICT r2 weak 2): the same network evaluated by
+    the oracle in fp64 is the noise-free gradient; the oracle in fp32 (= the reference's arithmetic) deviates from it by
+    rounding amplified through arg-max / ReLU-kink near-ties, and the HIP path deviates by the same order -- over all
+    parameters, relative L2 error vs fp64 of the HIP gradients <= 3 x that of the fp32 oracle (+1e-5) for PointNet and DGCNN
+    (measured: 5.5e-4 vs 5.9e-4 and 1.6e-5 vs 1.4e-5), and no single significant parameter tensor off by more than 10 x
+    its fp32-oracle error (+1e-4).  PointNet++ on this seed measures 4.2e-3 against 7.4e-4: its gradients are the worst
+    conditioned of the four (three nested max-pools, see test_pointnet2_gradient_error_statistic_over_8_seeds for the
+    multi-seed statistic that replaces a single-seed pin); bounded here at 1e-2."""
+    e_gpu, e_ref, got, g32, g64, keys, tot = _gradient_errors(name, 5, 3)
     top = sorted(keys, key=lambda k: -float((got[k] - g64[k]).norm()))[:6]
     if os.environ.get('SUG_GRADERR_ALL'):          # diagnostic: every parameter, error relative to its OWN norm
         for k in keys:
@@ -296,3 +366,21 @@ def test_gradient_error_is_fp32_rounding_of_the_reference_arithmetic(name):
             continue                       # e.g. conv biases in front of BatchNorm: true gradient 0
         a, b = float((got[k] - g64[k]).norm()) / n, float((g32[k] - g64[k]).norm()) / n
         assert a <= 10.0 * b + 1e-4, (k, a, b)
+
+
+def test_pointnet2_gradient_error_statistic_over_8_seeds():
+    """a single-seed ratio (4.2e-3 for HIP vs 7.4e-4 for the fp32 reference arithmetic, both against
+    fp64) is not a bound.  Here the same measurement over 8 (weight seed, data seed) pairs at B=2, N=2048: per pair the
+    ratio r = (HIP error vs fp64) / (fp32-oracle error vs fp64).  If the HIP backward were biased, r would sit above 1 on
+    every seed; if the deviation is near-tie noise of the nested max-pools (either fp32 path flips a different handful of
+    winners than fp64), r scatters around 1 with a heavy tail.  Asserted: median r <= 2."""
+    import statistics
+    ratios, rows = [], []
+    for i in range(8):
+        e_gpu, e_ref, *_ = _gradient_errors('Pointnet2', 40 + i, 140 + i, B=2)
+        ratios.append(e_gpu / max(e_ref, 1e-12))
+        rows.append((e_gpu, e_ref))
+    print('PointNet++ gradient error vs fp64 over 8 seeds: (HIP, fp32 oracle) = %s' % [('%.2e' % a, '%.2e' % b) for a, b in rows])
+    print('ratio HIP / fp32-oracle: median %.2f, max %.2f, min %.2f' % (statistics.median(ratios), max(ratios), min(ratios)))
+    assert statistics.median(ratios) <= 2.0, ratios
+    assert max(a for a, _ in rows) <= 2e-2, rows

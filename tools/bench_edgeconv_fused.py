@@ -11,10 +11,25 @@ FLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-ffp-contract=o
 vp, i32, i64, f32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 
 
-def build(tag, defs):
-    out = os.path.join(tempfile.gettempdir(), 'libef_%s.so' % tag)
+def lib_path(tag):
+    return os.path.join(tempfile.gettempdir(), 'libef_%s.so' % tag)
+
+
+def compile_variant(tag, defs):
+    """hipcc in a child process: NEVER call this from a process that runs under rocprofv3 (the profiler's preload
+    initialises the GPU in every child, and hipcc execs clang / lld: the forbidden exec from a GPU-initialised process).
+    The --pmc flow is two commands: `--build-only "<defs>"` un-profiled, then EF_ONLY under the profiler (load only)."""
+    out = lib_path(tag)
     files = [os.path.join(SRC, f) for f in ('edgeconv_fused.hip', 'edgeconv.hip', 'capi.cpp')]
     subprocess.run(['/opt/rocm/bin/hipcc'] + FLAGS + defs + files + ['-o', out], check=True)
+    return out
+
+
+def build(tag, defs, compile=True):
+    out = compile_variant(tag, defs) if compile else lib_path(tag)
+    if not os.path.exists(out):
+        raise RuntimeError('%s is missing: run `python tools/bench_edgeconv_fused.py --build-only "%s"` first '
+                           '(outside rocprofv3)' % (out, ' '.join(defs)))
     L = ctypes.CDLL(out)
     L.sug_edgeconv_fused_layer_fwd.argtypes = [vp, i64, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, f32, f32,
                                                vp, vp, vp, vp, vp, vp, i64, vp, vp, i64, vp, vp]
@@ -67,10 +82,13 @@ if __name__ == '__main__':
                 ('neither', ['-DSUG_EF_ABL_NOACT', '-DSUG_EF_ABL_NOGATHER', '-DSUG_EF_ABL_NOMFMA']),
                 ('neither, no x loads', ['-DSUG_EF_ABL_NOACT', '-DSUG_EF_ABL_NOGATHER', '-DSUG_EF_ABL_NOMFMA', '-DSUG_EF_ABL_NOLOADX']),
                 ('no x loads', ['-DSUG_EF_ABL_NOACT', '-DSUG_EF_ABL_NOLOADX'])] + \
-               [(t, d.split()) for t, d in (a.split('=', 1) for a in sys.argv[1:])]
+               [(t, d.split()) for t, d in (a.split('=', 1) for a in sys.argv[1:] if '=' in a)]
+    if len(sys.argv) >= 2 and sys.argv[1] == '--build-only':     # un-profiled step of the --pmc flow: compile, touch no GPU
+        print(compile_variant('only', (sys.argv[2] if len(sys.argv) > 2 else '').split()))
+        sys.exit(0)
     only = os.environ.get('EF_ONLY')           # one variant, layer 2 shape, few launches: for a rocprofv3 --pmc pass
-    if only:
-        L = build('only', only.split())
+    if only is not None:
+        L = build('only', only.split(), compile=False)           # load the prebuilt library only: no child process here
         print(time_layer(L, 64, 64, 0, iters=5))
         sys.exit(0)
     libs = [(t, build(t.replace(' ', '_').replace(',', ''), d)) for t, d in variants]

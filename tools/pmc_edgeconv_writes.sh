@@ -6,9 +6,12 @@
 # these dispatches.  Variants: product | main kernel alone | without the arg store | without the z store.
 cd /tmp && export TMPDIR=/tmp
 for v in " " "-DSUG_EF_ABL_NOACT" "-DSUG_EF_ABL_NOACT -DSUG_EF_ABL_NOARG" "-DSUG_EF_ABL_NOACT -DSUG_EF_ABL_NOZ"; do
+  # step 1, NOT profiled: hipcc builds the variant (hipcc execs clang/lld -- never under the profiler's preload)
+  python3 $GRAFT_REPO_ROOT/tools/bench_edgeconv_fused.py --build-only "$v" || exit 1
   for ctr in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/px
-    EF_ONLY="$v" rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/px -o p -- python3 $GRAFT_REPO_ROOT/tools/bench_edgeconv_fused.py > /dev/null 2>&1
+    # step 2, profiled: the process only ctypes-loads the prebuilt library (no child processes); one counter per pass
+    EF_ONLY="$v" rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/px -o p -- python3 $GRAFT_REPO_ROOT/tools/bench_edgeconv_fused.py > /tmp/px.log 2>&1 || { tail -20 /tmp/px.log; exit 1; }
     f=$(find /tmp/px -name "*counter_collection.csv" | head -1)
     python3 - "$f" "$ctr" "$v" <<'PY'
 import csv, sys, collections
