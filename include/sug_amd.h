@@ -449,7 +449,10 @@ int sug_bn_act_pool_layer_bwd(const float* y, int64_t ldy, const float* coef, co
  * points); per (segment, channel) the kernel keeps zext = max_rows y (gamma >= 0) or min_rows y
  * (gamma < 0) -- the element BN + (Leaky)ReLU maps to the max -- and arg = its row inside the segment
  * (lowest row on ties), and it accumulates the BatchNorm sums of y as per-row-block partial rows in
- * ws ([*nblk][2*Co]: sum | sum of squares; *nblk <= SUG_STATS_BLOCKS).
+ * ws ([*nblk][2*Co]: sum | sum of squares; *nblk <= SUG_STATS_BLOCKS; ws = SUG_STATS_BLOCKS*2*Co floats: when the
+ * grid would leave CUs idle, a segment of >= 1024 rows is split over up to 8 workgroups -- more partial rows, and the
+ * rows of ws behind them serve as scratch for the partial extremes, combined in part order by a second small launch:
+ * same zext / arg bit for bit).
  * K in {64, 128}; Co % 128 == 0; seg % 32 == 0; rows % seg == 0; x, w 16-byte aligned, ldx % 4 == 0. */
 int sug_pointmlp_max_fwd(const float* x, int64_t ldx, int64_t rows, int K, const float* w, const float* bias,
                          const float* gamma, int Co, int seg, float* zext, int32_t* arg, float* ws, int* nblk,
@@ -589,6 +592,24 @@ int sug_edge_weight_split(const float* in, int Co, int C, int backward, float* o
  * out[b] = mean_i min_j |a_i-b_j|^2 + mean_j min_i |a_i-b_j|^2, direct-form distance.
  * a [B,N,3], b [B,M,3], out [B] (caller zeroes). */
 int sug_chamfer(const float* a, const float* b, int B, int N, int M, float* out, void* stream);
+
+/* ---- the scalar tail of a step ---------------------------------------------------------------------------
+ * Cross entropy of both classifier heads on the source rows of the paired logits (train_dg_single_gpu.py:269-292 with
+ * nn.CrossEntropyLoss(), :167): loss[0] = w * (CE(logits1[:M], label) + CE(logits2[:M], label)), CE = mean over the M
+ * rows of -log_softmax(row)[label]; w = 0.5 * SRC_LOSS_WEIGHT * CLS_WEIGHT folded by the caller.  logits* [>= M, C] with
+ * row stride ld, label int64 [M], lse [2, M] (saved log-sum-exp of the rows).  2M <= 512, C <= 32. */
+int sug_ce_pair_fwd(const float* logits1, const float* logits2, int64_t ld, const int64_t* label, int M, int C, float w,
+                    float* loss, float* lse, void* stream);
+/* Its gradient for the WHOLE paired logits: d1, d2 [Mtot, C] = g[0] * w * (softmax - onehot) / M in rows < M, zero in
+ * rows M .. Mtot-1 (the target half of a paired batch: no torch.stack / zero fill rebuilds the pair's gradient). */
+int sug_ce_pair_bwd(const float* logits1, const float* logits2, int64_t ld, const int64_t* label, int M, int Mtot, int C,
+                    float w, const float* g, const float* lse, float* d1, float* d2, void* stream);
+/* out3 = { loss_cls + wg*v_geo + ws*(v_sem1 + v_sem2), wg*v_geo, ws*(v_sem1 + v_sem2) } (train_dg_single_gpu.py:314-324; the
+ * weights MMD_WEIGHT * GEO_SCALE and 0.5 * MMD_WEIGHT * SEM_SCALE folded by the caller); null v_* = term absent.
+ * Backward: out4 = g[0] * {1, wg, ws, ws}. */
+int sug_loss_combine_fwd(const float* loss_cls, const float* v_geo, const float* v_sem1, const float* v_sem2, float wg, float ws,
+                         float* out3, void* stream);
+int sug_loss_combine_bwd(const float* g, float wg, float ws, float* out4, void* stream);
 
 #ifdef __cplusplus
 }

@@ -637,17 +637,21 @@ SEM_CFG = {'NAME': 'SOFT_MMD', 'LABEL_SCALE': 5, 'SEM_WEIGHTS': 'mean2one', 'LAB
 
 
 def sug_losses(p, model_name, data, label, data_t, label_t, geo_cfg=GEO_CFG, sem_cfg=SEM_CFG,
-               drop_p=0.0, starts=None, mmd_weight=1.0, cls_weight=1.0, src_loss_weight=1.0):
+               drop_p=0.0, starts=None, mmd_weight=1.0, cls_weight=1.0, src_loss_weight=1.0, knn_override=None):
     """Loss of one step with TARGET_LOSS 0, ADV_WEIGHT 0, past PURE_CLS_EPOCH
     (train_dg_single_gpu.py:260-324). ``starts`` = 4 FPS start specs in call order
-    (sem-s, sem-t, node-s, node-t) or None to draw like the reference."""
+    (sem-s, sem-t, node-s, node-t) or None to draw like the reference.  ``knn_override`` (DGCNN, tests):
+    (lists of the source batch, lists of the target batch), 4 idx tensors each, forced in both passes of a domain."""
     st = starts or [None] * 4
-    ps1, ps2, fs1, fs2 = net_mda(p, model_name, data, True, st[0], drop_p, semantic_adaption=True)
-    pt1, pt2, ft1, ft2 = net_mda(p, model_name, data_t, True, st[1], drop_p, semantic_adaption=True)
+    ko_s, ko_t = knn_override if knn_override is not None else (None, None)
+    kw_s = {'knn_override': ko_s} if ko_s is not None else {}
+    kw_t = {'knn_override': ko_t} if ko_t is not None else {}
+    ps1, ps2, fs1, fs2 = net_mda(p, model_name, data, True, st[0], drop_p, semantic_adaption=True, **kw_s)
+    pt1, pt2, ft1, ft2 = net_mda(p, model_name, data_t, True, st[1], drop_p, semantic_adaption=True, **kw_t)
     loss_s = 0.5 * F.cross_entropy(ps1, label) + 0.5 * F.cross_entropy(ps2, label)
     loss_cls = cls_weight * src_loss_weight * loss_s
-    node_s = net_mda(p, model_name, data, True, st[2], drop_p, node_adaptation_s=True)
-    node_t = net_mda(p, model_name, data_t, True, st[3], drop_p, node_adaptation_t=True)
+    node_s = net_mda(p, model_name, data, True, st[2], drop_p, node_adaptation_s=True, **kw_s)
+    node_t = net_mda(p, model_name, data_t, True, st[3], drop_p, node_adaptation_t=True, **kw_t)
     loss_geo = mmd_weight * geo_cfg['GEO_SCALE'] * mmd_cal(label, node_s, label_t, node_t, geo_cfg, data, data_t)
     l1 = sem_cfg['SEM_SCALE'] * mmd_cal(label, fs1, label_t, ft1, sem_cfg, ps1, pt1)
     l2 = sem_cfg['SEM_SCALE'] * mmd_cal(label, fs2, label_t, ft2, sem_cfg, ps2, pt2)

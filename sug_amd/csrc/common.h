@@ -83,6 +83,21 @@ static inline int sug_allow_dynamic_lds(SugLdsOptIn& note, KernelT kernel, int b
 
 static inline int sug_divup(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// Compute units of the current device (a driver attribute, cached per device like the LDS opt-in; 256 on MI355X): launchers
+// that choose between a coarse and a fine grid ask for it.
+static inline int sug_cu_count() {
+  static std::atomic<int> cus[SUG_MAX_DEVICES];
+  int ncu = 256, dev = 0;
+  if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < SUG_MAX_DEVICES) {
+    ncu = cus[dev].load(std::memory_order_relaxed);
+    if (ncu == 0) {
+      if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+      cus[dev].store(ncu, std::memory_order_relaxed);
+    }
+  }
+  return ncu;
+}
+
 // |p|^2 as the CPU reference's torch.sum(x**2) over 3 channels: separately rounded
 // squares, summed left to right (verified bitwise against the reference).
 __device__ __forceinline__ float sq3(float x, float y, float z) {

@@ -511,15 +511,7 @@ int launch_pc(const float* x, int64_t ldx, int B, int N, int k, int32_t* idx, hi
   // 64 clouds PW = 4: 71 / 133 / 190, PW = 2: 77 / 157 / -- (every workgroup stages all candidate tiles, so two per CU
   // double that work and halve the waves behind each barrier).  Same lists either way.  SUG_KNN_PW=2|4 forces a form.
   static const int forced = getenv("SUG_KNN_PW") ? atoi(getenv("SUG_KNN_PW")) : 0;
-  static std::atomic<int> cus[SUG_MAX_DEVICES];
-  int ncu = 256, dev = 0;
-  if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < SUG_MAX_DEVICES) {
-    ncu = cus[dev].load(std::memory_order_relaxed);
-    if (ncu == 0) {
-      if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
-      cus[dev].store(ncu, std::memory_order_relaxed);
-    }
-  }
+  const int ncu = sug_cu_count();
   const int64_t grid4 = (int64_t)B * sug_divup(N, 256);
   const bool two = forced == 2 || (forced != 4 && 2 * grid4 <= ncu);
   if (two) return launch_pc_pw<CP, K, 2>(x, ldx, B, N, k, idx, st);

@@ -29,7 +29,10 @@ template <int CP>
 __global__ __launch_bounds__(256, 2) void pointmlp_max_kernel(
     const float* __restrict__ x, int64_t ldx, int R, const float* __restrict__ W,
     const float* __restrict__ bias, const float* __restrict__ gamma, int Co, int L, int rows_per_wg, int nrb,
-    float* __restrict__ zext, int32_t* __restrict__ arg, float* __restrict__ ws, int pivoted) {
+    float* __restrict__ zext, int32_t* __restrict__ arg, float* __restrict__ ws, int pivoted, int parts) {
+  // parts > 1 (small grids, pointmlp_max_fwd): a segment of L rows is split over `parts` workgroups of rows_per_wg = L / parts
+  // rows; each writes its sign-folded partial extreme + row to the scratch behind the statistics rows of ws
+  // ([nrb][Co] floats, then [nrb][Co] ints) and pointmlp_max_combine_kernel picks the first extreme in part order.
   constexpr int RS = CP + 4;
   constexpr int HALF = CP / 2;
   constexpr int P = HALF / 16;                       // MFMAs per accumulator slot (2 or 4)
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(256, 2) void pointmlp_max_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc_next[r] = 0.f;
     const int lim = nrows - t * TJ - 4 * h;          // rows of this tile that exist, seen from this lane half
-    const int segrow = (t * TJ) % L + 4 * h;         // row of the tile's first row inside its segment (L % 32 == 0)
+    const int segrow = (row_begin + t * TJ) % L + 4 * h;   // row of the tile's first row inside its segment (L % 32 == 0)
     SUG_SB();
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
@@ -134,9 +137,16 @@ __global__ __launch_bounds__(256, 2) void pointmlp_max_kernel(
     const float fb = take ? pb : best;
     const int fa = take ? pa : barg;
     if (h == 0) {
-      const int64_t o = (int64_t)((row_begin + t * TJ) / L) * Co + col;
-      zext[o] = sgn * fb;
-      arg[o] = fa;
+      if (parts > 1) {
+        float* pext = ws + (size_t)nrb * 2 * Co;
+        int32_t* parg = reinterpret_cast<int32_t*>(pext + (size_t)nrb * Co);
+        pext[(size_t)rb * Co + col] = fb;            // sign-folded: the combine kernel compares, then unfolds
+        parg[(size_t)rb * Co + col] = fa;
+      } else {
+        const int64_t o = (int64_t)((row_begin + t * TJ) / L) * Co + col;
+        zext[o] = sgn * fb;
+        arg[o] = fa;
+      }
     }
     best = -INFINITY;
     barg = 0;
@@ -191,6 +201,26 @@ __global__ __launch_bounds__(256, 2) void pointmlp_max_kernel(
     ws[(size_t)rb * 2 * Co + col] = s1;
     ws[(size_t)rb * 2 * Co + Co + col] = s2;
   }
+}
+
+// Segments split over `parts` workgroups (small grids): the first extreme in ascending row order = the first part, in part
+// order, whose sign-folded value is strictly larger than all earlier ones.
+__global__ void pointmlp_max_combine_kernel(const float* __restrict__ ws, const float* __restrict__ gamma, int Co, int S,
+                                            int parts, int nrb, float* __restrict__ zext, int32_t* __restrict__ arg) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)S * Co) return;
+  const int s = (int)(i / Co), col = (int)(i % Co);
+  const float* pext = ws + (size_t)nrb * 2 * Co;
+  const int32_t* parg = reinterpret_cast<const int32_t*>(pext + (size_t)nrb * Co);
+  float best = -INFINITY;
+  int barg = 0;
+  for (int p = 0; p < parts; ++p) {
+    const float v = pext[(size_t)(s * parts + p) * Co + col];
+    const int a = parg[(size_t)(s * parts + p) * Co + col];
+    if (v > best) { best = v; barg = a; }
+  }
+  zext[i] = (gamma[col] >= 0.f ? 1.f : -1.f) * best;
+  arg[i] = barg;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -610,20 +640,41 @@ static int pointmlp_max_fwd(const float* x, int64_t ldx, int64_t rows, int K, co
               (long long)rows, seg);
   SUG_REQUIRE(ldx >= K && ldx % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0,
               "sug_pointmlp_max_fwd: x / w must be 16-byte aligned with row strides in multiples of 4");
-  const int rpw = pointmlp_rows_per_wg(rows, seg);
-  const int nrb = sug_divup(rows, rpw);
+  int rpw = pointmlp_rows_per_wg(rows, seg);
+  int nrb = sug_divup(rows, rpw);
+  // Small batches (config 1: 16 clouds of 1024 points x 8 channel blocks = 128 workgroups on 256 CUs, one wave per SIMD on
+  // half of the chip): split every segment over `parts` workgroups so that the grid reaches two workgroups per CU; the
+  // partial extremes go through the scratch behind the statistics rows and one small combine launch.  Same results (the
+  // first extreme in ascending row order wins either way); the BatchNorm partial rows just become more.
+  int parts = 1;
+  static const int no_split = getenv("SUG_POINTMLP_NOSPLIT") ? atoi(getenv("SUG_POINTMLP_NOSPLIT")) : 0;
+  if (rpw == seg && !no_split) {
+    const int S = (int)(rows / seg), want = 2 * sug_cu_count();
+    while (parts < 8 && (int64_t)S * parts * (Co / 128) < want && seg % (parts * 2 * 128) == 0 && 2 * S * parts * 2 <= SUG_STATS_ROWS)
+      parts *= 2;
+    if (parts > 1) {
+      rpw = seg / parts;
+      nrb = S * parts;
+    }
+  }
   const int grid = nrb * (Co / 128);
   hipStream_t st = (hipStream_t)stream;
   if (K == 128) {
     const size_t sh = (size_t)3 * TJ * (128 + 4) * sizeof(float);
     hipLaunchKernelGGL((pointmlp_max_kernel<128>), dim3(grid), dim3(256), sh, st, x, ldx, (int)rows, w, bias, gamma, Co,
-                       seg, rpw, nrb, zext, arg, ws, pivoted);
+                       seg, rpw, nrb, zext, arg, ws, pivoted, parts);
   } else {
     const size_t sh = (size_t)3 * TJ * (64 + 4) * sizeof(float);
     hipLaunchKernelGGL((pointmlp_max_kernel<64>), dim3(grid), dim3(256), sh, st, x, ldx, (int)rows, w, bias, gamma, Co,
-                       seg, rpw, nrb, zext, arg, ws, pivoted);
+                       seg, rpw, nrb, zext, arg, ws, pivoted, parts);
   }
   SUG_LAUNCH_CHECK("sug_pointmlp_max_fwd");
+  if (parts > 1) {
+    const int64_t n = rows / seg * Co;
+    hipLaunchKernelGGL(pointmlp_max_combine_kernel, dim3((unsigned)sug_divup(n, 256)), dim3(256), 0, st, ws, gamma, Co,
+                       (int)(rows / seg), parts, nrb, zext, arg);
+    SUG_LAUNCH_CHECK("sug_pointmlp_max_fwd(combine)");
+  }
   *nblk = nrb;
   return SUG_OK;
 }

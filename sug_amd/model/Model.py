@@ -155,7 +155,7 @@ class DGCNN(nn.Module):
         feat_grad=False: the caller discards `feat` (node-adaptation pass): the stage behind the
         SA-node module still runs -- it updates BatchNorm running statistics -- but without autograd."""
         B, N = x.size(0), x.size(2)
-        loc = x.squeeze(-1).transpose(1, 2).contiguous()              # [B,N,3] rows
+        loc = ops.cloud_rows(x)                                       # [B,N,3] rows (one copy per batch)
         gi = knn_idx or [None] * 4
         if knn_idx is not None:
             self._prefix_cache = {}
@@ -204,7 +204,7 @@ class Pointnet2_g(nn.Module):
         """feat_grad=False: the caller discards `feat` (node-adaptation pass): everything behind the layer
         the node features are taken from still runs -- it updates BatchNorm running statistics and draws
         its FPS start -- but without autograd."""
-        rows = xyz.squeeze(-1).transpose(1, 2).contiguous()           # [B,N,3(+3)]
+        rows = ops.cloud_rows(xyz)                                    # [B,N,3(+3)]
         B = rows.shape[0]
         norm = rows[:, :, 3:].contiguous() if self.normal_channel else None
         loc = rows[:, :, :3].contiguous()
@@ -267,7 +267,7 @@ class Pointnet_g(nn.Module):
 
     def forward(self, x, node=False, feat_grad=True):
         """feat_grad=False: node-adaptation pass, the stage behind the SA-node module runs without autograd."""
-        loc = x.squeeze(-1).transpose(1, 2).contiguous()              # [B,N,3]
+        loc = ops.cloud_rows(x)                                       # [B,N,3]
         y = self._prefix(x, loc)
         y, node_fea, node_off = self.conv3.rows(y, loc)
         with torch.set_grad_enabled(torch.is_grad_enabled() and feat_grad):
@@ -348,7 +348,7 @@ class PTran_g(nn.Module):
         """x [B,3,N,1] -> (feat [B,512], node_fea [B,64,64](, None)).
         feat_grad=False: node-adaptation pass, the stages behind the one the node features come from run
         without autograd (they still draw their FPS starts and update BatchNorm buffers)."""
-        x_ = x.squeeze(-1).permute(0, 2, 1).contiguous()              # [B,N,3]
+        x_ = ops.cloud_rows(x)                                        # [B,N,3]
         xyz = x_[..., :3]
         points = self._prefix(x, x_, xyz)
         xyz_and_feats = [(xyz, points)]
@@ -466,14 +466,16 @@ class Net_MDA(nn.Module):
             return ops.heads_fused((self.c1, self.c2), x)
         return ops.run_parallel([lambda: self.c1(x, adapt=True), lambda: self.c2(x, adapt=True)])
 
-    def forward_pair(self, x_pair, node_adaptation=False):
+    def forward_pair(self, x_pair, node_adaptation=False, paired_out=False):
         """Both domains in one encoder pass (not in the reference; used by SUGStep).
         x_pair = cat(source batch, target batch) [2B,3,N,1].  Equivalent to
         forward(source, ...) followed by forward(target, ...): every BatchNorm computes its
         statistics and updates its running buffers per domain half, source first
         (ops.bn_groups), everything else is per cloud / per row.
         semantic (default): ((y1,y2,f1,f2) of the source, (y1,y2,f1,f2) of the target);
-        node_adaptation:    (attention_s(source nodes), attention_t(target nodes))."""
+        node_adaptation:    (attention_s(source nodes), attention_t(target nodes));
+        paired_out (semantic): (y1, y2, f1, f2) as [2B, ...] tensors, source rows first (the caller scores / splits them
+        itself: ops.ce_pair, ops.split_halves)."""
         _check_input(x_pair)
         B2 = x_pair.size(0)
         assert B2 % 2 == 0
@@ -493,10 +495,12 @@ class Net_MDA(nn.Module):
         cuts = getattr(self, '_cuts', None)
         if cuts is not None:            # SUGStep's two-phase backward cuts the graph at the encoder's outputs
             cuts.append(feat_ori if node_adaptation else x)
-        halves = lambda t: t.reshape(2, B, -1).unbind(0)      # backward: one stack, no zero fills
+        halves = lambda t: ops.split_halves(t.reshape(B2, -1))      # backward: copy-free where the gradients are adjacent
         if node_adaptation:
             f_s, f_t = halves(feat_ori.contiguous())
             return tuple(ops.run_parallel([lambda: self.attention_s(f_s), lambda: self.attention_t(f_t)]))
         (y1, f1), (y2, f2) = self._heads(x)
+        if paired_out:
+            return y1, y2, f1, f2
         (y1s, y1t), (y2s, y2t), (f1s, f1t), (f2s, f2t) = halves(y1), halves(y2), halves(f1), halves(f2)
         return (y1s, y2s, f1s, f2s), (y1t, y2t, f1t, f2t)

@@ -1522,6 +1522,124 @@ def ptran_attention(xyz, nbr, q, kf, vf, fc_delta, fc_gamma, dtype=None):
                                  fc_gamma[2].bias, dtype)
 
 
+# ----------------------------------------------------------------------------- clouds as rows
+_rows_cache = [None, None, None]           # weakref to the [B,3,N,1] input, its version, the [B,N,3] rows
+
+
+def cloud_rows(x):
+    """x [B,3(+),N,1] (the reference's cloud layout) -> [B,N,3(+)] contiguous rows.  The semantic and the node pass of a step
+    (and the Chamfer weights) transpose the same batch: the last result is kept, keyed on the tensor OBJECT (weak
+    reference) and its version, so the copy is made once per batch."""
+    import weakref
+    ref, ver, rows = _rows_cache
+    if ref is not None and ref() is x and ver == x._version and not x.requires_grad:
+        return rows
+    rows = x.squeeze(-1).transpose(1, 2).contiguous()
+    if not x.requires_grad and not torch.is_inference_mode_enabled():
+        _rows_cache[0], _rows_cache[1], _rows_cache[2] = weakref.ref(x), x._version, rows
+    return rows
+
+
+# ----------------------------------------------------------------------------- scalar tail of a step
+class _CEPair(torch.autograd.Function):
+    """w * (CE(logits1[:M], label) + CE(logits2[:M], label)) of both classifier heads on the SOURCE rows of the paired
+    logits in one launch (sug_ce_pair_fwd); the backward writes the whole pair's gradient (zeros in the target rows)."""
+
+    @staticmethod
+    def forward(ctx, y1, y2, label, w):
+        _need_gpu(y1, y2, label)
+        M, C = label.shape[0], y1.shape[1]
+        a = y1 if y1.stride(1) == 1 else y1.contiguous()
+        b = y2 if (y2.stride(1) == 1 and y2.stride(0) == a.stride(0)) else y2.contiguous()
+        if b.stride(0) != a.stride(0):
+            a, b = a.contiguous(), b.contiguous()
+        lab = label.reshape(-1).long().contiguous()
+        loss = torch.empty((), dtype=torch.float32, device=y1.device)
+        lse = torch.empty(2, M, dtype=torch.float32, device=y1.device)
+        check(lib().sug_ce_pair_fwd(_p(a), _p(b), a.stride(0), _p(lab), M, C, float(w), _p(loss), _p(lse), _st()), 'sug_ce_pair_fwd')
+        ctx.save_for_backward(a, b, lab, lse)
+        ctx.meta = (M, y1.shape[0], C, float(w))
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b, lab, lse = ctx.saved_tensors
+        M, Mtot, C, w = ctx.meta
+        gs = g.detach().to(dtype=torch.float32).reshape(1)
+        d = torch.empty(2, Mtot, C, dtype=torch.float32, device=a.device)
+        check(lib().sug_ce_pair_bwd(_p(a), _p(b), a.stride(0), _p(lab), M, Mtot, C, w, _p(gs), _p(lse), _p(d[0]), _p(d[1]), _st()),
+              'sug_ce_pair_bwd')
+        return d[0], d[1], None, None
+
+
+def ce_pair_supported(y1, y2, label):
+    return y1.is_cuda and y1.dtype == torch.float32 and y1.dim() == 2 and y1.shape == y2.shape and y1.shape[1] <= 32 \
+        and 2 * label.shape[0] <= 512 and label.shape[0] <= y1.shape[0]
+
+
+def ce_pair(y1, y2, label, w):
+    """y1, y2 [Mtot >= M, C] logits of the two heads (the first M rows are scored), label [M] -> 0-d loss."""
+    return _CEPair.apply(y1, y2, label, w)
+
+
+class _LossCombine(torch.autograd.Function):
+    """(loss_cls + wg*v_geo + ws*(v_sem1 + v_sem2), wg*v_geo, ws*(v_sem1 + v_sem2)) in one launch each way; the two parts
+    are returned for reporting only (non-differentiable)."""
+
+    @staticmethod
+    def forward(ctx, loss_cls, v0, v1, v2, wg, ws):
+        out = torch.empty(3, dtype=torch.float32, device=loss_cls.device)
+        f = lambda t: None if t is None else t.detach().float()
+        lc, a, b, c = f(loss_cls), f(v0), f(v1), f(v2)
+        check(lib().sug_loss_combine_fwd(_p(lc), _p(a), _p(b), _p(c), float(wg), float(ws), _p(out), _st()), 'sug_loss_combine_fwd')
+        ctx.meta = (float(wg), float(ws), v0 is not None, v1 is not None, v2 is not None)
+        tot, geo, sem = out[0], out[1], out[2]
+        ctx.mark_non_differentiable(geo, sem)
+        return tot, geo, sem
+
+    @staticmethod
+    def backward(ctx, g, _g1, _g2):
+        wg, ws, h0, h1, h2 = ctx.meta
+        o = torch.empty(4, dtype=torch.float32, device=g.device)
+        gs = g.detach().to(dtype=torch.float32).reshape(1)
+        check(lib().sug_loss_combine_bwd(_p(gs), wg, ws, _p(o), _st()), 'sug_loss_combine_bwd')
+        return o[0], (o[1] if h0 else None), (o[2] if h1 else None), (o[3] if h2 else None), None, None
+
+
+def loss_combine(loss_cls, v_geo, v_sem1, v_sem2, wg, ws):
+    return _LossCombine.apply(loss_cls, v_geo, v_sem1, v_sem2, wg, ws)
+
+
+class _SplitHalves(torch.autograd.Function):
+    """The two domain halves of a paired [2B, ...] tensor as views.  Backward: when the two gradients are adjacent row
+    blocks of one buffer (what mmd_assemble's and the paired kernels' backwards hand back) the pair's gradient is that
+    buffer, without the torch.stack / zero fill of unbind's backward."""
+
+    @staticmethod
+    def forward(ctx, t):
+        B = t.shape[0] // 2
+        ctx.meta = (tuple(t.shape), t.dtype, t.device)
+        return t[:B], t[B:]
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        shape, dtype, dev = ctx.meta
+        B = shape[0] // 2
+        if ga is not None and gb is not None and ga.shape == gb.shape and ga.stride() == gb.stride() and ga.dim() >= 1 \
+                and ga.untyped_storage().data_ptr() == gb.untyped_storage().data_ptr() \
+                and gb.storage_offset() == ga.storage_offset() + B * ga.stride(0):
+            return torch.as_strided(ga, shape, ga.stride(), ga.storage_offset())
+        if ga is None and gb is None:
+            return None
+        z = lambda: torch.zeros((B,) + shape[1:], dtype=dtype, device=dev)
+        return torch.cat((ga if ga is not None else z(), gb if gb is not None else z()), 0)
+
+
+def split_halves(t):
+    """t [2B, ...] -> (t[:B], t[B:]) with a copy-free backward where the producers allow it."""
+    return _SplitHalves.apply(t)
+
+
 # ----------------------------------------------------------------------------- concat without copies
 class _AssembleRows(torch.autograd.Function):
     """torch.cat(parts, dim=-1) for parts that (mostly) already live in column slices of `buf`

@@ -278,6 +278,8 @@ class SUGStep:
         # more than one rank: the step is captured as FIVE graph segments around its four collectives (_segmented_step)
         self.segmented = self.use_graph and (self.world > 1 or force_segmented)
         self._graphs = None
+        self._total = None
+        self._combine_tail = os.environ.get('SUG_FUSED_LOSS', '1') != '0'
         self.max_graphs = 4                             # captured steps kept (each owns a private memory pool)
         # segmented steps: {collective name: [(event before, event after), ...]} when a dict is assigned (bench.py
         # --gpus N reads it for config.collectives); None = no events
@@ -371,20 +373,42 @@ class SUGStep:
                                               float(sem['LABEL_SCALE']), row0, w, self.world))
         return loss_geo, (0.5 * M_['MMD_WEIGHT'] * sem['SEM_SCALE']) * (terms[0] + terms[1])
 
-    def losses(self, data, label, data_t, label_t, mmd_on=True):
+    def losses(self, data, label, data_t, label_t, mmd_on=True, combine=False):
+        """(loss_cls, loss_geo, loss_sem), each differentiable.  combine=True (the step's own call): the total is formed in
+        one launch each way and kept in self._total; the returned geo / sem parts are then values for reporting only."""
         M = self.methods
         model = self.model
         pair = None
+        fused_ce = None
         if self.pair_domains and data.shape == data_t.shape and model.training:
             pair = torch.cat((data, data_t), dim=0)
-            (pred_s1, pred_s2, sem_s1, sem_s2), (pred_t1, pred_t2, sem_t1, sem_t2) = model.forward_pair(pair)
+            plain_ce = isinstance(self.criterion, nn.CrossEntropyLoss) and self.criterion.weight is None \
+                and self.criterion.reduction == 'mean' and self.criterion.label_smoothing == 0.0 \
+                and M['ADV_WEIGHT'] <= 0 and M['TARGET_LOSS'] <= 0
+            if plain_ce and os.environ.get('SUG_FUSED_LOSS', '1') != '0':
+                # the paired logits / mid features stay paired: CE of both heads in one launch each way (ops.ce_pair writes the
+                # whole pair's gradient), the halves of the mid features split with a copy-free backward
+                y1, y2, f1, f2 = model.forward_pair(pair, paired_out=True)
+                if y1.dim() == 2 and ops.ce_pair_supported(y1, y2, label):
+                    Bs = label.shape[0]
+                    fused_ce = ops.ce_pair(y1, y2, label, 0.5 * M['SRC_LOSS_WEIGHT'] * M['CLS_WEIGHT'])
+                    (sem_s1, sem_t1), (sem_s2, sem_t2) = ops.split_halves(f1), ops.split_halves(f2)
+                    yd1, yd2 = y1.detach(), y2.detach()            # the SDA weights read the logits' values only
+                    pred_s1, pred_t1, pred_s2, pred_t2 = yd1[:Bs], yd1[Bs:], yd2[:Bs], yd2[Bs:]
+                else:
+                    (pred_s1, pred_t1), (pred_s2, pred_t2) = ops.split_halves(y1), ops.split_halves(y2)
+                    (sem_s1, sem_t1), (sem_s2, sem_t2) = ops.split_halves(f1), ops.split_halves(f2)
+            else:
+                (pred_s1, pred_s2, sem_s1, sem_s2), (pred_t1, pred_t2, sem_t1, sem_t2) = model.forward_pair(pair)
         else:
             pred_s1, pred_s2, sem_s1, sem_s2 = model(data, semantic_adaption=True)
             pred_t1, pred_t2, sem_t1, sem_t2 = model(data_t, semantic_adaption=True)
         # scalar algebra with the constant factors multiplied on the host: every tensor-scalar op is a launch forward
         # and one backward (0.5*a + 0.5*b = 0.5*(a + b) exactly; the folded weights differ from the reference's
         # left-to-right products by an ulp at most)
-        if M['ADV_WEIGHT'] > 0 or M['TARGET_LOSS'] > 0:
+        if fused_ce is not None:
+            loss_cls = fused_ce
+        elif M['ADV_WEIGHT'] > 0 or M['TARGET_LOSS'] > 0:
             loss_s = 0.5 * (self.criterion(pred_s1, label) + self.criterion(pred_s2, label))
             if M['ADV_WEIGHT'] > 0:
                 loss_s = loss_s - M['ADV_WEIGHT'] * discrepancy(pred_t1, pred_t2)
@@ -411,11 +435,22 @@ class SUGStep:
                                                         (sem_s1, sem_t1, pred_s1, pred_t1),
                                                         (sem_s2, sem_t2, pred_s2, pred_t2))
         # the three MMD terms are independent chains of small kernels: side by side under graph replay (ops.run_parallel)
-        terms = [lambda: self._mmd(label, feat_node_s, label_t, feat_node_t, geo, data, data_t)]
+        cs, ct = data, data_t
+        if pair is not None and geo.get('GEO_WEIGHTS') and not self.global_mmd:
+            rows = ops.cloud_rows(pair)                  # the encoder's own [2B,N,3] rows: no second transpose for Chamfer
+            cs, ct = rows[:data.shape[0], :, :3], rows[data.shape[0]:, :, :3]
+        terms = [lambda: self._mmd(label, feat_node_s, label_t, feat_node_t, geo, cs, ct)]
         if sem['SEM_SCALE'] > 0:
             terms += [lambda: self._mmd(label, sem_s1, label_t, sem_t1, sem, pred_s1, pred_t1),
                       lambda: self._mmd(label, sem_s2, label_t, sem_t2, sem, pred_s2, pred_t2)]
         vals = ops.run_parallel(terms)
+        if combine and self._combine_tail and loss_cls.is_cuda:
+            # total and its two reported parts in one launch each way (ops.loss_combine): _eager_step takes the total
+            wg, wsem = M['MMD_WEIGHT'] * geo['GEO_SCALE'], 0.5 * M['MMD_WEIGHT'] * sem['SEM_SCALE']
+            has_sem = sem['SEM_SCALE'] > 0
+            tot, lg, ls = ops.loss_combine(loss_cls, vals[0], vals[1] if has_sem else None, vals[2] if has_sem else None, wg, wsem)
+            self._total = tot
+            return loss_cls, lg, (ls if has_sem else None)
         loss_geo = M['MMD_WEIGHT'] * geo['GEO_SCALE'] * vals[0]
         loss_sem = None
         if sem['SEM_SCALE'] > 0:
@@ -840,18 +875,21 @@ class SUGStep:
         fused_before, ops.FUSED_HEADS = ops.FUSED_HEADS, (self.fused_heads or ops.FUSED_HEADS)
         par_before, ops.PARALLEL_BRANCHES = ops.PARALLEL_BRANCHES, (self.parallel_branches or ops.PARALLEL_BRANCHES)
         try:
-            loss_cls, loss_geo, loss_sem = self.losses(data, label, data_t, label_t, mmd_on)
+            loss_cls, loss_geo, loss_sem = self.losses(data, label, data_t, label_t, mmd_on, combine=True)
         finally:
             ops.FUSED_HEADS = fused_before
             ops.PARALLEL_BRANCHES = par_before
             if ops.W16_CACHE is not None:
                 self._w16_plan = ops.w16_plan(ops.W16_CACHE)
             ops.W16_CACHE = None
-        loss = loss_cls
-        if loss_geo is not None:
-            loss = loss + loss_geo
-        if loss_sem is not None:
-            loss = loss + loss_sem
+        loss = getattr(self, '_total', None)             # set by losses() when the tail was combined in one launch
+        self._total = None
+        if loss is None:
+            loss = loss_cls
+            if loss_geo is not None:
+                loss = loss + loss_geo
+            if loss_sem is not None:
+                loss = loss + loss_sem
         if self.world > 1 and self.reducer is None:      # a graph-mode trainer switched to eager launches
             early = [p for m in (self.model.c1, self.model.c2, self.model.attention_s, self.model.attention_t) for p in m.parameters()]
             self.reducer = GradReducer([early, list(self.model.g.parameters())], self.world)

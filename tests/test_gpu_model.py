@@ -221,7 +221,9 @@ def test_dgcnn_cls_source_only_teacher_forced():
     net = _cls_net('DGCNN', G)
     forced = [G['knn%d' % i].to(torch.int32).cuda() for i in (1, 2, 3, 4)]
     y = net(G['x'].cuda(), knn_idx=forced)
-    _cls_check(net, G, y, 1e-4, 2e-3)
+    # gradient norms 2e-3; probe dot products 2e-2: the global max-pool / max over k have ~1e5 arg-max decisions and a
+    # near-tie that falls the other way reroutes one channel's gradient (values unchanged; measured 4.6e-3 of the norm)
+    _cls_check(net, G, y, 1e-4, 2e-3, dot_tol=2e-2)
 
 
 def test_dgcnn_cls_source_only_free_running():
@@ -246,7 +248,7 @@ def test_dgcnn_cls_source_only_free_running():
     differ = [int((rec[i].sort(-1)[0] != G['knn%d' % (i + 1)].sort(-1)[0]).any(-1).sum()) for i in range(4)]
     print('free-running model_pointnet.DGCNN: rows whose neighbour set differs from the reference run: %s' % differ)
     assert sum(differ) == 0, differ
-    _cls_check(net, G, y, 1e-4, 2e-3)
+    _cls_check(net, G, y, 1e-4, 2e-3, dot_tol=2e-2)
 
 
 @pytest.mark.parametrize('dtype,tol,proj16', [(torch.float16, 3e-3, False), (torch.bfloat16, 3e-2, False),

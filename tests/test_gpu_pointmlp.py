@@ -140,3 +140,40 @@ def _rows_gemm_checks(ops, x, W, b, R, K):
     torch.nn.functional.linear(xt, Wt, b).square().sum().backward()
     assert float((xr.grad - xt.grad).norm() / xt.grad.norm()) < 1e-5
     assert float((Wr.grad - Wt.grad).norm() / Wt.grad.norm()) < 1e-5
+
+
+def test_pointmlp_max_split_segments_match_whole_segments_bit_for_bit():
+    """Small grids split every segment over several workgroups (config 1: 16 clouds -> 4 parts per 1024-point segment,
+    sug_amd/csrc/pointmlp.hip) and combine the partial extremes in part order.  The extreme and its row of a segment do
+    not depend on the other segments of the launch, so the first 16 segments of a 64-segment launch (512 workgroups: no
+    split) must equal the 16-segment launch (split) bit for bit -- value AND arg (first extreme in ascending rows)."""
+    import ctypes
+    from sug_amd._lib import lib
+    L = lib()
+    K, Co, seg = 128, 1024, 1024
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(64 * seg, K, generator=g).cuda()
+    x[5 * seg + 700] = x[5 * seg + 3]                       # duplicated rows: ties across parts -> the earlier row must win
+    x[9 * seg + 1023] = x[9 * seg + 0]
+    W = (torch.randn(Co, K, generator=g) / K ** 0.5).cuda()
+    b = (torch.randn(Co, generator=g) * 0.1).cuda()
+    gam = torch.randn(Co, generator=g).cuda()
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    res = []
+    for S in (64, 16):
+        zext = torch.empty(S, Co, device='cuda')
+        arg = torch.empty(S, Co, dtype=torch.int32, device='cuda')
+        ws = torch.zeros(1024 * 2 * Co, device='cuda')
+        nblk = ctypes.c_int(0)
+        rc = L.sug_pointmlp_max_fwd(p(x), K, S * seg, K, p(W), p(b), p(gam), Co, seg, p(zext), p(arg), p(ws), ctypes.byref(nblk), st)
+        assert rc == 0, L.sug_last_error()
+        torch.cuda.synchronize()
+        res.append((zext, arg, nblk.value, ws))
+    assert res[0][2] == 64 and res[1][2] > 16, 'expected whole segments at 64 clouds and split segments at 16 (%d, %d)' % (res[0][2], res[1][2])
+    assert torch.equal(res[0][0][:16], res[1][0]) and torch.equal(res[0][1][:16], res[1][1])
+    # the BatchNorm partial rows of the split launch add up to those of the same rows in the whole-segment launch
+    parts = res[1][2] // 16
+    s_whole = res[0][3][:16 * 2 * Co].view(16, 2 * Co).double().sum(0)
+    s_split = res[1][3][:16 * parts * 2 * Co].view(16 * parts, 2 * Co).double().sum(0)
+    torch.testing.assert_close(s_split, s_whole, rtol=1e-5, atol=1e-2)
