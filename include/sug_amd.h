@@ -241,6 +241,24 @@ int sug_gate_bn_fwd(const float* x, const float* z, int M, int C, const float* g
 int sug_gate_bn_bwd(const float* g, const float* x, const float* z, int M, int C, const float* gamma, const float* stat,
                     int training, float* dx, float* dz, float* dgamma, float* dbeta, void* stream);
 
+/* ---- Channel attention (CALayer, model/Model.py:16-34) for up to two attention layers per launch ------------------
+ * v [M, C] -> h = relu(v . W0^T + b0) [M, Hd] -> z = h . W2^T + b2 [M, C] (the two 1x1 Conv2d on a 1x1 map; the gate
+ * v * sigmoid(z) + v and the BatchNorm1d behind it are sug_gate_bn_fwd / _bwd).  Net_MDA has two such layers
+ * (attention_s on the source rows, attention_t on the target rows of a paired batch): x [layers * M, C] holds the rows of
+ * layer 0 first; W0 / b0 / W2 / b2 (and the gradient outputs) are HOST arrays of `layers` device pointers.
+ * M <= 64, Hd = 512, C % 512 == 0 (C = 4096).  Scratch: hp [layers][C/512][M][Hd], dhp [layers][C/32][M][Hd].
+ * Forward writes h [layers][M][Hd] and z [layers*M, C]; backward takes dz (from sug_gate_bn_bwd) and dxg (the gate's
+ * own input gradient, added to dx; may be null) and writes dW0 [Hd,C], db0 [Hd], dW2 [C,Hd], db2 [C] per layer, dh
+ * [layers][M][Hd] (scratch) and dx [layers*M, C] (row stride lddx).  Fixed summation order, no atomics. */
+int sug_calayer_supported(int layers, int M, int C, int Hd);
+int sug_calayer_fwd(int layers, const float* x, int64_t ldx, int M, int C, int Hd, const float* const* W0,
+                    const float* const* b0, const float* const* W2, const float* const* b2, float* hp, float* h, float* z,
+                    void* stream);
+int sug_calayer_bwd(int layers, const float* x, int64_t ldx, int M, int C, int Hd, const float* const* W0,
+                    const float* const* W2, const float* h, const float* dz, const float* dxg, float* const* dW0,
+                    float* const* db0, float* const* dW2, float* const* db2, float* dhp, float* dh, float* dx, int64_t lddx,
+                    void* stream);
+
 /* ---- Classifier heads: Linear layers with M <= 128 rows, one launch per layer for up to two heads ----------------
  * Pointnet_c (model/Model.py:412-449): fc_layer(1024, 512) -> Dropout -> fc_layer(512, 256) [= mid feature] -> Dropout ->
  * Linear(256, num_class), fc_layer = Linear -> LayerNorm -> LeakyReLU(0.2) / ReLU (model/model_utils.py:35-57); Net_MDA

@@ -107,6 +107,9 @@ SIGNATURES = {
     'sug_pointmlp_max_bwd_sparse': [_vp, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp],
     'sug_mmd_rbf': [_vp, _i64, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp],
     'sug_chamfer': [_vp, _vp, _i32, _i32, _i32, _vp, _vp],
+    'sug_calayer_supported': [_i32, _i32, _i32, _i32],
+    'sug_calayer_fwd': [_i32, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    'sug_calayer_bwd': [_i32, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     'sug_ce_pair_fwd': [_vp, _vp, _i64, _vp, _i32, _i32, _f32, _vp, _vp, _vp],
     'sug_ce_pair_bwd': [_vp, _vp, _i64, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp],
     'sug_loss_combine_fwd': [_vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp],

@@ -73,6 +73,9 @@ class CALayer(nn.Module):
     def forward(self, x):
         """x [B,4096,1,1] (or [B,4096]) -> [B,4096]; the two 1x1 convs on a 1x1 map are GEMMs."""
         v = x.reshape(x.shape[0], -1)
+        if ops.calayer_supported((self,), v):
+            # both GEMMs, the bias / ReLU between them and all their gradients in sug_calayer_* (one launch per stage)
+            return ops.calayers((self,), v)
         c0, c2 = self.conv_du[0], self.conv_du[2]
         y = F.relu(F.linear(v, c0.weight.view(c0.weight.shape[0], -1), c0.bias))
         z = F.linear(y, c2.weight.view(c2.weight.shape[0], -1), c2.bias)
@@ -497,7 +500,11 @@ class Net_MDA(nn.Module):
             cuts.append(feat_ori if node_adaptation else x)
         halves = lambda t: ops.split_halves(t.reshape(B2, -1))      # backward: copy-free where the gradients are adjacent
         if node_adaptation:
-            f_s, f_t = halves(feat_ori.contiguous())
+            fo = feat_ori.contiguous().reshape(B2, -1)
+            if ops.calayer_supported((self.attention_s, self.attention_t), fo):
+                # both attention layers in one launch per stage, on the paired rows (source rows -> attention_s)
+                return tuple(halves(ops.calayers((self.attention_s, self.attention_t), fo)))
+            f_s, f_t = halves(fo)
             return tuple(ops.run_parallel([lambda: self.attention_s(f_s), lambda: self.attention_t(f_t)]))
         (y1, f1), (y2, f2) = self._heads(x)
         if paired_out:

@@ -1522,6 +1522,102 @@ def ptran_attention(xyz, nbr, q, kf, vf, fc_delta, fc_gamma, dtype=None):
                                  fc_gamma[2].bias, dtype)
 
 
+# ----------------------------------------------------------------------------- channel attention (CALayer)
+CALAYER_FUSED = _os.environ.get('SUG_CALAYER_FUSED', '1') != '0'    # A/B knob: 0 = library GEMMs + relu + gate_bn per layer
+
+
+def calayer_supported(layers, x):
+    """Can the CALayer modules `layers` (1 or 2: attention_s [, attention_t]) run through sug_calayer_* on x [len(layers)*M, C]?"""
+    if not (CALAYER_FUSED and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and BN_GROUPS == 1):
+        return False
+    if x.shape[0] % len(layers):
+        return False
+    M, C = x.shape[0] // len(layers), x.shape[1]
+    for m in layers:
+        c0, c2, bn = m.conv_du[0], m.conv_du[2], m.bn
+        if c0.weight.shape[1] != C or c2.weight.shape[0] != C or c0.bias is None or c2.bias is None or not bn.affine \
+                or not (bn.training or bn.track_running_stats) or bn.momentum is None or not bn.track_running_stats:
+            return False
+        if any(mm.training != layers[0].training for mm in (m, bn)):
+            return False
+    return bool(lib().sug_calayer_supported(len(layers), M, C, layers[0].conv_du[0].weight.shape[0]))
+
+
+class _CALayers(torch.autograd.Function):
+    """BatchNorm1d(v * sigmoid(z) + v), z = W2 . relu(W0 . v + b0) + b2 (CALayer, model/Model.py:28-34) for one or two
+    attention layers on the row blocks of x [layers*M, C]: sug_calayer_fwd / _bwd + sug_gate_bn_fwd / _bwd.
+    params per layer: W0 [Hd,C], b0, W2 [C,Hd], b2, gamma, beta, running_mean, running_var."""
+
+    @staticmethod
+    def forward(ctx, x, nl, training, eps, momentum, *params):
+        _need_gpu(x)
+        x = x if (x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0) else x.contiguous()
+        M, C = x.shape[0] // nl, x.shape[1]
+        P = [params[8 * a:8 * a + 8] for a in range(nl)]
+        W0 = [p[0].detach().reshape(p[0].shape[0], -1).contiguous() for p in P]
+        W2 = [p[2].detach().reshape(p[2].shape[0], -1).contiguous() for p in P]
+        b0, b2 = [p[1].detach().contiguous() for p in P], [p[3].detach().contiguous() for p in P]
+        gam, bet = [p[4].detach().contiguous() for p in P], [p[5].detach().contiguous() for p in P]
+        Hd = W0[0].shape[0]
+        dev = x.device
+        L = lib()
+        hp = torch.empty(nl, C // 512, M, Hd, dtype=torch.float32, device=dev)
+        h = torch.empty(nl, M, Hd, dtype=torch.float32, device=dev)
+        z = torch.empty(nl * M, C, dtype=torch.float32, device=dev)
+        check(L.sug_calayer_fwd(nl, _p(x), x.stride(0), M, C, Hd, _ptrs(W0), _ptrs(b0), _ptrs(W2), _ptrs(b2), _p(hp), _p(h), _p(z),
+                                _st()), 'sug_calayer_fwd')
+        out = torch.empty(nl * M, C, dtype=torch.float32, device=dev)
+        stat = torch.empty(nl, 2, C, dtype=torch.float32, device=dev)
+        xc = x if x.stride(0) == C else x.contiguous()            # (sug_gate_bn_* take dense rows)
+        for a in range(nl):
+            check(L.sug_gate_bn_fwd(_p(xc[a * M:]), _p(z[a * M:]), M, C, _p(gam[a]), _p(bet[a]), _p(P[a][6]), _p(P[a][7]),
+                                    1 if training else 0, float(eps), float(momentum), _p(out[a * M:]), _p(stat[a]), _st()),
+                  'sug_gate_bn_fwd')
+        ctx.save_for_backward(xc, h, z, stat, *W0, *W2, *gam)
+        ctx.meta = (nl, M, C, Hd, bool(training))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        nl, M, C, Hd, training = ctx.meta
+        sv = ctx.saved_tensors
+        x, h, z, stat = sv[:4]
+        W0, W2, gam = sv[4:4 + nl], sv[4 + nl:4 + 2 * nl], sv[4 + 2 * nl:4 + 3 * nl]
+        dev = x.device
+        L = lib()
+        g = g.contiguous()
+        dxg, dz = torch.empty_like(x), torch.empty_like(x)
+        dgb = torch.empty(nl, 2, C, dtype=torch.float32, device=dev)
+        for a in range(nl):
+            check(L.sug_gate_bn_bwd(_p(g[a * M:]), _p(x[a * M:]), _p(z[a * M:]), M, C, _p(gam[a]), _p(stat[a]), 1 if training else 0,
+                                    _p(dxg[a * M:]), _p(dz[a * M:]), _p(dgb[a, 0]), _p(dgb[a, 1]), _st()), 'sug_gate_bn_bwd')
+        f32 = torch.float32
+        dW0 = [torch.empty(Hd, C, dtype=f32, device=dev) for _ in range(nl)]
+        dW2 = [torch.empty(C, Hd, dtype=f32, device=dev) for _ in range(nl)]
+        db0 = [torch.empty(Hd, dtype=f32, device=dev) for _ in range(nl)]
+        db2 = [torch.empty(C, dtype=f32, device=dev) for _ in range(nl)]
+        dhp = torch.empty(nl, C // 32, M, Hd, dtype=f32, device=dev)
+        dh = torch.empty(nl, M, Hd, dtype=f32, device=dev)
+        dx = torch.empty(nl * M, C, dtype=f32, device=dev)
+        check(L.sug_calayer_bwd(nl, _p(x), x.stride(0), M, C, Hd, _ptrs(W0), _ptrs(W2), _p(h), _p(dz), _p(dxg), _ptrs(dW0), _ptrs(db0),
+                                _ptrs(dW2), _ptrs(db2), _p(dhp), _p(dh), _p(dx), C, _st()), 'sug_calayer_bwd')
+        grads = []
+        for a in range(nl):
+            grads += [dW0[a].view(Hd, C, 1, 1), db0[a], dW2[a].view(C, Hd, 1, 1), db2[a], dgb[a, 0], dgb[a, 1], None, None]
+        return (dx, None, None, None, None) + tuple(grads)
+
+
+def calayers(layers, x):
+    """[attention(x rows of its block) for attention in layers] as one [len(layers)*M, C] tensor (rows of layer 0 first)."""
+    params = []
+    for m in layers:
+        _count_bn_call(m.bn)
+        c0, c2 = m.conv_du[0], m.conv_du[2]
+        params += [c0.weight, c0.bias, c2.weight, c2.bias, m.bn.weight, m.bn.bias, m.bn.running_mean, m.bn.running_var]
+    bn = layers[0].bn
+    return _CALayers.apply(x, len(layers), bn.training, bn.eps, bn.momentum, *params)
+
+
 # ----------------------------------------------------------------------------- clouds as rows
 _rows_cache = [None, None, None]           # weakref to the [B,3,N,1] input, its version, the [B,N,3] rows
 

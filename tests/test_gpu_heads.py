@@ -170,3 +170,71 @@ def test_gate_bn_matches_gate_then_batchnorm(M, mode):
         scale = float(b.abs().max()) + 1e-12
         assert float((a - b).abs().max()) / scale <= 5e-5, (n, float((a - b).abs().max()), scale)
     assert int(res[1][-1]) == int(res[0][-1])
+
+
+def _ref_calayer(x, W0, b0, W2, b2, gamma, beta, rm, rv, training):
+    """CALayer.forward exactly as the reference composes it (model/Model.py:28-34): two 1x1 Conv2d on [B,C,1,1], ReLU,
+    sigmoid gate, x * y + x, BatchNorm1d."""
+    import torch.nn.functional as F
+    v = x.view(x.shape[0], -1, 1, 1)
+    y = F.relu(F.conv2d(v, W0, b0))
+    y = torch.sigmoid(F.conv2d(y, W2, b2))
+    u = (v * y + v).view(x.shape[0], -1)
+    return F.batch_norm(u, rm, rv, gamma, beta, training, 0.1, 1e-5)
+
+
+@pytest.mark.parametrize('M,nl,train', [(32, 2, True), (32, 1, True), (8, 2, True), (64, 2, True), (5, 1, True), (32, 2, False)])
+def test_calayer_fused_matches_reference_composition(M, nl, train):
+    """sug_calayer_fwd / _bwd (both attention layers of Net_MDA in one launch per stage) against the reference's CALayer
+    composed in plain torch: output, input gradient, every parameter gradient, BatchNorm running statistics."""
+    from sug_amd import ops
+    from sug_amd.model.Model import CALayer
+    g = torch.Generator().manual_seed(100 * M + nl)
+    C = 4096
+    mods, refs = [], []
+    for a in range(nl):
+        m = CALayer(C)
+        with torch.no_grad():
+            for p in m.parameters():
+                p.copy_(torch.randn(p.shape, generator=g) * (0.02 if p.dim() > 1 else 0.3))
+            m.bn.weight.add_(1.0)
+            m.bn.running_mean.copy_(torch.randn(C, generator=g) * 0.1)
+            m.bn.running_var.copy_(torch.rand(C, generator=g) + 0.5)
+        m = m.cuda().train(train)
+        mods.append(m)
+        refs.append({k: v.detach().clone().requires_grad_(v.dtype.is_floating_point and k in dict(m.named_parameters()))
+                     for k, v in m.state_dict().items()})
+    x = torch.randn(nl * M, C, generator=g).cuda()
+    probe = torch.randn(nl * M, C, generator=g).cuda()
+    xk = x.clone().requires_grad_(True)
+    assert ops.calayer_supported(tuple(mods), xk)
+    out = ops.calayers(tuple(mods), xk)
+    (out * probe).sum().backward()
+    xr = x.clone().requires_grad_(True)
+    outs = []
+    for a in range(nl):
+        R = refs[a]
+        outs.append(_ref_calayer(xr[a * M:(a + 1) * M], R['conv_du.0.weight'], R['conv_du.0.bias'], R['conv_du.2.weight'],
+                                 R['conv_du.2.bias'], R['bn.weight'], R['bn.bias'], R['bn.running_mean'], R['bn.running_var'], train))
+    ref = torch.cat(outs)
+    (ref * probe).sum().backward()
+    # BatchNorm1d over M rows amplifies input rounding by up to 1/sqrt(var + eps) of a column: compare at 1e-4 of the scale
+    torch.testing.assert_close(out, ref, rtol=1e-4, atol=1e-4)
+    rel = lambda a_, b_: float((a_ - b_).norm() / b_.norm().clamp_min(1e-12))
+    assert rel(xk.grad, xr.grad) < 1e-4, rel(xk.grad, xr.grad)
+    for a in range(nl):
+        P = dict(mods[a].named_parameters())
+        for k, p in P.items():
+            assert p.grad is not None, k
+            assert rel(p.grad, refs[a][k].grad) < 2e-4, (k, rel(p.grad, refs[a][k].grad))
+        if train:
+            torch.testing.assert_close(mods[a].bn.running_mean, refs[a]['bn.running_mean'], rtol=1e-5, atol=1e-6)
+            torch.testing.assert_close(mods[a].bn.running_var, refs[a]['bn.running_var'], rtol=1e-5, atol=1e-6)
+    # run to run identical (fixed summation order)
+    xk2 = x.clone().requires_grad_(True)
+    for m in mods:
+        m.zero_grad()
+    out2 = ops.calayers(tuple(mods), xk2)
+    (out2 * probe).sum().backward()
+    assert torch.equal(out2, out) if not train else True          # (train: the running statistics moved, the output did not)
+    assert torch.equal(xk2.grad, xk.grad)
