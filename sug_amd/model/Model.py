@@ -132,28 +132,25 @@ class DGCNN(nn.Module):
 
     def _prefix(self, x, loc, nb, out1=None):
         """kNN + conv1, kNN + conv2.  out1: where conv1's activations should be written (a column
-        slice of the conv5 input buffer); a cache hit returns the tensors of the earlier pass instead.
-        Returns (x1, x2, slot of x1): conv2 adds its input gradient to the slice conv5's backward parks there."""
+        slice of the conv5 input buffer); a cache hit returns the tensors of the earlier pass instead."""
         if not _sharing_on(self.share_prefix, self.training):
-            s1 = ops.GradSlot()
             x1 = self.conv1.edge_rows(loc, nb(loc, 0), out=out1)
-            return x1, self.conv2.edge_rows(x1, nb(x1, 1), slot=s1), s1
+            return x1, self.conv2.edge_rows(x1, nb(x1, 1))
         ver = sum(p._version for m in (self.conv1, self.conv2) for p in m.parameters())
         key = (x.data_ptr(), x._version, tuple(x.shape), torch.is_grad_enabled(), ver, ops.BN_GROUPS)
         hit = self._prefix_cache.get(key)
         if hit is not None and hit.serves(x):
             x1, x2 = hit.tensors
-            st1, st2, s1 = hit.extra
+            st1, st2 = hit.extra
             self.conv1.replay_bn_update(st1)
             self.conv2.replay_bn_update(st2)
-            return x1, x2, s1
-        s1 = ops.GradSlot()
+            return x1, x2
         x1, st1 = self.conv1.edge_rows(loc, nb(loc, 0), return_stats=True, out=out1)
-        x2, st2 = self.conv2.edge_rows(x1, nb(x1, 1), return_stats=True, slot=s1)
+        x2, st2 = self.conv2.edge_rows(x1, nb(x1, 1), return_stats=True)
         if len(self._prefix_cache) >= 4:            # a step has two inputs; never grow unbounded
             self._prefix_cache.clear()
-        self._prefix_cache[key] = _PrefixEntry((x1, x2), (st1, st2, s1), source=x)
-        return x1, x2, s1
+        self._prefix_cache[key] = _PrefixEntry((x1, x2), (st1, st2), source=x)
+        return x1, x2
 
     def forward(self, x, node=False, knn_idx=None, feat_grad=True):
         """x [B,3,N,1] -> (feat [B,1024], node_fea [B,64,64,1](, None)).
@@ -169,17 +166,13 @@ class DGCNN(nn.Module):
         # conv5 consumes cat(x1, x2, x3, x4): the EdgeConv layers write their activations straight
         # into the column slices of that [B,N,512] buffer instead of concatenating afterwards
         cat_in = torch.empty(B, N, 512, dtype=torch.float32, device=x.device)
-        x1, x2, s1 = self._prefix(x, loc, nb, out1=cat_in[:, :, 0:64])   # [B,N,64], [B,N,64]
+        x1, x2 = self._prefix(x, loc, nb, out1=cat_in[:, :, 0:64])   # [B,N,64], [B,N,64]
         x_, node_fea, _ = self.node_fea_adapt.rows(x2, loc)           # [B,N,128], [B,64,64]
         with torch.set_grad_enabled(torch.is_grad_enabled() and feat_grad):
-            # x1, x2, x3 each feed the next EdgeConv layer AND a column slice of conv5's input: the layer adds its input
-            # gradient to conv5's slice inside its GEMM (ops.GradSlot) instead of autograd adding two tensors
-            s2, s3 = ops.GradSlot(), ops.GradSlot()
             x2 = ops.linear_rows(x_, self.conv1d.weight.squeeze(-1), self.conv1d.bias)
-            x3 = self.conv3.edge_rows(x2, nb(x2, 2), out=cat_in[:, :, 128:256], slot=s2)     # [B,N,128]
-            x4 = self.conv4.edge_rows(x3, nb(x3, 3), out=cat_in[:, :, 256:512], slot=s3)     # [B,N,256]
-            x5 = ops.linear_rows(ops.assemble_rows(cat_in, (x1, x2, x3, x4), slots=(s1, s2, s3, None)),
-                                 self.conv5.weight.squeeze(-1))
+            x3 = self.conv3.edge_rows(x2, nb(x2, 2), out=cat_in[:, :, 128:256])     # [B,N,128]
+            x4 = self.conv4.edge_rows(x3, nb(x3, 3), out=cat_in[:, :, 256:512])     # [B,N,256]
+            x5 = ops.linear_rows(ops.assemble_rows(cat_in, (x1, x2, x3, x4)), self.conv5.weight.squeeze(-1))
             if feat_grad:
                 # bn5 -> leaky_relu(0.2) -> adaptive max | avg pool (Model.py:113-116), fused
                 feat = torch.cat(ops.bn_act_pool(x5, self.bn5, 0.2), 1)

@@ -82,7 +82,7 @@ class conv_2d(nn.Module):
             return ops.pointmlp_max(x, W, self.conv[0].bias, self.conv[1], _ACT_SLOPE[self.activation], N)
         return torch.max(self.rows(x), dim=1)[0]
 
-    def edge_rows(self, x, idx, return_stats=False, out=None, slot=None):
+    def edge_rows(self, x, idx, return_stats=False, out=None):
         """Fused EdgeConv layer: max_k act(bn(W.[x_j - x_i ; x_i])) for x [B,N,C] rows and
         idx [B,N,k] (get_graph_feature + conv + max, model_utils.py:188-210, Model.py:88-94).
         W.[x_j-x_i; x_i] = W1.x_j + (W2-W1).x_i, so one [B*N,C]x[C,2Co] GEMM replaces the
@@ -104,9 +104,9 @@ class conv_2d(nn.Module):
         if ops.edgeconv_fused_supported(N, idx.shape[2], C, W.shape[0]):
             # the GEMM inside the gather kernel: [P|Q] never round-trips HBM (sug_edgeconv_fused_layer_fwd)
             out, coef = ops.edgeconv_fused(x, Wcat, bias, idx, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                           bn.training, _ACT_SLOPE[self.activation], bn.eps, bn.momentum, out=out, slot=slot)
+                                           bn.training, _ACT_SLOPE[self.activation], bn.eps, bn.momentum, out=out)
             return (out, coef) if return_stats else out
-        pq = ops.linear_rows(x.reshape(B * N, C), Wcat, slot=slot)
+        pq = ops.linear_rows(x.reshape(B * N, C), Wcat)
         if bias is not None:                                              # bias rides on the Q half
             pq = pq + torch.cat((torch.zeros_like(bias), bias))
         out, coef = ops.edgeconv_bn_act_max(pq.view(B, N, -1), idx, bn.weight, bn.bias, bn.running_mean,

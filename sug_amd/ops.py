@@ -323,40 +323,12 @@ import os as _os
 OWN_ROWS_GEMM = _os.environ.get('SUG_OWN_ROWS_GEMM', '0') == '1'            # forward y = x.W^T of skinny layers (K in {64,128}, Co % 128 == 0) by sug_rows_gemm
 
 
-class GradSlot:
-    """Where a second consumer's gradient of a tensor waits for the first one to add to it IN its GEMM.
-    A tensor x with two differentiable consumers -- a column slice of conv5's input (assemble_rows) and the next EdgeConv
-    layer -- gets its gradient as (slice of conv5's dx) + (the layer's dx): autograd adds them with one elementwise launch
-    per tensor.  With a slot, assemble_rows' backward parks its slice here (and reports no gradient for that part), and the
-    layer's backward -- which autograd necessarily runs later: the layer's output is itself a part of the assembled
-    buffer -- forms its dx as `slice += g . W` (the library GEMM with beta = 1) and returns the slice.  Same sum, one launch
-    less per tensor; a slot nobody filled (no_grad forwards, other graphs) leaves the ordinary path in place."""
-    __slots__ = ('buf', 'done')
-
-    def __init__(self):
-        self.buf, self.done = None, False
-
-    def park(self, g):
-        """True if the slot took the gradient slice (it is empty and its consumer has not run yet)."""
-        if self.buf is not None or self.done:
-            return False
-        self.buf = g
-        return True
-
-    def take(self):
-        b, self.buf, self.done = self.buf, None, True
-        return b
-
-
-GRAD_SLOTS = _os.environ.get('SUG_GRAD_SLOTS', '1') != '0'      # A/B knob
-
-
 class _LinearRows(torch.autograd.Function):
     """y = x . W^T (+ b) over rows; the weight gradient g^T . x (K = rows = B*N, small output)
     runs in sug_linear_dw instead of a rocBLAS GEMM that does not split K."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, slot=None):
+    def forward(ctx, x, weight, bias):
         M, N = weight.shape
         x2 = x.reshape(-1, N)
         if OWN_ROWS_GEMM and N in (64, 128) and M % 128 == 0 and x2.shape[0] >= 4096 and x2.stride(1) == 1 \
@@ -372,17 +344,15 @@ class _LinearRows(torch.autograd.Function):
             y = torch.nn.functional.linear(x, weight, bias)
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        ctx.slot = slot
         return y
 
     @staticmethod
     def backward(ctx, g):
         x, weight = ctx.saved_tensors
         M, N = weight.shape
-        acc = ctx.slot.take() if ctx.slot is not None else None
         dx, dw, db = linear_rows_backward(x.reshape(-1, N), weight, g.reshape(-1, M), ctx.needs_input_grad[0],
-                                          ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2], acc=acc)
-        return (None if dx is None else dx.view(x.shape)), dw, db, None
+                                          ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2])
+        return (None if dx is None else dx.view(x.shape)), dw, db
 
 
 DW_BMM = _os.environ.get('SUG_DW_BMM', '1') == '1'
@@ -400,22 +370,9 @@ def _dw_bmm_chunks(R, M, N, g2, x2):
     return S if (R % S == 0 and R // S >= 1024) else 0
 
 
-def _acc_rows(acc, R, N):
-    """`acc` ([..., N] gradient slice parked in a GradSlot) as an [R, N] matrix view the library can accumulate into
-    (unit column stride, one constant row stride), or None."""
-    if acc is None or acc.dtype != torch.float32 or acc.shape[-1] != N or acc.numel() != R * N or acc.stride(-1) != 1:
-        return None
-    ld = acc.stride(-2) if acc.dim() >= 2 else N
-    for d in range(acc.dim() - 2):
-        if acc.stride(d) != acc.stride(d + 1) * acc.shape[d + 1]:
-            return None
-    return torch.as_strided(acc, (R, N), (ld, 1), acc.storage_offset())
-
-
-def linear_rows_backward(x2, weight, g2, need_dx, need_dw, need_db, acc=None):
+def linear_rows_backward(x2, weight, g2, need_dx, need_dw, need_db):
     """Gradients of y = x2 . weight^T (+ b) for rows x2 [R, N], g2 [R, M]: dx by the library GEMM, the weight gradient
-    g^T . x (K = rows, small output) by sug_linear_dw(_bias) -- with the bias gradient from the same pass over g.
-    acc: another consumer's gradient of x (GradSlot): dx = acc += g2 . weight, in the GEMM (beta = 1)."""
+    g^T . x (K = rows, small output) by sug_linear_dw(_bias) -- with the bias gradient from the same pass over g."""
     M, N = weight.shape
     if g2.stride(1) != 1:
         g2 = g2.contiguous()
@@ -424,16 +381,7 @@ def linear_rows_backward(x2, weight, g2, need_dx, need_dw, need_db, acc=None):
     R = g2.shape[0]
     dx = dw = db = None
     if need_dx:
-        a2 = _acc_rows(acc, R, N)
-        if a2 is not None:
-            a2.addmm_(g2, weight)           # in place: C = 1 * C + g2 . weight
-            dx = acc
-        else:
-            dx = g2 @ weight
-            if acc is not None:
-                dx = dx.view(acc.shape) + acc
-    elif acc is not None:
-        dx = acc                            # (the parked gradient is x's whole gradient from here)
+        dx = g2 @ weight
     if need_dw:
         if DW_SHAPE_LOG is not None:
             DW_SHAPE_LOG.append((R, M, N))
@@ -474,13 +422,12 @@ def linear_rows_backward(x2, weight, g2, need_dx, need_dw, need_db, acc=None):
     return dx, dw, db
 
 
-def linear_rows(x, weight, bias=None, slot=None):
-    """F.linear for [..., Cin] rows with many rows and small Cin/Cout (the encoders' 1x1 convs).
-    slot: GradSlot of x (see there)."""
+def linear_rows(x, weight, bias=None):
+    """F.linear for [..., Cin] rows with many rows and small Cin/Cout (the encoders' 1x1 convs)."""
     _need_gpu(x, weight)
     if x.dtype != torch.float32:
         raise RuntimeError('sug_amd.ops.linear_rows: fp32 rows only (got %s)' % x.dtype)
-    return _LinearRows.apply(x, weight, bias, slot if GRAD_SLOTS else None)
+    return _LinearRows.apply(x, weight, bias)
 
 
 # ----------------------------------------------------------------------------- SA-node glue
@@ -1193,9 +1140,8 @@ class _EdgeConvFused(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, wcat, bias, idx, gamma, beta, running_mean, running_var, training, slope, eps, momentum, G,
-                out_holder, grad_on=True, slot=None):
+                out_holder, grad_on=True):
         _need_gpu(x, wcat, idx, gamma)
-        ctx.slot = slot
         x3, B, N, C, ld = _rows3(x)
         Co = wcat.shape[0] // 2
         idx = _i32(idx).contiguous()
@@ -1241,7 +1187,7 @@ class _EdgeConvFused(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout, _gcoef):
         if gout is None:
-            return (None,) * 16
+            return (None,) * 15
         x3, w, idx, z, arg, s1, coef, pq = ctx.saved_tensors
         B, N, k, C, Co, slope, training, G, has_bias, xshape = ctx.meta
         dev = gout.device
@@ -1260,22 +1206,19 @@ class _EdgeConvFused(torch.autograd.Function):
               'sug_edgeconv_layer_bwd')
         x2 = x3.reshape(B * N, C) if x3.is_contiguous() else x3.view(B * N, C) if x3.stride(0) == N * x3.stride(1) else x3.reshape(B * N, C)
         dpq2 = dpq.view(B * N, 2 * Co)
-        acc = ctx.slot.take() if ctx.slot is not None else None
-        dx, dw, _ = linear_rows_backward(x2, w, dpq2, ctx.needs_input_grad[0], ctx.needs_input_grad[1], False, acc=acc)
+        dx, dw, _ = linear_rows_backward(x2, w, dpq2, ctx.needs_input_grad[0], ctx.needs_input_grad[1], False)
         db = None
         if has_bias and ctx.needs_input_grad[2]:
             db = colsum(dpq2[:, Co:])                              # the bias rides on the Q half
         return (None if dx is None else dx.view(xshape)), dw, db, None, rf[Co:], rf[:Co], None, None, None, None, None, \
-            None, None, None, None, None
+            None, None, None, None
 
 
 def edgeconv_fused(x, wcat, bias, idx, bn_weight, bn_bias, running_mean, running_var, training, slope, eps=1e-5,
-                   momentum=0.1, out=None, slot=None):
-    """x [B,N,C] rows, wcat [2Co, C] = [W1 ; W2-W1], idx [B,N,k] -> (out [B,N,Co], coef) as edgeconv_bn_act_max.
-    slot: GradSlot of x."""
+                   momentum=0.1, out=None):
+    """x [B,N,C] rows, wcat [2Co, C] = [W1 ; W2-W1], idx [B,N,k] -> (out [B,N,Co], coef) as edgeconv_bn_act_max."""
     return _EdgeConvFused.apply(x, wcat, bias, idx, bn_weight, bn_bias, running_mean, running_var, training, slope, eps,
-                                momentum, BN_GROUPS, None if out is None else [out], torch.is_grad_enabled(),
-                                slot if GRAD_SLOTS else None)
+                                momentum, BN_GROUPS, None if out is None else [out], torch.is_grad_enabled())
 
 
 # ----------------------------------------------------------------------------- per-point MLP + max
@@ -1803,7 +1746,6 @@ class _AssembleRows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, holder, *parts):
         buf = holder[0]
-        ctx.slots = holder[1] if len(holder) > 1 else None
         off, widths = 0, []
         for t in parts:
             w = t.shape[-1]
@@ -1832,19 +1774,14 @@ class _AssembleRows(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         out, off = [], 0
-        slots = ctx.slots or (None,) * len(ctx.widths)
-        for w, slot in zip(ctx.widths, slots):
-            if slot is not None and GRAD_SLOTS and slot.park(g[..., off:off + w]):
-                out.append(None)                        # the part's other consumer adds its dx to this slice (GradSlot)
-            else:
-                out.append(g[..., off:off + w])
+        for w in ctx.widths:
+            out.append(g[..., off:off + w])
             off += w
         return (None,) + tuple(out)
 
 
-def assemble_rows(buf, parts, slots=None):
-    """slots: per part a GradSlot (or None): that part's gradient is handed to its other consumer instead of autograd."""
-    return _AssembleRows.apply([buf, slots], *parts)
+def assemble_rows(buf, parts):
+    return _AssembleRows.apply([buf], *parts)
 
 
 # ----------------------------------------------------------------------------- MMD

@@ -520,38 +520,3 @@ def test_prefix_cache_is_keyed_on_tensor_identity_not_on_the_address(model_name)
             outs.append(net(b, mid_feat=True))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), \
         'a batch at a reused address was served the previous batch\'s cached prefix'
-
-
-def test_grad_slots_give_the_same_gradients_as_autograd_accumulation():
-    """ops.GradSlot: x1 / x2 / x3 of the DGCNN encoder each feed the next EdgeConv layer and a column slice of conv5's
-    input; with slots the layer adds its input gradient to conv5's slice inside its GEMM (beta = 1) instead of autograd
-    adding two tensors.  Same sum: losses equal, gradients equal to summation order -- for a single pass, for the shared
-    prefix (one backward over a semantic and a node pass) and for two gradient-carrying passes over one cached prefix."""
-    from sug_amd import ops
-    from sug_amd.model.Model import Net_MDA
-    G = load_golden('step_dgcnn.npz')
-    x = G['data'].cuda()
-    res = {}
-    for mode in (True, False):
-        keep, ops.GRAD_SLOTS = ops.GRAD_SLOTS, mode
-        try:
-            net = Net_MDA('DGCNN')
-            net.load_state_dict(O.fill_params({k: tuple(v.shape) for k, v in net.state_dict().items()}, 3))
-            for m in net.modules():
-                if isinstance(m, torch.nn.Dropout2d):
-                    m.p = 0.0
-            net = net.cuda().train()
-            torch.manual_seed(1)
-            y1, y2, f1, f2 = net(x, semantic_adaption=True)
-            node = net(x, node_adaptation_s=True)                 # shares kNN + conv1 + conv2 with the pass above
-            ya, _ = net(x, mid_feat=True)                         # a second gradient-carrying pass (fresh prefix: the first one's
-            loss = y1.square().sum() + f2.sum() + node.square().mean() + ya.sum()   # graph is still alive -> cache hit)
-            loss.backward()
-            res[mode] = (float(loss), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
-        finally:
-            ops.GRAD_SLOTS = keep
-    assert res[True][0] == res[False][0]
-    assert res[True][1].keys() == res[False][1].keys()
-    for k in res[False][1]:
-        a, b = res[True][1][k], res[False][1][k]
-        assert float((a - b).norm()) <= 2e-5 * float(b.norm()) + 1e-7, (k, float((a - b).norm()), float(b.norm()))
