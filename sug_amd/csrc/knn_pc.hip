@@ -35,6 +35,23 @@
 #include "common.h"
 #include "mfma_tile.h"
 
+#if defined(SUG_KNN_ABL_SEED) || defined(SUG_KNN_ABL_COUNT)
+// Ablation builds only (tools/bench_knn_pc.py seed): an ORACLE threshold per query ([B, N] scores: the exact K-th best score,
+// computed by the caller) seeds the consumer's threshold before the first tile -- the upper bound of what any threshold
+// seeding can save; and a counter of the candidates that pass the scan (accepted candidates per query).
+__device__ const float* g_knn_seed = nullptr;
+__device__ unsigned long long g_knn_accepted = 0ull;
+extern "C" int sug_knn_abl_set_seed(const float* seed) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_knn_seed), &seed, sizeof(seed)) == hipSuccess ? 0 : -1;
+}
+extern "C" long long sug_knn_abl_accepted(int reset) {
+  unsigned long long v = 0ull, z = 0ull;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_knn_accepted), sizeof(v)) != hipSuccess) return -1;
+  if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_knn_accepted), &z, sizeof(z)) != hipSuccess) return -1;
+  return (long long)v;
+}
+#endif
+
 namespace {
 using namespace sug_tile;
 
@@ -289,6 +306,13 @@ __global__ __launch_bounds__(128 * PW, 2) void knn_pc_kernel(const float* __rest
     const unsigned FXMAX = (1u << (31 - idb)) - 2u;
     float scale = 1.f, inv_scale = 1.f;
     float thr = -FLT_MAX;                      // candidates with score >= thr may still enter the list
+#ifdef SUG_KNN_ABL_SEED
+    if (g_knn_seed != nullptr && q < N) thr = g_knn_seed[(int64_t)b * N + q];
+    const float seed_thr = thr;
+#endif
+#ifdef SUG_KNN_ABL_COUNT
+    unsigned acc_count = 0u;
+#endif
 
     // score of candidate slot c of the current tile: pairwise_distance = -xx - inner - xx^T, inner = -2*dot
     // (model_utils.py:179-181); the same three roundings wherever it is evaluated
@@ -325,7 +349,10 @@ __global__ __launch_bounds__(128 * PW, 2) void knn_pc_kernel(const float* __rest
           smin = fminf(smin, sz >= thr ? sz : INFINITY);
           smin = fminf(smin, sw >= thr ? sw : INFINITY);
         }
-        const float R = (smin < 0.f && smin > -FLT_MAX) ? -smin : 1.f;      // no finite negative score: any range will do
+        float R = (smin < 0.f && smin > -FLT_MAX) ? -smin : 1.f;            // no finite negative score: any range will do
+#ifdef SUG_KNN_ABL_SEED
+        if (seed_thr > -FLT_MAX && seed_thr < 0.f) R = -seed_thr * 1.01f;   // every accepted d lies below the seed
+#endif
         scale = (float)FXMAX / R;
         inv_scale = R / (float)FXMAX;
         if (!(scale < FLT_MAX) || !(inv_scale > 0.f)) { scale = 1.f; inv_scale = 1.f; }
@@ -357,6 +384,9 @@ __global__ __launch_bounds__(128 * PW, 2) void knn_pc_kernel(const float* __rest
       if (t > 0) mask = 0u;
 #endif
       const int pc = __popc(mask);
+#ifdef SUG_KNN_ABL_COUNT
+      acc_count += (unsigned)pc;
+#endif
       unsigned long long cand = ~0ull;
       int nit = 0;
 #pragma unroll
@@ -411,12 +441,23 @@ __global__ __launch_bounds__(128 * PW, 2) void knn_pc_kernel(const float* __rest
       // margin (+3, 2e-6 relative) covers the roundings of d*scale, of scale and of this product (buckets < 2^21)
       const int lk = L[KP - 1];
       thr = lk == EMPTY ? -FLT_MAX : -((float)((lk >> idb) + 3) * inv_scale * 1.000002f);
+#ifdef SUG_KNN_ABL_SEED
+      thr = fmaxf(thr, seed_thr);                // never looser than the seed
+#endif
 #ifdef SUG_KNN_SERIAL
       __syncthreads();
 #endif
       __syncthreads();
     }
 
+#ifdef SUG_KNN_ABL_COUNT
+    {
+      unsigned long long tot = (unsigned long long)(q < N ? acc_count : 0u);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+      if (lane == 0) atomicAdd(&g_knn_accepted, tot);
+    }
+#endif
     // ---- result.  Buckets (key >> idb) order the candidates as their exact scores do, except inside a bucket.
     bool amb = false;
 #pragma unroll

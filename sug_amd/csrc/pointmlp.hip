@@ -773,7 +773,13 @@ extern "C" int sug_pointmlp_max_bwd_sparse(const float* a, const int32_t* arg, c
   const int64_t S = rows / seg;
   SUG_REQUIRE(S < (1ll << 30), "sug_pointmlp_max_bwd_sparse: too many segments");
   hipStream_t st = (hipStream_t)stream;
-  const int chunks = sug_divup(seg, 128);
+  // rows per workgroup of the dx pass: 128, or fewer (down to 16) when that grid would leave CUs idle (config 1: 8 segments
+  // of 1024 rows per domain group = 64 workgroups; the sums of a row do not depend on the chunking)
+  int chunks = sug_divup(seg, 128);
+  {
+    const int64_t want = 2 * (int64_t)sug_cu_count();
+    while (S * chunks < want && seg / (chunks * 2) >= 16) chunks *= 2;
+  }
   int64_t g64 = S * chunks;
   const int grid = (int)(g64 < 4096 ? g64 : 4096);
   const size_t sh = (size_t)Co * 8 + (Co > 256 ? (size_t)Co * 16 : 0);      // a, arg (+ 4 compacted channel lists)

@@ -15,6 +15,9 @@ model = sys.argv[1] if len(sys.argv) > 1 else 'DGCNN'
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 N = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
 dev = torch.device('cuda')
+if len(sys.argv) > 4 and sys.argv[4] == 'fp16':
+    from sug_amd.model import Ptran_transformer as PT
+    PT.GEMM_DTYPE, PT.PROJ_16BIT = torch.float16, True
 torch.manual_seed(666)
 net = Net_MDA(model).to(dev).train()
 tr = SUGStep(net, use_graph=False, methods=BENCH_METHODS)

@@ -48,6 +48,44 @@ if __name__ == '__main__':
                     ('no staging only', NC + ['-DSUG_KNN_ABL_NOSTAGE'])]
     if len(sys.argv) > 1 and sys.argv[1] == 'ab':             # careful A/B of two builds: interleaved rounds, median and minimum
         variants = [('product', []), ('staging inside the chain', ['-DSUG_KNN_STAGE_MID'])]
+    if len(sys.argv) > 1 and sys.argv[1] == 'seed':
+        # Upper bound of threshold seeding: the consumer's threshold starts at the ORACLE value (the exact
+        # K-th best score of every query, computed here with torch), and the candidates that pass the scan are counted.
+        # Inputs: Gaussian rows (as the other ablations) and the features of a random-init DGCNN forward (layers 2-4 of the
+        # benchmark: spatially smooth, what the step really feeds the kernel).
+        Lc = build('count', ['-DSUG_KNN_ABL_COUNT', '-DSUG_KNN_ABL_SEED'])
+        Lp = build('product', [])
+        Lc.sug_knn_abl_set_seed.argtypes = [ctypes.c_void_p]
+        Lc.sug_knn_abl_accepted.restype = ctypes.c_longlong
+        from sug_amd import ops
+        from sug_amd.model.Model import Net_MDA
+        from bench import synth
+        net = Net_MDA('DGCNN').cuda().train()
+        feats = []
+        real_knn = ops.knn
+        ops.knn = lambda f, k: (feats.append(f.detach().clone()), real_knn(f, k))[1]
+        with torch.no_grad():
+            net(synth(64, 1024, 666, 'cuda')[0], semantic_adaption=True)
+        ops.knn = real_knn
+        inputs = [('gaussian C=%d' % C, torch.randn(64, 1024, C, device='cuda')) for C in (3, 64, 128)] + \
+                 [('DGCNN layer %d input, C=%d' % (i + 1, f.shape[-1]), f.contiguous()) for i, f in enumerate(feats[:4])]
+        for tag, x in inputs:
+            B, N, C = x.shape
+            xd = x.double()
+            d = (xd * xd).sum(-1, keepdim=True) - 2 * xd @ xd.transpose(1, 2) + (xd * xd).sum(-1).unsqueeze(1)
+            dK = d.topk(20, largest=False)[0][:, :, 19]
+            seed = (-(dK * (1 + 1e-5)) - 1e-5).float().contiguous()          # score threshold, slightly loose
+            row = []
+            for name, sd in (('running threshold (product)', None), ('oracle seed', seed)):
+                Lc.sug_knn_abl_set_seed(None if sd is None else ctypes.c_void_p(sd.data_ptr()))
+                Lc.sug_knn_abl_accepted(1)
+                t = time_knn(Lc, x, 20, 20)
+                torch.cuda.synchronize()
+                acc = Lc.sug_knn_abl_accepted(1) / (23 * B * N)
+                row.append('%s: %.1f us, %.1f accepted candidates per query' % (name, t, acc))
+            Lc.sug_knn_abl_set_seed(None)
+            print('%-34s product build %.1f us | counting build: %s' % (tag, time_knn(Lp, x, 20, 20), ' | '.join(row)), flush=True)
+        sys.exit(0)
     libs = [(t, build(t.replace(' ', '_').replace(',', '').replace('+', 'p'), d)) for t, d in variants]
     for C in (3, 64, 128):
         x = torch.randn(64, 1024, C, device='cuda')
