@@ -203,6 +203,38 @@ class Pointnet2_g(nn.Module):
         """Point counts of the farthest_point_sample calls of one forward, in call order."""
         return [N, self.sa1.npoint]
 
+    def plan_geometry(self, xyz, passes, groups=1):
+        """Sampling and grouping indices of `passes` forwards over the same batch xyz [B,3,N,1], in one set of launches
+        (not in the reference; used by SUGStep: the semantic and the node pass of a step).  FPS and ball query read the
+        coordinates and the start draws only; the draws are made here, in the order the `passes` forwards would make them
+        (per pass and domain group: sa1's, then sa2's -- pointnet2_utils.py:72), so the random stream is unchanged.
+        Returns a list of per-pass plans for ops.GEOMETRY_PLAN."""
+        if self.normal_channel or self.sa1.group_all or self.sa2.group_all:
+            return None
+        loc = ops.cloud_rows(xyz)[:, :, :3].contiguous()
+        B, N = loc.shape[0], loc.shape[1]
+        S1, S2 = self.sa1.npoint, self.sa2.npoint
+        st1, st2 = [], []
+        for _ in range(passes):
+            if ops.START_PROVIDER is not None or groups == 1:
+                st1.append(ops.draw_start(B, N))
+                st2.append(ops.draw_start(B, S1))
+            else:                   # one forward per domain group in the reference: group 0 draws (N, S1), then group 1
+                d = [[torch.randint(0, n, (B // groups,), dtype=torch.long) for n in (N, S1)] for _ in range(groups)]
+                st1.append(torch.cat([d[g][0] for g in range(groups)]))
+                st2.append(torch.cat([d[g][1] for g in range(groups)]))
+        dev = loc.device
+        cat_starts = lambda sts: torch.cat([t.to(device=dev, dtype=torch.int32, non_blocking=True) for t in sts])
+        locp = loc.repeat(passes, 1, 1) if passes > 1 else loc
+        f1 = ops.fps(locp, S1, cat_starts(st1))
+        nx1 = ops.gather_rows(locp, f1)
+        i1 = ops.ball_query(locp, nx1, self.sa1.radius, self.sa1.nsample)
+        f2 = ops.fps(nx1, S2, cat_starts(st2))
+        nx2 = ops.gather_rows(nx1, f2)
+        i2 = ops.ball_query(nx1, nx2, self.sa2.radius, self.sa2.nsample)
+        return [[(nx1[p * B:(p + 1) * B], i1[p * B:(p + 1) * B]), (nx2[p * B:(p + 1) * B], i2[p * B:(p + 1) * B])]
+                for p in range(passes)]
+
     def forward(self, xyz, node=False, feat_grad=True):
         """feat_grad=False: the caller discards `feat` (node-adaptation pass): everything behind the layer
         the node features are taken from still runs -- it updates BatchNorm running statistics and draws
@@ -469,6 +501,17 @@ class Net_MDA(nn.Module):
             return ops.heads_fused((self.c1, self.c2), x)
         return ops.run_parallel([lambda: self.c1(x, adapt=True), lambda: self.c2(x, adapt=True)])
 
+    def plan_pair_geometry(self, x_pair, passes=2):
+        """Both passes of a step over the paired batch (semantic, then node adaptation): their sampling / grouping
+        indices in one set of launches where the encoder supports it (Pointnet2_g.plan_geometry).  The plans are
+        consumed, in order, by the next `passes` forward_pair calls on the same tensor."""
+        self._geometry = None
+        if hasattr(self.g, 'plan_geometry') and self.training:
+            plans = self.g.plan_geometry(x_pair, passes, groups=2)
+            if plans:
+                import weakref
+                self._geometry = (weakref.ref(x_pair), plans)
+
     def forward_pair(self, x_pair, node_adaptation=False, paired_out=False):
         """Both domains in one encoder pass (not in the reference; used by SUGStep).
         x_pair = cat(source batch, target batch) [2B,3,N,1].  Equivalent to
@@ -484,12 +527,26 @@ class Net_MDA(nn.Module):
         assert B2 % 2 == 0
         B = B2 // 2
         queue = None
-        if ops.START_PROVIDER is None:
+        geom = getattr(self, '_geometry', None)
+        geometry = None
+        if geom is not None:
+            if geom[0]() is x_pair and geom[1]:
+                geometry = geom[1].pop(0)           # this pass's indices were computed (and its starts drawn) up front
+            if not geom[1] or geom[0]() is not x_pair:
+                self._geometry = None
+        if ops.START_PROVIDER is None and geometry is None:
             # CPU-generator draws in the reference's order: all FPS calls of the source forward,
             # then all of the target forward
             plan = self.g.fps_plan(x_pair.size(2)) if hasattr(self.g, 'fps_plan') else [x_pair.size(2)]
             draws = [[torch.randint(0, n, (B,), dtype=torch.long) for n in plan] for _ in range(2)]
             queue = [torch.cat((draws[0][c], draws[1][c])) for c in range(len(plan))]
+        keep_plan, ops.GEOMETRY_PLAN = ops.GEOMETRY_PLAN, (list(geometry) if geometry is not None else None)
+        try:
+            return self._forward_pair(x_pair, node_adaptation, paired_out, queue, B, B2)
+        finally:
+            ops.GEOMETRY_PLAN = keep_plan
+
+    def _forward_pair(self, x_pair, node_adaptation, paired_out, queue, B, B2):
         with ops.bn_groups(2), ops.start_queue(queue), ops.deferred_bn_counts():
             if node_adaptation:
                 x, feat_ori, _ = self.g(x_pair, node=True, feat_grad=False)     # only the node features are used

@@ -55,6 +55,13 @@ def sample_and_group_idx(npoint, radius, nsample, xyz):
     """The index half of sample_and_group (model/pointnet2_utils.py:107-124): same FPS start draw and kernels,
     -> new_xyz [B,S,3], idx [B,S,nsample] int32; the grouped tensor itself is not formed."""
     B, N, _ = xyz.shape
+    plan = ops.GEOMETRY_PLAN
+    if plan:
+        new_xyz, idx = plan.pop(0)              # computed up front for this pass (Pointnet2_g.plan_geometry)
+        if new_xyz.shape != (B, npoint, 3) or idx.shape != (B, npoint, nsample):
+            raise RuntimeError('geometry plan does not match the encoder: %s / %s for (%d, %d, %d)' % (
+                tuple(new_xyz.shape), tuple(idx.shape), B, npoint, nsample))
+        return new_xyz, idx
     start = ops.draw_start(B, N)
     fps_idx = ops.fps(xyz, npoint, start)
     new_xyz = ops.gather_rows(xyz, fps_idx)

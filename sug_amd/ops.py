@@ -93,6 +93,14 @@ def start_queue(q):
         START_QUEUE = old
 
 
+# Geometry of several encoder passes over ONE batch, computed up front (Pointnet2_g.plan_geometry): farthest-point sampling and
+# ball query depend on the coordinates and the start draws only, so the semantic and the node pass of a step can share
+# their launches (FPS is one workgroup per cloud and `npoint` dependent rounds: 128 clouds fill half of the chip for
+# 0.34 ms; both passes in one launch take the same 0.34 ms).  A list of (new_xyz, idx) per sample_and_group call, in call
+# order; pointnet2_utils.sample_and_group_idx pops from it.
+GEOMETRY_PLAN = None
+
+
 def draw_start(B, N):
     if START_PROVIDER is not None:
         return START_PROVIDER(B, N)

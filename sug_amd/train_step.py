@@ -382,6 +382,8 @@ class SUGStep:
         fused_ce = None
         if self.pair_domains and data.shape == data_t.shape and model.training:
             pair = torch.cat((data, data_t), dim=0)
+            if mmd_on and M['MMD_WEIGHT'] > 0 and hasattr(model, 'plan_pair_geometry') and os.environ.get('SUG_PLAN_GEOMETRY', '1') != '0':
+                model.plan_pair_geometry(pair, passes=2)    # FPS / ball query of the semantic AND the node pass in one set of launches
             plain_ce = isinstance(self.criterion, nn.CrossEntropyLoss) and self.criterion.weight is None \
                 and self.criterion.reduction == 'mean' and self.criterion.label_smoothing == 0.0 \
                 and M['ADV_WEIGHT'] <= 0 and M['TARGET_LOSS'] <= 0
@@ -599,6 +601,8 @@ class SUGStep:
             try:
                 model._cuts = S['cuts'] = []
                 pair = torch.cat((data, data_t), dim=0)
+                if mmd_on and hasattr(model, 'plan_pair_geometry') and os.environ.get('SUG_PLAN_GEOMETRY', '1') != '0':
+                    model.plan_pair_geometry(pair, passes=2)
                 (p_s1, p_s2, f_s1, f_s2), (p_t1, p_t2, f_t1, f_t2) = model.forward_pair(pair)
                 S['loss_cls'] = (0.5 * M_['SRC_LOSS_WEIGHT'] * M_['CLS_WEIGHT']) * (self.criterion(p_s1, label) +
                                                                                    self.criterion(p_s2, label))

@@ -520,3 +520,37 @@ def test_prefix_cache_is_keyed_on_tensor_identity_not_on_the_address(model_name)
             outs.append(net(b, mid_feat=True))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), \
         'a batch at a reused address was served the previous batch\'s cached prefix'
+
+
+def test_planned_geometry_of_both_passes_is_the_same_step(monkeypatch):
+    """PointNet++: the farthest-point sampling / ball query of the semantic and the node pass of a step run as ONE set of
+    launches over both passes (Pointnet2_g.plan_geometry) -- same start draws in the same order, same kernels on the same
+    coordinates, so losses, gradients and BatchNorm buffers are bit-identical to the pass-by-pass form."""
+    from bench import BENCH_METHODS, synth
+    from sug_amd.model.Model import Net_MDA
+    from sug_amd.train_step import SUGStep
+    res = []
+    for planned in ('1', '0'):
+        monkeypatch.setenv('SUG_PLAN_GEOMETRY', planned)
+        net = Net_MDA('Pointnet2')
+        net.load_state_dict(O.fill_params({k: tuple(v.shape) for k, v in net.state_dict().items()}, 4))
+        for m in net.modules():
+            if isinstance(m, torch.nn.Dropout2d):
+                m.p = 0.0
+        net = net.cuda().train()
+        tr = SUGStep(net, lr=0.0, weight_decay=0.0, methods=BENCH_METHODS)
+        data = synth(4, 2048, 11, 'cuda')
+        torch.manual_seed(123)
+        lc, lg, ls = tr.losses(*data)
+        (lc + lg + ls).backward()
+        nxt = int(torch.randint(0, 1 << 30, (1,)))               # the CPU generator is left where the other form leaves it
+        res.append(([float(lc), float(lg), float(ls)], {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None},
+                    {k: v.clone() for k, v in net.state_dict().items() if 'running' in k}, nxt))
+    assert res[0][0] == res[1][0], (res[0][0], res[1][0])
+    assert res[0][3] == res[1][3]
+    for k in res[1][2]:
+        assert torch.equal(res[0][2][k], res[1][2][k]), k
+    gmax = max(float(g.abs().max()) for g in res[1][1].values())
+    for k in res[1][1]:
+        # (the first SA layer's backward sums over unsorted reverse lists: order not fixed run to run)
+        torch.testing.assert_close(res[0][1][k], res[1][1][k], rtol=1e-4, atol=1e-6 * gmax)
