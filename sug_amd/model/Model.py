@@ -152,6 +152,10 @@ class DGCNN(nn.Module):
         self._prefix_cache[key] = _PrefixEntry((x1, x2), (st1, st2), source=x)
         return x1, x2
 
+    def plan_geometry(self, x, passes, groups=1):
+        """FPS + ball query of the SA-node module for `passes` forwards over the same batch, in one set of launches."""
+        return self.node_fea_adapt.plan_geometry(ops.cloud_rows(x), passes, groups)
+
     def forward(self, x, node=False, knn_idx=None, feat_grad=True):
         """x [B,3,N,1] -> (feat [B,1024], node_fea [B,64,64,1](, None)).
         `knn_idx` (4 tensors [B,N,k]) overrides the neighbour graphs (tests: teacher forcing).
@@ -299,6 +303,10 @@ class Pointnet_g(nn.Module):
             self._prefix_cache.clear()
         self._prefix_cache[key] = _PrefixEntry((y,), rec, source=x)
         return y
+
+    def plan_geometry(self, x, passes, groups=1):
+        """FPS + ball query of the SA-node module (conv3) for `passes` forwards over the same batch, in one set of launches."""
+        return self.conv3.plan_geometry(ops.cloud_rows(x), passes, groups)
 
     def forward(self, x, node=False, feat_grad=True):
         """feat_grad=False: node-adaptation pass, the stage behind the SA-node module runs without autograd."""

@@ -192,10 +192,16 @@ class adapt_layer_off(nn.Module):
         """fea [B,N,64], loc [B,N,3] -> (out [B,N,128], node_fea [B,num_node,64], node_off [B,num_node,3])."""
         B, N, _ = loc.shape
         S = self.num_node
-        start = ops.draw_start(B, N)           # CPU generator, point_utils.py:17
-        fidx = ops.fps(loc, S, start)                                 # [B,S]
-        f_loc = ops.gather_rows(loc, fidx)                            # [B,S,3]
-        gidx = ops.ball_query(loc, f_loc, 0.3, 64)                    # [B,S,64]
+        plan = ops.GEOMETRY_PLAN
+        if plan:
+            fidx, f_loc, gidx = plan.pop(0)    # computed up front for this pass (plan_geometry below)
+            if fidx.shape != (B, S) or gidx.shape[:2] != (B, S):
+                raise RuntimeError('geometry plan does not match the SA-node module')
+        else:
+            start = ops.draw_start(B, N)           # CPU generator, point_utils.py:17
+            fidx = ops.fps(loc, S, start)                                 # [B,S]
+            f_loc = ops.gather_rows(loc, fidx)                            # [B,S,3]
+            gidx = ops.ball_query(loc, f_loc, 0.3, 64)                    # [B,S,64]
         # pred_offset on (fea_j - fea_c) is linear before the tanh: project once (one GEMM), then
         # gather / tanh / weight / mean in one kernel (sug_node_offset_*)
         w_off = self.pred_offset[0].weight.view(self.offset_dim, -1)
@@ -215,6 +221,26 @@ class adapt_layer_off(nn.Module):
         else:
             out = torch.cat((fea, point_utils.interpolate_rows(loc, n_loc, node_fea, 3)), dim=2)
         return out, node_fea, node_off
+
+    def plan_geometry(self, loc, passes, groups=1):
+        """The coordinate-only part of `passes` forwards over the same clouds loc [B,N,3] -- FPS start draws (in the order
+        the forwards would make them), FPS, the sampled coordinates, the radius-0.3 ball query -- in one set of launches
+        (SUGStep: the semantic and the node pass of a step).  -> per pass [(fidx, f_loc, gidx)] for ops.GEOMETRY_PLAN."""
+        B, N, _ = loc.shape
+        S = self.num_node
+        starts = []
+        for _ in range(passes):
+            if ops.START_PROVIDER is not None or groups == 1:
+                starts.append(ops.draw_start(B, N))
+            else:
+                starts.append(torch.cat([torch.randint(0, N, (B // groups,), dtype=torch.long) for _ in range(groups)]))
+        dev = loc.device
+        st = torch.cat([t.to(device=dev, dtype=torch.int32, non_blocking=True) for t in starts])
+        locp = loc.repeat(passes, 1, 1) if passes > 1 else loc
+        fidx = ops.fps(locp, S, st)
+        f_loc = ops.gather_rows(locp, fidx)
+        gidx = ops.ball_query(locp, f_loc, 0.3, 64)
+        return [[(fidx[p * B:(p + 1) * B], f_loc[p * B:(p + 1) * B], gidx[p * B:(p + 1) * B])] for p in range(passes)]
 
     def forward(self, input_fea, input_loc):
         """input_fea [B,64,N,1], input_loc [B,3,N] -> (output_fea [B,128,N,1], node_fea [B,64,S,1],

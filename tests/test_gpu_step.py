@@ -522,9 +522,10 @@ def test_prefix_cache_is_keyed_on_tensor_identity_not_on_the_address(model_name)
         'a batch at a reused address was served the previous batch\'s cached prefix'
 
 
-def test_planned_geometry_of_both_passes_is_the_same_step(monkeypatch):
-    """PointNet++: the farthest-point sampling / ball query of the semantic and the node pass of a step run as ONE set of
-    launches over both passes (Pointnet2_g.plan_geometry) -- same start draws in the same order, same kernels on the same
+@pytest.mark.parametrize('model_name,N', [('Pointnet2', 2048), ('DGCNN', 1024), ('Pointnet', 1024)])
+def test_planned_geometry_of_both_passes_is_the_same_step(monkeypatch, model_name, N):
+    """The farthest-point sampling / ball query of the semantic and the node pass of a step (PointNet++'s two SA layers; the
+    SA-node module of DGCNN / PointNet) run as ONE set of launches over both passes (plan_geometry) -- same start draws in the same order, same kernels on the same
     coordinates: the classification / semantic losses and the BatchNorm buffers are bit-identical to the pass-by-pass form
     (the geometric MMD term carries the Chamfer weights, whose float atomics are not ordered: 1e-6)."""
     from bench import BENCH_METHODS, synth
@@ -533,14 +534,14 @@ def test_planned_geometry_of_both_passes_is_the_same_step(monkeypatch):
     res = []
     for planned in ('1', '0'):
         monkeypatch.setenv('SUG_PLAN_GEOMETRY', planned)
-        net = Net_MDA('Pointnet2')
+        net = Net_MDA(model_name)
         net.load_state_dict(O.fill_params({k: tuple(v.shape) for k, v in net.state_dict().items()}, 4))
         for m in net.modules():
             if isinstance(m, torch.nn.Dropout2d):
                 m.p = 0.0
         net = net.cuda().train()
         tr = SUGStep(net, lr=0.0, weight_decay=0.0, methods=BENCH_METHODS)
-        data = synth(4, 2048, 11, 'cuda')
+        data = synth(4, N, 11, 'cuda')
         torch.manual_seed(123)
         lc, lg, ls = tr.losses(*data)
         (lc + lg + ls).backward()
