@@ -555,5 +555,6 @@ def test_planned_geometry_of_both_passes_is_the_same_step(monkeypatch, model_nam
         assert torch.equal(res[0][2][k], res[1][2][k]), k
     gmax = max(float(g.abs().max()) for g in res[1][1].values())
     for k in res[1][1]:
-        # (the first SA layer's backward sums over unsorted reverse lists: order not fixed run to run)
-        torch.testing.assert_close(res[0][1][k], res[1][1][k], rtol=1e-4, atol=1e-6 * gmax)
+        # (the first SA layer's backward sums over unsorted reverse lists: order not fixed run to run; conv biases in front
+        # of BatchNorm have true gradient 0 and carry only that noise)
+        torch.testing.assert_close(res[0][1][k], res[1][1][k], rtol=1e-4, atol=1e-5 * gmax)
