@@ -107,6 +107,10 @@ SIGNATURES = {
     'sug_pointmlp_max_bwd_sparse': [_vp, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp],
     'sug_mmd_rbf': [_vp, _i64, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp],
     'sug_chamfer': [_vp, _vp, _i32, _i32, _i32, _vp, _vp],
+    'sug_sa_first_geo_fwd': [_vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _f32, _f32,
+                             _vp, _vp, _vp, _vp, _vp, _vp],
+    'sug_sa_first_geo_bwd': [_vp, _vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp,
+                             _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     'sug_calayer_supported': [_i32, _i32, _i32, _i32],
     'sug_calayer_fwd': [_i32, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     'sug_calayer_bwd': [_i32, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],

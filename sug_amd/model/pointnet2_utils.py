@@ -108,9 +108,18 @@ class PointNetSetAbstraction(nn.Module):
             new_xyz, idx = sample_and_group_idx(self.npoint, self.radius, self.nsample, xyz)
             conv = self.mlp_convs[0]
             w = conv.weight.view(conv.weight.shape[0], -1)
-            P = ops.linear_rows(xyz if points is None else torch.cat((xyz, points), dim=-1), w)
-            Q = ops.sub_row_bias(ops.linear_rows(new_xyz, w[:, :3]), conv.bias)
-            g = ops.sa_first_layer(P, Q, idx, self.mlp_bns[0])
+            if ops.SA_FIRST_GEO and xyz.shape[-1] == 3:
+                # coordinate part from the difference the reference forms: y = Pf[j] + b + Wx.(x_j - c_s) (sug_sa_first_geo_*);
+                # Px and Q only route the gradients of Wx and b (their values are not read by the kernel)
+                wx = w[:, :3].contiguous()
+                Px = ops.linear_rows(xyz, wx)
+                Pf = None if points is None else ops.linear_rows(points, w[:, 3:].contiguous())
+                Q = ops.sub_row_bias(ops.linear_rows(new_xyz, wx), conv.bias)
+                g = ops.sa_first_layer_geo(Pf, Px, Q, idx, xyz, new_xyz, wx, conv.bias, self.mlp_bns[0])
+            else:
+                P = ops.linear_rows(xyz if points is None else torch.cat((xyz, points), dim=-1), w)
+                Q = ops.sub_row_bias(ops.linear_rows(new_xyz, w[:, :3]), conv.bias)
+                g = ops.sa_first_layer(P, Q, idx, self.mlp_bns[0])
             first = 1
         else:
             new_xyz, g = sample_and_group(self.npoint, self.radius, self.nsample, xyz, points)

@@ -655,6 +655,73 @@ class _SAFirstLayer(torch.autograd.Function):
         return dP, dQ, None, rf[C:], rf[:C], None, None, None, None, None, None
 
 
+class _SAFirstLayerGeo(torch.autograd.Function):
+    """relu(BN(Pf[idx] + b + Wx . (xyz[idx] - new_xyz))) over the ball-query lists (sug_sa_first_geo_fwd / bwd): the first
+    layer of a set-abstraction MLP with the coordinate part taken from the difference the reference forms.  Px (= Wx . xyz
+    per point) and Q (= Wx . new_xyz - b per centroid) enter only as autograd nodes: their VALUES are not read, their
+    gradients (dP, dQ) route the loss to Wx and b through the ordinary linear backward."""
+
+    @staticmethod
+    def forward(ctx, Pf, Px, Q, idx, xyz, cent, Wx, bias, gamma, beta, running_mean, running_var, training, eps, momentum, G):
+        _need_gpu(Px, Q, idx, xyz)
+        idx = _i32(idx).contiguous()
+        B, N, C = Px.shape
+        S, ns = idx.shape[1], idx.shape[2]
+        if B % G:
+            raise RuntimeError('sa_first_layer: %d clouds do not split into %d domain groups' % (B, G))
+        dev = Px.device
+        Pfc = None if Pf is None else Pf.detach().contiguous()
+        xyz, cent = xyz.detach().contiguous(), cent.detach().contiguous()
+        Wxc = Wx.detach().contiguous()
+        bc = None if bias is None else bias.detach().contiguous()
+        g, b = gamma.detach().contiguous(), beta.detach().contiguous()
+        if training:
+            coef = torch.empty(G, 5, C, dtype=torch.float32, device=dev)
+        else:
+            coef = eval_coef(g, b, running_mean, running_var, eps).unsqueeze(0).repeat(G, 1, 1)
+        Z = torch.empty(B, S, ns, C, dtype=torch.float32, device=dev)
+        ws = torch.empty(STATS_BLOCKS * 2 * C, dtype=torch.float32, device=dev)
+        check(lib().sug_sa_first_geo_fwd(_p(Pfc), C, _p(xyz), _p(cent), _p(Wxc), 3, _p(bc), _p(idx), B, N, S, ns, C, G, _p(g), _p(b),
+                                         1 if training else 0, eps, momentum, _p(running_mean), _p(running_var), _p(coef), _p(Z),
+                                         _p(ws), _st()), 'sug_sa_first_geo_fwd')
+        saved = [idx, coef, xyz, cent, Wxc] + ([Pfc] if Pfc is not None else []) + ([bc] if bc is not None else [])
+        ctx.save_for_backward(*saved)
+        ctx.meta = (bool(training), G, Pfc is not None, bc is not None, N, C)
+        return Z
+
+    @staticmethod
+    def backward(ctx, gz):
+        training, G, has_p, has_b, N, C = ctx.meta
+        sv = list(ctx.saved_tensors)
+        idx, coef, xyz, cent, Wxc = sv[:5]
+        Pfc = sv[5] if has_p else None
+        bc = sv[5 + int(has_p)] if has_b else None
+        B, S, ns = idx.shape
+        dev = gz.device
+        gz = gz.contiguous()
+        red = torch.zeros(G + 1, 2 * C, dtype=torch.float64, device=dev)
+        dP = torch.empty(B, N, C, dtype=torch.float32, device=dev)
+        dQ = torch.empty(B, S, C, dtype=torch.float32, device=dev)
+        rf = torch.empty(2 * C, dtype=torch.float32, device=dev)
+        ws = torch.empty(STATS_BLOCKS * 2 * C, dtype=torch.float32, device=dev)
+        off = torch.empty(B, N + 1, dtype=torch.int32, device=dev)
+        ent = torch.empty(B, S * ns, dtype=torch.int32, device=dev)
+        segsum = torch.empty(2, B, S, C, dtype=torch.float32, device=dev)
+        check(lib().sug_sa_first_geo_bwd(_p(gz), _p(Pfc), C, _p(xyz), _p(cent), _p(Wxc), 3, _p(bc), _p(idx), B, N, S, ns, C, G,
+                                         1 if training else 0, _p(coef), _p(red), _p(off), _p(ent), _p(segsum), _p(dP), _p(dQ),
+                                         _p(ws), _p(rf), _st()), 'sug_sa_first_geo_bwd')
+        return (dP if has_p else None), dP, dQ, None, None, None, None, None, rf[C:], rf[:C], None, None, None, None, None, None
+
+
+SA_FIRST_GEO = _os.environ.get('SUG_SA_FIRST_GEO', '1') != '0'  # 0: the P[j] - Q[s] form of round 2 (A/B, diagnostics)
+
+
+def sa_first_layer_geo(Pf, Px, Q, idx, xyz, cent, Wx, bias, bn):
+    _count_bn_call(bn)
+    return _SAFirstLayerGeo.apply(Pf, Px, Q, idx, xyz, cent, Wx, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                  bn.training, bn.eps, bn.momentum, BN_GROUPS)
+
+
 SA_FIRST = _os.environ.get('SUG_SA_FIRST', '1') != '0'          # 0: grouped tensor + GEMM (the reference's arithmetic) instead
 
 

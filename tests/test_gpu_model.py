@@ -370,19 +370,27 @@ def test_gradient_error_is_fp32_rounding_of_the_reference_arithmetic(name):
         assert a <= 10.0 * b + 1e-4, (k, a, b)
 
 
-def test_pointnet2_gradient_error_statistic_over_8_seeds():
+def test_pointnet2_gradient_error_statistic_over_16_seeds():
     """a single-seed ratio (4.2e-3 for HIP vs 7.4e-4 for the fp32 reference arithmetic, both against
-    fp64) is not a bound.  Here the same measurement over 8 (weight seed, data seed) pairs at B=2, N=2048: per pair the
+    fp64) is not a bound.  Here the same measurement over 16 (weight seed, data seed) pairs at B=2, N=2048: per pair the
     ratio r = (HIP error vs fp64) / (fp32-oracle error vs fp64).  If the HIP backward were biased, r would sit above 1 on
     every seed; if the deviation is near-tie noise of the nested max-pools (either fp32 path flips a different handful of
-    winners than fp64), r scatters around 1 with a heavy tail.  Asserted: median r <= 2."""
+    winners than fp64), r scatters around 1 with a heavy tail.
+    Round-4 measurements (tests/diagnostics/diag_pn2_seeds.py, 16 seeds): with the P[j] - Q[s] first layer of round 2 the
+    median ratio was 1.28 and the geometric mean 1.64 (10 of 16 above 1); with the grouped-tensor first layer
+    (SUG_SA_FIRST=0) 1.00 / 1.01 (6 of 16) -- the located cause: P - Q cancels two O(1) terms to a value of the size of
+    the ball radius.  The first layer now forms the coordinate difference first (sug_sa_first_geo_*).  Asserted: median
+    r <= 2 (the bar of the review) and geometric mean <= 2."""
+    import math
     import statistics
     ratios, rows = [], []
-    for i in range(8):
-        e_gpu, e_ref, *_ = _gradient_errors('Pointnet2', 40 + i, 140 + i, B=2)
+    for i in range(16):
+        e_gpu, e_ref, *_ = _gradient_errors('Pointnet2', 40 + i, 140 + i, B=2, verbose=False)
         ratios.append(e_gpu / max(e_ref, 1e-12))
         rows.append((e_gpu, e_ref))
-    print('PointNet++ gradient error vs fp64 over 8 seeds: (HIP, fp32 oracle) = %s' % [('%.2e' % a, '%.2e' % b) for a, b in rows])
-    print('ratio HIP / fp32-oracle: median %.2f, max %.2f, min %.2f' % (statistics.median(ratios), max(ratios), min(ratios)))
-    assert statistics.median(ratios) <= 2.0, ratios
+    gm = math.exp(sum(math.log(r) for r in ratios) / len(ratios))
+    print('PointNet++ gradient error vs fp64 over 16 seeds: (HIP, fp32 oracle) = %s' % [('%.2e' % a, '%.2e' % b) for a, b in rows])
+    print('ratio HIP / fp32-oracle: median %.2f, geometric mean %.2f, max %.2f, min %.2f, above 1: %d of %d' % (
+        statistics.median(ratios), gm, max(ratios), min(ratios), sum(r > 1 for r in ratios), len(ratios)))
+    assert statistics.median(ratios) <= 2.0 and gm <= 2.0, ratios
     assert max(a for a, _ in rows) <= 2e-2, rows

@@ -21,13 +21,15 @@ def _reference(xyz, points, new_xyz, idx, W, b, bn, groups):
     return torch.cat(outs)
 
 
+@pytest.mark.parametrize('geo', [False, True])
 @pytest.mark.parametrize('B,N,S,ns,D,C,groups,train', [
     (4, 256, 64, 32, 0, 64, 1, True),        # sa1: xyz only
     (4, 128, 32, 64, 128, 128, 2, True),     # sa2: xyz + 128 features, paired domains
     (2, 200, 50, 20, 5, 64, 1, True),        # ragged sizes, ns not a multiple of the row batch
     (4, 128, 32, 64, 128, 128, 1, False),    # eval mode (running statistics)
 ])
-def test_sa_first_layer_vs_torch(B, N, S, ns, D, C, groups, train):
+def test_sa_first_layer_vs_torch(B, N, S, ns, D, C, groups, train, geo):
+    """geo: the round-4 form y = Pf[j] + b + Wx.(x_j - c_s) (sug_sa_first_geo_*); else P[j] - Q[s] (sug_sa_first_*)."""
     from sug_amd import ops
     g = torch.Generator().manual_seed(B + N + C)
     xyz = torch.rand(B, N, 3, generator=g).cuda()
@@ -57,9 +59,16 @@ def test_sa_first_layer_vs_torch(B, N, S, ns, D, C, groups, train):
     Wk, bk = W.clone().requires_grad_(True), b.clone().requires_grad_(True)
     pk = points.clone().requires_grad_(True) if D else None
     with ops.bn_groups(groups):
-        P = ops.linear_rows(xyz if pk is None else torch.cat((xyz, pk), dim=-1), Wk)
-        Q = ops.linear_rows(new_xyz, Wk[:, :3]) - bk
-        out = ops.sa_first_layer(P, Q, idx, bn_k)
+        if geo:
+            wx = Wk[:, :3].contiguous()
+            Px = ops.linear_rows(xyz, wx)
+            Pf = None if pk is None else ops.linear_rows(pk, Wk[:, 3:].contiguous())
+            Q = ops.sub_row_bias(ops.linear_rows(new_xyz, wx), bk)
+            out = ops.sa_first_layer_geo(Pf, Px, Q, idx, xyz, new_xyz, wx, bk, bn_k)
+        else:
+            P = ops.linear_rows(xyz if pk is None else torch.cat((xyz, pk), dim=-1), Wk)
+            Q = ops.linear_rows(new_xyz, Wk[:, :3]) - bk
+            out = ops.sa_first_layer(P, Q, idx, bn_k)
     (out * probe).sum().backward()
 
     torch.testing.assert_close(out, ref, rtol=1e-4, atol=1e-4)
@@ -109,3 +118,37 @@ def test_sa_first_layer_config3_shape_is_finite():
     # variable lies in (0.2, 0.6) whatever its shape
     m = outs[0].view(2, -1, C).mean(dim=1)
     assert float(m.min()) > 0.2 and float(m.max()) < 0.6
+
+
+def test_sa_first_geo_form_has_the_reference_conditioning():
+    """Why the geometric form: with coordinates of O(1) and neighbours inside a ball of radius 0.2, P[j] - Q[s] subtracts two
+    O(|W| |x|) numbers to get one of O(|W| r); y = b + Wx.(x_j - c_s) forms the small difference first, as the reference's
+    grouped tensor does.  Against fp64 the pre-activations of the geo form are at least 2x closer than those of P - Q (measured
+    ~5x), and within 2x of the reference composition's own fp32 error."""
+    from sug_amd import ops
+    g = torch.Generator().manual_seed(7)
+    B, N, S, ns, C = 2, 2048, 256, 32, 64
+    xyz = (torch.rand(B, N, 3, generator=g) * 2 - 1).cuda()
+    new_xyz = xyz[:, :S].clone()
+    # neighbours inside a small ball: offsets of size 0.2
+    off = (torch.rand(B, S, ns, 3, generator=g) * 0.4 - 0.2).cuda()
+    idx = torch.randint(0, N, (B, S, ns), generator=g, dtype=torch.int32).cuda()
+    bi = torch.arange(B, device='cuda').view(B, 1, 1)
+    xyz = xyz.clone()
+    xyz[bi.expand(B, S, ns).reshape(-1), idx.long().reshape(-1)] = (new_xyz.view(B, S, 1, 3) + off).reshape(-1, 3)
+    W = torch.randn(C, 3, generator=g).cuda()
+    b = (torch.randn(C, generator=g) * 0.1).cuda()
+    bn = torch.nn.BatchNorm1d(C).cuda().eval()              # eval mode with unit statistics: z = relu(y) shows y itself
+    with torch.no_grad():
+        bn.running_var.fill_(1.0 - bn.eps)
+        d64 = (xyz.double()[bi, idx.long()] - new_xyz.double().view(B, S, 1, 3)) @ W.double().t() + b.double()
+        ref32 = (xyz[bi, idx.long()] - new_xyz.view(B, S, 1, 3)) @ W.t() + b
+        P = ops.linear_rows(xyz, W)
+        Q = ops.linear_rows(new_xyz, W) - b
+        y_pq = ops.sa_first_layer(P, Q, idx, bn)
+        y_geo = ops.sa_first_layer_geo(None, P, Q, idx, xyz, new_xyz, W, b, bn)
+    pos = d64 > 0.05                                        # compare where the ReLU passes the value
+    e = lambda y: float(((y.double() - d64)[pos]).abs().max())
+    e_pq, e_geo, e_ref = e(y_pq), e(y_geo), e(ref32)
+    print('max |y - fp64| on the passing entries: P - Q %.2e, geometric %.2e, reference composition in fp32 %.2e' % (e_pq, e_geo, e_ref))
+    assert e_geo <= 0.5 * e_pq and e_geo <= 2.0 * e_ref + 1e-7
