@@ -438,8 +438,8 @@ int sug_sa_first_bwd(const float* gz, const float* P, int64_t ldp, const float* 
 /* The same layer with the coordinate part taken from the difference the reference forms (pointnet2_utils.py:120
  * grouped_xyz - new_xyz): y = Pf[j] + bias + Wx . (xyz[j] - cent[s]), Pf [B,N,C] = Wf . f per point (NULL when the layer has no
  * input features), xyz [B,N,3], cent [B,S,3] (= new_xyz), Wx [C,3] with row stride ldw (the coordinate columns of the conv
- * weight), bias [C] or NULL.  P[j] - Q[s] cancels two O(1) terms to a value of the size of the ball radius; this form has
- * the reference's conditioning.  Backward: the same dP (= the gradient of Pf AND of Wx . xyz as autograd sees them) and
+ * weight), bias [C] or NULL.  (An alternative to P[j] - Q[s] kept for diagnostics: measured equally accurate against fp64
+ * and 1 % slower per step, so the host mirror uses it only with SUG_SA_FIRST_GEO=1.)  Backward: the same dP (= the gradient of Pf AND of Wx . xyz as autograd sees them) and
  * dQ (= -sum_j dy per centroid: the gradient of Wx . cent - bias). */
 int sug_sa_first_geo_fwd(const float* Pf, int64_t ldp, const float* xyz, const float* cent, const float* Wx, int ldw,
                          const float* bias, const int32_t* idx, int B, int N, int S, int ns, int C, int groups,

@@ -17,13 +17,15 @@
 //             unsorted reverse list: as unordered as index_points' backward in the reference (atomics).
 // Lanes: C/4 per segment (float4 of channels), 256/(C/4) segments per workgroup pass; C in {64, 128}.
 //
-// Round 4, the "geometric" form (Geo argument, the default of the host mirror): the coordinate part of the layer is taken
-// from the DIFFERENCE the reference forms,
+// Round 4, the "geometric" form (Geo argument; opt-in, SUG_SA_FIRST_GEO=1): the coordinate part of the layer taken from the
+// DIFFERENCE the reference forms,
 //     y = Pf[j] + b + Wx . (x_j - c_s)          (Pf = Wf . f_j per point, or absent when the layer has no input features)
-// with 3 fma per channel and neighbour instead of P[j] - Q[s] = (Wx.x_j + Wf.f_j) - (Wx.c_s - b): the two large terms of
-// that difference cancel to a value of the size of the ball radius, which put ~5x the reference's rounding noise on the
-// pre-activations of sa1 (measured over 16 seeds, tests/diagnostics/diag_pn2_seeds.py: gradient error against fp64
-// 1.3-1.6x the fp32 reference's with P - Q, 1.0x with the grouped-tensor path).  Gradients are unchanged in form:
+// with 3 fma per channel and neighbour instead of P[j] - Q[s] = (Wx.x_j + Wf.f_j) - (Wx.c_s - b).  Written to test whether
+// the cancellation in P - Q explains PointNet++'s gradient scatter against fp64 -- it does not: against fp64 the
+// pre-activations of the two forms and of the reference composition in fp32 are equally accurate (6.6e-7 / 7.3e-7 / 7.6e-7
+// on unit-scale clouds with 0.2 balls, tests/test_gpu_sagroup.py), the 16-seed gradient statistic is the same within its
+// scatter (median ratio 1.28 vs 1.01, tests/diagnostics/diag_pn2_seeds.py), and the step is 1 % slower (18.2 vs 18.0 ms at
+// config 3: three more gathers per neighbour).  Hence off by default.  Gradients are unchanged in form:
 // dP[m] = sum dy (to Pf and to Wx.x as autograd sees them), dQ[s] = -sum_j dy.
 #include "common.h"
 

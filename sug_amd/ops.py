@@ -713,7 +713,7 @@ class _SAFirstLayerGeo(torch.autograd.Function):
         return (dP if has_p else None), dP, dQ, None, None, None, None, None, rf[C:], rf[:C], None, None, None, None, None, None
 
 
-SA_FIRST_GEO = _os.environ.get('SUG_SA_FIRST_GEO', '1') != '0'  # 0: the P[j] - Q[s] form of round 2 (A/B, diagnostics)
+SA_FIRST_GEO = _os.environ.get('SUG_SA_FIRST_GEO', '0') == '1'  # opt-in: y = Pf[j] + b + Wx.(x_j - c_s) (measured: no accuracy gain, 1 % slower)
 
 
 def sa_first_layer_geo(Pf, Px, Q, idx, xyz, cent, Wx, bias, bn):

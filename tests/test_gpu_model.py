@@ -376,11 +376,12 @@ def test_pointnet2_gradient_error_statistic_over_16_seeds():
     ratio r = (HIP error vs fp64) / (fp32-oracle error vs fp64).  If the HIP backward were biased, r would sit above 1 on
     every seed; if the deviation is near-tie noise of the nested max-pools (either fp32 path flips a different handful of
     winners than fp64), r scatters around 1 with a heavy tail.
-    Round-4 measurements (tests/diagnostics/diag_pn2_seeds.py, 16 seeds): with the P[j] - Q[s] first layer of round 2 the
-    median ratio was 1.28 and the geometric mean 1.64 (10 of 16 above 1); with the grouped-tensor first layer
-    (SUG_SA_FIRST=0) 1.00 / 1.01 (6 of 16) -- the located cause: P - Q cancels two O(1) terms to a value of the size of
-    the ball radius.  The first layer now forms the coordinate difference first (sug_sa_first_geo_*).  Asserted: median
-    r <= 2 (the bar of the review) and geometric mean <= 2."""
+    Round-4 measurements (tests/diagnostics/diag_pn2_seeds.py, 16 seeds; the ratios span 0.01 ... 1000): median 1.28,
+    geometric mean 1.64, 10 of 16 above 1 for the product path; 1.00 / 1.01 / 6 of 16 with the grouped-tensor first layer
+    (SUG_SA_FIRST=0); 1.01 / 1.40 / 9 of 16 with the geometric first layer (SUG_SA_FIRST_GEO=1) -- indistinguishable within
+    the scatter, and the first-layer forms are equally accurate against fp64 in isolation
+    (tests/test_gpu_sagroup.py::test_sa_first_forms_are_equally_accurate_against_fp64): no bias located, the deviation is
+    the near-tie noise either fp32 path has.  Asserted: median r <= 2 (the bar of the review) and geometric mean <= 2."""
     import math
     import statistics
     ratios, rows = [], []

@@ -120,18 +120,18 @@ def test_sa_first_layer_config3_shape_is_finite():
     assert float(m.min()) > 0.2 and float(m.max()) < 0.6
 
 
-def test_sa_first_geo_form_has_the_reference_conditioning():
-    """Why the geometric form: with coordinates of O(1) and neighbours inside a ball of radius 0.2, P[j] - Q[s] subtracts two
-    O(|W| |x|) numbers to get one of O(|W| r); y = b + Wx.(x_j - c_s) forms the small difference first, as the reference's
-    grouped tensor does.  Against fp64 the pre-activations of the geo form are at least 2x closer than those of P - Q (measured
-    ~5x), and within 2x of the reference composition's own fp32 error."""
+def test_sa_first_forms_are_equally_accurate_against_fp64():
+    """Does the cancellation in P[j] - Q[s] (two O(|W| |x|) numbers for a value of O(|W| r)) cost accuracy against the
+    reference's grouped form W.(x_j - c_s)?  Measured on unit-scale clouds with 0.2 balls: no -- against fp64 the
+    pre-activations of P - Q, of the geometric form (sug_sa_first_geo_*) and of the reference composition in fp32 agree to
+    the same 7e-7 (6.6e-7 / 7.3e-7 / 7.6e-7).  Asserted: both kernel forms within 2x the reference composition's own fp32
+    error."""
     from sug_amd import ops
     g = torch.Generator().manual_seed(7)
     B, N, S, ns, C = 2, 2048, 256, 32, 64
     xyz = (torch.rand(B, N, 3, generator=g) * 2 - 1).cuda()
     new_xyz = xyz[:, :S].clone()
-    # neighbours inside a small ball: offsets of size 0.2
-    off = (torch.rand(B, S, ns, 3, generator=g) * 0.4 - 0.2).cuda()
+    off = (torch.rand(B, S, ns, 3, generator=g) * 0.4 - 0.2).cuda()          # neighbours inside a small ball
     idx = torch.randint(0, N, (B, S, ns), generator=g, dtype=torch.int32).cuda()
     bi = torch.arange(B, device='cuda').view(B, 1, 1)
     xyz = xyz.clone()
@@ -151,4 +151,4 @@ def test_sa_first_geo_form_has_the_reference_conditioning():
     e = lambda y: float(((y.double() - d64)[pos]).abs().max())
     e_pq, e_geo, e_ref = e(y_pq), e(y_geo), e(ref32)
     print('max |y - fp64| on the passing entries: P - Q %.2e, geometric %.2e, reference composition in fp32 %.2e' % (e_pq, e_geo, e_ref))
-    assert e_geo <= 0.5 * e_pq and e_geo <= 2.0 * e_ref + 1e-7
+    assert e_geo <= 2.0 * e_ref + 1e-7 and e_pq <= 2.0 * e_ref + 1e-7
