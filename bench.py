@@ -494,11 +494,16 @@ def main():
         for _ in range(2):
             trainer.step(data, lab, data_t, lab_t)
         sync()
-        t1 = time.perf_counter()
-        for _ in range(max(args.eager_steps, 1)):
-            trainer.step(data, lab, data_t, lab_t)
-        sync()
-        eager_ms = 1e3 * (time.perf_counter() - t1) / max(args.eager_steps, 1)
+        gc.collect()
+        gc.disable()
+        try:
+            t1 = time.perf_counter()
+            for _ in range(max(args.eager_steps, 1)):
+                trainer.step(data, lab, data_t, lab_t)
+            sync()
+            eager_ms = 1e3 * (time.perf_counter() - t1) / max(args.eager_steps, 1)
+        finally:
+            gc.enable()
         # per-kernel event timings: a few more eager steps, each queued BEHIND a spin kernel that holds the GPU while the
         # host enqueues the whole step -- the kernels then run back to back and an event pair brackets the kernel alone
         # (launched live, an event pair also spans the host's gap to the next launch whenever the host is the slower side)
@@ -542,11 +547,18 @@ def main():
         for _ in range(3):
             trainer.step(data, lab, data_t, lab_t)
         sync()
-        t1 = time.perf_counter()
-        for _ in range(args.caller_steps):
-            trainer.step(data, lab, data_t, lab_t)
-        sync()
-        caller_ms = 1e3 * (time.perf_counter() - t1) / args.caller_steps
+        # (an eager step creates ~10^4 Python objects; a generation-2 collection of the interpreter inside these few steps
+        # reads as +3 ms per step -- collected before, held off during the window, as for the headline region)
+        gc.collect()
+        gc.disable()
+        try:
+            t1 = time.perf_counter()
+            for _ in range(args.caller_steps):
+                trainer.step(data, lab, data_t, lab_t)
+            sync()
+            caller_ms = 1e3 * (time.perf_counter() - t1) / args.caller_steps
+        finally:
+            gc.enable()
         trainer.pair_domains, trainer.share_prefix = keep
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
