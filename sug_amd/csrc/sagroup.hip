@@ -70,7 +70,7 @@ __device__ __forceinline__ float4 geo_y(const GeoLane& L, const float4& pf, floa
 
 // MODE 0: statistics of y;  MODE 1: z = relu(scale*y + shift);
 // MODE 2: backward sums (g = gz * [u > 0]; sum g, sum g*xhat; per segment sum_j g -> segsum[0], sum_j y -> segsum[1])
-template <int MODE>
+template <int MODE, bool GEO>
 __global__ __launch_bounds__(256) void sa_first_kernel(
     const float* __restrict__ P, int64_t ldp, const float* __restrict__ Q, const int32_t* __restrict__ idx,
     int N, int S, int ns, int C, int64_t seg0, int64_t seg1, int segs_per_block, const float* __restrict__ coef,
@@ -92,9 +92,9 @@ __global__ __launch_bounds__(256) void sa_first_kernel(
     mean = ld4(coef + 2 * C + c); rstd = ld4(coef + 3 * C + c);
   }
   float4 a1 = make_float4(0, 0, 0, 0), a2 = a1;
-  const bool use_geo = geo.xyz != nullptr;
+  constexpr bool use_geo = GEO;            // compile-time: the P - Q instantiation carries none of the geometric code
   GeoLane GL;
-  if (use_geo) GL = geo_lane(geo, c);
+  if constexpr (GEO) GL = geo_lane(geo, c);
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   // MODE 0: sums about the pivot y of the group's first row (common.h); workgroup 0 publishes it for the finalize
   float4 piv = make_float4(0, 0, 0, 0);
@@ -202,6 +202,7 @@ __global__ __launch_bounds__(256) void sa_first_kernel(
 //   dy[e] = scale*g[e] - (scale/M) * (dbeta + xhat[e] * dgamma),  y[e] = P[m] - Q[s],  g[e] = gz[e] * [scale*y + shift > 0]
 // (gz rows are read whole, once each, in reverse-list order), then dQ[s] = -sum_j dy[s,j] from the segment sums
 // sg = sum_j g, sy = sum_j y:  dQ = -(scale*sg - (scale/M) * (ns*dbeta + dgamma*rstd*(sy - ns*mean))).
+template <bool GEO>
 __global__ __launch_bounds__(256) void sa_first_bwd_point_kernel(
     const float* __restrict__ P, int64_t ldp, const float* __restrict__ Q, int N, int S, int ns, int C, int Bg, int bpc,
     const float* __restrict__ coef_all, const double* __restrict__ red_all, int64_t red_stride, float invM,
@@ -212,9 +213,9 @@ __global__ __launch_bounds__(256) void sa_first_bwd_point_kernel(
   const int lp = threadIdx.x % LPS, slot = threadIdx.x / LPS;
   const int c = lp * 4;
   const int b = blockIdx.x / bpc, chunk = blockIdx.x % bpc;
-  const bool use_geo = geo.xyz != nullptr;
+  constexpr bool use_geo = GEO;
   GeoLane GL;
-  if (use_geo) GL = geo_lane(geo, c);
+  if constexpr (GEO) GL = geo_lane(geo, c);
   const float* coef = coef_all + (int64_t)(b / Bg) * 5 * C;
   const double* red = red_all + (int64_t)(b / Bg) * red_stride;
   const float4 scale = ld4(coef + c), shift = ld4(coef + C + c), mean = ld4(coef + 2 * C + c), rstd = ld4(coef + 3 * C + c);
@@ -323,15 +324,23 @@ static int sa_first_fwd(const float* P, int64_t ldp, const float* Q, const int32
     float* cg = coef + (int64_t)g * 5 * C;
     const int64_t s0 = g * segs_g, s1 = s0 + segs_g;
     if (training) {
-      hipLaunchKernelGGL((sa_first_kernel<0>), dim3(pl.nblk), dim3(256), sh, st, P, ldp, Q, idx, N, S, ns, C, s0, s1,
-                         pl.segs_per_block, nullptr, nullptr, nullptr, nullptr, 0, ws, geo);
+      if (geo.xyz)
+        hipLaunchKernelGGL((sa_first_kernel<0, true>), dim3(pl.nblk), dim3(256), sh, st, P, ldp, Q, idx, N, S, ns, C, s0, s1,
+                           pl.segs_per_block, nullptr, nullptr, nullptr, nullptr, 0, ws, geo);
+      else
+        hipLaunchKernelGGL((sa_first_kernel<0, false>), dim3(pl.nblk), dim3(256), sh, st, P, ldp, Q, idx, N, S, ns, C, s0, s1,
+                           pl.segs_per_block, nullptr, nullptr, nullptr, nullptr, 0, ws, geo);
       SUG_LAUNCH_CHECK("sug_sa_first_fwd(stats)");
       if (int rc = sug_stats_finalize(ws, pl.nblk, C, gamma, beta, (double)segs_g * ns, eps, momentum, running_mean,
                                       running_var, cg, st, ws + SUG_PIVOT_OFFSET(C)))
         return rc;
     }
-    hipLaunchKernelGGL((sa_first_kernel<1>), dim3(pl.nblk), dim3(256), 0, st, P, ldp, Q, idx, N, S, ns, C, s0, s1,
-                       pl.segs_per_block, cg, nullptr, Z, nullptr, 0, nullptr, geo);
+    if (geo.xyz)
+      hipLaunchKernelGGL((sa_first_kernel<1, true>), dim3(pl.nblk), dim3(256), 0, st, P, ldp, Q, idx, N, S, ns, C, s0, s1,
+                         pl.segs_per_block, cg, nullptr, Z, nullptr, 0, nullptr, geo);
+    else
+      hipLaunchKernelGGL((sa_first_kernel<1, false>), dim3(pl.nblk), dim3(256), 0, st, P, ldp, Q, idx, N, S, ns, C, s0, s1,
+                         pl.segs_per_block, cg, nullptr, Z, nullptr, 0, nullptr, geo);
     SUG_LAUNCH_CHECK("sug_sa_first_fwd(apply)");
   }
   return SUG_OK;
@@ -386,8 +395,12 @@ static int sa_first_bwd(const float* gz, const float* P, int64_t ldp, const floa
     const float* cg = coef + (int64_t)g * 5 * C;
     double* rg = red + (int64_t)g * 2 * C;
     const int64_t s0 = g * segs_g, s1 = s0 + segs_g;
-    hipLaunchKernelGGL((sa_first_kernel<2>), dim3(pl.nblk), dim3(256), sh, st, P, ldp, Q, idx, N, S, ns, C, s0, s1,
-                       pl.segs_per_block, cg, gz, nullptr, segsum, segsum_stride, ws, geo);
+    if (geo.xyz)
+      hipLaunchKernelGGL((sa_first_kernel<2, true>), dim3(pl.nblk), dim3(256), sh, st, P, ldp, Q, idx, N, S, ns, C, s0, s1,
+                         pl.segs_per_block, cg, gz, nullptr, segsum, segsum_stride, ws, geo);
+    else
+      hipLaunchKernelGGL((sa_first_kernel<2, false>), dim3(pl.nblk), dim3(256), sh, st, P, ldp, Q, idx, N, S, ns, C, s0, s1,
+                         pl.segs_per_block, cg, gz, nullptr, segsum, segsum_stride, ws, geo);
     SUG_LAUNCH_CHECK("sug_sa_first_bwd(reduce)");
     if (int rc = sug_reduce_partials(ws, pl.nblk, 2 * C, rg, st)) return rc;
   }
@@ -396,8 +409,12 @@ static int sa_first_bwd(const float* gz, const float* P, int64_t ldp, const floa
   const int slots = 256 / (C >> 2);
   int bpc = sug_divup(N > S ? N : S, slots);
   while (bpc > 1 && (int64_t)B * bpc > 8192) bpc = (bpc + 1) / 2;
-  hipLaunchKernelGGL(sa_first_bwd_point_kernel, dim3(B * bpc), dim3(256), 0, st, P, ldp, Q, N, S, ns, C, B / groups, bpc,
-                     coef, ru, (int64_t)(training ? 2 * C : 0), invM, gz, rev_off, rev_ent, segsum, segsum_stride, dP, dQ, geo);
+  if (geo.xyz)
+    hipLaunchKernelGGL(sa_first_bwd_point_kernel<true>, dim3(B * bpc), dim3(256), 0, st, P, ldp, Q, N, S, ns, C, B / groups, bpc,
+                       coef, ru, (int64_t)(training ? 2 * C : 0), invM, gz, rev_off, rev_ent, segsum, segsum_stride, dP, dQ, geo);
+  else
+    hipLaunchKernelGGL(sa_first_bwd_point_kernel<false>, dim3(B * bpc), dim3(256), 0, st, P, ldp, Q, N, S, ns, C, B / groups, bpc,
+                       coef, ru, (int64_t)(training ? 2 * C : 0), invM, gz, rev_off, rev_ent, segsum, segsum_stride, dP, dQ, geo);
   SUG_LAUNCH_CHECK("sug_sa_first_bwd(apply)");
   if (dgb) return sug_fold_groups(red, groups, 2 * C, dgb, stream);
   return SUG_OK;
