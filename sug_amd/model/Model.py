@@ -239,14 +239,22 @@ class Pointnet2_g(nn.Module):
         return [[(nx1[p * B:(p + 1) * B], i1[p * B:(p + 1) * B]), (nx2[p * B:(p + 1) * B], i2[p * B:(p + 1) * B])]
                 for p in range(passes)]
 
-    def forward(self, xyz, node=False, feat_grad=True):
+    def forward(self, xyz, node=False, feat_grad=True, need_node=True):
         """feat_grad=False: the caller discards `feat` (node-adaptation pass): everything behind the layer
         the node features are taken from still runs -- it updates BatchNorm running statistics and draws
-        its FPS start -- but without autograd."""
+        its FPS start -- but without autograd.  need_node=False: the caller discards the node features (semantic pass):
+        the max over the groups of sa1's middle layer (a pass over [B,512,32,64]) is not formed."""
         rows = ops.cloud_rows(xyz)                                    # [B,N,3(+3)]
         B = rows.shape[0]
         norm = rows[:, :, 3:].contiguous() if self.normal_channel else None
         loc = rows[:, :, :3].contiguous()
+        if not need_node:
+            l1_xyz, l1_pts = self.sa1.rows(loc, norm)                 # [B,512,3], [B,512,128]
+            with torch.set_grad_enabled(torch.is_grad_enabled() and feat_grad):
+                l2_xyz, l2_pts = self.sa2.rows(l1_xyz, l1_pts)
+                _, l3_pts = self.sa3.rows(l2_xyz, l2_pts)
+            feat = l3_pts.reshape(B, 1024)
+            return (feat, None, None) if node else (feat, None)
         l1_xyz, l1_pts, node_fea = self.sa1.rows(loc, norm, adapt=True, tail_grad=feat_grad)   # [B,512,3], [B,512,128], [B,512,64]
         with torch.set_grad_enabled(torch.is_grad_enabled() and feat_grad):
             l2_xyz, l2_pts = self.sa2.rows(l1_xyz, l1_pts)
@@ -482,11 +490,14 @@ class Net_MDA(nn.Module):
                 node_adaptation_t=False, semantic_adaption=False):
         _check_input(x)
         only_node = (node_adaptation_s or node_adaptation_t) and not (node_vis or mid_feat)
+        only_feat = not (node_vis or mid_feat or node_adaptation_s or node_adaptation_t)
         if only_node:
             x, feat_ori, node_idx = self.g(x, node=True, feat_grad=False)       # the pooled feature is not used
+        elif only_feat and self._g_skips_node():
+            x, feat_ori, node_idx = self.g(x, node=True, need_node=False)       # the node features are not used
         else:
             x, feat_ori, node_idx = self.g(x, node=True)
-        batch_size = feat_ori.size(0)
+        batch_size = (feat_ori if feat_ori is not None else x).size(0)
         if node_vis:
             return node_idx
         if mid_feat:
@@ -501,6 +512,13 @@ class Net_MDA(nn.Module):
         if not semantic_adaption:
             return y1, y2
         return y1, y2, sem_feature1, sem_feature2
+
+    def _g_skips_node(self):
+        """Does the encoder take need_node=False (PointNet++: the node features are a separate reduction there)?"""
+        if not hasattr(self, '_skip_node_ok'):
+            import inspect
+            self._skip_node_ok = 'need_node' in inspect.signature(self.g.forward).parameters
+        return self._skip_node_ok
 
     def _heads(self, x):
         """[(logits, mid feature)] of c1 and c2 on the pooled feature x: one launch per layer for both heads
@@ -558,6 +576,8 @@ class Net_MDA(nn.Module):
         with ops.bn_groups(2), ops.start_queue(queue), ops.deferred_bn_counts():
             if node_adaptation:
                 x, feat_ori, _ = self.g(x_pair, node=True, feat_grad=False)     # only the node features are used
+            elif self._g_skips_node():
+                x, feat_ori, _ = self.g(x_pair, node=True, need_node=False)     # only the pooled feature is used
             else:
                 x, feat_ori, _ = self.g(x_pair, node=True)
         cuts = getattr(self, '_cuts', None)
