@@ -9,7 +9,7 @@ fp16 = len(sys.argv) > 5 and sys.argv[4] == 'fp16'
 caller = len(sys.argv) > 5 and sys.argv[4] == 'caller'
 out = sys.argv[-1]
 os.environ.update(PYTORCH_TUNABLEOP_ENABLED='1', PYTORCH_TUNABLEOP_TUNING='1', PYTORCH_TUNABLEOP_FILENAME=out,
-                  PYTORCH_TUNABLEOP_MAX_TUNING_DURATION_MS='15', PYTORCH_TUNABLEOP_MAX_WARMUP_DURATION_MS='2')
+                  PYTORCH_TUNABLEOP_MAX_TUNING_DURATION_MS=os.environ.get('SUG_TUNE_MS', '15'), PYTORCH_TUNABLEOP_MAX_WARMUP_DURATION_MS='2')
 import torch
 import torch.cuda.tunable as tn
 from bench import synth, BENCH_METHODS
