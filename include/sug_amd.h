@@ -44,8 +44,8 @@ extern "C" {
 
 const char* sug_last_error(void);
 /* ABI version of the loaded library (bumped when a signature changes; 3: sug_adam_step_capturable gained lr_dev,
- * round-3 entry points).  A binding checks sug_abi_version() == SUG_ABI_VERSION of the header it was written against. */
-#define SUG_ABI_VERSION 3
+ * round-3 entry points; 4: sug_chamfer / sug_node_offset_bwd became reproducible -- sug_chamfer takes a workspace).  A binding checks sug_abi_version() == SUG_ABI_VERSION of the header it was written against. */
+#define SUG_ABI_VERSION 4
 int sug_abi_version(void);
 
 /* ---- kNN graph ----------------------------------------------------------
@@ -122,6 +122,15 @@ int sug_gather_rows(const float* feat, int64_t ldf, const int32_t* idx,
 /* dfeat[b, idx[b,s], :] += g[b,s,:]  (dfeat must be zero-initialised by the caller) */
 int sug_scatter_add_rows(const float* g, int64_t ldg, const int32_t* idx,
                          int B, int N, int S, int C, float* dfeat, int64_t ldf, void* stream);
+/* The same sum in ONE fixed order (reproducible bit for bit): sorted reverse lists of idx (which entries name point n,
+ * ascending), then dfeat[b,n,:] = sum over n's entries of g -- every row of dfeat is WRITTEN (no zero fill by the caller).
+ * ws: sug_scatter_rows_workspace(B, N, S) int32.  The reverse lists are built in LDS: sug_scatter_rows_ordered_supported()
+ * is 0 when S entries per cloud do not fit (callers then use sug_scatter_add_rows: atomics, unordered, as the reference's
+ * index_points backward). */
+int64_t sug_scatter_rows_workspace(int B, int N, int S);
+int sug_scatter_rows_ordered_supported(int B, int N, int S);
+int sug_scatter_rows_ordered(const float* g, int64_t ldg, const int32_t* idx, int B, int N, int S, int C,
+                             float* dfeat, int64_t ldf, int32_t* ws, void* stream);
 
 /* out[b,s,c] = max_j feat[b, idx[b,s,j], c], arg[b,s,c] = the winning point index
  * (replaces index_points + torch.max(dim=-1), model/model_utils.py:122-123). */
@@ -622,8 +631,10 @@ int sug_edge_weight_split(const float* in, int Co, int C, int backward, float* o
 /* Chamfer distance per cloud pair (SDA geometric weights; geometric_weights(),
  * model/mmd.py:107-131 -- third-party op in the reference, parity unpinned):
  * out[b] = mean_i min_j |a_i-b_j|^2 + mean_j min_i |a_i-b_j|^2, direct-form distance.
- * a [B,N,3], b [B,M,3], out [B] (caller zeroes). */
-int sug_chamfer(const float* a, const float* b, int B, int N, int M, float* out, void* stream);
+ * a [B,N,3], b [B,M,3], out [B] (written, not accumulated); ws: sug_chamfer_workspace(B, N, M) floats -- the partial sums
+ * of the workgroups, folded per cloud in block order (no float atomics: the value is reproducible run to run). */
+int64_t sug_chamfer_workspace(int B, int N, int M);
+int sug_chamfer(const float* a, const float* b, int B, int N, int M, float* out, float* ws, void* stream);
 
 /* ---- the scalar tail of a step ---------------------------------------------------------------------------
  * Cross entropy of both classifier heads on the source rows of the paired logits (train_dg_single_gpu.py:269-292 with

@@ -27,6 +27,8 @@ SIGNATURES = {
     'sug_three_nn': [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
     'sug_gather_rows': [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp],
     'sug_scatter_add_rows': [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp],
+    'sug_scatter_rows_ordered_supported': [_i32, _i32, _i32],
+    'sug_scatter_rows_ordered': [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp],
     'sug_group_max': [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
     'sug_group_max_bwd': [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp],
     'sug_edgeconv_fwd': [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -106,7 +108,7 @@ SIGNATURES = {
                                    _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
     'sug_pointmlp_max_bwd_sparse': [_vp, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp],
     'sug_mmd_rbf': [_vp, _i64, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp],
-    'sug_chamfer': [_vp, _vp, _i32, _i32, _i32, _vp, _vp],
+    'sug_chamfer': [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
     'sug_sa_first_geo_fwd': [_vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _f32, _f32,
                              _vp, _vp, _vp, _vp, _vp, _vp],
     'sug_sa_first_geo_bwd': [_vp, _vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp,
@@ -147,13 +149,17 @@ def lib():
         L.sug_colsum_workspace.argtypes = [_i64, _i32]
         L.sug_ptran_colsum_workspace.restype = ctypes.c_int64
         L.sug_ptran_colsum_workspace.argtypes = [_i64]
+        L.sug_chamfer_workspace.restype = ctypes.c_int64
+        L.sug_scatter_rows_workspace.restype = ctypes.c_int64
+        L.sug_scatter_rows_workspace.argtypes = [_i32, _i32, _i32]
+        L.sug_chamfer_workspace.argtypes = [_i32, _i32, _i32]
         L.sug_adam_chunk.restype = ctypes.c_int
         L.sug_adam_chunk.argtypes = []
         L.sug_last_error.restype = ctypes.c_char_p
         L.sug_last_error.argtypes = []
         L.sug_abi_version.restype = ctypes.c_int
         L.sug_abi_version.argtypes = []
-        if L.sug_abi_version() != 3:
+        if L.sug_abi_version() != 4:
             raise RuntimeError('sug_amd: ABI version mismatch, rebuild libsug_amd.so')
         _lib = L
     return _lib

@@ -130,6 +130,90 @@ __global__ __launch_bounds__(1024) void node_offset_bwd_lds_kernel(const float* 
   for (int i = threadIdx.x; i < N * 3; i += 1024) db[i] = s_d[i];
 }
 
+// The same without float atomics (the default whenever P >= 1 accumulator planes of the cloud's [N,3] gradient fit LDS): wave w
+// of the workgroup owns the nodes w, w + P, ... and its own plane, and takes them one after the other; inside a node the
+// lanes are its neighbours (64 per trip).  Lanes that name the same point (the ball query pads a short list by repeating
+// its first hit) are combined at the LOWEST such lane in ascending lane order -- found with an LDS integer atomicMin on a
+// per-wave tag table, the duplicates then walked with uniform readlanes -- and that lane adds to the plane with a plain
+// read-modify-write; the node's centre term -sum_j v (lane-strided sums, fixed xor tree) follows.  At the end the planes
+// are folded in plane order.  Every sum has one fixed order: the gradient is reproducible bit for bit (the LDS-atomic
+// kernel above left the order to the hardware, as the reference's index_points backward does).
+template <int P>
+__global__ __launch_bounds__(64 * P) void node_offset_bwd_ordered_kernel(const float* __restrict__ proj,
+                                                                         const float* __restrict__ loc,
+                                                                         const int32_t* __restrict__ fidx,
+                                                                         const int32_t* __restrict__ gidx,
+                                                                         const float* __restrict__ goff, int N, int S,
+                                                                         int ns, float* __restrict__ dproj) {
+  extern __shared__ __attribute__((aligned(16))) float s_o[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* plane = s_o + (size_t)wave * 3 * N;                                   // [P][N*3]
+  int* tag = reinterpret_cast<int*>(s_o + (size_t)P * 3 * N) + (size_t)wave * N;   // [P][N]
+  const int b = blockIdx.x;
+  for (int i = lane; i < 3 * N; i += 64) plane[i] = 0.f;
+  __builtin_amdgcn_wave_barrier();
+  const float* pb = proj + (int64_t)b * N * 3;
+  const float* lb = loc + (int64_t)b * N * 3;
+  const float inv = 1.0f / (float)ns;
+  for (int sn = wave; sn < S; sn += P) {
+    const int e = b * S + sn;
+    int f = fidx[e];
+    f = f < 0 ? 0 : (f >= N ? N - 1 : f);
+    const float pcx = pb[f * 3 + 0], pcy = pb[f * 3 + 1], pcz = pb[f * 3 + 2];
+    const float lcx = lb[f * 3 + 0], lcy = lb[f * 3 + 1], lcz = lb[f * 3 + 2];
+    const float gx = goff[e * 3 + 0] * inv, gy = goff[e * 3 + 1] * inv, gz = goff[e * 3 + 2] * inv;
+    float cx = 0.f, cy = 0.f, cz = 0.f;
+    const int32_t* g = gidx + (int64_t)e * ns;
+    for (int j0 = 0; j0 < ns; j0 += 64) {
+      const int j = j0 + lane;
+      int n = j < ns ? g[j] : -1;
+      if (n >= N) n = -1;
+      float vx = 0.f, vy = 0.f, vz = 0.f;
+      if (n >= 0) {
+        const float tx = tanhf(pb[n * 3 + 0] - pcx), ty = tanhf(pb[n * 3 + 1] - pcy), tz = tanhf(pb[n * 3 + 2] - pcz);
+        vx = gx * (lb[n * 3 + 0] - lcx) * (1.f - tx * tx);
+        vy = gy * (lb[n * 3 + 1] - lcy) * (1.f - ty * ty);
+        vz = gz * (lb[n * 3 + 2] - lcz) * (1.f - tz * tz);
+        tag[n] = 0x7fffffff;
+      }
+      cx += vx; cy += vy; cz += vz;
+      __builtin_amdgcn_wave_barrier();
+      if (n >= 0) atomicMin(&tag[n], lane);
+      __builtin_amdgcn_wave_barrier();
+      const int leader = n >= 0 ? tag[n] : lane;
+      unsigned long long dup = __ballot(leader != lane);
+      float ax = vx, ay = vy, az = vz;
+      while (dup) {
+        const int i = __builtin_ctzll(dup);
+        dup &= dup - 1;
+        const int li = __builtin_amdgcn_readlane(leader, i);
+        const float dx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vx), i));
+        const float dy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vy), i));
+        const float dz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vz), i));
+        const bool mine = lane == li;
+        ax = mine ? ax + dx : ax; ay = mine ? ay + dy : ay; az = mine ? az + dz : az;
+      }
+      if (n >= 0 && leader == lane) {
+        plane[n * 3 + 0] += ax; plane[n * 3 + 1] += ay; plane[n * 3 + 2] += az;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    cx = wave_sum_f(cx); cy = wave_sum_f(cy); cz = wave_sum_f(cz);
+    if (lane == 0) {
+      plane[f * 3 + 0] -= cx; plane[f * 3 + 1] -= cy; plane[f * 3 + 2] -= cz;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+  float* db = dproj + (int64_t)b * N * 3;
+  for (int i = threadIdx.x; i < N * 3; i += 64 * P) {
+    float a = s_o[i];
+#pragma unroll
+    for (int p = 1; p < P; ++p) a += s_o[(size_t)p * 3 * N + i];
+    db[i] = a;
+  }
+}
+
 // 16 lanes x float4 per point (C2 = 64 interpolated channels); generic C2 % 4 == 0 via a loop.
 __global__ __launch_bounds__(256) void interp3_cat_fwd_kernel(const float* __restrict__ fea, int64_t ldf,
                                                               int C1, const float* __restrict__ node,
@@ -357,6 +441,35 @@ extern "C" int sug_node_offset_bwd(const float* proj, const float* loc, const in
   SUG_REQUIRE(B > 0 && N > 0 && S > 0 && ns > 0, "sug_node_offset_bwd: bad shape");
   const int total = B * S;
   hipStream_t st = (hipStream_t)stream;
+  {                                                          // accumulator planes of a cloud fit LDS: fixed summation order
+    static const int unordered = getenv("SUG_NODE_OFFSET_UNORDERED") ? atoi(getenv("SUG_NODE_OFFSET_UNORDERED")) : 0;
+    const size_t per_plane = (size_t)N * 4 * sizeof(float);        // [N,3] floats + [N] tags
+    if (!unordered && per_plane <= 150 * 1024) {
+      if (8 * per_plane <= 150 * 1024) {
+        static SugLdsOptIn note;
+        if (int rc = sug_allow_dynamic_lds(note, &node_offset_bwd_ordered_kernel<8>, 150 * 1024, "sug_node_offset_bwd")) return rc;
+        hipLaunchKernelGGL(node_offset_bwd_ordered_kernel<8>, dim3(B), dim3(512), 8 * per_plane, st, proj, loc, fidx, gidx, goff, N,
+                           S, ns, dproj);
+      } else if (4 * per_plane <= 150 * 1024) {
+        static SugLdsOptIn note;
+        if (int rc = sug_allow_dynamic_lds(note, &node_offset_bwd_ordered_kernel<4>, 150 * 1024, "sug_node_offset_bwd")) return rc;
+        hipLaunchKernelGGL(node_offset_bwd_ordered_kernel<4>, dim3(B), dim3(256), 4 * per_plane, st, proj, loc, fidx, gidx, goff, N,
+                           S, ns, dproj);
+      } else if (2 * per_plane <= 150 * 1024) {
+        static SugLdsOptIn note;
+        if (int rc = sug_allow_dynamic_lds(note, &node_offset_bwd_ordered_kernel<2>, 150 * 1024, "sug_node_offset_bwd")) return rc;
+        hipLaunchKernelGGL(node_offset_bwd_ordered_kernel<2>, dim3(B), dim3(128), 2 * per_plane, st, proj, loc, fidx, gidx, goff, N,
+                           S, ns, dproj);
+      } else {
+        static SugLdsOptIn note;
+        if (int rc = sug_allow_dynamic_lds(note, &node_offset_bwd_ordered_kernel<1>, 150 * 1024, "sug_node_offset_bwd")) return rc;
+        hipLaunchKernelGGL(node_offset_bwd_ordered_kernel<1>, dim3(B), dim3(64), per_plane, st, proj, loc, fidx, gidx, goff, N, S,
+                           ns, dproj);
+      }
+      SUG_LAUNCH_CHECK("sug_node_offset_bwd");
+      return SUG_OK;
+    }
+  }
   if ((size_t)N * 3 * sizeof(float) <= 60 * 1024) {          // the cloud's gradient fits LDS: no global atomics
     hipLaunchKernelGGL(node_offset_bwd_lds_kernel, dim3(B), dim3(1024), (size_t)N * 3 * sizeof(float), st, proj, loc, fidx,
                        gidx, goff, N, S, ns, dproj);

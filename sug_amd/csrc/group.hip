@@ -100,6 +100,89 @@ __global__ __launch_bounds__(256) void copy_rows2d_kernel(const float* __restric
   }
 }
 
+// index_points backward without float atomics: dfeat[b, n, :] = sum of g[b, e, :] over the entries e of n's reverse list
+// (sug_reverse_lists, sorted: ascending e), every destination row written once -- zero for an empty list, so the caller
+// does not zero-fill.  Lanes: C/4 (float4) or C per destination.
+template <int V>
+__global__ __launch_bounds__(256) void gather_sum_rows_kernel(const float* __restrict__ g, int64_t ldg,
+                                                              const int32_t* __restrict__ rev_off,
+                                                              const int32_t* __restrict__ rev_ent, int N, int S, int C,
+                                                              int64_t total, float* __restrict__ dfeat, int64_t ldf) {
+  const int CV = C / V;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int c = (int)(t % CV) * V;
+    const int64_t row = t / CV;        // b*N + n
+    const int64_t b = row / N;
+    const int n = (int)(row - b * N);
+    const int32_t* off = rev_off + b * (N + 1) + n;
+    const int e0 = off[0], e1 = off[1];
+    const int32_t* ent = rev_ent + b * S;
+    float acc[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[v] = 0.f;
+    for (int i = e0; i < e1; ++i) {
+      const float* gr = g + (b * S + ent[i]) * ldg + c;
+      if (V == 4) {
+        const float4 q = *reinterpret_cast<const float4*>(gr);
+        acc[0] += q.x; acc[1] += q.y; acc[2] += q.z; acc[3] += q.w;
+      } else {
+#pragma unroll
+        for (int v = 0; v < V; ++v) acc[v] += gr[v];
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < V; ++v) dfeat[row * ldf + c + v] = acc[v];
+  }
+}
+
+// The same without float atomics for S <= 64 groups per cloud (the SA-node module): a wave per (cloud, channel), lane = group s.
+// Lanes whose groups picked the same point are combined at the LOWEST such lane in ascending s order, and that lane alone
+// stores: one fixed summation order, so the gradient is reproducible bit for bit.  The lowest lane of a point comes from an
+// LDS integer atomicMin on a per-wave tag table (integer atomics are order-free); only the lanes that are not their point's
+// first (the duplicates) are then walked with uniform readlanes.  The workgroup stages a [S][16-channel] panel of arg / g
+// through LDS so that the global reads stay coalesced.
+constexpr int GMB_CH = 16;      // channels per workgroup (4 per wave): 4 x more workgroups than a 64-channel panel
+__global__ __launch_bounds__(256) void group_max_bwd_ordered_kernel(const float* __restrict__ g,
+                                                                    const int32_t* __restrict__ arg, int N, int S, int C,
+                                                                    float* __restrict__ dfeat, int64_t ldf) {
+  extern __shared__ __attribute__((aligned(16))) int s_gm[];
+  int (*s_arg)[GMB_CH + 1] = reinterpret_cast<int (*)[GMB_CH + 1]>(s_gm);                          // [64][17]
+  float (*s_g)[GMB_CH + 1] = reinterpret_cast<float (*)[GMB_CH + 1]>(s_gm + 64 * (GMB_CH + 1));    // [64][17]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int* tag = s_gm + 2 * 64 * (GMB_CH + 1) + wv * N;                                                // [4][N]
+  const int b = blockIdx.y, c0 = blockIdx.x * GMB_CH;
+  const int cc = (C - c0 < GMB_CH) ? C - c0 : GMB_CH;
+  for (int e = threadIdx.x; e < S * GMB_CH; e += 256) {
+    const int sI = e / GMB_CH, c = e % GMB_CH;
+    const bool in = c < cc;
+    const int64_t o = ((int64_t)b * S + sI) * C + c0 + c;
+    s_arg[sI][c] = in ? arg[o] : -1;
+    s_g[sI][c] = in ? g[o] : 0.f;
+  }
+  __syncthreads();
+  for (int c = wv; c < cc; c += 4) {
+    int j = lane < S ? s_arg[lane][c] : -1;
+    if (j >= N) j = -1;
+    const float gv = lane < S ? s_g[lane][c] : 0.f;
+    if (j >= 0) tag[j] = 0x7fffffff;
+    __builtin_amdgcn_wave_barrier();
+    if (j >= 0) atomicMin(&tag[j], lane);
+    __builtin_amdgcn_wave_barrier();
+    const int leader = j >= 0 ? tag[j] : lane;
+    unsigned long long dup = __ballot(leader != lane);
+    float acc = gv;
+    while (dup) {                                   // duplicates in ascending lane order, each added at its point's first lane
+      const int i = __builtin_ctzll(dup);
+      dup &= dup - 1;
+      const int li = __builtin_amdgcn_readlane(leader, i);
+      const float gi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gv), i));
+      acc = (lane == li) ? acc + gi : acc;
+    }
+    if (j >= 0 && leader == lane) dfeat[((int64_t)b * N + j) * ldf + c0 + c] = acc;
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 }  // namespace
 
 extern "C" int sug_gather_rows(const float* feat, int64_t ldf, const int32_t* idx, int B, int N, int S,
@@ -124,6 +207,37 @@ extern "C" int sug_scatter_add_rows(const float* g, int64_t ldg, const int32_t* 
   return SUG_OK;
 }
 
+extern "C" int64_t sug_scatter_rows_workspace(int B, int N, int S) { return (int64_t)B * (N + 1) + (int64_t)B * S; }
+
+extern "C" int sug_scatter_rows_ordered_supported(int B, int N, int S) {
+  int RS = 1;
+  while (RS < 8 && B * RS < 256 && N / (RS * 2) >= 64) RS *= 2;
+  const int Nr = (N + RS - 1) / RS;
+  return ((size_t)(2 * Nr + 32 + (size_t)S) * sizeof(int) <= 160 * 1024) ? 1 : 0;
+}
+
+extern "C" int sug_scatter_rows_ordered(const float* g, int64_t ldg, const int32_t* idx, int B, int N, int S, int C,
+                                        float* dfeat, int64_t ldf, int32_t* ws, void* stream) {
+  SUG_REQUIRE(g && idx && dfeat && ws, "sug_scatter_rows_ordered: null pointer");
+  SUG_REQUIRE(B > 0 && N > 0 && S > 0 && C > 0 && ldf >= C && ldg >= C, "sug_scatter_rows_ordered: bad shape");
+  SUG_REQUIRE(sug_scatter_rows_ordered_supported(B, N, S), "sug_scatter_rows_ordered: %d entries per cloud do not fit the LDS-resident "
+              "reverse-list build (use sug_scatter_add_rows)", S);
+  int32_t* rev_off = ws;
+  int32_t* rev_ent = ws + (int64_t)B * (N + 1);
+  hipStream_t st = (hipStream_t)stream;
+  if (int rc = sug_reverse_lists(idx, B, S, N, 1, rev_off, rev_ent, st)) return rc;
+  const bool v4 = C % 4 == 0 && ldg % 4 == 0 && ((uintptr_t)g % 16) == 0;
+  const int64_t total = (int64_t)B * N * (v4 ? C / 4 : C);
+  if (v4)
+    hipLaunchKernelGGL((gather_sum_rows_kernel<4>), dim3(ew_grid(total)), dim3(256), 0, st, g, ldg, rev_off, rev_ent, N, S, C, total,
+                       dfeat, ldf);
+  else
+    hipLaunchKernelGGL((gather_sum_rows_kernel<1>), dim3(ew_grid(total)), dim3(256), 0, st, g, ldg, rev_off, rev_ent, N, S, C, total,
+                       dfeat, ldf);
+  SUG_LAUNCH_CHECK("sug_scatter_rows_ordered");
+  return SUG_OK;
+}
+
 extern "C" int sug_group_max(const float* feat, int64_t ldf, const int32_t* idx, int B, int N, int S,
                              int ns, int C, float* out, int32_t* arg, void* stream) {
   SUG_REQUIRE(feat && idx && out && arg, "sug_group_max: null pointer");
@@ -140,6 +254,16 @@ extern "C" int sug_group_max_bwd(const float* g, const int32_t* arg, int B, int 
   SUG_REQUIRE(g && arg && dfeat, "sug_group_max_bwd: null pointer");
   SUG_REQUIRE(B > 0 && N > 0 && S > 0 && C > 0 && ldf >= C, "sug_group_max_bwd: bad shape");
   const int64_t total = (int64_t)B * S * C;
+  static const int unordered = getenv("SUG_GROUP_MAX_UNORDERED") ? atoi(getenv("SUG_GROUP_MAX_UNORDERED")) : 0;
+  const size_t sh = ((size_t)2 * 64 * (GMB_CH + 1) + (size_t)4 * N) * sizeof(int);
+  if (S <= 64 && B <= 65535 && sh <= 150 * 1024 && !unordered) {      // fixed summation order (dfeat zeroed by the caller, as for the atomic form)
+    static SugLdsOptIn note;
+    if (int rc = sug_allow_dynamic_lds(note, &group_max_bwd_ordered_kernel, 150 * 1024, "sug_group_max_bwd")) return rc;
+    hipLaunchKernelGGL(group_max_bwd_ordered_kernel, dim3(sug_divup(C, GMB_CH), B), dim3(256), sh, (hipStream_t)stream, g, arg, N, S, C,
+                       dfeat, ldf);
+    SUG_LAUNCH_CHECK("sug_group_max_bwd");
+    return SUG_OK;
+  }
   hipLaunchKernelGGL(group_max_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, g,
                      arg, N, S, C, total, dfeat, ldf);
   SUG_LAUNCH_CHECK("sug_group_max_bwd");

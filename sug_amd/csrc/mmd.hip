@@ -171,10 +171,11 @@ __global__ __launch_bounds__(256) void mmd_rbf_small_kernel(const float* __restr
     unsafeAtomicAdd(&sums[threadIdx.x], ((s_sum[0][threadIdx.x] + s_sum[1][threadIdx.x]) + s_sum[2][threadIdx.x]) + s_sum[3][threadIdx.x]);
 }
 
-// out[b] += (1/N) * sum_i min_j |a_i - b_j|^2   (one direction; called twice)
+// part[b][blockIdx.x] = sum over this workgroup's points i of min_j |a_i - b_j|^2   (one direction; called twice, then
+// chamfer_fold_kernel adds a cloud's partial sums in block order: no float atomics, the result is reproducible)
 __global__ __launch_bounds__(256) void chamfer_dir_kernel(const float* __restrict__ a,
                                                           const float* __restrict__ bpts, int N, int M,
-                                                          float* __restrict__ out) {
+                                                          float* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) float s_p[];  // M x (x, y, z, pad): one b128 broadcast read per candidate
   const int b = blockIdx.y;                                    // (three b32 reads per candidate made this LDS-issue bound)
   const float* bb = bpts + (int64_t)b * M * 3;
@@ -210,13 +211,22 @@ __global__ __launch_bounds__(256) void chamfer_dir_kernel(const float* __restric
     best = o < best ? o : best;
   }
   best = (cl == 0 && i < N) ? best : 0.f;
-  // one hardware float add per workgroup (atomicAdd(float*) compiles to a compare-and-swap loop here: 128 of them
-  // per cloud on the same address cost more than the distance loop, 91 -> 52 us for both directions)
   __shared__ float s_w[256 / WAVE];
   const float s = wave_sum_f(best);
   if ((threadIdx.x & (WAVE - 1)) == 0) s_w[threadIdx.x / WAVE] = s;
   __syncthreads();
-  if (threadIdx.x == 0) unsafeAtomicAdd(&out[b], (((s_w[0] + s_w[1]) + s_w[2]) + s_w[3]) / (float)N);
+  if (threadIdx.x == 0) part[(int64_t)b * gridDim.x + blockIdx.x] = ((s_w[0] + s_w[1]) + s_w[2]) + s_w[3];
+}
+
+// out[b] = (sum of the nbn partial sums of direction a -> b) / N + (sum of the nbm partial sums of b -> a) / M, block order
+__global__ __launch_bounds__(256) void chamfer_fold_kernel(const float* __restrict__ pn, int nbn, const float* __restrict__ pm,
+                                                           int nbm, int B, float inv_n, float inv_m, float* __restrict__ out) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  float sn = 0.f, sm = 0.f;
+  for (int i = 0; i < nbn; ++i) sn += pn[(int64_t)b * nbn + i];
+  for (int i = 0; i < nbm; ++i) sm += pm[(int64_t)b * nbm + i];
+  out[b] = sn * inv_n + sm * inv_m;
 }
 
 
@@ -392,13 +402,21 @@ extern "C" int sug_mmd_rbf_value(const float* z, int64_t ldz, int m, int D, cons
   return SUG_OK;
 }
 
-extern "C" int sug_chamfer(const float* a, const float* b, int B, int N, int M, float* out,
+extern "C" int64_t sug_chamfer_workspace(int B, int N, int M) {
+  return (int64_t)B * (sug_divup(4 * (int64_t)N, 256) + sug_divup(4 * (int64_t)M, 256));
+}
+
+extern "C" int sug_chamfer(const float* a, const float* b, int B, int N, int M, float* out, float* ws,
                            void* stream) {
-  SUG_REQUIRE(a && b && out, "sug_chamfer: null pointer");
+  SUG_REQUIRE(a && b && out && ws, "sug_chamfer: null pointer");
   SUG_REQUIRE(B > 0 && N > 0 && M > 0 && N <= 5000 && M <= 5000 && B <= 65535, "sug_chamfer: bad shape");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(chamfer_dir_kernel, dim3(sug_divup(4 * N, 256), B), dim3(256), (size_t)M * 4 * sizeof(float), st, a, b, N, M, out);
-  hipLaunchKernelGGL(chamfer_dir_kernel, dim3(sug_divup(4 * M, 256), B), dim3(256), (size_t)N * 4 * sizeof(float), st, b, a, M, N, out);
+  const int nbn = sug_divup(4 * N, 256), nbm = sug_divup(4 * M, 256);
+  float* pm = ws + (int64_t)B * nbn;
+  hipLaunchKernelGGL(chamfer_dir_kernel, dim3(nbn, B), dim3(256), (size_t)M * 4 * sizeof(float), st, a, b, N, M, ws);
+  hipLaunchKernelGGL(chamfer_dir_kernel, dim3(nbm, B), dim3(256), (size_t)N * 4 * sizeof(float), st, b, a, M, N, pm);
+  hipLaunchKernelGGL(chamfer_fold_kernel, dim3(sug_divup(B, 256)), dim3(256), 0, st, ws, nbn, pm, nbm, B, 1.0f / (float)N,
+                     1.0f / (float)M, out);
   SUG_LAUNCH_CHECK("sug_chamfer");
   return SUG_OK;
 }

@@ -10,11 +10,11 @@
 // (b, s) -> ns neighbour indices, gather P rows (a cloud's P matrix stays in L2) and
 //   forward:  batch statistics of y = P[idx] - Q (pass 1), z = relu(BN(y)) written once (pass 2);
 //   backward: BatchNorm sums from gz and the recomputed y, and per segment sum_j g and sum_j y (pass 1); then, by
-//             DESTINATION point over the reverse lists of the ball-query lists (sug_reverse_lists, unsorted),
+//             DESTINATION point over the reverse lists of the ball-query lists (sug_reverse_lists, sorted since round 4),
 //             dP[m] = sum over the rows that gathered m of dy -- plain stores, no atomics (global float atomics
 //             ran this pass at 0.94 ms per call, LDS float adds at 0.45 ms) -- and dQ[s] = -sum_j dy[s,j] in closed
 //             form from the per-segment sums (dy is affine in g and y).  The order of a point's sum follows the
-//             unsorted reverse list: as unordered as index_points' backward in the reference (atomics).
+//             sorted reverse list (ascending row): a fixed order, where index_points' backward in the reference is atomics.
 // Lanes: C/4 per segment (float4 of channels), 256/(C/4) segments per workgroup pass; C in {64, 128}.
 //
 // Round 4, the "geometric" form (Geo argument; opt-in, SUG_SA_FIRST_GEO=1): the coordinate part of the layer taken from the
@@ -390,7 +390,10 @@ static int sa_first_bwd(const float* gz, const float* P, int64_t ldp, const floa
   const float invM = (float)(1.0 / ((double)segs_g * ns));
   const int64_t segsum_stride = (int64_t)B * S * C;
   // which rows gathered each point (order inside a list: as the atomics of the build left it)
-  if (int rc = sug_reverse_lists(idx, B, S * ns, N, 0, rev_off, rev_ent, st)) return rc;
+  // sorted lists: a point's sum runs over its rows in ascending (centroid, neighbour) order -- reproducible bit for bit
+  // (SUG_SA_UNSORTED=1: the lists as the build's atomics left them, the reference's own index_points-backward freedom)
+  static const int unsorted = getenv("SUG_SA_UNSORTED") ? atoi(getenv("SUG_SA_UNSORTED")) : 0;
+  if (int rc = sug_reverse_lists(idx, B, S * ns, N, unsorted ? 0 : 1, rev_off, rev_ent, st)) return rc;
   for (int g = 0; g < groups; ++g) {
     const float* cg = coef + (int64_t)g * 5 * C;
     double* rg = red + (int64_t)g * 2 * C;

@@ -219,15 +219,17 @@ class Pointnet2_g(nn.Module):
         B, N = loc.shape[0], loc.shape[1]
         S1, S2 = self.sa1.npoint, self.sa2.npoint
         st1, st2 = [], []
+        dev = loc.device
         for _ in range(passes):
-            if ops.START_PROVIDER is not None or groups == 1:
+            if groups == 1:
                 st1.append(ops.draw_start(B, N))
                 st2.append(ops.draw_start(B, S1))
             else:                   # one forward per domain group in the reference: group 0 draws (N, S1), then group 1
-                d = [[torch.randint(0, n, (B // groups,), dtype=torch.long) for n in (N, S1)] for _ in range(groups)]
-                st1.append(torch.cat([d[g][0] for g in range(groups)]))
-                st2.append(torch.cat([d[g][1] for g in range(groups)]))
-        dev = loc.device
+                # (the same order in eager and in graph mode -- the graph's start feeder records / replays the group draws --
+                # so a captured step and its eager twin see the same starts)
+                d = [[ops.draw_group_start(B // groups, n) for n in (N, S1)] for _ in range(groups)]
+                st1.append(torch.cat([d[g][0].to(device=dev, dtype=torch.int32, non_blocking=True) for g in range(groups)]))
+                st2.append(torch.cat([d[g][1].to(device=dev, dtype=torch.int32, non_blocking=True) for g in range(groups)]))
         cat_starts = lambda sts: torch.cat([t.to(device=dev, dtype=torch.int32, non_blocking=True) for t in sts])
         locp = loc.repeat(passes, 1, 1) if passes > 1 else loc
         f1 = ops.fps(locp, S1, cat_starts(st1))
@@ -560,11 +562,13 @@ class Net_MDA(nn.Module):
                 geometry = geom[1].pop(0)           # this pass's indices were computed (and its starts drawn) up front
             if not geom[1] or geom[0]() is not x_pair:
                 self._geometry = None
-        if ops.START_PROVIDER is None and geometry is None:
-            # CPU-generator draws in the reference's order: all FPS calls of the source forward,
-            # then all of the target forward
-            plan = self.g.fps_plan(x_pair.size(2)) if hasattr(self.g, 'fps_plan') else [x_pair.size(2)]
-            draws = [[torch.randint(0, n, (B,), dtype=torch.long) for n in plan] for _ in range(2)]
+        plan = self.g.fps_plan(x_pair.size(2)) if hasattr(self.g, 'fps_plan') else [x_pair.size(2)]
+        if geometry is None and (ops.START_PROVIDER is None or len(plan) > 1):
+            # CPU-generator draws in the reference's order: all FPS calls of the source forward, then all of the target
+            # forward.  Under a graph's start feeder the same order is recorded / replayed (one device slice per draw), so a
+            # captured step and its eager twin see the same starts; with ONE FPS call per forward a single draw of 2B
+            # starts is the same stream and needs no concatenation.
+            draws = [[ops.draw_group_start(B, n) for n in plan] for _ in range(2)]
             queue = [torch.cat((draws[0][c], draws[1][c])) for c in range(len(plan))]
         keep_plan, ops.GEOMETRY_PLAN = ops.GEOMETRY_PLAN, (list(geometry) if geometry is not None else None)
         try:

@@ -102,16 +102,23 @@ GEOMETRY_PLAN = None
 
 
 def draw_start(B, N):
-    if START_PROVIDER is not None:
-        return START_PROVIDER(B, N)
-    if START_QUEUE:
+    if START_QUEUE:                 # draws made up front for this forward (Net_MDA.forward_pair: the reference's order)
         t = START_QUEUE.pop(0)
         if t.numel() != B:
             raise RuntimeError('FPS start plan does not match the encoder (%d starts for %d clouds)' % (t.numel(), B))
         return t
+    if START_PROVIDER is not None:
+        return START_PROVIDER(B, N)
     G = BN_GROUPS
     if G > 1 and B % G == 0:        # one CPU-generator draw per reference forward call
         return torch.cat([torch.randint(0, N, (B // G,), dtype=torch.long) for _ in range(G)])
+    return torch.randint(0, N, (B,), dtype=torch.long)
+
+
+def draw_group_start(B, N):
+    """One reference forward's draw (B clouds of one domain group), through the graph's start feeder when one is active."""
+    if START_PROVIDER is not None:
+        return START_PROVIDER(B, N)
     return torch.randint(0, N, (B,), dtype=torch.long)
 
 
@@ -260,6 +267,9 @@ def three_nn(query, cand):
 
 
 # ----------------------------------------------------------------------------- gathers
+SCATTER_ORDERED = __import__('os').environ.get('SUG_SCATTER_ORDERED', '1') != '0'      # index_points backward in a fixed order (0: float atomics)
+
+
 class _GatherRows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feat, idx):
@@ -279,8 +289,15 @@ class _GatherRows(torch.autograd.Function):
         B, N, C = ctx.shape
         S = idx2.shape[1]
         g = g.reshape(B, S, C).contiguous()
+        L = lib()
+        if SCATTER_ORDERED and L.sug_scatter_rows_ordered_supported(B, N, S):
+            # fixed summation order (sorted reverse lists): index_points' backward reproducible bit for bit
+            d = torch.empty(B, N, C, dtype=torch.float32, device=g.device)
+            ws = torch.empty(L.sug_scatter_rows_workspace(B, N, S), dtype=torch.int32, device=g.device)
+            check(L.sug_scatter_rows_ordered(_p(g), C, _p(idx2), B, N, S, C, _p(d), C, _p(ws), _st()), 'sug_scatter_rows_ordered')
+            return d, None
         d = torch.zeros(B, N, C, dtype=torch.float32, device=g.device)
-        check(lib().sug_scatter_add_rows(_p(g), C, _p(idx2), B, N, S, C, _p(d), C, _st()), 'sug_scatter_add_rows')
+        check(L.sug_scatter_add_rows(_p(g), C, _p(idx2), B, N, S, C, _p(d), C, _st()), 'sug_scatter_add_rows')
         return d, None
 
 
@@ -2190,6 +2207,7 @@ def chamfer(a, b):
     a, b = a.detach().contiguous(), b.detach().contiguous()
     B, N, _ = a.shape
     M = b.shape[1]
-    out = torch.zeros(B, dtype=torch.float32, device=a.device)
-    check(lib().sug_chamfer(_p(a), _p(b), B, N, M, _p(out), _st()), 'sug_chamfer')
+    out = torch.empty(B, dtype=torch.float32, device=a.device)
+    ws = torch.empty(lib().sug_chamfer_workspace(B, N, M), dtype=torch.float32, device=a.device)
+    check(lib().sug_chamfer(_p(a), _p(b), B, N, M, _p(out), _p(ws), _st()), 'sug_chamfer')
     return out

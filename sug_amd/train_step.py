@@ -289,9 +289,10 @@ class SUGStep:
             if (self.use_graph and os.environ.get('SUG_GRAPH_GUARD') == '1') else None
         from .optim import Adam as _SugAdam
         AdamCls = _SugAdam if own_adam else torch.optim.Adam
-        # fused small ops (LayerNorm heads) pay off once the host no longer launches; scoped to this trainer's
-        # forwards (set and restored around self.losses())
-        self.fused_heads = self.use_graph
+        # fused small ops (LayerNorm + activation of the heads in one launch); scoped to this trainer's forwards (set and
+        # restored around self.losses()).  On in eager AND in graph mode since round 4: both modes then run the same kernels,
+        # and a captured step equals its eager twin bit for bit (tests/test_gpu_determinism.py)
+        self.fused_heads = on_gpu
         # opt-in (SUG_PARALLEL_BRANCHES=1): independent small-kernel chains (heads, attention layers, MMD terms) on forked
         # streams inside the captured graph.  Measured SLOWER on ROCm 7.2 / MI355X (5.35 vs 5.26 ms per step: a cross-stream
         # edge of a hipGraph costs more than the ~5 us kernels it lets overlap), hence off.

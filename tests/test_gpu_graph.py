@@ -94,11 +94,8 @@ def test_graph_follows_eager_through_lr_schedule_with_one_graph():
             assert len(tr._graphs) == 1, 'one graph serves every learning rate'
             steps = {float(v['step']) for v in tr.optimizer_c.state_dict()['state'].values()}
             assert steps == {float(len(lrs))}, steps
-    for x, y in zip(res[False][0], res[True][0]):
-        assert abs(x - y) <= 1e-5 * max(1.0, abs(x)), res
-    for a, b in zip(res[False], res[True]):
-        for x, y in zip(a, b):
-            assert abs(x - y) <= 2e-2 * max(1.0, abs(x)), res       # same noise bound as two eager runs
+    # every sum of the step has one fixed order (round 4, tests/test_gpu_determinism.py): the captured step IS its eager twin
+    assert res[False] == res[True], res
 
 
 def test_device_lr_is_what_the_update_uses():
@@ -148,9 +145,7 @@ def test_graph_dropped_when_an_optimizer_plan_changes():
             steps = {float(v['step']) for v in tr.optimizer_g.state_dict()['state'].values()}
             assert steps == {6.0}, steps
         res[use_graph] = out
-    for a, b in zip(res[False], res[True]):
-        for x, y in zip(a, b):
-            assert abs(x - y) <= 2e-2 * max(1.0, abs(x)), res
+    assert res[False] == res[True], res         # the re-captured step continues the eager twin's trajectory bit for bit
 
 
 def test_graph_cache_is_bounded():
