@@ -155,54 +155,108 @@ __global__ __launch_bounds__(64 * P) void node_offset_bwd_ordered_kernel(const f
   const float* pb = proj + (int64_t)b * N * 3;
   const float* lb = loc + (int64_t)b * N * 3;
   const float inv = 1.0f / (float)ns;
-  for (int sn = wave; sn < S; sn += P) {
-    const int e = b * S + sn;
-    int f = fidx[e];
-    f = f < 0 ? 0 : (f >= N ? N - 1 : f);
-    const float pcx = pb[f * 3 + 0], pcy = pb[f * 3 + 1], pcz = pb[f * 3 + 2];
-    const float lcx = lb[f * 3 + 0], lcy = lb[f * 3 + 1], lcz = lb[f * 3 + 2];
-    const float gx = goff[e * 3 + 0] * inv, gy = goff[e * 3 + 1] * inv, gz = goff[e * 3 + 2] * inv;
-    float cx = 0.f, cy = 0.f, cz = 0.f;
-    const int32_t* g = gidx + (int64_t)e * ns;
-    for (int j0 = 0; j0 < ns; j0 += 64) {
-      const int j = j0 + lane;
-      int n = j < ns ? g[j] : -1;
-      if (n >= N) n = -1;
-      float vx = 0.f, vy = 0.f, vz = 0.f;
-      if (n >= 0) {
-        const float tx = tanhf(pb[n * 3 + 0] - pcx), ty = tanhf(pb[n * 3 + 1] - pcy), tz = tanhf(pb[n * 3 + 2] - pcz);
-        vx = gx * (lb[n * 3 + 0] - lcx) * (1.f - tx * tx);
-        vy = gy * (lb[n * 3 + 1] - lcy) * (1.f - ty * ty);
-        vz = gz * (lb[n * 3 + 2] - lcz) * (1.f - tz * tz);
-        tag[n] = 0x7fffffff;
-      }
-      cx += vx; cy += vy; cz += vz;
-      __builtin_amdgcn_wave_barrier();
-      if (n >= 0) atomicMin(&tag[n], lane);
-      __builtin_amdgcn_wave_barrier();
-      const int leader = n >= 0 ? tag[n] : lane;
-      unsigned long long dup = __ballot(leader != lane);
-      float ax = vx, ay = vy, az = vz;
-      while (dup) {
-        const int i = __builtin_ctzll(dup);
-        dup &= dup - 1;
-        const int li = __builtin_amdgcn_readlane(leader, i);
-        const float dx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vx), i));
-        const float dy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vy), i));
-        const float dz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vz), i));
-        const bool mine = lane == li;
-        ax = mine ? ax + dx : ax; ay = mine ? ay + dy : ay; az = mine ? az + dz : az;
-      }
-      if (n >= 0 && leader == lane) {
-        plane[n * 3 + 0] += ax; plane[n * 3 + 1] += ay; plane[n * 3 + 2] += az;
-      }
-      __builtin_amdgcn_wave_barrier();
+  // one node's lanes: dedupe (lowest lane of a point collects its duplicates in lane order), add to the plane
+  auto add_node = [&](int n, float vx, float vy, float vz) {
+    if (n >= 0) tag[n] = 0x7fffffff;
+    __builtin_amdgcn_wave_barrier();
+    if (n >= 0) atomicMin(&tag[n], lane);
+    __builtin_amdgcn_wave_barrier();
+    const int leader = n >= 0 ? tag[n] : lane;
+    unsigned long long dup = __ballot(leader != lane);
+    float ax = vx, ay = vy, az = vz;
+    while (dup) {
+      const int i = __builtin_ctzll(dup);
+      dup &= dup - 1;
+      const int li = __builtin_amdgcn_readlane(leader, i);
+      const float dx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vx), i));
+      const float dy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vy), i));
+      const float dz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vz), i));
+      const bool mine = lane == li;
+      ax = mine ? ax + dx : ax; ay = mine ? ay + dy : ay; az = mine ? az + dz : az;
     }
+    if (n >= 0 && leader == lane) {
+      plane[n * 3 + 0] += ax; plane[n * 3 + 1] += ay; plane[n * 3 + 2] += az;
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
+  auto centre = [&](int f, float cx, float cy, float cz) {
     cx = wave_sum_f(cx); cy = wave_sum_f(cy); cz = wave_sum_f(cz);
     if (lane == 0) {
       plane[f * 3 + 0] -= cx; plane[f * 3 + 1] -= cy; plane[f * 3 + 2] -= cz;
     }
     __builtin_amdgcn_wave_barrier();
+  };
+  if (ns <= 64) {
+    // one trip per node; the loads run two nodes ahead of the arithmetic: indices (centre point, this lane's neighbour,
+    // the node's offset gradient) of node k+2 and the gathered rows of node k+1 are in flight while node k is added
+    struct Idx { int f, n; float gx, gy, gz; };
+    struct Val { float pc[3], lc[3], pn[3], ln[3]; };
+    auto load_idx = [&](int sn) {
+      Idx r;
+      const int e = b * S + sn;
+      int f = fidx[e];
+      r.f = f < 0 ? 0 : (f >= N ? N - 1 : f);
+      int n = lane < ns ? gidx[(int64_t)e * ns + lane] : -1;
+      r.n = n >= N ? -1 : n;
+      r.gx = goff[e * 3 + 0] * inv; r.gy = goff[e * 3 + 1] * inv; r.gz = goff[e * 3 + 2] * inv;
+      return r;
+    };
+    auto load_val = [&](const Idx& ix) {
+      Val v;
+      const int n = ix.n >= 0 ? ix.n : ix.f;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        v.pc[d] = pb[ix.f * 3 + d]; v.lc[d] = lb[ix.f * 3 + d];
+        v.pn[d] = pb[n * 3 + d];    v.ln[d] = lb[n * 3 + d];
+      }
+      return v;
+    };
+    Idx i0 = {}, i1 = {};
+    Val v0 = {};
+    if (wave < S) { i0 = load_idx(wave); v0 = load_val(i0); }
+    if (wave + P < S) i1 = load_idx(wave + P);
+    for (int sn = wave; sn < S; sn += P) {
+      const Idx ci = i0;
+      const Val cv = v0;
+      i0 = i1;
+      if (sn + P < S) v0 = load_val(i0);
+      if (sn + 2 * P < S) i1 = load_idx(sn + 2 * P);
+      float vx = 0.f, vy = 0.f, vz = 0.f;
+      if (ci.n >= 0) {
+        const float tx = tanhf(cv.pn[0] - cv.pc[0]), ty = tanhf(cv.pn[1] - cv.pc[1]), tz = tanhf(cv.pn[2] - cv.pc[2]);
+        vx = ci.gx * (cv.ln[0] - cv.lc[0]) * (1.f - tx * tx);
+        vy = ci.gy * (cv.ln[1] - cv.lc[1]) * (1.f - ty * ty);
+        vz = ci.gz * (cv.ln[2] - cv.lc[2]) * (1.f - tz * tz);
+      }
+      add_node(ci.n, vx, vy, vz);
+      centre(ci.f, vx, vy, vz);
+    }
+  } else {
+    for (int sn = wave; sn < S; sn += P) {
+      const int e = b * S + sn;
+      int f = fidx[e];
+      f = f < 0 ? 0 : (f >= N ? N - 1 : f);
+      const float pcx = pb[f * 3 + 0], pcy = pb[f * 3 + 1], pcz = pb[f * 3 + 2];
+      const float lcx = lb[f * 3 + 0], lcy = lb[f * 3 + 1], lcz = lb[f * 3 + 2];
+      const float gx = goff[e * 3 + 0] * inv, gy = goff[e * 3 + 1] * inv, gz = goff[e * 3 + 2] * inv;
+      float cx = 0.f, cy = 0.f, cz = 0.f;
+      const int32_t* g = gidx + (int64_t)e * ns;
+      for (int j0 = 0; j0 < ns; j0 += 64) {
+        const int j = j0 + lane;
+        int n = j < ns ? g[j] : -1;
+        if (n >= N) n = -1;
+        float vx = 0.f, vy = 0.f, vz = 0.f;
+        if (n >= 0) {
+          const float tx = tanhf(pb[n * 3 + 0] - pcx), ty = tanhf(pb[n * 3 + 1] - pcy), tz = tanhf(pb[n * 3 + 2] - pcz);
+          vx = gx * (lb[n * 3 + 0] - lcx) * (1.f - tx * tx);
+          vy = gy * (lb[n * 3 + 1] - lcy) * (1.f - ty * ty);
+          vz = gz * (lb[n * 3 + 2] - lcz) * (1.f - tz * tz);
+        }
+        cx += vx; cy += vy; cz += vz;
+        add_node(n, vx, vy, vz);
+      }
+      centre(f, cx, cy, cz);
+    }
   }
   __syncthreads();
   float* db = dproj + (int64_t)b * N * 3;
