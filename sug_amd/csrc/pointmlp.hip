@@ -14,8 +14,8 @@
 // weight rows stay in registers as the B operand (lane l: channel l&31, k = 2s + (l>>5));
 // 32-row tiles of x stream global -> registers -> LDS (mfma_tile.h) and feed the A operand;
 // y tile (rows x channels) = 16 accumulator registers per lane: channel l&31, rows
-// (r&3) + 8*(r>>2) + 4*(l>>5).  The epilogue of tile t (bias, BN sums, running extreme) is VALU work
-// issued between the MFMAs of tile t+1.
+// (r&3) + 8*(r>>2) + 4*(l>>5).  The epilogue of tile t (bias, BN sums, running extreme) is a block of VALU
+// work behind the MFMA chain of tile t+1 (the tile's LDS staging and global loads surround both).
 //
 // FLOPs 2*R*K*Co on the fp32 matrix pipe (157 TFLOP/s peak); algorithmic bytes
 // 4*R*K (x, once per 128-channel block through L2) + 4*Co*K + 8*(R/L)*Co.
@@ -35,7 +35,6 @@ __global__ __launch_bounds__(256, 2) void pointmlp_max_kernel(
   // ([nrb][Co] floats, then [nrb][Co] ints) and pointmlp_max_combine_kernel picks the first extreme in part order.
   constexpr int RS = CP + 4;
   constexpr int HALF = CP / 2;
-  constexpr int P = HALF / 16;                       // MFMAs per accumulator slot (2 or 4)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* s_tile = reinterpret_cast<float*>(smem);    // [3][TJ][RS]
 
@@ -92,41 +91,40 @@ __global__ __launch_bounds__(256, 2) void pointmlp_max_kernel(
   auto tbuf = [&](int t) { return s_tile + (t % 3) * TJ * RS; };
 
 #define SUG_SB() __builtin_amdgcn_sched_barrier(0)
-  // MFMA chain of the NEXT tile, issued in pieces between the epilogue steps of the CURRENT one
+  // MFMA chain of the NEXT tile, back to back, then the epilogue of the CURRENT one as one block of VALU work.  (Rounds 2-3
+  // issued the chain in pieces between the epilogue steps; on gfx950 fp32 MFMA and VALU do not overlap on a SIMD, so there
+  // is nothing to hide -- measured equal, tools/ab_pointmlp.py: 162.0 vs 162.3 us at 64 x 1024 rows, K = 128, Co = 1024;
+  // 204.7 vs 200.9 us at the sa1 shape -- and this form is the simpler one.)
   auto step = [&](const f32x16& acc_cur, f32x16& acc_next, const float* __restrict__ arow, int t) {
-    float av[HALF];
+    const int lim = nrows - t * TJ - 4 * h;          // rows of this tile that exist, seen from this lane half
+    const int segrow = (row_begin + t * TJ) % L + 4 * h;   // row of the tile's first row inside its segment (L % 32 == 0)
+    auto epi = [&](int c) {
+      const int rt = (c & 3) + 8 * (c >> 2);       // row inside the tile (+ 4h)
+      const bool valid = rt < lim;
+      const float y = __fadd_rn(acc_cur[c], bj);
+      const float yv = valid ? y - pvt : 0.f;
+      s1 += yv;
+      s2 = fmaf(yv, yv, s2);
+      const float tt = valid ? sgn * y : -INFINITY;
+      const bool up = tt > best;                   // strict: the first extreme of a lane's ascending rows wins
+      best = up ? tt : best;
+      barg = up ? segrow + rt : barg;
+    };
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_next[r] = 0.f;
+    SUG_SB();
 #pragma unroll
     for (int g = 0; g < HALF / 4; ++g) {
       const float4 a4 = *reinterpret_cast<const float4*>(arow + 4 * g);
-      av[4 * g + 0] = a4.x; av[4 * g + 1] = a4.y; av[4 * g + 2] = a4.z; av[4 * g + 3] = a4.w;
+      acc_next = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, bq[4 * g + 0], acc_next, 0, 0, 0);
+      acc_next = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, bq[4 * g + 1], acc_next, 0, 0, 0);
+      acc_next = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, bq[4 * g + 2], acc_next, 0, 0, 0);
+      acc_next = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, bq[4 * g + 3], acc_next, 0, 0, 0);
     }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc_next[r] = 0.f;
-    const int lim = nrows - t * TJ - 4 * h;          // rows of this tile that exist, seen from this lane half
-    const int segrow = (row_begin + t * TJ) % L + 4 * h;   // row of the tile's first row inside its segment (L % 32 == 0)
     SUG_SB();
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-      acc_next = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c * P + 0], bq[c * P + 0], acc_next, 0, 0, 0);
-      SUG_SB();
-      {
-        const int rt = (c & 3) + 8 * (c >> 2);       // row inside the tile (+ 4h)
-        const bool valid = rt < lim;
-        const float y = __fadd_rn(acc_cur[c], bj);
-        const float yv = valid ? y - pvt : 0.f;
-        s1 += yv;
-        s2 = fmaf(yv, yv, s2);
-        const float tt = valid ? sgn * y : -INFINITY;
-        const bool up = tt > best;                   // strict: the first extreme of a lane's ascending rows wins
-        best = up ? tt : best;
-        barg = up ? segrow + rt : barg;
-      }
-      SUG_SB();
-#pragma unroll
-      for (int p = 1; p < P; ++p)
-        acc_next = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c * P + p], bq[c * P + p], acc_next, 0, 0, 0);
-      SUG_SB();
-    }
+    for (int c = 0; c < 16; ++c) epi(c);
+    SUG_SB();
   };
 
   // a segment ends with this tile: merge the two lane halves (other rows, same channel) and emit
