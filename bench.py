@@ -141,6 +141,35 @@ def device_kernel_durations(run_steps):
     return out
 
 
+def kernel_timestamps_in_child(args):
+    """device_kernel_durations() of a few replays of the same captured step, run by a child `bench.py --timestamps-child`
+    (same model / batch / launch switches, one rank, no other pass).  None if the child fails or times out."""
+    import subprocess, tempfile
+    out = os.path.join(tempfile.gettempdir(), 'sug_bench_timestamps_%d.json' % os.getpid())
+    cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--model', args.model, '--batch', str(args.batch),
+           '--npoints', str(args.npoints), '--warmup', '3', '--profile-steps', str(max(args.profile_steps, 1)),
+           '--timestamps-child', out]
+    for flag, on in (('--fp16', args.fp16), ('--no-share-prefix', args.no_share_prefix), ('--no-tuned-gemms', args.no_tuned_gemms),
+                     ('--no-pair', args.no_pair)):
+        if on:
+            cmd.append(flag)
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT',
+                                                               'GROUP_RANK', 'ROLE_RANK', 'LOCAL_WORLD_SIZE', 'TORCHELASTIC_RUN_ID')}
+    try:
+        r = subprocess.run(cmd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=600)
+        if r.returncode != 0 or not os.path.exists(out):
+            print('bench.py: kernel-timestamp child failed (rc %s); HIP-event timings stand' % r.returncode, file=sys.stderr)
+            return None
+        with open(out) as f:
+            return json.load(f) or None
+    except Exception as e:
+        print('bench.py: kernel-timestamp child skipped (%s)' % str(e).splitlines()[0], file=sys.stderr)
+        return None
+    finally:
+        if os.path.exists(out):
+            os.remove(out)
+
+
 def kernel_table(profs, exact=None):
     """{name: [(ev0, ev1, shape), ...]} -> {name: launches, avg / total ms, GB/s, TFLOP/s, bound, frac}."""
     kern = {}
@@ -313,6 +342,10 @@ def main():
                          'and exit BEFORE any model / kernel call (launch + rendezvous + relay check; works without a GPU '
                          'with SUG_BENCH_BACKEND=gloo)')
     ap.add_argument('--plain', action='store_true', help='only warm-up + timed steps (for rocprofv3 kernel traces): no extra passes')
+    ap.add_argument('--timestamps-child', default=None, metavar='OUT.json',
+                    help='(internal) warm up, replay --profile-steps captured steps under torch.profiler, write the device '
+                         'kernel durations to OUT.json and exit: bench.py runs this pass in a CHILD process because roctracer '
+                         'under hipGraph replay occasionally crashes the process (segmentation fault in ~1 of 12 runs)')
     ap.add_argument('--eager-steps', type=int, default=10,
                     help='graph mode: extra eager steps after the timed region (per-kernel HIP-event timings, eager ms/step)')
     ap.add_argument('--profile-steps', type=int, default=5,
@@ -426,6 +459,17 @@ def main():
             trainer.step(data, lab, data_t, lab_t)
         sync()
     graph_mode = trainer.use_graph
+    if args.timestamps_child:
+        out = {}
+        if graph_mode:
+            def _replays():
+                for _ in range(max(args.profile_steps, 1)):
+                    trainer.step(data, lab, data_t, lab_t)
+                sync()
+            out = device_kernel_durations(_replays)
+        with open(args.timestamps_child, 'w') as f:
+            json.dump(out, f)
+        return
     # The interpreter's full (generation-2) collection walks every object torch has created so
     # far: a ~70 ms pause that otherwise lands somewhere in the first 20 steps.  Collect now and
     # freeze the survivors (what a long-running training loop reaches after its first minutes).
@@ -445,17 +489,12 @@ def main():
     if graph_mode and not args.plain:
         # kernel durations INSIDE the measured launch mode: the device kernels' own timestamps (torch.profiler = roctracer,
         # what `rocprofv3 --kernel-trace` reads) over a few more replays of the captured step
-        try:
-            def _replays():
-                for _ in range(max(args.profile_steps, 1)):
-                    trainer.step(data, lab, data_t, lab_t)
-                sync()
-            exact_ms = device_kernel_durations(_replays)
-            if not any('knn_pc_kernel' in k for k in exact_ms):
-                exact_ms = None                                  # the tracer did not see inside the graph launches
-        except Exception as e:
-            print('bench.py: kernel-timestamp pass skipped (%s)' % str(e).splitlines()[0], file=sys.stderr)
-            exact_ms = None
+        # -- in a CHILD process (rank 0 only, a one-rank replica of the same step): roctracer under hipGraph replay crashed
+        # the process now and then (segmentation fault after the profiler started, ~1 of 12 runs on ROCm 7.2), and a crash
+        # here must not take the measurement with it; if the child fails, the HIP-event readings below stand
+        exact_ms = kernel_timestamps_in_child(args) if rank == 0 else None
+        if exact_ms is not None and not any('knn_pc_kernel' in k for k in exact_ms):
+            exact_ms = None                                      # the tracer did not see inside the graph launches
     collectives = None
     if (world > 1 or args.segmented) and graph_mode and getattr(trainer, 'segmented', False):
         # per-collective milliseconds (events on the compute stream around the eager RCCL calls between the graph replays)
@@ -513,18 +552,7 @@ def main():
             trainer.step(data, lab, data_t, lab_t)
             sync()
         extra_prof, ops.PROFILE, ops.PROFILE_ONLY = ops.PROFILE, None, set(timed_family)
-        if exact_ms is None:
-            # fall-back: the single-launch ops (kNN) from kernel timestamps of queued eager steps
-            try:
-                def _queued_steps():
-                    for _ in range(max(args.profile_steps, 1)):
-                        hold_gpu(2.5 * eager_ms)
-                        trainer.step(data, lab, data_t, lab_t)
-                        sync()
-                exact_ms = device_kernel_durations(_queued_steps)
-            except Exception as e:                                  # profiler unavailable: the event readings stand
-                print('bench.py: kernel-timestamp pass skipped (%s)' % str(e).splitlines()[0], file=sys.stderr)
-                exact_ms = None
+        # (no in-process profiler pass as a fall-back: if the child failed, the HIP-event readings of the queued steps stand)
     else:
         # the other hand-written layer kernels (EdgeConv layer calls, per-point MLP + max): a few extra steps
         # outside the timed region, for the `kernels` table only

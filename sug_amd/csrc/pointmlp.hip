@@ -71,8 +71,13 @@ __global__ __launch_bounds__(256, 2) void pointmlp_max_kernel(
       bq[4 * g + 3] = h ? hi.w : hi.z;
     }
   }
-  const float bj = bias ? bias[col] : 0.f;
   const float sgn = gamma[col] >= 0.f ? 1.f : -1.f;
+  // The sign of gamma is folded into the weights and the bias: the accumulator then holds sgn * y EXACTLY (negation commutes
+  // with every rounding of the fma chain), the running extreme is a plain maximum, and the BatchNorm sums are taken of
+  // sgn * (y - pivot): sum(sgn * v) = sgn * sum(v) and the squares do not see the sign, so s1 is un-folded once at the end.
+#pragma unroll
+  for (int e = 0; e < HALF; ++e) bq[e] *= sgn;
+  const float bj = bias ? sgn * bias[col] : 0.f;
   // pivot of the BatchNorm sums (common.h): y of the launch's first row for this channel, the same fma chain in every
   // workgroup (each lane half over its half of k, halves added): the sums below are taken about it
   float pvt = 0.f;
@@ -80,8 +85,8 @@ __global__ __launch_bounds__(256, 2) void pointmlp_max_kernel(
     float d = 0.f;
 #pragma unroll
     for (int e = 0; e < HALF; ++e) d = fmaf(x[2 * e + h], bq[e], d);
-    pvt = __fadd_rn(d + __shfl_xor(d, 32), bj);
-    if (rb == 0 && h == 0) ws[SUG_PIVOT_OFFSET(Co) + col] = pvt;
+    pvt = __fadd_rn(d + __shfl_xor(d, 32), bj);          // sgn * (pivot of y)
+    if (rb == 0 && h == 0) ws[SUG_PIVOT_OFFSET(Co) + col] = sgn * pvt;
   }
 
   float s1 = 0.f, s2 = 0.f;                          // BN sums of this lane's rows of this channel
@@ -96,18 +101,18 @@ __global__ __launch_bounds__(256, 2) void pointmlp_max_kernel(
   // is nothing to hide -- measured equal, tools/ab_pointmlp.py: 162.0 vs 162.3 us at 64 x 1024 rows, K = 128, Co = 1024;
   // 204.7 vs 200.9 us at the sa1 shape -- and this form is the simpler one.)
   auto step = [&](const f32x16& acc_cur, f32x16& acc_next, const float* __restrict__ arow, int t) {
-    const int lim = nrows - t * TJ - 4 * h;          // rows of this tile that exist, seen from this lane half
-    const int segrow = (row_begin + t * TJ) % L + 4 * h;   // row of the tile's first row inside its segment (L % 32 == 0)
+    // every tile is full: a workgroup's rows are whole segments (or equal parts of one) and L % 32 == 0
+    const int segrow = (row_begin + t * TJ) % L + 4 * h;   // row of the tile's first row inside its segment
+    // (the bias / pivot / BatchNorm-sum steps as packed fp32 operations -- v_pk_add_f32, v_pk_fma_f32 on register pairs --
+    // measured 2 % SLOWER than the scalar forms below: tools/ab_pointmlp.py, 177.7 vs 173.7 us at the sa1 shape)
     auto epi = [&](int c) {
       const int rt = (c & 3) + 8 * (c >> 2);       // row inside the tile (+ 4h)
-      const bool valid = rt < lim;
-      const float y = __fadd_rn(acc_cur[c], bj);
-      const float yv = valid ? y - pvt : 0.f;
+      const float y = __fadd_rn(acc_cur[c], bj);   // sgn * (x.w + b)
+      const float yv = y - pvt;
       s1 += yv;
       s2 = fmaf(yv, yv, s2);
-      const float tt = valid ? sgn * y : -INFINITY;
-      const bool up = tt > best;                   // strict: the first extreme of a lane's ascending rows wins
-      best = up ? tt : best;
+      const bool up = y > best;                    // strict: the first extreme of a lane's ascending rows wins
+      best = up ? y : best;
       barg = up ? segrow + rt : barg;
     };
 #pragma unroll
@@ -196,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void pointmlp_max_kernel(
   s1 += __shfl_xor(s1, 32);
   s2 += __shfl_xor(s2, 32);
   if (h == 0) {
-    ws[(size_t)rb * 2 * Co + col] = s1;
+    ws[(size_t)rb * 2 * Co + col] = sgn * s1;
     ws[(size_t)rb * 2 * Co + Co + col] = s2;
   }
 }

@@ -1,6 +1,8 @@
 """GPU parity of two full SUG training steps (DGCNN, B=4) against the reference run recorded
 in tests/golden/step_dgcnn.npz: per-step (loss_cls, loss_geo_mmd, loss_sem_mmd) and
 post-step parameter checksums."""
+import os
+
 import pytest
 import torch
 
@@ -390,36 +392,26 @@ def test_fp16_mode_weight_copies_follow_the_optimizer():
 @pytest.mark.parametrize('model_name', ['DGCNN', 'Pointnet', 'Pointnet2', 'PTran', 'PTran_fp16'])
 def test_training_step_issues_no_device_memsets(model_name):
     """A replayed step graph must not contain memset nodes on this stack (they were not reliably
-    ordered under replay -- garbage MMD values, NaN weights).  One step under the profiler: no memset on the device."""
-    from torch.profiler import profile, ProfilerActivity
-    from sug_amd.model.Model import Net_MDA
-    from sug_amd.model import Ptran_transformer as PT
-    from sug_amd.train_step import SUGStep
-    fp16 = model_name.endswith('_fp16')
-    model_name = model_name.split('_')[0]
-    g = torch.Generator().manual_seed(3)
-    B, N = 4, 1024
-    data = (torch.rand(B, 3, N, 1, generator=g) * 2 - 1).cuda()
-    data_t = (torch.rand(B, 3, N, 1, generator=g) * 2 - 1).cuda()
-    label = torch.randint(0, 10, (B,), generator=g).cuda()
-    label_t = torch.randint(0, 10, (B,), generator=g).cuda()
-    torch.manual_seed(1)
-    try:
-        if fp16:
-            PT.GEMM_DTYPE, PT.PROJ_16BIT = torch.float16, True
-        tr = SUGStep(Net_MDA(model_name).cuda().train(), use_graph=False)
-        for _ in range(2):
-            tr.step(data, label, data_t, label_t)
-        torch.cuda.synchronize()
-        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
-            tr.step(data, label, data_t, label_t)
-            torch.cuda.synchronize()
-    finally:
-        PT.GEMM_DTYPE, PT.PROJ_16BIT = None, False
-    names = [k.name for e in prof.events() for k in (e.kernels or [])]
-    assert names, 'the profiler saw no kernels'
-    bad = [n for n in names if 'emset' in n or 'fillBuffer' in n]
-    assert not bad, bad[:5]
+    ordered under replay -- garbage MMD values, NaN weights).  One step under the profiler: no memset on the device.
+    The profiled step runs in a child process (tests/memset_probe.py): the profiler's own teardown crashes the process now
+    and then on this stack (segmentation fault inside stop_trace), which must not take the test run down."""
+    import json
+    import subprocess
+    import sys
+    probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'memset_probe.py')
+    cmd = [sys.executable, probe] + model_name.split('_')
+    res = None
+    for attempt in range(3):
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        lines = [l for l in r.stdout.decode().splitlines() if l.startswith('PROBE ')]
+        if lines:
+            res = json.loads(lines[-1][6:])
+            break
+        assert r.returncode < 0, 'probe failed (rc %d): %s' % (r.returncode, r.stderr.decode()[-800:])     # killed by a signal: retry
+    if res is None:
+        pytest.skip('torch.profiler crashed the probe process three times')
+    assert res['kernels'] > 0, 'the profiler saw no kernels'
+    assert not res['memsets'], res['memsets']
 
 
 def test_automatic_prefix_sharing_is_exact_and_safe():
