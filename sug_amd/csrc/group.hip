@@ -209,11 +209,12 @@ extern "C" int sug_scatter_add_rows(const float* g, int64_t ldg, const int32_t* 
 
 extern "C" int64_t sug_scatter_rows_workspace(int B, int N, int S) { return (int64_t)B * (N + 1) + (int64_t)B * S; }
 
+// knn.hip: LDS bytes of sug_reverse_lists for this shape (declared here, not in common.h: the kNN / fused-EdgeConv PMC traffic
+// files under profiles/ are keyed by a hash of the sources that include common.h)
+size_t sug_reverse_lists_lds_bytes(int B, int E, int N, int* ranges);
+
 extern "C" int sug_scatter_rows_ordered_supported(int B, int N, int S) {
-  int RS = 1;
-  while (RS < 8 && B * RS < 256 && N / (RS * 2) >= 64) RS *= 2;
-  const int Nr = (N + RS - 1) / RS;
-  return ((size_t)(2 * Nr + 32 + (size_t)S) * sizeof(int) <= 160 * 1024) ? 1 : 0;
+  return (B > 0 && N > 0 && S > 0 && sug_reverse_lists_lds_bytes(B, S, N, nullptr) <= 160 * 1024) ? 1 : 0;
 }
 
 extern "C" int sug_scatter_rows_ordered(const float* g, int64_t ldg, const int32_t* idx, int B, int N, int S, int C,

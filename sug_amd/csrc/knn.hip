@@ -357,16 +357,24 @@ extern "C" int sug_knn(const float* x, int64_t ldx, int B, int N, int C, int k, 
   return dispatch_knn_c<32>(x, ldx, B, N, C, k, idx, st);
 }
 
+// LDS bytes of the reverse-list build for B clouds of E entries into N destinations (and its destination ranges per cloud):
+// callers that need to know beforehand whether sug_reverse_lists will take the shape compare this with 160 KB
+size_t sug_reverse_lists_lds_bytes(int B, int E, int N, int* ranges) {
+  int RS = 1;                                    // destination ranges per cloud: >= 256 workgroups when B allows
+  while (RS < 8 && B * RS < 256 && N / (RS * 2) >= 64) RS *= 2;
+  const int Nr = (N + RS - 1) / RS;
+  if (ranges) *ranges = RS;
+  return (size_t)(2 * Nr + 2 * (1024 / 64) + (size_t)E) * sizeof(int);
+}
+
 // reverse lists of B clouds with E index entries each, destinations in [0, N)
 int sug_reverse_lists(const int32_t* idx, int B, int E, int N, int sorted, int32_t* rev_off, int32_t* rev_ent,
                       hipStream_t st) {
   SUG_REQUIRE(idx && rev_off && rev_ent, "sug_reverse_lists: null pointer");
   SUG_REQUIRE(B > 0 && N > 0 && E > 0, "sug_reverse_lists: bad shape");
   constexpr int BLOCK = 1024;
-  int RS = 1;                                    // destination ranges per cloud: >= 256 workgroups when B allows
-  while (RS < 8 && B * RS < 256 && N / (RS * 2) >= 64) RS *= 2;
-  const int Nr = (N + RS - 1) / RS;
-  size_t sh = (size_t)(2 * Nr + 2 * (BLOCK / 64) + (size_t)E) * sizeof(int);
+  int RS = 0;
+  const size_t sh = sug_reverse_lists_lds_bytes(B, E, N, &RS);
   SUG_REQUIRE(sh <= 160 * 1024, "sug_reverse_lists: %d entries per cloud are too many for the LDS-resident build", E);
   static SugLdsOptIn note;
   if (int rc = sug_allow_dynamic_lds(note, &knn_reverse_kernel<BLOCK>, 160 * 1024, "sug_reverse_lists")) return rc;
