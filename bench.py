@@ -141,40 +141,46 @@ def device_kernel_durations(run_steps):
     return out
 
 
-def kernel_timestamps_in_child(args):
-    """device_kernel_durations() of a few replays of the same captured step, run by a child `bench.py --timestamps-child`
-    (same model / batch / launch switches, one rank, no other pass).  None if the child fails or times out."""
+def kernel_timestamps_in_child(args, want_events=False):
+    """A child `bench.py --timestamps-child` (same model / batch / launch switches, ONE rank, no other pass) replays the
+    captured step a few times under torch.profiler and returns {'exact': {kernel: [ms, ...]} or None, 'events': ...}.
+    want_events: the child first times the hand-written families with HIP events on queued eager steps (what a one-rank
+    parent does in-process) -- {name: [[ms, shape], ...]} -- and writes that out before the profiler pass, so it survives a
+    crash of the latter.  Nothing usable -> {'exact': None, 'events': None}."""
     import subprocess, tempfile
     out = os.path.join(tempfile.gettempdir(), 'sug_bench_timestamps_%d.json' % os.getpid())
     cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--model', args.model, '--batch', str(args.batch),
            '--npoints', str(args.npoints), '--warmup', '3', '--profile-steps', str(max(args.profile_steps, 1)),
            '--timestamps-child', out]
     for flag, on in (('--fp16', args.fp16), ('--no-share-prefix', args.no_share_prefix), ('--no-tuned-gemms', args.no_tuned_gemms),
-                     ('--no-pair', args.no_pair)):
+                     ('--no-pair', args.no_pair), ('--child-events', want_events)):
         if on:
             cmd.append(flag)
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT',
                                                                'GROUP_RANK', 'ROLE_RANK', 'LOCAL_WORLD_SIZE', 'TORCHELASTIC_RUN_ID')}
+    res = {'exact': None, 'events': None}
     try:
         r = subprocess.run(cmd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=600)
-        if r.returncode != 0 or not os.path.exists(out):
+        if r.returncode != 0:
             print('bench.py: kernel-timestamp child failed (rc %s); HIP-event timings stand' % r.returncode, file=sys.stderr)
-            return None
-        with open(out) as f:
-            return json.load(f) or None
+        if os.path.exists(out):
+            with open(out) as f:
+                got = json.load(f)
+            res['exact'] = got.get('exact') or None
+            res['events'] = got.get('events') or None
     except Exception as e:
         print('bench.py: kernel-timestamp child skipped (%s)' % str(e).splitlines()[0], file=sys.stderr)
-        return None
     finally:
         if os.path.exists(out):
             os.remove(out)
+    return res
 
 
 def kernel_table(profs, exact=None):
     """{name: [(ev0, ev1, shape), ...]} -> {name: launches, avg / total ms, GB/s, TFLOP/s, bound, frac}."""
     kern = {}
     for name, recs in profs.items():
-        ms = [a.elapsed_time(b) for a, b, _ in recs]
+        ms = [a if b is None else a.elapsed_time(b) for a, b, _ in recs]      # (ms, None, shape): timed by the child process
         ev_total = sum(ms)                 # the ONE timing source every candidate has: used for ranking (ADVICE r3)
         timing = 'HIP events around the C-ABI call'
         needle = DEVICE_KERNEL_OF.get(name)
@@ -346,6 +352,7 @@ def main():
                     help='(internal) warm up, replay --profile-steps captured steps under torch.profiler, write the device '
                          'kernel durations to OUT.json and exit: bench.py runs this pass in a CHILD process because roctracer '
                          'under hipGraph replay occasionally crashes the process (segmentation fault in ~1 of 12 runs)')
+    ap.add_argument('--child-events', action='store_true', help='(internal, with --timestamps-child) also HIP-event timings of eager steps')
     ap.add_argument('--eager-steps', type=int, default=10,
                     help='graph mode: extra eager steps after the timed region (per-kernel HIP-event timings, eager ms/step)')
     ap.add_argument('--profile-steps', type=int, default=5,
@@ -460,15 +467,38 @@ def main():
         sync()
     graph_mode = trainer.use_graph
     if args.timestamps_child:
-        out = {}
+        # Stage A (only when asked: the multi-rank parent has no eager pass of its own): HIP-event readings of every
+        # hand-written family on eager steps queued behind a spin kernel, written out BEFORE stage B can crash.
+        res = {'exact': None, 'events': None}
+        if args.child_events:
+            trainer.use_graph = False
+            for _ in range(2):
+                trainer.step(data, lab, data_t, lab_t)
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                trainer.step(data, lab, data_t, lab_t)
+            sync()
+            ems = 1e3 * (time.perf_counter() - t1) / 3
+            ops.PROFILE_ONLY, ops.PROFILE = set(all_families), {}
+            for _ in range(max(args.profile_steps, 1)):
+                hold_gpu(2.5 * ems)
+                trainer.step(data, lab, data_t, lab_t)
+                sync()
+            res['events'] = {k: [[a.elapsed_time(b), shp] for a, b, shp in v] for k, v in ops.PROFILE.items()}
+            ops.PROFILE, ops.PROFILE_ONLY = None, set(timed_family)
+            trainer.use_graph = graph_mode
+            with open(args.timestamps_child, 'w') as f:
+                json.dump(res, f)
+        # Stage B: the device kernels' own timestamps over a few replays of the captured step
         if graph_mode:
             def _replays():
                 for _ in range(max(args.profile_steps, 1)):
                     trainer.step(data, lab, data_t, lab_t)
                 sync()
-            out = device_kernel_durations(_replays)
+            res['exact'] = device_kernel_durations(_replays)
         with open(args.timestamps_child, 'w') as f:
-            json.dump(out, f)
+            json.dump(res, f)
         return
     # The interpreter's full (generation-2) collection walks every object torch has created so
     # far: a ~70 ms pause that otherwise lands somewhere in the first 20 steps.  Collect now and
@@ -486,15 +516,18 @@ def main():
     prof, ops.PROFILE = ({} if graph_mode else ops.PROFILE), None
     eager_ms = None
     exact_ms = None
+    child_events = None
     if graph_mode and not args.plain:
         # kernel durations INSIDE the measured launch mode: the device kernels' own timestamps (torch.profiler = roctracer,
         # what `rocprofv3 --kernel-trace` reads) over a few more replays of the captured step
         # -- in a CHILD process (rank 0 only, a one-rank replica of the same step): roctracer under hipGraph replay crashed
         # the process now and then (segmentation fault after the profiler started, ~1 of 12 runs on ROCm 7.2), and a crash
         # here must not take the measurement with it; if the child fails, the HIP-event readings below stand
-        exact_ms = kernel_timestamps_in_child(args) if rank == 0 else None
+        child = kernel_timestamps_in_child(args, want_events=(world > 1 or args.segmented)) if rank == 0 else {'exact': None, 'events': None}
+        exact_ms = child['exact']
         if exact_ms is not None and not any('knn_pc_kernel' in k for k in exact_ms):
             exact_ms = None                                      # the tracer did not see inside the graph launches
+        child_events = child['events']
     collectives = None
     if (world > 1 or args.segmented) and graph_mode and getattr(trainer, 'segmented', False):
         # per-collective milliseconds (events on the compute stream around the eager RCCL calls between the graph replays)
@@ -524,12 +557,15 @@ def main():
                                 'each eager collective; bucket1_exposed = wait for bucket 1 after the encoder backward it '
                                 'runs under; bucket1_alone = the same message all-reduced with nothing beside it'
                                 % max(args.profile_steps, 1))
-    if args.plain or ((world > 1 or args.segmented) and graph_mode):        # (multi-rank: nothing but the timed region)
+    if args.plain or ((world > 1 or args.segmented) and graph_mode):
+        # multi-rank: nothing but the timed region in this process; the per-kernel timings of the hand-written families
+        # come from rank 0's one-rank child (the kernels are the same: the per-GPU share is what every rank runs)
         extra_prof = {}
+        if not args.plain and graph_mode and rank == 0 and child_events:
+            extra_prof = {k: [(ms, None, {kk: vv for kk, vv in shp.items()}) for ms, shp in v] for k, v in child_events.items()}
     elif graph_mode:
         # eager steps of the same trainer: per-kernel event timings of every hand-written family + eager ms/step
         trainer.use_graph = False
-        trainer.fused_heads = False             # the eager launch mode as a caller without graphs runs it
         for _ in range(2):
             trainer.step(data, lab, data_t, lab_t)
         sync()

@@ -221,3 +221,32 @@ def test_two_rank_step_rccl():
     if torch.cuda.device_count() < 2:
         pytest.skip('needs 2 HIP devices (RCCL over xGMI)')
     _check(_run('nccl'))
+
+
+def test_bench_two_ranks_end_to_end_gloo_on_one_gpu():
+    """`python bench.py --gpus 2` the way the driver starts a multi-GPU run, with gloo standing in for RCCL and both ranks on
+    the one device of this box: bench.launch_ranks -> torch.distributed.run -> two ranks -> five graph segments around the
+    four collectives -> per-collective milliseconds -> rank 0's one-rank child process for the kernel timings -> ONE JSON
+    line on stdout with roofline, kernels and config.collectives filled in.  (The step time itself means nothing here: two
+    processes share a GPU and gloo moves the gradients through the host.)"""
+    import json
+    import subprocess
+    env = dict(os.environ, SUG_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '3', '--batch', '4',
+                        '--no-cpu-baseline', '--no-other-workloads', '--caller-steps', '0', '--eager-steps', '1', '--profile-steps', '1'],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith('{')]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['value'] > 0 and d['scaling'] == 'weak' and d['config']['parallelism'] == 'dp2'
+    assert d['config']['clouds_per_step'] == 16 and d['config']['launch'].startswith('segmented hipGraph')
+    col = d['config']['collectives']
+    assert col['backend'] == 'gloo' and col['world_size'] == 2
+    assert set(col['ms']) >= {'all_gather_packed', 'sums_all_reduce', 'bucket1_exposed', 'bucket2_all_reduce', 'bucket1_alone'}
+    assert all(v >= 0 for v in col['ms'].values()) and col['bytes']['bucket1'] > col['bytes']['bucket2'] > 0
+    assert d['roofline'] is not None and d['roofline']['kernel'].startswith('knn') and 0 < d['roofline']['frac'] < 1
+    assert any(k.startswith('edgeconv') for k in d['kernels'])
+    assert all(v is not None for v in d['losses'])
