@@ -215,6 +215,10 @@ class Pointnet2_g(nn.Module):
         Returns a list of per-pass plans for ops.GEOMETRY_PLAN."""
         if self.normal_channel or self.sa1.group_all or self.sa2.group_all:
             return None
+        # only sample_and_group_idx consumes a plan: a layer that takes the grouped-tensor path (SUG_SA_FIRST=0, an
+        # unsupported width) draws its own start, so planning would draw twice and break the reference's random stream
+        if not all(sa.takes_index_path() for sa in (self.sa1, self.sa2)):
+            return None
         loc = ops.cloud_rows(xyz)[:, :, :3].contiguous()
         B, N = loc.shape[0], loc.shape[1]
         S1, S2 = self.sa1.npoint, self.sa2.npoint
@@ -488,10 +492,18 @@ class Net_MDA(nn.Module):
         self.c1 = Pointnet_c(dgcnn_flag=self.dgcnn_flag, PTran_flag=self.PTran_flag)
         self.c2 = Pointnet_c(dgcnn_flag=self.dgcnn_flag, PTran_flag=self.PTran_flag)
 
+    # `forward(..., semantic_adaption=True, node_adaptation_s=True)` (or node_adaptation_t) is the opt-in
+    # single-pass dual-output call: ONE encoder evaluation feeds the two heads AND the attention layer.  The reference
+    # (model/Model.py:505-509) tests node_adaptation_* first and would return the attention branch alone for this flag
+    # combination -- which none of its callers passes; set `dual_output_on_both_flags = False` for that literal behaviour.
+    dual_output_on_both_flags = True
+
     def forward(self, x, constant=1, adaptation=False, node_vis=False, mid_feat=False, node_adaptation_s=False,
                 node_adaptation_t=False, semantic_adaption=False):
         _check_input(x)
-        only_node = (node_adaptation_s or node_adaptation_t) and not (node_vis or mid_feat)
+        dual = self.dual_output_on_both_flags and semantic_adaption and (node_adaptation_s or node_adaptation_t) \
+            and not (node_vis or mid_feat)
+        only_node = (node_adaptation_s or node_adaptation_t) and not (node_vis or mid_feat or dual)
         only_feat = not (node_vis or mid_feat or node_adaptation_s or node_adaptation_t)
         if only_node:
             x, feat_ori, node_idx = self.g(x, node=True, feat_grad=False)       # the pooled feature is not used
@@ -504,6 +516,18 @@ class Net_MDA(nn.Module):
             return node_idx
         if mid_feat:
             return x, feat_ori
+        if dual:
+            # what train_dg_single_gpu.py:260-264 + :309-310 obtain from TWO calls on the same batch.  In train mode the
+            # second call recomputes the first one's encoder bit for bit when its FPS start draw is the same (BatchNorm
+            # uses batch statistics, dropout sits in the heads only), so the values and -- one graph instead of two equal
+            # ones -- the gradients are those of the two-call form with tied draws.  Documented differences: ONE FPS
+            # start draw per sampling stage instead of two, BatchNorm running statistics of the encoder updated once.
+            att = self.attention_s if node_adaptation_s else self.attention_t
+            node = att(feat_ori.contiguous().view(batch_size, -1))
+            if adaptation:
+                x = grad_reverse(x, constant)
+            (y1, sem_feature1), (y2, sem_feature2) = self._heads(x)
+            return y1, y2, sem_feature1, sem_feature2, node
         if node_adaptation_s:
             return self.attention_s(feat_ori.contiguous().view(batch_size, -1))
         elif node_adaptation_t:
@@ -540,7 +564,7 @@ class Net_MDA(nn.Module):
                 import weakref
                 self._geometry = (weakref.ref(x_pair), plans)
 
-    def forward_pair(self, x_pair, node_adaptation=False, paired_out=False):
+    def forward_pair(self, x_pair, node_adaptation=False, paired_out=False, dual=False):
         """Both domains in one encoder pass (not in the reference; used by SUGStep).
         x_pair = cat(source batch, target batch) [2B,3,N,1].  Equivalent to
         forward(source, ...) followed by forward(target, ...): every BatchNorm computes its
@@ -549,7 +573,10 @@ class Net_MDA(nn.Module):
         semantic (default): ((y1,y2,f1,f2) of the source, (y1,y2,f1,f2) of the target);
         node_adaptation:    (attention_s(source nodes), attention_t(target nodes));
         paired_out (semantic): (y1, y2, f1, f2) as [2B, ...] tensors, source rows first (the caller scores / splits them
-        itself: ops.ce_pair, ops.split_halves)."""
+        itself: ops.ce_pair, ops.split_halves);
+        dual (the single-pass step): ONE encoder evaluation feeds heads and attention layers -- returns the
+        semantic result (in the form `paired_out` selects) followed by (attention_s(source nodes), attention_t(target
+        nodes)); see forward() for what that changes against the two-pass form."""
         _check_input(x_pair)
         B2 = x_pair.size(0)
         assert B2 % 2 == 0
@@ -572,13 +599,19 @@ class Net_MDA(nn.Module):
             queue = [torch.cat((draws[0][c], draws[1][c])) for c in range(len(plan))]
         keep_plan, ops.GEOMETRY_PLAN = ops.GEOMETRY_PLAN, (list(geometry) if geometry is not None else None)
         try:
-            return self._forward_pair(x_pair, node_adaptation, paired_out, queue, B, B2)
+            out = self._forward_pair(x_pair, node_adaptation, paired_out, queue, B, B2, dual)
+            left = len(ops.GEOMETRY_PLAN or ())
         finally:
             ops.GEOMETRY_PLAN = keep_plan
+        if left:        # a planned entry nobody popped = a sampling stage that drew its start a second time
+            raise RuntimeError('geometry plan of this pass was not consumed by the encoder (%d entries left)' % left)
+        return out
 
-    def _forward_pair(self, x_pair, node_adaptation, paired_out, queue, B, B2):
+    def _forward_pair(self, x_pair, node_adaptation, paired_out, queue, B, B2, dual=False):
         with ops.bn_groups(2), ops.start_queue(queue), ops.deferred_bn_counts():
-            if node_adaptation:
+            if dual:
+                x, feat_ori, _ = self.g(x_pair, node=True)                      # heads AND attention layers read this pass
+            elif node_adaptation:
                 x, feat_ori, _ = self.g(x_pair, node=True, feat_grad=False)     # only the node features are used
             elif self._g_skips_node():
                 x, feat_ori, _ = self.g(x_pair, node=True, need_node=False)     # only the pooled feature is used
@@ -586,17 +619,26 @@ class Net_MDA(nn.Module):
                 x, feat_ori, _ = self.g(x_pair, node=True)
         cuts = getattr(self, '_cuts', None)
         if cuts is not None:            # SUGStep's two-phase backward cuts the graph at the encoder's outputs
-            cuts.append(feat_ori if node_adaptation else x)
+            if dual:
+                cuts.extend((x, feat_ori))
+            else:
+                cuts.append(feat_ori if node_adaptation else x)
         halves = lambda t: ops.split_halves(t.reshape(B2, -1))      # backward: copy-free where the gradients are adjacent
-        if node_adaptation:
+        nodes = None
+        if node_adaptation or dual:
             fo = feat_ori.contiguous().reshape(B2, -1)
             if ops.calayer_supported((self.attention_s, self.attention_t), fo):
                 # both attention layers in one launch per stage, on the paired rows (source rows -> attention_s)
-                return tuple(halves(ops.calayers((self.attention_s, self.attention_t), fo)))
-            f_s, f_t = halves(fo)
-            return tuple(ops.run_parallel([lambda: self.attention_s(f_s), lambda: self.attention_t(f_t)]))
+                nodes = tuple(halves(ops.calayers((self.attention_s, self.attention_t), fo)))
+            else:
+                f_s, f_t = halves(fo)
+                nodes = tuple(ops.run_parallel([lambda: self.attention_s(f_s), lambda: self.attention_t(f_t)]))
+            if not dual:
+                return nodes
         (y1, f1), (y2, f2) = self._heads(x)
         if paired_out:
-            return y1, y2, f1, f2
-        (y1s, y1t), (y2s, y2t), (f1s, f1t), (f2s, f2t) = halves(y1), halves(y2), halves(f1), halves(f2)
-        return (y1s, y2s, f1s, f2s), (y1t, y2t, f1t, f2t)
+            sem = (y1, y2, f1, f2)
+        else:
+            (y1s, y1t), (y2s, y2t), (f1s, f1t), (f2s, f2t) = halves(y1), halves(y2), halves(f1), halves(f2)
+            sem = ((y1s, y2s, f1s, f2s), (y1t, y2t, f1t, f2t))
+        return sem + (nodes,) if dual else sem

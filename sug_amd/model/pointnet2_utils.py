@@ -95,6 +95,12 @@ class PointNetSetAbstraction(nn.Module):
             last = out_channel
         self.group_all = group_all
 
+    def takes_index_path(self):
+        """True if rows() runs its first MLP layer on the neighbour lists (sample_and_group_idx -- the only consumer of an
+        ops.GEOMETRY_PLAN) instead of forming the grouped tensor."""
+        return (not self.group_all) and len(self.mlp_convs) > 1 and \
+            ops.sa_first_layer_supported(self.mlp_convs[0].out_channels)
+
     def rows(self, xyz, points, adapt=False, tail_grad=True):
         """xyz [B,N,3], points [B,N,D] or None -> new_xyz [B,S,3], feats [B,S,D'](, node [B,S,D1]).
         tail_grad=False (with adapt): the layers behind the one the node features come from run without
@@ -102,7 +108,7 @@ class PointNetSetAbstraction(nn.Module):
         first = 0
         if self.group_all:
             new_xyz, g = sample_and_group_all(xyz, points)
-        elif ops.sa_first_layer_supported(self.mlp_convs[0].out_channels) and len(self.mlp_convs) > 1:
+        elif self.takes_index_path():
             # first layer on the neighbour lists: W.[x_j - c_s ; f_j] + b = P[j] - Q[s], P per point, Q per centroid
             # (the grouped [B,S,ns,3+D] tensor and the pre-activation tensor are never formed)
             new_xyz, idx = sample_and_group_idx(self.npoint, self.radius, self.nsample, xyz)

@@ -239,8 +239,13 @@ class _StartFeeder:
 class SUGStep:
     def __init__(self, model, lr=1e-3, weight_decay=5e-5, lr_scaler=1.0, methods=None, criterion=None,
                  global_mmd=True, fused_adam=None, share_prefix=True, use_graph=False, pair_domains=True,
-                 force_segmented=False):
+                 force_segmented=False, single_pass=False):
         self.model = model
+        # ONE encoder evaluation per domain feeds the heads and the attention layers, instead of the
+        # semantic + node pass of train_dg_single_gpu.py:260-264, :309-310.  Same losses and gradients as the two-pass step
+        # whose node pass draws the FPS starts of its semantic pass; differences: one start draw per sampling stage and
+        # step instead of two, the encoder's BatchNorm running statistics move once per step instead of twice.
+        self.single_pass = bool(single_pass)
         self.base_lr, self.lr_scaler = float(lr), float(lr_scaler)
         # source and target batch go through the encoder as one 2B-cloud batch with per-domain
         # BatchNorm statistics (Net_MDA.forward_pair): same results, half the launches
@@ -381,9 +386,12 @@ class SUGStep:
         model = self.model
         pair = None
         fused_ce = None
+        nodes = None                # single_pass: the attention features came out of the semantic forward already
         if self.pair_domains and data.shape == data_t.shape and model.training:
             pair = torch.cat((data, data_t), dim=0)
-            if mmd_on and M['MMD_WEIGHT'] > 0 and hasattr(model, 'plan_pair_geometry') and os.environ.get('SUG_PLAN_GEOMETRY', '1') != '0':
+            dual = self.single_pass and mmd_on and M['MMD_WEIGHT'] > 0
+            if mmd_on and M['MMD_WEIGHT'] > 0 and not dual and hasattr(model, 'plan_pair_geometry') \
+                    and os.environ.get('SUG_PLAN_GEOMETRY', '1') != '0':
                 model.plan_pair_geometry(pair, passes=2)    # FPS / ball query of the semantic AND the node pass in one set of launches
             plain_ce = isinstance(self.criterion, nn.CrossEntropyLoss) and self.criterion.weight is None \
                 and self.criterion.reduction == 'mean' and self.criterion.label_smoothing == 0.0 \
@@ -391,7 +399,10 @@ class SUGStep:
             if plain_ce and os.environ.get('SUG_FUSED_LOSS', '1') != '0':
                 # the paired logits / mid features stay paired: CE of both heads in one launch each way (ops.ce_pair writes the
                 # whole pair's gradient), the halves of the mid features split with a copy-free backward
-                y1, y2, f1, f2 = model.forward_pair(pair, paired_out=True)
+                if dual:
+                    y1, y2, f1, f2, nodes = model.forward_pair(pair, paired_out=True, dual=True)
+                else:
+                    y1, y2, f1, f2 = model.forward_pair(pair, paired_out=True)
                 if y1.dim() == 2 and ops.ce_pair_supported(y1, y2, label):
                     Bs = label.shape[0]
                     fused_ce = ops.ce_pair(y1, y2, label, 0.5 * M['SRC_LOSS_WEIGHT'] * M['CLS_WEIGHT'])
@@ -401,8 +412,15 @@ class SUGStep:
                 else:
                     (pred_s1, pred_t1), (pred_s2, pred_t2) = ops.split_halves(y1), ops.split_halves(y2)
                     (sem_s1, sem_t1), (sem_s2, sem_t2) = ops.split_halves(f1), ops.split_halves(f2)
+            elif dual:
+                (pred_s1, pred_s2, sem_s1, sem_s2), (pred_t1, pred_t2, sem_t1, sem_t2), nodes = \
+                    model.forward_pair(pair, dual=True)
             else:
                 (pred_s1, pred_s2, sem_s1, sem_s2), (pred_t1, pred_t2, sem_t1, sem_t2) = model.forward_pair(pair)
+        elif self.single_pass and mmd_on and M['MMD_WEIGHT'] > 0:
+            pred_s1, pred_s2, sem_s1, sem_s2, node_s = model(data, semantic_adaption=True, node_adaptation_s=True)
+            pred_t1, pred_t2, sem_t1, sem_t2, node_t = model(data_t, semantic_adaption=True, node_adaptation_t=True)
+            nodes = (node_s, node_t)
         else:
             pred_s1, pred_s2, sem_s1, sem_s2 = model(data, semantic_adaption=True)
             pred_t1, pred_t2, sem_t1, sem_t2 = model(data_t, semantic_adaption=True)
@@ -426,7 +444,9 @@ class SUGStep:
                                                                           self.criterion(pred_s2, label))
         if not mmd_on or M['MMD_WEIGHT'] <= 0:
             return loss_cls, None, None
-        if pair is not None:
+        if nodes is not None:
+            feat_node_s, feat_node_t = nodes
+        elif pair is not None:
             feat_node_s, feat_node_t = model.forward_pair(pair, node_adaptation=True)
         else:
             feat_node_s = model(data, node_adaptation_s=True)
@@ -482,7 +502,7 @@ class SUGStep:
                 hyp.append(o.graph_key())
             else:
                 hyp.append(tuple((g['lr'], tuple(g['betas']), g['eps'], g['weight_decay']) for g in o.param_groups))
-        return (mmd_on, tuple(tuple(t.shape) for t in tensors), tuple(hyp))
+        return (mmd_on, self.single_pass, tuple(tuple(t.shape) for t in tensors), tuple(hyp))
 
     def _plan_generations(self):
         return tuple(getattr(o, 'plan_generation', 0) for o in self._opts())
@@ -602,13 +622,18 @@ class SUGStep:
             try:
                 model._cuts = S['cuts'] = []
                 pair = torch.cat((data, data_t), dim=0)
-                if mmd_on and hasattr(model, 'plan_pair_geometry') and os.environ.get('SUG_PLAN_GEOMETRY', '1') != '0':
+                dual = self.single_pass and mmd_on
+                if mmd_on and not dual and hasattr(model, 'plan_pair_geometry') and os.environ.get('SUG_PLAN_GEOMETRY', '1') != '0':
                     model.plan_pair_geometry(pair, passes=2)
-                (p_s1, p_s2, f_s1, f_s2), (p_t1, p_t2, f_t1, f_t2) = model.forward_pair(pair)
+                if dual:
+                    (p_s1, p_s2, f_s1, f_s2), (p_t1, p_t2, f_t1, f_t2), (node_s, node_t) = model.forward_pair(pair, dual=True)
+                else:
+                    (p_s1, p_s2, f_s1, f_s2), (p_t1, p_t2, f_t1, f_t2) = model.forward_pair(pair)
                 S['loss_cls'] = (0.5 * M_['SRC_LOSS_WEIGHT'] * M_['CLS_WEIGHT']) * (self.criterion(p_s1, label) +
                                                                                    self.criterion(p_s2, label))
                 if mmd_on:
-                    node_s, node_t = model.forward_pair(pair, node_adaptation=True)
+                    if not dual:
+                        node_s, node_t = model.forward_pair(pair, node_adaptation=True)
                     S['loc'] = (node_s, node_t, f_s1, f_t1, f_s2, f_t2)
                     vals = [label, label_t, node_s.detach(), node_t.detach(), f_s1.detach(), f_t1.detach(), f_s2.detach(),
                             f_t2.detach(), p_s1.detach(), p_t1.detach(), p_s2.detach(), p_t2.detach()]

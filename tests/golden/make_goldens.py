@@ -569,9 +569,125 @@ def gen_step_seeds():
          B=np.int32(B), N=np.int32(N))
 
 
+def gen_eval(name, B, N, seed, fname):
+    """Eval-mode forwards (utils/eval_utils.py:5-88 calls model.eval() and then `pred1, pred2 = model(data)`;
+    train_dg_single_gpu.py:364 deep-copies the best model for it): ONE train-mode forward on a first batch so that the
+    BatchNorm running statistics are not the initial ones, then net.eval() and every Net_MDA.forward mode on a second
+    batch.  Eval-mode farthest-point sampling still draws its random start (point_utils.py:17): seeded per call."""
+    g = torch.Generator().manual_seed(seed)
+    x_tr, x = O.synth_clouds(B, N, g), O.synth_clouds(B, N, g)
+    net = r_M.Net_MDA(name)
+    p0 = _load(net, seed)
+    _no_dropout(net)            # (eval mode ignores dropout anyway; the train-mode warm-up forward must not draw from it)
+    fps_ranges = {'Pointnet2': [N, 512], 'PTran': [N, 256, 64, 16]}.get(name, [N])
+    multi = len(fps_ranges) > 1
+    net.train()
+    torch.manual_seed(seed + 1)
+    with torch.no_grad():
+        net(x_tr, semantic_adaption=True)
+    sd1 = {k: v.clone() for k, v in net.state_dict().items()}
+    net.eval()
+    out = {'x_train': x_tr, 'x': x, 'seed': seed}
+    with torch.no_grad():
+        torch.manual_seed(seed + 2)
+        y1, y2 = net(x)
+        torch.manual_seed(seed + 3)
+        z1, z2, s1, s2 = net(x, semantic_adaption=True)
+        torch.manual_seed(seed + 4)
+        node_s = net(x, node_adaptation_s=True)
+        torch.manual_seed(seed + 5)
+        node_t = net(x, node_adaptation_t=True)
+        torch.manual_seed(seed + 6)
+        feat, node = net(x, mid_feat=True)
+    out.update(y1=y1, y2=y2, z1=z1, z2=z2, s1=s1, s2=s2, node_s=node_s, node_t=node_t, mid_feat=feat,
+               mid_node=node.reshape(B, -1))
+    for k, v in net.state_dict().items():           # eval mode must not touch any buffer
+        assert torch.equal(v, sd1[k]), k
+    bn_names = [k for k in sd1 if k.endswith('running_mean') or k.endswith('running_var')]
+    out['bn_names'] = np.array(bn_names)
+    out['bn_sum'] = np.array([sd1[k].double().sum().item() for k in bn_names])
+    for i in range(6):
+        torch.manual_seed(seed + 1 + i)
+        out['start%d' % i] = torch.stack([torch.randint(0, r, (B,)) for r in fps_ranges]) if multi else torch.randint(0, N, (B,))
+
+    # restatement check: same train-mode warm-up, then training=False
+    p = {k: v.clone() for k, v in p0.items()}
+    st = lambda i: (tuple(out['start%d' % i]) if multi else [out['start%d' % i]])
+    with torch.no_grad():
+        O.net_mda(p, name, x_tr, True, st(0), semantic_adaption=True)
+        for k in bn_names:
+            same(p[k], sd1[k], '%s warm-up %s' % (name, k), 2e-6)
+        o = O.net_mda(p, name, x, False, st(1))
+        same(o[0], y1, name + ' eval y1', 2e-6), same(o[1], y2, name + ' eval y2', 2e-6)
+        o = O.net_mda(p, name, x, False, st(2), semantic_adaption=True)
+        for a, b, nm in zip(o, (z1, z2, s1, s2), ('z1', 'z2', 's1', 's2')):
+            same(a, b, '%s eval %s' % (name, nm), 2e-6)
+        same(O.net_mda(p, name, x, False, st(3), node_adaptation_s=True), node_s, name + ' eval node_s', 2e-5)
+        same(O.net_mda(p, name, x, False, st(4), node_adaptation_t=True), node_t, name + ' eval node_t', 2e-5)
+        of, on = O.net_mda(p, name, x, False, st(5), mid_feat=True)
+        same(of, feat, name + ' eval mid_feat', 2e-6), same(on.reshape(B, -1), node.reshape(B, -1), name + ' eval mid_node', 2e-6)
+        for k in bn_names:
+            same(p[k], sd1[k], '%s eval left %s alone' % (name, k), 0.0)
+    if name == 'DGCNN':
+        # the four neighbour lists of the plain eval forward (teacher forcing where feature-space near-ties are CPU-dependent)
+        with torch.no_grad():
+            torch.manual_seed(seed + 2)
+            _, _, (x1, x2, x3, x4) = O.dgcnn_g({k: v.clone() for k, v in sd1.items()}, 'g.', x, False, out['start1'])
+            for i, t in enumerate((x.squeeze(-1), x1, x2, x3)):
+                out['knn%d' % (i + 1)] = r_mu.knn(t, 20)
+    save(fname, **out)
+
+
+def gen_eval_cls():
+    """The three source-only classifiers of train_source.py (model/model_pointnet.py) in eval mode, after one train-mode
+    forward: logits of a second batch."""
+    out = {}
+    for tag, ctor, ofn, B, N, seed in (('pointnet', r_mp.Pointnet_cls, O.pointnet_cls, 4, 1024, 41),
+                                       ('pointnet2', r_mp.Pointnet2_cls, O.pointnet2_cls, 4, 2048, 42),
+                                       ('dgcnn', r_mp.DGCNN, O.dgcnn_cls, 2, 1024, 43)):
+        g = torch.Generator().manual_seed(seed)
+        x_tr, x = O.synth_clouds(B, N, g), O.synth_clouds(B, N, g)
+        net = ctor()
+        p0 = _load(net, seed)
+        _no_dropout(net)
+        net.train()
+        with torch.no_grad():
+            torch.manual_seed(seed + 1)
+            net(x_tr)
+            sd1 = {k: v.clone() for k, v in net.state_dict().items()}
+            net.eval()
+            torch.manual_seed(seed + 2)
+            y = net(x)
+        for k, v in net.state_dict().items():
+            assert torch.equal(v, sd1[k]), k
+        rec = {'x_train': x_tr, 'x': x, 'y': y, 'seed': seed}
+        p = {k: v.clone() for k, v in p0.items()}
+        with torch.no_grad():
+            if tag == 'pointnet2':
+                for i in range(2):
+                    torch.manual_seed(seed + 1 + i)
+                    rec['start%d' % i] = torch.stack([torch.randint(0, r, (B,)) for r in (N, 512)])
+                ofn(p, x_tr, True, tuple(rec['start0']))
+                o = ofn(p, x, False, tuple(rec['start1']))
+            elif tag == 'dgcnn':
+                ofn(p, x_tr, True)
+                o, (x1, x2, x3, x4) = ofn(p, x, False)
+                for i, t in enumerate((x.squeeze(-1), x1, x2, x3)):
+                    rec['knn%d' % (i + 1)] = r_mu.knn(t, 20)
+            else:
+                ofn(p, x_tr, True)
+                o = ofn(p, x, False)
+        same(o, y, 'eval cls ' + tag, 2e-6)
+        bn_names = [k for k in sd1 if k.endswith('running_mean') or k.endswith('running_var')]
+        rec['bn_names'] = np.array(bn_names)
+        rec['bn_sum'] = np.array([sd1[k].double().sum().item() for k in bn_names])
+        out.update({tag + '_' + k: v for k, v in rec.items()})
+    save('eval_cls.npz', **out)
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['ops', 'mmd', 'pointnet_cls', 'dgcnn', 'pointnet', 'pointnet2', 'ptran', 'step', 'focal', 'ptran2048',
-                             'pointnet2_b4', 'pointnet2_cls', 'dgcnn_cls', 'step_seeds']
+                             'pointnet2_b4', 'pointnet2_cls', 'dgcnn_cls', 'step_seeds', 'eval']
     if 'ops' in which:
         gen_ops()
     if 'mmd' in which:
@@ -600,3 +716,9 @@ if __name__ == '__main__':
         gen_pointnet2_cls()
     if 'dgcnn_cls' in which:
         gen_dgcnn_cls()
+    if 'eval' in which:                 # eval-mode forwards (utils/eval_utils.py:5-88) after one train-mode forward
+        gen_eval('DGCNN', 2, 1024, 51, 'eval_dgcnn.npz')
+        gen_eval('Pointnet', 4, 1024, 52, 'eval_pointnet.npz')
+        gen_eval('Pointnet2', 2, 2048, 53, 'eval_pointnet2.npz')
+        gen_eval('PTran', 2, 1024, 54, 'eval_ptran.npz')
+        gen_eval_cls()

@@ -1,0 +1,137 @@
+"""Eval-mode parity (utils/eval_utils.py:5-88 calls model.eval() and then `pred1, pred2 = model(data)`;
+train_dg_single_gpu.py:364 deep-copies the best model for it): after ONE train-mode forward on a first batch, every
+Net_MDA.forward mode of the four backbones and the three source-only classifiers in eval mode against the reference
+runs of tests/golden/eval_*.npz -- logits / semantic features / node features within 1e-4, buffers untouched."""
+import copy
+
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import ref_cpu as O
+
+pytestmark = pytest.mark.gpu
+
+MULTI = ('Pointnet2', 'PTran')
+
+
+def close(a, b, tol, what):
+    a, b = a.detach().cpu().float(), b.float()
+    err = (a - b).abs().max().item()
+    scale = max(1.0, b.abs().max().item())
+    assert err <= tol * scale, '%s: max abs err %.3e (scale %.3g, tol %.1e)' % (what, err, scale, tol)
+    return err
+
+
+def _build(name, seed):
+    from sug_amd.model.Model import Net_MDA
+    net = Net_MDA(name)
+    net.load_state_dict(O.fill_params({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed))
+    for m in net.modules():
+        if isinstance(m, (torch.nn.Dropout, torch.nn.Dropout2d)):
+            m.p = 0.0
+    return net.cuda()
+
+
+@pytest.mark.parametrize('name,fname', [('DGCNN', 'eval_dgcnn.npz'), ('Pointnet', 'eval_pointnet.npz'),
+                                        ('Pointnet2', 'eval_pointnet2.npz'), ('PTran', 'eval_ptran.npz')])
+def test_net_mda_eval_mode_matches_reference(name, fname):
+    from sug_amd import ops
+    G = load_golden(fname)
+    seed = G['seed']
+    net = _build(name, seed).train()
+    x_tr, x = G['x_train'].cuda(), G['x'].cuda()
+    B = x.shape[0]
+    torch.manual_seed(seed + 1)
+    with torch.no_grad():
+        net(x_tr, semantic_adaption=True)
+    sd = net.state_dict()
+    for k, v in zip(G['bn_names'], G['bn_sum'].tolist()):
+        got = sd[k].double().sum().item()
+        assert abs(got - v) <= 2e-4 * max(1.0, abs(v)), 'BN buffer %s after the train-mode forward: %.8g vs %.8g' % (k, got, v)
+    # the evaluated model is a deep copy in the reference's driver (train_dg_single_gpu.py:364)
+    net = copy.deepcopy(net).eval()
+    before = {k: v.clone() for k, v in net.state_dict().items()}
+    rec, real_knn = [], ops.knn
+
+    def spy(f, k):
+        idx = real_knn(f, k)
+        rec.append(idx.cpu().long())
+        return idx
+    with torch.no_grad():
+        torch.manual_seed(seed + 2)
+        ops.knn = spy
+        try:
+            y1, y2 = net(x)
+        finally:
+            ops.knn = real_knn
+        torch.manual_seed(seed + 3)
+        z1, z2, s1, s2 = net(x, semantic_adaption=True)
+        torch.manual_seed(seed + 4)
+        node_s = net(x, node_adaptation_s=True)
+        torch.manual_seed(seed + 5)
+        node_t = net(x, node_adaptation_t=True)
+        torch.manual_seed(seed + 6)
+        feat, node = net(x, mid_feat=True)
+    if name == 'DGCNN':
+        assert len(rec) == 4
+        assert torch.equal(rec[0], G['knn1']), 'xyz neighbour graph must be bit-exact in eval mode too'
+        differ = [int((rec[i].sort(-1)[0] != G['knn%d' % (i + 1)].sort(-1)[0]).any(-1).sum()) for i in range(4)]
+        print('eval-mode DGCNN: rows whose neighbour set differs from the reference run: %s' % differ)
+        assert sum(differ) == 0, differ
+    errs = [close(y1, G['y1'], 1e-4, 'eval logits c1'), close(y2, G['y2'], 1e-4, 'eval logits c2'),
+            close(z1, G['z1'], 1e-4, 'eval logits c1 (semantic_adaption)'), close(z2, G['z2'], 1e-4, 'eval logits c2 (semantic_adaption)'),
+            close(s1, G['s1'], 1e-4, 'eval sem feature c1'), close(s2, G['s2'], 1e-4, 'eval sem feature c2'),
+            close(feat, G['mid_feat'], 1e-4, 'eval mid feat'),
+            close(node.reshape(B, -1), G['mid_node'], 1e-4, 'eval mid node'),
+            # eval-mode BatchNorm1d of the attention layers uses running statistics: no 1/sqrt(eps) amplification here
+            close(node_s, G['node_s'], 1e-4, 'eval attention_s(node features)'),
+            close(node_t, G['node_t'], 1e-4, 'eval attention_t(node features)')]
+    print(name, 'eval-mode max abs errors', ['%.1e' % e for e in errs])
+    for k, v in net.state_dict().items():
+        assert torch.equal(v, before[k]), 'eval mode changed buffer / parameter ' + k
+
+
+@pytest.mark.parametrize('name', ['Pointnet', 'DGCNN'])
+def test_net_mda_eval_mode_paired_and_single_calls_agree(name):
+    """forward_pair in eval mode (running statistics: nothing couples the clouds) == two separate eval calls, the FPS
+    starts drawn in the same order (source forward, then target forward)."""
+    G = load_golden('eval_pointnet.npz' if name == 'Pointnet' else 'eval_dgcnn.npz')
+    net = _build(name, G['seed']).eval()
+    xs, xt = G['x'].cuda(), G['x_train'].cuda()
+    with torch.no_grad():
+        torch.manual_seed(3)
+        a = net(xs, semantic_adaption=True)
+        b = net(xt, semantic_adaption=True)
+        torch.manual_seed(3)
+        pa, pb = net.forward_pair(torch.cat((xs, xt)))
+    for u, v in zip(a + b, pa + pb):
+        assert float((u - v).abs().max()) <= 1e-5 * max(1.0, float(u.abs().max()))
+
+
+@pytest.mark.parametrize('tag,cls', [('pointnet', 'Pointnet_cls'), ('pointnet2', 'Pointnet2_cls'), ('dgcnn', 'DGCNN')])
+def test_source_only_classifiers_eval_mode(tag, cls):
+    from sug_amd.model import model_pointnet as MP
+    G = load_golden('eval_cls.npz')
+    seed = G[tag + '_seed']
+    net = getattr(MP, cls)()
+    net.load_state_dict(O.fill_params({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed))
+    for m in net.modules():
+        if isinstance(m, (torch.nn.Dropout, torch.nn.Dropout2d)):
+            m.p = 0.0
+    net = net.cuda().train()
+    with torch.no_grad():
+        torch.manual_seed(seed + 1)
+        net(G[tag + '_x_train'].cuda())
+        sd = net.state_dict()
+        for k, v in zip(G[tag + '_bn_names'], G[tag + '_bn_sum'].tolist()):
+            got = sd[k].double().sum().item()
+            assert abs(got - v) <= 2e-4 * max(1.0, abs(v)), 'BN buffer %s: %.8g vs %.8g' % (k, got, v)
+        net.eval()
+        before = {k: v.clone() for k, v in net.state_dict().items()}
+        torch.manual_seed(seed + 2)
+        y = net(G[tag + '_x'].cuda())
+    e = close(y, G[tag + '_y'], 1e-4, 'eval logits ' + cls)
+    print(cls, 'eval-mode logits max abs err %.1e' % e)
+    for k, v in net.state_dict().items():
+        assert torch.equal(v, before[k]), 'eval mode changed ' + k

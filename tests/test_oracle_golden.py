@@ -182,3 +182,71 @@ def test_step_driver_lr_schedules():
         assert math.isclose(lr_dis, want_dis, rel_tol=1e-12)
         assert all(g['lr'] == lr_dis for g in tr.optimizer_dis.param_groups)
         assert all(g['lr'] == lr_g for g in tr.optimizer_g.param_groups)
+
+
+_EVAL_FPS = {'Pointnet2': lambda N: [N, 512], 'PTran': lambda N: [N, 256, 64, 16]}
+
+
+def _eval_starts(G, name, i):
+    s = G['start%d' % i]
+    return tuple(s) if name in _EVAL_FPS else [s]
+
+
+@pytest.mark.parametrize('name,fname', [('DGCNN', 'eval_dgcnn.npz'), ('Pointnet', 'eval_pointnet.npz'),
+                                        ('Pointnet2', 'eval_pointnet2.npz'), ('PTran', 'eval_ptran.npz')])
+def test_eval_mode_oracle_vs_golden(name, fname):
+    """Eval-mode forwards (utils/eval_utils.py:5-88: model.eval(), then `pred1, pred2 = model(data)`): the restatement with
+    training=False after ONE train-mode forward reproduces the reference's eval outputs and leaves the buffers alone."""
+    from sug_amd.model.Model import Net_MDA
+    G = load_golden(fname)
+    p = O.fill_params({k: tuple(v.shape) for k, v in Net_MDA(name).state_dict().items()}, G['seed'])
+    B = G['x'].shape[0]
+    tol = dict(rtol=1e-5, atol=2e-5)
+    with torch.no_grad():
+        O.net_mda(p, name, G['x_train'], True, _eval_starts(G, name, 0), semantic_adaption=True)
+        for k, v in zip(G['bn_names'], G['bn_sum'].tolist()):
+            assert abs(p[k].double().sum().item() - v) <= 1e-5 * max(1.0, abs(v)), k
+        before = {k: p[k].clone() for k in G['bn_names']}
+        y1, y2 = O.net_mda(p, name, G['x'], False, _eval_starts(G, name, 1))
+        torch.testing.assert_close(y1, G['y1'], **tol)
+        torch.testing.assert_close(y2, G['y2'], **tol)
+        z1, z2, s1, s2 = O.net_mda(p, name, G['x'], False, _eval_starts(G, name, 2), semantic_adaption=True)
+        torch.testing.assert_close(z2, G['z2'], **tol)
+        torch.testing.assert_close(s1, G['s1'], **tol)
+        node_s = O.net_mda(p, name, G['x'], False, _eval_starts(G, name, 3), node_adaptation_s=True)
+        torch.testing.assert_close(node_s, G['node_s'], rtol=1e-4, atol=1e-4)
+        node_t = O.net_mda(p, name, G['x'], False, _eval_starts(G, name, 4), node_adaptation_t=True)
+        torch.testing.assert_close(node_t, G['node_t'], rtol=1e-4, atol=1e-4)
+        feat, node = O.net_mda(p, name, G['x'], False, _eval_starts(G, name, 5), mid_feat=True)
+        torch.testing.assert_close(feat, G['mid_feat'], **tol)
+        torch.testing.assert_close(node.reshape(B, -1), G['mid_node'], **tol)
+    for k in G['bn_names']:
+        assert torch.equal(p[k], before[k]), 'eval mode changed ' + k
+    # the recorded start draws are what the CPU generator yields for the reference's seeds
+    N = G['x'].shape[2]
+    torch.manual_seed(G['seed'] + 2)
+    first = torch.randint(0, N, (B,))
+    assert torch.equal(first, G['start1'][0] if name in _EVAL_FPS else G['start1'])
+
+
+def test_eval_mode_classifiers_oracle_vs_golden():
+    """model/model_pointnet.py classifiers in eval mode after one train-mode forward (train_source.py's eval loop)."""
+    G = load_golden('eval_cls.npz')
+    from sug_amd.model import model_pointnet as MP
+    for tag, cls, fn in (('pointnet', 'Pointnet_cls', O.pointnet_cls), ('pointnet2', 'Pointnet2_cls', O.pointnet2_cls),
+                         ('dgcnn', 'DGCNN', O.dgcnn_cls)):
+        net = getattr(MP, cls)()
+        p = O.fill_params({k: tuple(v.shape) for k, v in net.state_dict().items()}, G[tag + '_seed'])
+        with torch.no_grad():
+            if tag == 'pointnet2':
+                fn(p, G[tag + '_x_train'], True, tuple(G[tag + '_start0']))
+                y = fn(p, G[tag + '_x'], False, tuple(G[tag + '_start1']))
+            elif tag == 'dgcnn':
+                fn(p, G[tag + '_x_train'], True)
+                y, _ = fn(p, G[tag + '_x'], False)
+            else:
+                fn(p, G[tag + '_x_train'], True)
+                y = fn(p, G[tag + '_x'], False)
+        torch.testing.assert_close(y, G[tag + '_y'], rtol=1e-5, atol=2e-5)
+        for k, v in zip(G[tag + '_bn_names'], G[tag + '_bn_sum'].tolist()):
+            assert abs(p[k].double().sum().item() - v) <= 1e-5 * max(1.0, abs(v)), k
