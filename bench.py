@@ -153,7 +153,7 @@ def kernel_timestamps_in_child(args, want_events=False):
            '--npoints', str(args.npoints), '--warmup', '3', '--profile-steps', str(max(args.profile_steps, 1)),
            '--timestamps-child', out]
     for flag, on in (('--fp16', args.fp16), ('--no-share-prefix', args.no_share_prefix), ('--no-tuned-gemms', args.no_tuned_gemms),
-                     ('--no-pair', args.no_pair), ('--child-events', want_events)):
+                     ('--no-pair', args.no_pair), ('--child-events', want_events), ('--single-pass', args.single_pass)):
         if on:
             cmd.append(flag)
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT',
@@ -201,7 +201,7 @@ def kernel_table(profs, exact=None):
     return kern
 
 
-def other_workload(model_name, B, N, fp16, dev, steps=10, warmup=3, profile_steps=3):
+def other_workload(model_name, B, N, fp16, dev, steps=10, warmup=3, profile_steps=3, single_pass_too=True):
     """One more BASELINE configuration in the same process: `steps` hipGraph-replayed SUG steps after `warmup`,
     then a few eager steps with kernel events for the dominant hand-written kernel."""
     from sug_amd import ops
@@ -226,6 +226,20 @@ def other_workload(model_name, B, N, fp16, dev, steps=10, warmup=3, profile_step
         torch.cuda.synchronize()
         ms = 1e3 * (time.perf_counter() - t0) / steps
         vals = [None if l is None else float(l) for l in losses]
+        # the opt-in single-pass step of the same model, same batch: captured and replayed the same way
+        sp_ms = None
+        if single_pass_too:
+            tr1 = SUGStep(model, lr=1e-3, weight_decay=5e-5, use_graph=True, methods=BENCH_METHODS, single_pass=True)
+            for _ in range(max(warmup, 3)):
+                tr1.step(*batch)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(steps):
+                tr1.step(*batch)
+            torch.cuda.synchronize()
+            sp_ms = 1e3 * (time.perf_counter() - t1) / steps
+            tr1.drop_graphs()
+            tr1 = None
         tr.use_graph = False
         tr.fused_heads = False
         tr.step(*batch)
@@ -247,6 +261,12 @@ def other_workload(model_name, B, N, fp16, dev, steps=10, warmup=3, profile_step
                            + (', fp16 transformer linears' if fp16 else ''),
                'dtype': 'f16' if fp16 else 'f32', 'ms_per_step': ms, 'clouds_per_sec': 2 * B / (ms * 1e-3), 'steps': steps,
                'warmup': max(warmup, 3), 'launch': 'hipGraph replay of the whole step', 'losses': vals}
+        import bench_work
+        n_params, adam_elems = param_counts(model)
+        out['step_roofline'] = bench_work.step_roofline(model_name, B, N, ms, fp16=fp16, n_params=n_params, adam_elems=adam_elems)
+        if sp_ms is not None:
+            out['single_pass_ms_per_step'] = sp_ms
+            out['single_pass_clouds_per_sec'] = 2 * B / (sp_ms * 1e-3)
         if kern:
             dom = max(kern, key=lambda n: kern[n]['rank_ms'])
             kd = kern[dom]
@@ -263,9 +283,37 @@ def other_workload(model_name, B, N, fp16, dev, steps=10, warmup=3, profile_step
         torch.cuda.empty_cache()
 
 
-def cpu_baseline(B, N, steps=1):
+def param_counts(model):
+    """(parameter elements of the model, parameter elements summed over the three Adam optimizers of a step)."""
+    n_g = sum(p.numel() for p in model.g.parameters())
+    n_c = sum(p.numel() for m in (model.c1, model.c2) for p in m.parameters())
+    n_a = sum(p.numel() for m in (model.attention_s, model.attention_t) for p in m.parameters())
+    n_off = sum(p.numel() for k, p in model.g.named_parameters() if 'pred_offset' in k)
+    return n_g + n_c + n_a, (n_g - n_off) + n_c + (n_g + n_a)       # optimizer_g, optimizer_c, optimizer_dis
+
+
+def cpu_model_string():
+    """Model name of the host CPU the baseline ran on (/proc/cpuinfo), with the number of logical CPUs the process may use."""
+    name = None
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.lower().startswith('model name'):
+                    name = line.split(':', 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    return '%s (%d logical CPUs visible)' % (name or 'unknown CPU', avail)
+
+
+def cpu_baseline(B, N, steps=1, model_name='DGCNN'):
     """The CPU oracle's full SUG step (same algorithm as the reference: materialised [B,N,N]
-    distances + topk, k-expanded EdgeConv tensors, 4 encoder passes, 3 MMDs, backward, 3 Adam)."""
+    distances + topk / sort, k-expanded EdgeConv and attention tensors, 4 encoder passes, 3 MMDs, backward, 3 Adam)
+    -> (clouds per second, seconds)."""
     from oracle import ref_cpu as O
     from sug_amd.model.Model import Net_MDA
     # the GPU box exposes all host CPUs but grants a 16-core share per GPU: more threads than
@@ -275,7 +323,7 @@ def cpu_baseline(B, N, steps=1):
     except AttributeError:
         avail = os.cpu_count() or 1
     torch.set_num_threads(int(os.environ.get('SUG_CPU_THREADS', min(avail, 16))))
-    net = Net_MDA('DGCNN')
+    net = Net_MDA(model_name)
     p = O.as_params(net.state_dict())
     g = [v for k, v in p.items() if k.startswith('g.') and v.requires_grad]
     opt = [torch.optim.Adam([v for k, v in p.items() if k.startswith('g.') and v.requires_grad and 'pred_offset' not in k], lr=1e-3, weight_decay=5e-5),
@@ -286,17 +334,26 @@ def cpu_baseline(B, N, steps=1):
     def run(batch, n):
         data, lab, data_t, lab_t = synth(batch, N, 666, 'cpu')
         for _ in range(n):
-            lc, lg, ls = O.sug_losses(p, 'DGCNN', data, lab, data_t, lab_t, geo, sem, drop_p=0.4)
+            lc, lg, ls = O.sug_losses(p, model_name, data, lab, data_t, lab_t, geo, sem, drop_p=0.4)
             (lc + lg + ls).backward()
             opt[2].step(); opt[0].step(); opt[1].step()
             for o in opt:
                 o.zero_grad()
 
-    run(2, 1)                                   # untimed: thread pool / allocator warm-up
+    if model_name != 'PTran':
+        run(2, 1)                               # untimed: thread pool / allocator warm-up (PTran: a step is ~20 s, no warm-up)
     t0 = time.perf_counter()
     run(B, steps)
     dt = time.perf_counter() - t0
     return 2 * B * steps / dt, dt
+
+
+def cpu_record(model_name, B, N, steps, note=''):
+    cps, secs = cpu_baseline(B, N, steps, model_name)
+    return {'value': cps, 'unit': 'point-clouds/sec', 'cores': torch.get_num_threads(), 'kind': 'port', 'cpu': cpu_model_string(),
+            'sample': '%d full SUG step%s (oracle/ref_cpu.py, fp32 = the reference arithmetic), %s N=%d, batch %d per domain '
+                      '(%d clouds per step), %.1f s on %d torch threads%s'
+                      % (steps, '' if steps == 1 else 's', model_name, N, B, 2 * B, secs, torch.get_num_threads(), note)}
 
 
 def launch_ranks(n, argv):
@@ -361,6 +418,9 @@ def main():
                     help='recompute the kNN+conv1/conv2 stage in the node passes instead of sharing it (identical results)')
     ap.add_argument('--no-tuned-gemms', action='store_true',
                     help='library GEMMs by the default heuristic instead of the recorded TunableOp choices (sug_amd/tuning)')
+    ap.add_argument('--single-pass', action='store_true',
+                    help='time the opt-in single-pass dual-output step (SURVEY 8 f2) instead of the exact two-pass step; the line '
+                         'then says so in config.workload (not the headline configuration)')
     ap.add_argument('--no-pair', action='store_true',
                     help='separate encoder passes for the source and the target batch (identical results)')
     args = ap.parse_args()
@@ -432,7 +492,8 @@ def main():
 
     def make_trainer(use_graph):
         return SUGStep(model, lr=1e-3, weight_decay=5e-5, share_prefix=not args.no_share_prefix, use_graph=use_graph,
-                       pair_domains=not args.no_pair, methods=BENCH_METHODS, force_segmented=args.segmented)
+                       pair_domains=not args.no_pair, methods=BENCH_METHODS, force_segmented=args.segmented,
+                       single_pass=args.single_pass)
 
     trainer = make_trainer(want_graph)
     B, N = args.batch, args.npoints
@@ -624,6 +685,24 @@ def main():
         finally:
             gc.enable()
         trainer.pair_domains, trainer.share_prefix = keep
+    # The opt-in single-pass step (SUGStep(single_pass=True)): one encoder evaluation per domain feeds heads and
+    # attention layers.  Reported BESIDE the headline, never as it: it differs from the reference's step in two documented
+    # ways (one FPS start draw, BatchNorm running statistics of the encoder updated once).
+    single_ms = None
+    if args.caller_steps > 0 and not args.plain and world == 1 and not args.segmented and graph_mode and not args.single_pass:
+        tr1 = SUGStep(model, lr=1e-3, weight_decay=5e-5, share_prefix=not args.no_share_prefix, use_graph=True,
+                      pair_domains=not args.no_pair, methods=BENCH_METHODS, single_pass=True)
+        for _ in range(4):
+            tr1.step(data, lab, data_t, lab_t)
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(max(args.caller_steps, 20)):
+            tr1.step(data, lab, data_t, lab_t)
+        sync()
+        single_ms = 1e3 * (time.perf_counter() - t1) / max(args.caller_steps, 20)
+        tr1.drop_graphs()
+        tr1 = None
+    n_params, adam_elems = param_counts(model)
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -671,6 +750,15 @@ def main():
                 roofline['traffic_note'] = 'bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, profiles/pmc_traffic_%s.json; algorithmic %d' % (kernel_source_hash(dom), kd['bytes'])
             else:
                 roofline['traffic_note'] = 'no PMC passes on file for this kernel version (profiles/pmc_traffic_%s.json)' % kernel_source_hash(dom)
+        if roofline is not None:
+            import bench_work
+            roofline['step'] = bench_work.step_roofline(args.model, B, N, 1e3 * dt / args.steps, single_pass=args.single_pass,
+                                                        fp16=args.fp16 and args.model == 'PTran', n_params=n_params,
+                                                        adam_elems=adam_elems)
+            if single_ms is not None:
+                roofline['step_single_pass'] = {k: v for k, v in bench_work.step_roofline(
+                    args.model, B, N, single_ms, single_pass=True, n_params=n_params, adam_elems=adam_elems).items()
+                    if k in ('gflop', 'gbytes', 'ms', 'achieved_tflops', 'achieved_gbps', 'frac_mfma', 'frac_hbm')}
         others = None
         if world == 1 and not args.plain and not args.segmented and not args.no_other_workloads and args.model == 'DGCNN':
             # the other BASELINE configurations, driver-timed in the same line (configs 1, 3, 5 and N = 2048)
@@ -685,18 +773,28 @@ def main():
                     others.append({'workload': '%s N=%d batch=%d' % (nm, n_, b_), 'error': str(e).splitlines()[0][:200]})
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cps, secs = cpu_baseline(args.cpu_batch, N, args.cpu_steps)
-            cpu = {'value': cps, 'unit': 'point-clouds/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
-                   'sample': '%d full SUG steps (oracle/ref_cpu.py), DGCNN N=%d, batch %d per domain (%d clouds per step), '
-                             '%.1f s on %d torch threads' % (args.cpu_steps, N, args.cpu_batch, 2 * args.cpu_batch, secs,
-                                                            torch.get_num_threads())}
+            cpu = cpu_record(args.model, args.cpu_batch, N, args.cpu_steps)
+            if others:
+                # the CPU oracle beside every single-GPU configuration, on bounded samples of the same
+                # workloads: config 1 at its full batch, configs 3 / 5 at a reduced batch (the oracle's step time is linear
+                # in the batch: every cloud is independent through the encoder)
+                for rec, (nm, b_, n_, st_) in zip(others, (('Pointnet', 8, 1024, 3), ('Pointnet2', 8, 2048, 2), ('PTran', 2, 2048, 1))):
+                    if 'error' in rec:
+                        continue
+                    try:
+                        note = '' if nm == 'Pointnet' else '; sample batch reduced from the GPU workload\'s (clouds/s is batch-independent on the CPU)'
+                        rec['cpu_baseline'] = cpu_record(nm, b_, n_, st_, note)
+                        rec['gpu_over_cpu'] = round(rec['clouds_per_sec'] / rec['cpu_baseline']['value'], 1)
+                    except Exception as e:                       # a baseline must never take the measurement with it
+                        rec['cpu_baseline'] = {'error': str(e).splitlines()[0][:200]}
         out = {'metric': 'point-clouds/sec (train step, N=%d)' % N, 'value': value, 'unit': 'point-clouds/sec',
                'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
                'dtype': 'f16' if (args.fp16 and args.model == 'PTran') else 'f32',
                'data': 'synthetic',
                'config': {'workload': '%s, N=%d, batch=%d per domain per GPU, MSA+SDA losses on '
-                                      '(2 sem + 2 node forwards, 3 soft-MMD, backward, 3 Adam)' % (BACKBONE.get(args.model, args.model), N, B),
+                                      '(%s, 3 soft-MMD, backward, 3 Adam)' % (BACKBONE.get(args.model, args.model), N, B,
+                                      'OPT-IN SINGLE PASS: one dual-output forward per domain' if args.single_pass else '2 sem + 2 node forwards'),
                           'global_batch': world * B, 'global_batch_note': 'clouds per domain x world (the reference\'s batch_size); '
                                                                            'a step runs clouds_per_step = 2 x that (source + target)',
                           'parallelism': 'dp%d' % world, 'collectives': collectives,
@@ -711,6 +809,11 @@ def main():
                                                'memset nodes, inside the captured graph)'
                                                if graph_mode else 'own kernels, tuned library GEMMs for the listed shapes'),
                           'unchanged_caller_ms_per_step': caller_ms,
+                          'single_pass_ms_per_step': single_ms,
+                          'single_pass_clouds_per_sec': None if single_ms is None else world * 2 * B / (single_ms * 1e-3),
+                          'single_pass_note': 'opt-in SUGStep(single_pass=True), SURVEY 8 f2: one encoder evaluation per domain feeds '
+                                              'heads and attention layers; same losses / gradients as the two-pass step with tied FPS '
+                                              'starts, BatchNorm running statistics of the encoder updated once per step; NOT the headline',
                           'clouds_per_step': world * 2 * B,
                           'other_workloads': others,
                           **({'fp16_linears': 'k-expanded and per-point 512-wide linears of the transformer blocks'}

@@ -44,8 +44,8 @@ extern "C" {
 
 const char* sug_last_error(void);
 /* ABI version of the loaded library (bumped when a signature changes; 3: sug_adam_step_capturable gained lr_dev,
- * round-3 entry points; 4: sug_chamfer / sug_node_offset_bwd became reproducible -- sug_chamfer takes a workspace).  A binding checks sug_abi_version() == SUG_ABI_VERSION of the header it was written against. */
-#define SUG_ABI_VERSION 4
+ * round-3 entry points; 4: sug_chamfer / sug_node_offset_bwd became reproducible -- sug_chamfer takes a workspace; 5: sug_ce_pair_* take ignore_index, lse has 2M + 1 entries).  A binding checks sug_abi_version() == SUG_ABI_VERSION of the header it was written against. */
+#define SUG_ABI_VERSION 5
 int sug_abi_version(void);
 
 /* ---- kNN graph ----------------------------------------------------------
@@ -136,6 +136,9 @@ int sug_scatter_rows_ordered(const float* g, int64_t ldg, const int32_t* idx, in
  * (replaces index_points + torch.max(dim=-1), model/model_utils.py:122-123). */
 int sug_group_max(const float* feat, int64_t ldf, const int32_t* idx, int B, int N, int S,
                   int ns, int C, float* out, int32_t* arg, void* stream);
+/* Backward: dfeat[b, arg[b,s,c], c] += g[b,s,c].  CONTRACT: dfeat [B, N, ldf] must be ZERO-FILLED by the caller; it is not an
+ * accumulate-into entry point.  (S <= 64: a fixed-order kernel that STORES the sums of the touched entries; otherwise float
+ * atomics that ADD -- identical on a zeroed buffer, unspecified on any other.) */
 int sug_group_max_bwd(const float* g, const int32_t* arg, int B, int N, int S, int C,
                       float* dfeat, int64_t ldf, void* stream);
 
@@ -640,13 +643,17 @@ int sug_chamfer(const float* a, const float* b, int B, int N, int M, float* out,
  * Cross entropy of both classifier heads on the source rows of the paired logits (train_dg_single_gpu.py:269-292 with
  * nn.CrossEntropyLoss(), :167): loss[0] = w * (CE(logits1[:M], label) + CE(logits2[:M], label)), CE = mean over the M
  * rows of -log_softmax(row)[label]; w = 0.5 * SRC_LOSS_WEIGHT * CLS_WEIGHT folded by the caller.  logits* [>= M, C] with
- * row stride ld, label int64 [M], lse [2, M] (saved log-sum-exp of the rows).  2M <= 512, C <= 32. */
+ * row stride ld, label int64 [M], lse [2M + 1] (saved log-sum-exp of the rows; lse[2M] = number of rows that count).
+ * 2M <= 512, C <= 32.  Labels as nn.CrossEntropyLoss takes them: a row whose label == ignore_index (-100 by default in
+ * torch) contributes nothing and is left out of the mean; any other label outside [0, C) -- where torch raises -- makes
+ * the loss (and the gradient) NaN: never scored as some class. */
 int sug_ce_pair_fwd(const float* logits1, const float* logits2, int64_t ld, const int64_t* label, int M, int C, float w,
-                    float* loss, float* lse, void* stream);
-/* Its gradient for the WHOLE paired logits: d1, d2 [Mtot, C] = g[0] * w * (softmax - onehot) / M in rows < M, zero in
- * rows M .. Mtot-1 (the target half of a paired batch: no torch.stack / zero fill rebuilds the pair's gradient). */
+                    int64_t ignore_index, float* loss, float* lse, void* stream);
+/* Its gradient for the WHOLE paired logits: d1, d2 [Mtot, C] = g[0] * w * (softmax - onehot) / lse[2M] in the counting rows
+ * < M, zero in ignored rows and in rows M .. Mtot-1 (the target half of a paired batch: no torch.stack / zero fill rebuilds
+ * the pair's gradient). */
 int sug_ce_pair_bwd(const float* logits1, const float* logits2, int64_t ld, const int64_t* label, int M, int Mtot, int C,
-                    float w, const float* g, const float* lse, float* d1, float* d2, void* stream);
+                    float w, int64_t ignore_index, const float* g, const float* lse, float* d1, float* d2, void* stream);
 /* out3 = { loss_cls + wg*v_geo + ws*(v_sem1 + v_sem2), wg*v_geo, ws*(v_sem1 + v_sem2) } (train_dg_single_gpu.py:314-324; the
  * weights MMD_WEIGHT * GEO_SCALE and 0.5 * MMD_WEIGHT * SEM_SCALE folded by the caller); null v_* = term absent.
  * Backward: out4 = g[0] * {1, wg, ws, ws}. */

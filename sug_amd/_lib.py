@@ -116,8 +116,8 @@ SIGNATURES = {
     'sug_calayer_supported': [_i32, _i32, _i32, _i32],
     'sug_calayer_fwd': [_i32, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     'sug_calayer_bwd': [_i32, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
-    'sug_ce_pair_fwd': [_vp, _vp, _i64, _vp, _i32, _i32, _f32, _vp, _vp, _vp],
-    'sug_ce_pair_bwd': [_vp, _vp, _i64, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp],
+    'sug_ce_pair_fwd': [_vp, _vp, _i64, _vp, _i32, _i32, _f32, _i64, _vp, _vp, _vp],
+    'sug_ce_pair_bwd': [_vp, _vp, _i64, _vp, _i32, _i32, _i32, _f32, _i64, _vp, _vp, _vp, _vp, _vp],
     'sug_loss_combine_fwd': [_vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp],
     'sug_loss_combine_bwd': [_vp, _f32, _f32, _vp, _vp],
 }
@@ -159,7 +159,7 @@ def lib():
         L.sug_last_error.argtypes = []
         L.sug_abi_version.restype = ctypes.c_int
         L.sug_abi_version.argtypes = []
-        if L.sug_abi_version() != 4:
+        if L.sug_abi_version() != 5:
             raise RuntimeError('sug_amd: ABI version mismatch, rebuild libsug_amd.so')
         _lib = L
     return _lib

@@ -498,6 +498,8 @@ extern "C" int sug_node_offset_bwd(const float* proj, const float* loc, const in
   {                                                          // accumulator planes of a cloud fit LDS: fixed summation order
     static const int unordered = getenv("SUG_NODE_OFFSET_UNORDERED") ? atoi(getenv("SUG_NODE_OFFSET_UNORDERED")) : 0;
     const size_t per_plane = (size_t)N * 4 * sizeof(float);        // [N,3] floats + [N] tags
+    // (more than 64 KB of dynamic LDS needs the opt-in; on a device that refuses it -- none of the gfx950 parts -- the call
+    // fails with the driver's message rather than silently changing the summation order)
     if (!unordered && per_plane <= 150 * 1024) {
       if (8 * per_plane <= 150 * 1024) {
         static SugLdsOptIn note;

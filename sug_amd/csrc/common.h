@@ -24,10 +24,6 @@ void sug_set_error(const char* fmt, ...);
     }                                                                       \
   } while (0)
 
-// knn_mfma.hip
-int sug_knn_mfma_supported(const float* x, int64_t ldx, int C, int k);
-int sug_knn_mfma(const float* x, int64_t ldx, int B, int N, int C, int k, int32_t* idx, hipStream_t st);
-
 // BatchNorm batch statistics are accumulated about a PIVOT p[c] (one value of the group's data per channel): the
 // partial rows hold sum(x - p) | sum((x - p)^2) in fp32, the finalize kernels form mean = p + S1/n and
 // var = S2/n - (S1/n)^2 in fp64.  Unshifted fp32 partials lose the variance when |mean| >> std (E[x^2] - mean^2).
@@ -50,6 +46,7 @@ int sug_reverse_lists(const int32_t* idx, int B, int E, int N, int sorted, int32
 int sug_reduce_partials(const float* ws, int nblk, int W, double* out, hipStream_t st);
 
 // knn_pc.hip: producer / consumer MFMA kNN (C in {3, 64, 128}, k <= 20)
+int sug_knn_pc_supported(const float* x, int64_t ldx, int C, int k);
 int sug_knn_pc(const float* x, int64_t ldx, int B, int N, int C, int k, int32_t* idx, hipStream_t st);
 
 #define WAVE 64

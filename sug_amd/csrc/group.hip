@@ -257,9 +257,13 @@ extern "C" int sug_group_max_bwd(const float* g, const int32_t* arg, int B, int 
   const int64_t total = (int64_t)B * S * C;
   static const int unordered = getenv("SUG_GROUP_MAX_UNORDERED") ? atoi(getenv("SUG_GROUP_MAX_UNORDERED")) : 0;
   const size_t sh = ((size_t)2 * 64 * (GMB_CH + 1) + (size_t)4 * N) * sizeof(int);
-  if (S <= 64 && B <= 65535 && sh <= 150 * 1024 && !unordered) {      // fixed summation order (dfeat zeroed by the caller, as for the atomic form)
+  bool ordered = S <= 64 && B <= 65535 && sh <= 150 * 1024 && !unordered;
+  if (ordered && sh > 64 * 1024) {      // more than the default dynamic-LDS limit: opt in; a device that refuses takes the atomic form
     static SugLdsOptIn note;
-    if (int rc = sug_allow_dynamic_lds(note, &group_max_bwd_ordered_kernel, 150 * 1024, "sug_group_max_bwd")) return rc;
+    if (sug_allow_dynamic_lds(note, &group_max_bwd_ordered_kernel, 150 * 1024, "sug_group_max_bwd") != SUG_OK) ordered = false;
+  }
+  if (ordered) {      // fixed summation order; dfeat must arrive ZERO-FILLED in both forms (sug_amd.h: this one stores the touched
+                      // entries, the atomic one adds -- on a zeroed buffer the same result, on any other an unspecified one)
     hipLaunchKernelGGL(group_max_bwd_ordered_kernel, dim3(sug_divup(C, GMB_CH), B), dim3(256), sh, (hipStream_t)stream, g, arg, N, S, C,
                        dfeat, ldf);
     SUG_LAUNCH_CHECK("sug_group_max_bwd");

@@ -351,7 +351,7 @@ extern "C" int sug_knn(const float* x, int64_t ldx, int B, int N, int C, int k, 
   SUG_REQUIRE(ldx >= C, "sug_knn: ldx=%lld < C=%d", (long long)ldx, C);
   SUG_REQUIRE(B <= 65535, "sug_knn: B=%d exceeds grid.y", B);
   hipStream_t st = (hipStream_t)stream;
-  if (sug_knn_mfma_supported(x, ldx, C, k)) return sug_knn_mfma(x, ldx, B, N, C, k, idx, st);
+  if (sug_knn_pc_supported(x, ldx, C, k)) return sug_knn_pc(x, ldx, B, N, C, k, idx, st);
   if (k <= 16) return dispatch_knn_c<16>(x, ldx, B, N, C, k, idx, st);
   if (k <= 20) return dispatch_knn_c<20>(x, ldx, B, N, C, k, idx, st);
   return dispatch_knn_c<32>(x, ldx, B, N, C, k, idx, st);

@@ -568,6 +568,14 @@ int dispatch_pc(const float* x, int64_t ldx, int B, int N, int C, int k, int32_t
 
 }  // namespace
 
+// Returns 1 if the producer / consumer MFMA kernel handles this shape / alignment (else sug_knn uses the scalar kernel).
+int sug_knn_pc_supported(const float* x, int64_t ldx, int C, int k) {
+  if (k > 20) return 0;                 // K + 2 key registers per lane: larger k uses the scalar kernel
+  if (C == 3) return 1;
+  if (C != 64 && C != 128) return 0;
+  return ((uintptr_t)x % 16 == 0) && (ldx % 4 == 0);
+}
+
 int sug_knn_pc(const float* x, int64_t ldx, int B, int N, int C, int k, int32_t* idx, hipStream_t st) {
   if (k <= 16) return dispatch_pc<16>(x, ldx, B, N, C, k, idx, st);
   return dispatch_pc<20>(x, ldx, B, N, C, k, idx, st);

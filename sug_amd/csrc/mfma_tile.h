@@ -1,4 +1,4 @@
-// Row-tile staging for the fp32 MFMA kernels (knn_mfma.hip, pointmlp.hip): 32 rows of a
+// Row-tile staging for the fp32 MFMA kernels (knn_pc.hip, pointmlp.hip): 32 rows of a
 // [rows, CP] fp32 matrix travel global -> registers -> LDS, de-interleaved so that one
 // ds_read_b128 feeds the A operand of four consecutive v_mfma_f32_32x32x2_f32 k-steps.
 //

@@ -76,6 +76,8 @@ def chamfer_distances(pc_s, pc_t):
     """Per-pair Chamfer distance [m] of paired clouds ([m,3,N(,1)] or [m,N,3]): cd_distance,
     model/mmd.py:169-175 (mean of dist1 + mean of dist2)."""
     assert pc_s.shape[0] == pc_t.shape[0]
+    # the reference's own layout test (model/mmd.py:110): channel-first when dim 1 has 3 entries.  [m,N,3] rows with N == 3
+    # are therefore read as channel-first, exactly as there; internal callers only pass rows when N != 3
     if pc_s.shape[1] == 3:
         a = pc_s.reshape(pc_s.shape[0], 3, -1).transpose(1, 2)
         b = pc_t.reshape(pc_t.shape[0], 3, -1).transpose(1, 2)

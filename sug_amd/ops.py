@@ -6,6 +6,7 @@ CPU path.  Feature tensors are point-major rows [B,N,C].
 """
 import contextlib
 import ctypes
+import os as _os
 
 import torch
 
@@ -267,7 +268,7 @@ def three_nn(query, cand):
 
 
 # ----------------------------------------------------------------------------- gathers
-SCATTER_ORDERED = __import__('os').environ.get('SUG_SCATTER_ORDERED', '1') != '0'      # index_points backward in a fixed order (0: float atomics)
+SCATTER_ORDERED = _os.environ.get('SUG_SCATTER_ORDERED', '1') != '0'      # index_points backward in a fixed order (0: float atomics)
 
 
 class _GatherRows(torch.autograd.Function):
@@ -342,7 +343,6 @@ def group_max(feat, idx):
 DW_LIBRARY_SHAPES = set()
 DW_FORCE_LIBRARY = False        # tuning runs: every weight gradient through the library
 DW_SHAPE_LOG = None             # tuning runs: list collecting the (rows, M, N) seen
-import os as _os
 # measured on MI355X (graph mode, C2 step): the library's selection is 0.1-0.2 ms per step faster for these
 # forward GEMMs, tuned table or not -- the own kernel stays opt-in (SUG_OWN_ROWS_GEMM=1)
 OWN_ROWS_GEMM = _os.environ.get('SUG_OWN_ROWS_GEMM', '0') == '1'            # forward y = x.W^T of skinny layers (K in {64,128}, Co % 128 == 0) by sug_rows_gemm
@@ -727,6 +727,9 @@ class _SAFirstLayerGeo(torch.autograd.Function):
         check(lib().sug_sa_first_geo_bwd(_p(gz), _p(Pfc), C, _p(xyz), _p(cent), _p(Wxc), 3, _p(bc), _p(idx), B, N, S, ns, C, G,
                                          1 if training else 0, _p(coef), _p(red), _p(off), _p(ent), _p(segsum), _p(dP), _p(dQ),
                                          _p(ws), _p(rf), _st()), 'sug_sa_first_geo_bwd')
+        # Pf and Px receive the SAME gradient tensor on purpose (y depends on them only through Pf[j] + Px-routed terms with
+        # identical row gradients): both are non-leaf outputs of linear_rows whose backward only reads its upstream
+        # gradient, so the alias is never written through; a clone would cost a pass over [B,N,C]
         return (dP if has_p else None), dP, dQ, None, None, None, None, None, rf[C:], rf[:C], None, None, None, None, None, None
 
 
@@ -1714,10 +1717,19 @@ def calayers(layers, x):
 _rows_cache = [None, None, None]           # weakref to the [B,3,N,1] input, its version, the [B,N,3] rows
 
 
+def clear_rows_cache():
+    """Drop the cached rows of the last batch (SUGStep does after every step: the rows of a captured step live in the
+    graph's memory pool and must not be pinned by a module global)."""
+    _rows_cache[0] = _rows_cache[1] = _rows_cache[2] = None
+
+
 def cloud_rows(x):
     """x [B,3(+),N,1] (the reference's cloud layout) -> [B,N,3(+)] contiguous rows.  The semantic and the node pass of a step
     (and the Chamfer weights) transpose the same batch: the last result is kept, keyed on the tensor OBJECT (weak
-    reference) and its version, so the copy is made once per batch."""
+    reference) and its version, so the copy is made once per batch.
+    CONTRACT of the key: a write into `x` that does not bump `x._version` -- `x.data` arithmetic, a numpy view of the same
+    memory, a raw-pointer kernel -- is NOT seen; whoever refills a batch buffer that way calls clear_rows_cache() (or uses
+    copy_ / an in-place torch op, which bump the version).  SUGStep clears the cache at the end of every step."""
     import weakref
     ref, ver, rows = _rows_cache
     if ref is not None and ref() is x and ver == x._version and not x.requires_grad:
@@ -1734,7 +1746,7 @@ class _CEPair(torch.autograd.Function):
     logits in one launch (sug_ce_pair_fwd); the backward writes the whole pair's gradient (zeros in the target rows)."""
 
     @staticmethod
-    def forward(ctx, y1, y2, label, w):
+    def forward(ctx, y1, y2, label, w, ignore_index=-100):
         _need_gpu(y1, y2, label)
         M, C = label.shape[0], y1.shape[1]
         a = y1 if y1.stride(1) == 1 else y1.contiguous()
@@ -1743,21 +1755,22 @@ class _CEPair(torch.autograd.Function):
             a, b = a.contiguous(), b.contiguous()
         lab = label.reshape(-1).long().contiguous()
         loss = torch.empty((), dtype=torch.float32, device=y1.device)
-        lse = torch.empty(2, M, dtype=torch.float32, device=y1.device)
-        check(lib().sug_ce_pair_fwd(_p(a), _p(b), a.stride(0), _p(lab), M, C, float(w), _p(loss), _p(lse), _st()), 'sug_ce_pair_fwd')
+        lse = torch.empty(2 * M + 1, dtype=torch.float32, device=y1.device)     # + the number of counting rows
+        check(lib().sug_ce_pair_fwd(_p(a), _p(b), a.stride(0), _p(lab), M, C, float(w), int(ignore_index), _p(loss), _p(lse), _st()),
+              'sug_ce_pair_fwd')
         ctx.save_for_backward(a, b, lab, lse)
-        ctx.meta = (M, y1.shape[0], C, float(w))
+        ctx.meta = (M, y1.shape[0], C, float(w), int(ignore_index))
         return loss
 
     @staticmethod
     def backward(ctx, g):
         a, b, lab, lse = ctx.saved_tensors
-        M, Mtot, C, w = ctx.meta
+        M, Mtot, C, w, ign = ctx.meta
         gs = g.detach().to(dtype=torch.float32).reshape(1)
         d = torch.empty(2, Mtot, C, dtype=torch.float32, device=a.device)
-        check(lib().sug_ce_pair_bwd(_p(a), _p(b), a.stride(0), _p(lab), M, Mtot, C, w, _p(gs), _p(lse), _p(d[0]), _p(d[1]), _st()),
-              'sug_ce_pair_bwd')
-        return d[0], d[1], None, None
+        check(lib().sug_ce_pair_bwd(_p(a), _p(b), a.stride(0), _p(lab), M, Mtot, C, w, ign, _p(gs), _p(lse), _p(d[0]), _p(d[1]),
+                                    _st()), 'sug_ce_pair_bwd')
+        return d[0], d[1], None, None, None
 
 
 def ce_pair_supported(y1, y2, label):
@@ -1765,9 +1778,11 @@ def ce_pair_supported(y1, y2, label):
         and 2 * label.shape[0] <= 512 and label.shape[0] <= y1.shape[0]
 
 
-def ce_pair(y1, y2, label, w):
-    """y1, y2 [Mtot >= M, C] logits of the two heads (the first M rows are scored), label [M] -> 0-d loss."""
-    return _CEPair.apply(y1, y2, label, w)
+def ce_pair(y1, y2, label, w, ignore_index=-100):
+    """y1, y2 [Mtot >= M, C] logits of the two heads (the first M rows are scored), label [M] -> 0-d loss.
+    nn.CrossEntropyLoss label semantics: rows labelled `ignore_index` are skipped (and left out of the mean); any other
+    label outside [0, C) -- torch raises there -- turns the loss into NaN."""
+    return _CEPair.apply(y1, y2, label, w, ignore_index)
 
 
 class _LossCombine(torch.autograd.Function):

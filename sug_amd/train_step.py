@@ -405,7 +405,7 @@ class SUGStep:
                     y1, y2, f1, f2 = model.forward_pair(pair, paired_out=True)
                 if y1.dim() == 2 and ops.ce_pair_supported(y1, y2, label):
                     Bs = label.shape[0]
-                    fused_ce = ops.ce_pair(y1, y2, label, 0.5 * M['SRC_LOSS_WEIGHT'] * M['CLS_WEIGHT'])
+                    fused_ce = ops.ce_pair(y1, y2, label, 0.5 * M['SRC_LOSS_WEIGHT'] * M['CLS_WEIGHT'], self.criterion.ignore_index)
                     (sem_s1, sem_t1), (sem_s2, sem_t2) = ops.split_halves(f1), ops.split_halves(f2)
                     yd1, yd2 = y1.detach(), y2.detach()            # the SDA weights read the logits' values only
                     pred_s1, pred_t1, pred_s2, pred_t2 = yd1[:Bs], yd1[Bs:], yd2[:Bs], yd2[Bs:]
@@ -459,7 +459,7 @@ class SUGStep:
                                                         (sem_s2, sem_t2, pred_s2, pred_t2))
         # the three MMD terms are independent chains of small kernels: side by side under graph replay (ops.run_parallel)
         cs, ct = data, data_t
-        if pair is not None and geo.get('GEO_WEIGHTS') and not self.global_mmd:
+        if pair is not None and geo.get('GEO_WEIGHTS') and not self.global_mmd and pair.shape[2] != 3:   # (N == 3: [m,3,3] rows would read as channel-first, mmd.py:110)
             rows = ops.cloud_rows(pair)                  # the encoder's own [2B,N,3] rows: no second transpose for Chamfer
             cs, ct = rows[:data.shape[0], :, :3], rows[data.shape[0]:, :, :3]
         terms = [lambda: self._mmd(label, feat_node_s, label_t, feat_node_t, geo, cs, ct)]
@@ -740,6 +740,7 @@ class SUGStep:
             """The encoder's backward from the gradients at the cut; its parameter gradients -> flat bucket 2."""
             cg = S['cut_grads']
             torch.autograd.backward([t for t, _ in cg], [g for _, g in cg])
+            ops.clear_rows_cache()
             if self.share_prefix:
                 model.g.clear_prefix_cache()
             for m in self._split_layers:
@@ -926,6 +927,7 @@ class SUGStep:
         if self.reducer is not None:
             self.reducer.begin(mmd_on)
         loss.backward()
+        ops.clear_rows_cache()                           # the [2B,N,3] rows of this step's batch: not kept beyond the step
         if self.share_prefix:
             self.model.g.clear_prefix_cache()
         for m in self._split_layers:

@@ -27,6 +27,40 @@ def test_ce_pair_matches_torch_cross_entropy(M, Mtot, C):
     assert float(y1.grad[M:].abs().sum()) == 0.0 and float(y2.grad[M:].abs().sum()) == 0.0     # target rows: exact zeros
 
 
+@pytest.mark.parametrize('ignore_index', [-100, 3])
+def test_ce_pair_label_semantics_are_cross_entropy_loss_ones(ignore_index):
+    """nn.CrossEntropyLoss label semantics (ADVICE r4): rows labelled ignore_index are skipped and left out of the mean;
+    any other out-of-range label -- where torch raises -- poisons loss and gradient with NaN instead of being scored."""
+    from sug_amd import ops
+    M, Mtot, C = 16, 32, 10
+    g = torch.Generator().manual_seed(5)
+    y1 = (torch.randn(Mtot, C, generator=g) * 3).cuda().requires_grad_(True)
+    y2 = (torch.randn(Mtot, C, generator=g) * 3).cuda().requires_grad_(True)
+    lab = torch.randint(0, C, (M,), generator=g)
+    lab[lab == ignore_index] = (ignore_index + 1) % C
+    lab[[1, 7, 8]] = ignore_index
+    lab = lab.cuda()
+    r1, r2 = y1.detach().clone().requires_grad_(True), y2.detach().clone().requires_grad_(True)
+    crit = torch.nn.CrossEntropyLoss(ignore_index=ignore_index)
+    ref = 0.5 * (crit(r1[:M], lab) + crit(r2[:M], lab))
+    ref.backward()
+    got = ops.ce_pair(y1, y2, lab, 0.5, ignore_index)
+    got.backward()
+    torch.testing.assert_close(got, ref, rtol=2e-6, atol=1e-7)
+    torch.testing.assert_close(y1.grad, r1.grad, rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(y2.grad, r2.grad, rtol=1e-5, atol=1e-7)
+    assert float(y1.grad[[1, 7, 8]].abs().sum()) == 0.0
+    bad = lab.clone()
+    bad[2] = C                      # out of range and not the ignore label
+    if ignore_index == C:
+        return
+    z1 = y1.detach().clone().requires_grad_(True)
+    v = ops.ce_pair(z1, y2.detach(), bad, 0.5, ignore_index)
+    assert torch.isnan(v)
+    v.backward()
+    assert torch.isnan(z1.grad[2]).all()
+
+
 def test_loss_combine_matches_the_step_formula():
     from sug_amd import ops
     vals = [torch.tensor(v, device='cuda', requires_grad=True) for v in (2.31, 0.284, 0.571, -0.113)]

@@ -1,4 +1,5 @@
-"""Diagnostic: time sug_knn variants (ablation builds of knn_mfma.hip) on the GPU box.
+"""Diagnostic (round 1): time ablation builds of the single-wave kNN kernels (tools/ubench/knn_mfma_legacy.hip, no longer part
+of the product library) on the GPU box.
 Usage: python tools/bench_knn.py   (needs hipcc + a GPU)"""
 import ctypes, os, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,8 +12,8 @@ FLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-ffp-contract=o
 
 def build(tag, defs):
     out = os.path.join(tempfile.gettempdir(), 'libknn_%s.so' % tag)
-    files = [os.path.join(SRC, f) for f in ('knn.hip', 'knn_mfma.hip', 'capi.cpp')]
-    subprocess.run(['/opt/rocm/bin/hipcc'] + FLAGS + defs + files + ['-o', out], check=True)
+    files = [os.path.join(ROOT, 'tools', 'ubench', 'knn_mfma_legacy.hip'), os.path.join(SRC, 'capi.cpp')]
+    subprocess.run(['/opt/rocm/bin/hipcc'] + FLAGS + ['-I' + SRC, '-I' + os.path.join(ROOT, 'include')] + defs + files + ['-o', out], check=True)
     return ctypes.CDLL(out)
 
 
@@ -20,14 +21,14 @@ def time_knn(L, x, k, iters=20):
     B, N, C = x.shape
     idx = torch.empty(B, N, k, dtype=torch.int32, device=x.device)
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    L.sug_knn.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+    L.sug_knn_legacy.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                           ctypes.c_void_p, ctypes.c_void_p]
     for _ in range(3):
-        L.sug_knn(x.data_ptr(), C, B, N, C, k, idx.data_ptr(), st)
+        L.sug_knn_legacy(x.data_ptr(), C, B, N, C, k, idx.data_ptr(), st)
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(iters):
-        L.sug_knn(x.data_ptr(), C, B, N, C, k, idx.data_ptr(), st)
+        L.sug_knn_legacy(x.data_ptr(), C, B, N, C, k, idx.data_ptr(), st)
     b.record()
     torch.cuda.synchronize()
     return a.elapsed_time(b) / iters * 1e3

@@ -11,7 +11,7 @@ FLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-ffp-contract=o
 
 def build(tag, defs):
     out = os.path.join(tempfile.gettempdir(), 'libknnpc_%s.so' % tag)
-    files = [os.path.join(SRC, f) for f in ('knn.hip', 'knn_mfma.hip', 'knn_pc.hip', 'capi.cpp')]
+    files = [os.path.join(SRC, f) for f in ('knn.hip', 'knn_pc.hip', 'capi.cpp')]
     subprocess.run(['/opt/rocm/bin/hipcc'] + FLAGS + defs + files + ['-o', out], check=True)
     return ctypes.CDLL(out)
 

@@ -694,19 +694,11 @@ extern "C" int sug_debug_knn2p_occupancy(int C) {
 }
 #endif
 
-// Returns 1 if the MFMA path handles this shape/alignment (else the caller uses knn.hip).
-int sug_knn_mfma_supported(const float* x, int64_t ldx, int C, int k) {
-  if (k > 20) return 0;                 // LDS ring budget: larger k uses the scalar kernel
-  if (C == 3) return 1;
-  if (C != 64 && C != 128) return 0;
-  return ((uintptr_t)x % 16 == 0) && (ldx % 4 == 0);
-}
-
-int sug_knn_mfma(const float* x, int64_t ldx, int B, int N, int C, int k, int32_t* idx, hipStream_t st) {
-  // default: the producer / consumer kernel (knn_pc.hip).  SUG_KNN_LEGACY=1 selects the single-wave
-  // kernels of this file (kept for A/B timing, tools/bench_knn.py).
-  static const bool legacy = [] { const char* e = getenv("SUG_KNN_LEGACY"); return e && e[0] == '1'; }();
-  if (!legacy) return sug_knn_pc(x, ldx, B, N, C, k, idx, st);
+// Round-1 kernels, kept OUT of the product library for A/B timing only (tools/bench_knn.py builds this file together with
+// sug_amd/csrc/capi.cpp).  Shapes as sug_knn's MFMA path: C in {3, 64, 128}, k <= 20, 16-byte aligned rows.
+extern "C" int sug_knn_legacy(const float* x, int64_t ldx, int B, int N, int C, int k, int32_t* idx, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (k > 20 || (C != 3 && C != 64 && C != 128)) return SUG_ERR_ARG;
   if (k <= 16) return dispatch<16>(x, ldx, B, N, C, k, idx, st);
   return dispatch<20>(x, ldx, B, N, C, k, idx, st);
 }
