@@ -170,8 +170,12 @@ def test_grad_reducer_overlapped_buckets_match_plain_average():
                     torch.testing.assert_close(torch.from_numpy(got), (g0 + g1) / world, rtol=1e-6, atol=1e-7)
 
 
-def test_bench_launches_ranks_and_relays_rank0_json():
-    """`python bench.py --gpus 2` without a launcher starts the ranks itself (bench.launch_ranks:
+import pytest
+
+
+@pytest.mark.parametrize('world', [2, 8])
+def test_bench_launches_ranks_and_relays_rank0_json(world):
+    """(world = 8: the rank count of the driver's multi-GPU run, BASELINE configs 4 / 5.)  VERDICT r3 item 8: `python bench.py --gpus 2` without a launcher starts the ranks itself (bench.launch_ranks:
     torch.distributed.run as a child, rendezvous on 127.0.0.1 -- the seam of train_dg.py:59-66), the ranks form the
     process group and rank 0's JSON line comes back through the parent.  --rendezvous-only stops before any model or
     kernel call, so this runs on a machine without a GPU (gloo); on the GPU box the same path runs with nccl = RCCL."""
@@ -183,11 +187,11 @@ def test_bench_launches_ranks_and_relays_rank0_json():
     env = dict(os.environ, SUG_BENCH_BACKEND='gloo', OMP_NUM_THREADS='1')
     env.pop('WORLD_SIZE', None)
     env.pop('RANK', None)
-    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--rendezvous-only'],
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(world), '--rendezvous-only'],
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, r.stdout[-2000:]              # ONE JSON line, from rank 0
     out = json.loads(lines[0])
-    assert out['rendezvous'] == 'ok' and out['world_size'] == 2 and out['backend'] == 'gloo'
-    assert out['rank_sum'] == out['expected_rank_sum'] == 3.0
+    assert out['rendezvous'] == 'ok' and out['world_size'] == world and out['backend'] == 'gloo'
+    assert out['rank_sum'] == out['expected_rank_sum'] == world * (world + 1) / 2.0

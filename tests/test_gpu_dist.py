@@ -47,7 +47,7 @@ def _data(B, N, seed):
     return data, lab, data_t, lab_t
 
 
-def _worker(rank, world, port, backend, q, mode='eager', steps=2):
+def _worker(rank, world, port, backend, q, mode='eager', steps=2, B=4):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       HSA_ENABLE_IPC_MODE_LEGACY='0')
@@ -59,7 +59,7 @@ def _worker(rank, world, port, backend, q, mode='eager', steps=2):
     else:
         dist.init_process_group('gloo', rank=rank, world_size=world)
     from sug_amd.train_step import SUGStep
-    B, N = 4, 1024                              # global batch per domain; each rank owns B / world clouds
+    N = 1024                                    # B = global batch per domain; each rank owns B / world clouds
     data, lab, data_t, lab_t = _data(B, N, 5)
     lo, hi = rank * B // world, (rank + 1) * B // world
     shard = [t[lo:hi].to(dev) for t in (data, lab, data_t, lab_t)]
@@ -79,13 +79,12 @@ def _worker(rank, world, port, backend, q, mode='eager', steps=2):
     dist.destroy_process_group()
 
 
-def _run(backend, mode='eager', steps=2):
+def _run(backend, mode='eager', steps=2, world=2, B=4):
     import torch.multiprocessing as mp
-    world = 2
     port = _free_port()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, backend, q, mode, steps)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, backend, q, mode, steps, B)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
@@ -250,3 +249,62 @@ def test_bench_two_ranks_end_to_end_gloo_on_one_gpu():
     assert d['roofline'] is not None and d['roofline']['kernel'].startswith('knn') and 0 < d['roofline']['frac'] < 1
     assert any(k.startswith('edgeconv') for k in d['kernels'])
     assert all(v is not None for v in d['losses'])
+
+
+def test_four_rank_segmented_graph_gloo_on_one_gpu():
+    """World-size-specific arithmetic (row0 = rank * m_local, M = world * m_local rows in every MMD block, the packed
+    all-gather's layout, / world in the gradient buckets) at a world size other than 2: FOUR ranks on the one device of this
+    box (the box allows at most 6 processes on its card; the first real 8-rank run is the driver's), 2 clouds per domain and
+    rank, five captured segments around the four collectives.  Replicas identical after every step; the global MMD terms
+    identical on all ranks and equal to the single-process MMD of the gathered batch; per-rank CE = the shard's own."""
+    from sug_amd.model import mmd
+    from sug_amd.train_step import SUGStep, GEO_MMD
+    world, B, N = 4, 8, 1024
+    res = _run('gloo', 'segmented_graph', steps=3, world=world, B=B)
+    outs, chks = [r[1] for r in res], [r[2] for r in res]
+    for r in range(1, world):
+        assert (chks[r] == chks[0]).all(), 'parameters diverged between ranks 0 and %d' % r
+        for s in range(3):
+            assert outs[r][s][1] == outs[0][s][1] and outs[r][s][2] == outs[0][s][2], (r, outs)
+    data, lab, data_t, lab_t = _data(B, N, 5)
+    feats = []
+    for rank in range(world):
+        lo, hi = rank * B // world, (rank + 1) * B // world
+        net = _make(3).cuda().train()
+        torch.manual_seed(100 + rank)
+        d, l, dt, lt = [t[lo:hi].cuda() for t in (data, lab, data_t, lab_t)]
+        tr = SUGStep(net, global_mmd=False)
+        lc, _, _ = tr.losses(d, l, dt, lt)
+        assert abs(float(lc) - outs[rank][0][0]) <= 1e-4 * max(1.0, abs(outs[rank][0][0])), (rank, float(lc), outs[rank][0])
+        net = _make(3).cuda().train()
+        torch.manual_seed(100 + rank)
+        pair = torch.cat((d, dt))
+        with torch.no_grad():
+            net.forward_pair(pair)
+            fs, ft = net.forward_pair(pair, node_adaptation=True)
+        feats.append((l, lt, fs, ft))
+    cat = lambda i: torch.cat([f[i] for f in feats])
+    geo = float(mmd.mmd_cal(cat(0), cat(2), cat(1), cat(3), GEO_MMD))
+    assert abs(geo - outs[0][0][1]) <= 1e-4 * max(1.0, abs(geo)), (geo, outs[0][0])
+
+
+def test_bench_six_ranks_end_to_end_gloo_on_one_gpu():
+    """`bench.py --gpus 6 --batch 2` on one device over gloo (the most ranks this box lets share its card; --plain: no
+    kernel-timestamp child, which would be a seventh process on the GPU): launcher, six ranks, a non-power-of-two world,
+    M = 12 rows per domain in the global MMD, one JSON line with n_gpus = 6 and finite losses."""
+    import json
+    import math
+    import subprocess
+    env = dict(os.environ, SUG_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '6', '--steps', '2', '--warmup', '3', '--batch', '2',
+                        '--no-cpu-baseline', '--no-other-workloads', '--caller-steps', '0', '--plain'],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1100)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith('{')]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 6 and d['config']['parallelism'] == 'dp6' and d['config']['clouds_per_step'] == 24
+    assert d['config']['launch'].startswith('segmented hipGraph') and d['value'] > 0
+    assert all(v is not None and math.isfinite(v) for v in d['losses']), d['losses']
