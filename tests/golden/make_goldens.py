@@ -635,6 +635,11 @@ def gen_eval(name, B, N, seed, fname):
             _, _, (x1, x2, x3, x4) = O.dgcnn_g({k: v.clone() for k, v in sd1.items()}, 'g.', x, False, out['start1'])
             for i, t in enumerate((x.squeeze(-1), x1, x2, x3)):
                 out['knn%d' % (i + 1)] = r_mu.knn(t, 20)
+            # ... and of the train-mode warm-up forward (a near-tie that falls differently there moves the running statistics
+            # by ~1e-4, which is all the eval logits' tolerance: the GPU test teacher-forces the warm-up as well)
+            _, _, (x1, x2, x3, x4) = O.dgcnn_g({k: v.clone() for k, v in p0.items()}, 'g.', x_tr, True, out['start0'])
+            for i, t in enumerate((x_tr.squeeze(-1), x1, x2, x3)):
+                out['knn_train%d' % (i + 1)] = r_mu.knn(t, 20)
     save(fname, **out)
 
 

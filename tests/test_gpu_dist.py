@@ -288,23 +288,26 @@ def test_four_rank_segmented_graph_gloo_on_one_gpu():
     assert abs(geo - outs[0][0][1]) <= 1e-4 * max(1.0, abs(geo)), (geo, outs[0][0])
 
 
-def test_bench_six_ranks_end_to_end_gloo_on_one_gpu():
-    """`bench.py --gpus 6 --batch 2` on one device over gloo (the most ranks this box lets share its card; --plain: no
-    kernel-timestamp child, which would be a seventh process on the GPU): launcher, six ranks, a non-power-of-two world,
-    M = 12 rows per domain in the global MMD, one JSON line with n_gpus = 6 and finite losses."""
+def test_bench_three_ranks_end_to_end_gloo_on_one_gpu():
+    """`bench.py --gpus 3 --batch 2` on one device over gloo: a world size that is not a power of two (M = 6 rows per domain in
+    the global MMD, / 3 in the gradient buckets) through the launcher, the five graph segments and rank 0's kernel-timestamp
+    child.  (This test process + 3 ranks + the child = 5 processes on the card; the box allows 6 -- the first 8-rank run is
+    the driver's.)"""
     import json
     import math
     import subprocess
     env = dict(os.environ, SUG_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
     for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '6', '--steps', '2', '--warmup', '3', '--batch', '2',
-                        '--no-cpu-baseline', '--no-other-workloads', '--caller-steps', '0', '--plain'],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '3', '--steps', '2', '--warmup', '3', '--batch', '2',
+                        '--no-cpu-baseline', '--no-other-workloads', '--caller-steps', '0', '--eager-steps', '1', '--profile-steps', '1'],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1100)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     lines = [l for l in r.stdout.decode().splitlines() if l.startswith('{')]
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
-    assert d['n_gpus'] == 6 and d['config']['parallelism'] == 'dp6' and d['config']['clouds_per_step'] == 24
+    assert d['n_gpus'] == 3 and d['config']['parallelism'] == 'dp3' and d['config']['clouds_per_step'] == 12
     assert d['config']['launch'].startswith('segmented hipGraph') and d['value'] > 0
+    assert d['config']['collectives']['world_size'] == 3
     assert all(v is not None and math.isfinite(v) for v in d['losses']), d['losses']
+    assert d['roofline'] is not None and d['roofline']['step']['gflop'] > 0

@@ -58,7 +58,7 @@ def _dgcnn_eval_checks(net, G, x, rec, plain):
             torch.manual_seed(seed + 2)
             t1, t2 = net(x)
     finally:
-        net.g.forward = fwd
+        del net.g.forward
     print('teacher-forced eval logits: max abs err %.1e / %.1e' % (close(t1, G['y1'], 1e-4, 'eval logits c1 (teacher-forced)'),
                                                                      close(t2, G['y2'], 1e-4, 'eval logits c2 (teacher-forced)')))
     # (3) free-running, every forward mode, against the oracle on the HIP graphs
@@ -101,12 +101,23 @@ def test_net_mda_eval_mode_matches_reference(name, fname):
     x_tr, x = G['x_train'].cuda(), G['x'].cuda()
     B = x.shape[0]
     torch.manual_seed(seed + 1)
-    with torch.no_grad():
-        net(x_tr, semantic_adaption=True)
+    fwd = net.g.forward
+    if name == 'DGCNN':
+        # the warm-up forward on the reference run's graphs: a feature-space near-tie that falls differently here would move
+        # the running statistics by ~1e-4 (measured: 1.4e-4 on one buffer sum, 1.5e-4 on an eval logit), i.e. the whole
+        # eval tolerance; the free-running warm-up is covered by the train-mode tests
+        forced_tr = [G['knn_train%d' % i].to(torch.int32).cuda() for i in (1, 2, 3, 4)]
+        net.g.forward = lambda xx, **kw: fwd(xx, knn_idx=forced_tr, **kw)
+    try:
+        with torch.no_grad():
+            net(x_tr, semantic_adaption=True)
+    finally:
+        if name == 'DGCNN':
+            del net.g.forward
     sd = net.state_dict()
     for k, v in zip(G['bn_names'], G['bn_sum'].tolist()):
         got = sd[k].double().sum().item()
-        assert abs(got - v) <= 2e-4 * max(1.0, abs(v)), 'BN buffer %s after the train-mode forward: %.8g vs %.8g' % (k, got, v)
+        assert abs(got - v) <= 1e-4 * max(1.0, abs(v)), 'BN buffer %s after the train-mode forward: %.8g vs %.8g' % (k, got, v)
     # the evaluated model is a deep copy in the reference's driver (train_dg_single_gpu.py:364)
     net = copy.deepcopy(net).eval()
     before = {k: v.clone() for k, v in net.state_dict().items()}
