@@ -386,17 +386,27 @@ def ptran_g(p, pre, x, training=True, starts=(None, None, None, None)):
     return points.mean(1), node, None
 
 
-def pointnet_c(p, pre, x, dgcnn, adapt=False, drop_p=0.0, training=True, ptran=False):
+def _drop(y, drop_p, training, keep):
+    """nn.Dropout2d on a 2-D input = element-wise dropout (model/Model.py:428-431).  `keep` (bool mask of y's shape) replaces
+    the random draw by a given one -- same arithmetic, y * keep / (1 - p) -- so a test can hold the HIP path's dropout (which
+    draws from the GPU generator) against this restatement on the SAME mask."""
+    if keep is None or not training or drop_p <= 0:
+        return F.dropout(y, drop_p, training)
+    return y * (keep.to(y.dtype) / (1.0 - drop_p))      # torch: input * bernoulli(1 - p).div_(1 - p)
+
+
+def pointnet_c(p, pre, x, dgcnn, adapt=False, drop_p=0.0, training=True, ptran=False, keep=None):
     """Pointnet_c.forward, model/Model.py:436-449 (mlp1 is skipped under PTran_flag). Dropout2d
-    on a 2-D input acts element-wise; parity runs use drop_p=0."""
+    on a 2-D input acts element-wise; parity runs use drop_p=0 or given keep-masks `keep` = (mask1, mask2)."""
     act = 'leakyrelu' if dgcnn else 'relu'
     y = x
+    k1, k2 = keep if keep is not None else (None, None)
     if not ptran:
         y = fc_ln_act(p, pre + 'mlp1.', x, act)
-        y = F.dropout(y, drop_p, training)
+        y = _drop(y, drop_p, training, k1)
     y = fc_ln_act(p, pre + 'mlp2.', y, act)
     mid = y
-    y = F.dropout(y, drop_p, training)
+    y = _drop(y, drop_p, training, k2)
     y = F.linear(y, p[pre + 'mlp3.weight'], p[pre + 'mlp3.bias'])
     return (y, mid) if adapt else y
 
@@ -411,7 +421,7 @@ def calayer(p, pre, x, training=True):
 
 def net_mda(p, model_name, x, training=True, starts=None, drop_p=0.0, mid_feat=False,
             node_adaptation_s=False, node_adaptation_t=False, semantic_adaption=False,
-            knn_override=None):
+            knn_override=None, drop_keep=None):
     """Net_MDA.forward, model/Model.py:485-520 (adaptation/GradReverse is the identity, :37-50)."""
     if model_name == 'Pointnet':
         feat, node, _ = pointnet_g(p, 'g.', x, training, None if starts is None else starts[0])
@@ -431,11 +441,12 @@ def net_mda(p, model_name, x, training=True, starts=None, drop_p=0.0, mid_feat=F
         pre = 'attention_s.' if node_adaptation_s else 'attention_t.'
         return calayer(p, pre, node.contiguous().view(B, -1, 1, 1), training)
     dg, pt = model_name == 'DGCNN', model_name == 'PTran'
+    kc1, kc2 = drop_keep if drop_keep is not None else (None, None)     # keep-masks of (c1, c2), each (mask1, mask2)
     if not semantic_adaption:
-        return (pointnet_c(p, 'c1.', feat, dg, False, drop_p, training, pt),
-                pointnet_c(p, 'c2.', feat, dg, False, drop_p, training, pt))
-    y1, s1 = pointnet_c(p, 'c1.', feat, dg, True, drop_p, training, pt)
-    y2, s2 = pointnet_c(p, 'c2.', feat, dg, True, drop_p, training, pt)
+        return (pointnet_c(p, 'c1.', feat, dg, False, drop_p, training, pt, kc1),
+                pointnet_c(p, 'c2.', feat, dg, False, drop_p, training, pt, kc2))
+    y1, s1 = pointnet_c(p, 'c1.', feat, dg, True, drop_p, training, pt, kc1)
+    y2, s2 = pointnet_c(p, 'c2.', feat, dg, True, drop_p, training, pt, kc2)
     return y1, y2, s1, s2
 
 
@@ -637,7 +648,8 @@ SEM_CFG = {'NAME': 'SOFT_MMD', 'LABEL_SCALE': 5, 'SEM_WEIGHTS': 'mean2one', 'LAB
 
 
 def sug_losses(p, model_name, data, label, data_t, label_t, geo_cfg=GEO_CFG, sem_cfg=SEM_CFG,
-               drop_p=0.0, starts=None, mmd_weight=1.0, cls_weight=1.0, src_loss_weight=1.0, knn_override=None):
+               drop_p=0.0, starts=None, mmd_weight=1.0, cls_weight=1.0, src_loss_weight=1.0, knn_override=None,
+               drop_keep=None):
     """Loss of one step with TARGET_LOSS 0, ADV_WEIGHT 0, past PURE_CLS_EPOCH
     (train_dg_single_gpu.py:260-324). ``starts`` = 4 FPS start specs in call order
     (sem-s, sem-t, node-s, node-t) or None to draw like the reference.  ``knn_override`` (DGCNN, tests):
@@ -646,8 +658,9 @@ def sug_losses(p, model_name, data, label, data_t, label_t, geo_cfg=GEO_CFG, sem
     ko_s, ko_t = knn_override if knn_override is not None else (None, None)
     kw_s = {'knn_override': ko_s} if ko_s is not None else {}
     kw_t = {'knn_override': ko_t} if ko_t is not None else {}
-    ps1, ps2, fs1, fs2 = net_mda(p, model_name, data, True, st[0], drop_p, semantic_adaption=True, **kw_s)
-    pt1, pt2, ft1, ft2 = net_mda(p, model_name, data_t, True, st[1], drop_p, semantic_adaption=True, **kw_t)
+    dk_s, dk_t = drop_keep if drop_keep is not None else (None, None)    # (tests) given dropout keep-masks per domain
+    ps1, ps2, fs1, fs2 = net_mda(p, model_name, data, True, st[0], drop_p, semantic_adaption=True, drop_keep=dk_s, **kw_s)
+    pt1, pt2, ft1, ft2 = net_mda(p, model_name, data_t, True, st[1], drop_p, semantic_adaption=True, drop_keep=dk_t, **kw_t)
     loss_s = 0.5 * F.cross_entropy(ps1, label) + 0.5 * F.cross_entropy(ps2, label)
     loss_cls = cls_weight * src_loss_weight * loss_s
     node_s = net_mda(p, model_name, data, True, st[2], drop_p, node_adaptation_s=True, **kw_s)

@@ -250,3 +250,17 @@ def test_eval_mode_classifiers_oracle_vs_golden():
         torch.testing.assert_close(y, G[tag + '_y'], rtol=1e-5, atol=2e-5)
         for k, v in zip(G[tag + '_bn_names'], G[tag + '_bn_sum'].tolist()):
             assert abs(p[k].double().sum().item() - v) <= 1e-5 * max(1.0, abs(v)), k
+
+
+def test_oracle_dropout_with_a_given_mask_is_torch_dropout():
+    """oracle._drop(y, p, training, keep) (used to hold the HIP heads' dropout against the oracle on the SAME mask) is
+    F.dropout's arithmetic bit for bit: recover the mask torch draws under a seed, feed it back."""
+    import torch.nn.functional as F
+    y = torch.randn(64, 512)
+    torch.manual_seed(9)
+    want = F.dropout(y, 0.4, True)
+    torch.manual_seed(9)
+    keep = F.dropout(torch.ones_like(y), 0.4, True) > 0
+    assert torch.equal(O._drop(y, 0.4, True, keep), want)
+    assert 0.55 < float(keep.float().mean()) < 0.65
+    assert torch.equal(O._drop(y, 0.4, False, keep), y)
