@@ -47,7 +47,7 @@ def _data(B, N, seed):
     return data, lab, data_t, lab_t
 
 
-def _worker(rank, world, port, backend, q, mode='eager', steps=2, B=4):
+def _worker(rank, world, port, backend, q, mode='eager', steps=2, B=4, single_pass=False):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       HSA_ENABLE_IPC_MODE_LEGACY='0')
@@ -66,7 +66,7 @@ def _worker(rank, world, port, backend, q, mode='eager', steps=2, B=4):
     net = _make(3).to(dev).train()
     if mode == 'segmented_eager':
         os.environ['SUG_SEGMENTED_EAGER'] = '1'    # the segment / collective sequence of graph mode, uncaptured
-    tr = SUGStep(net, global_mmd=True, use_graph=(mode == 'segmented_graph'))
+    tr = SUGStep(net, global_mmd=True, use_graph=(mode == 'segmented_graph'), single_pass=single_pass)
     torch.manual_seed(100 + rank)                  # FPS start draws, per rank (train_dg.py:78)
     out = []
     for _ in range(steps):
@@ -79,12 +79,12 @@ def _worker(rank, world, port, backend, q, mode='eager', steps=2, B=4):
     dist.destroy_process_group()
 
 
-def _run(backend, mode='eager', steps=2, world=2, B=4):
+def _run(backend, mode='eager', steps=2, world=2, B=4, single_pass=False):
     import torch.multiprocessing as mp
     port = _free_port()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, backend, q, mode, steps, B)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, backend, q, mode, steps, B, single_pass)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
@@ -311,3 +311,27 @@ def test_bench_three_ranks_end_to_end_gloo_on_one_gpu():
     assert d['config']['collectives']['world_size'] == 3
     assert all(v is not None and math.isfinite(v) for v in d['losses']), d['losses']
     assert d['roofline'] is not None and d['roofline']['step']['gflop'] > 0
+
+
+def test_two_rank_single_pass_step_gloo_on_one_gpu():
+    """The opt-in single-pass step on two ranks: eager (bucketed all-reduce from autograd hooks), the uncaptured
+    segment sequence and the five captured segments agree -- first step to rounding, segmented-eager == segmented-graph bit
+    for bit -- the replicas stay identical, and the first step's losses equal the two-pass multi-rank step's CE exactly
+    (same semantic pass) while its geometric MMD differs only through the node pass's own FPS draw."""
+    runs = {m: _run('gloo', m, steps=3, single_pass=True) for m in ('eager', 'segmented_eager', 'segmented_graph')}
+    for m, res in runs.items():
+        (_, out0, chk0), (_, out1, chk1) = res
+        assert (chk0 == chk1).all(), '%s: parameters diverged between ranks' % m
+        for s in range(3):
+            assert out0[s][1] == out1[s][1] and out0[s][2] == out1[s][2], (m, out0, out1)
+    for r in range(2):
+        assert runs['segmented_eager'][r][1] == runs['segmented_graph'][r][1]
+        for a, b in zip(runs['eager'][r][1][0], runs['segmented_graph'][r][1][0]):
+            assert abs(a - b) <= 1e-5 * max(1.0, abs(a)), (runs['eager'][r][1], runs['segmented_graph'][r][1])
+    two = _run('gloo', 'segmented_graph', steps=1)
+    for r in range(2):
+        a, b = runs['segmented_graph'][r][1][0], two[r][1][0]
+        assert abs(a[0] - b[0]) <= 1e-6 * max(1.0, abs(b[0])), (a, b)          # CE: the same semantic pass
+        assert abs(a[2] - b[2]) <= 1e-6 * max(1.0, abs(b[2])), (a, b)          # semantic MMD likewise
+        assert abs(a[1] - b[1]) <= 5e-2 * max(1.0, abs(b[1])), (a, b)          # geometric MMD: another FPS draw of the nodes
+    print({m: res[0][1] for m, res in runs.items()})
