@@ -328,7 +328,7 @@ def test_two_rank_single_pass_step_gloo_on_one_gpu():
         assert runs['segmented_eager'][r][1] == runs['segmented_graph'][r][1]
         for a, b in zip(runs['eager'][r][1][0], runs['segmented_graph'][r][1][0]):
             assert abs(a - b) <= 1e-5 * max(1.0, abs(a)), (runs['eager'][r][1], runs['segmented_graph'][r][1])
-    two = _run('gloo', 'segmented_graph', steps=1)
+    two = _run('gloo', 'segmented_graph', steps=2)      # (>= 2 steps: the worker asserts that the capture has happened)
     for r in range(2):
         a, b = runs['segmented_graph'][r][1][0], two[r][1][0]
         assert abs(a[0] - b[0]) <= 1e-6 * max(1.0, abs(b[0])), (a, b)          # CE: the same semantic pass
