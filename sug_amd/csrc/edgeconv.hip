@@ -829,100 +829,6 @@ __global__ __launch_bounds__(1024) void edgeconv_bwd_lds_kernel(
   }
 }
 
-
-// OPT-IN (SUG_EDGECONV_BWD_UNORDERED=1), not bit-reproducible: the same gradient in SOURCE direction.  Instead of walking
-// every destination's sorted reverse list (which first has to be built: knn_reverse_kernel, 28 us per 64 clouds), every
-// source point n pushes its contributions into LDS accumulators of the destinations with float atomics (ds_add_f32):
-// a[n,c] into the row of its winner idx[n, arg[n,c]], Q[n,:] and a count into the rows of all k neighbours.  The order in
-// which a destination's terms arrive is the hardware's, so two runs may differ in the last bit -- the default path never
-// does (determinism); this form exists for the A/B the round-4 review asked for and as a speed knob.
-// Workgroup = (cloud, 16-channel slice); LDS: accumulators [N][18] for the a-term and the Q-sum (row stride 18 floats:
-// the 16 points a wave serves spread over the banks) + [N] counts = 148 KB at N = 1024.
-template <int SW, int KK>
-__global__ __launch_bounds__(1024) void edgeconv_bwd_src_kernel(
-    const float* __restrict__ a, const uint8_t* __restrict__ arg, const float* __restrict__ s1,
-    const float* __restrict__ pq, int64_t ldpq, const int32_t* __restrict__ idx, const float* __restrict__ coef_all,
-    const double* __restrict__ red_all, int B, int N, int Co, float invM, int Bg, int64_t coef_stride, int64_t red_stride,
-    float* __restrict__ dpq, int64_t lddpq) {
-  extern __shared__ __attribute__((aligned(16))) float s_lds[];
-  constexpr int LP = SW / 4;                   // lanes per point
-  constexpr int PPP = 1024 / LP;               // points per pass
-  constexpr int RS = SW + 2;                   // accumulator row stride (floats)
-  float* s_a = s_lds;                                                  // [N][RS]
-  float* s_q = s_lds + (size_t)N * RS;                                 // [N][RS]
-  int* s_cnt = reinterpret_cast<int*>(s_q + (size_t)N * RS);           // [N]
-  const int nslice = Co / SW;
-  int b, sl;
-  if ((B & 7) == 0) {
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    b = (j / nslice) * 8 + xcd;
-    sl = j % nslice;
-  } else {
-    b = blockIdx.x / nslice;
-    sl = blockIdx.x % nslice;
-  }
-  const int c0 = sl * SW;
-  const int64_t rowb = (int64_t)b * N;
-  const float* coef = coef_all + (int64_t)(b / Bg) * coef_stride;
-  const double* red = red_all + (int64_t)(b / Bg) * red_stride;
-  for (int e = threadIdx.x; e < 2 * N * RS + N; e += 1024) s_lds[e] = 0.f;      // (the counts: integer zero = 0.f bits)
-  __syncthreads();
-  const int lp = threadIdx.x % LP, slot = threadIdx.x / LP;
-  const int c = c0 + lp * 4;
-  for (int n = slot; n < N; n += PPP) {
-    const int64_t o = (rowb + n) * Co + c;
-    const float4 av = ld4(a + o), qv = ld4(pq + (rowb + n) * ldpq + Co + c);
-    const uint32_t g = *reinterpret_cast<const uint32_t*>(arg + o);
-    const int32_t* ir = idx + (rowb + n) * KK;
-    int nb[KK];
-#pragma unroll
-    for (int j = 0; j < KK; j += 4) {
-      const int4 v = *reinterpret_cast<const int4*>(ir + j);
-      nb[j] = v.x; nb[j + 1] = v.y; nb[j + 2] = v.z; nb[j + 3] = v.w;
-    }
-#pragma unroll
-    for (int j = 0; j < KK; ++j) {
-      float* d = s_q + nb[j] * RS + lp * 4;
-      atomicAdd(d + 0, qv.x); atomicAdd(d + 1, qv.y); atomicAdd(d + 2, qv.z); atomicAdd(d + 3, qv.w);
-      if (lp == 0) atomicAdd(s_cnt + nb[j], 1);
-    }
-    // the winner of each channel (its list slot is the arg byte): one more look-up of the cached list
-    atomicAdd(s_a + ir[g & 255u] * RS + lp * 4 + 0, av.x);
-    atomicAdd(s_a + ir[(g >> 8) & 255u] * RS + lp * 4 + 1, av.y);
-    atomicAdd(s_a + ir[(g >> 16) & 255u] * RS + lp * 4 + 2, av.z);
-    atomicAdd(s_a + ir[g >> 24] * RS + lp * 4 + 3, av.w);
-  }
-  const float4 sc = ld4(coef + c), mean = ld4(coef + 2 * Co + c), rstd = ld4(coef + 3 * Co + c);
-  const float dbx = (float)red[c + 0], dby = (float)red[c + 1], dbz = (float)red[c + 2], dbw = (float)red[c + 3];
-  const float dgx = (float)red[Co + c + 0], dgy = (float)red[Co + c + 1];
-  const float dgz = (float)red[Co + c + 2], dgw = (float)red[Co + c + 3];
-  const float fx = sc.x * invM, fy = sc.y * invM, fz = sc.z * invM, fw = sc.w * invM;
-  const float hx = fx * rstd.x * dgx, hy = fy * rstd.y * dgy, hz = fz * rstd.z * dgz, hw = fw * rstd.w * dgw;
-  const float kf = (float)KK;
-  __syncthreads();
-  for (int m = slot; m < N; m += PPP) {
-    const float* ra = s_a + m * RS + lp * 4;
-    const float* rq = s_q + m * RS + lp * 4;
-    const float ax = ra[0], ay = ra[1], az = ra[2], aw = ra[3];
-    const float qx = rq[0], qy = rq[1], qz = rq[2], qw = rq[3];
-    const float cf = (float)s_cnt[m];
-    const int64_t p = rowb + m;
-    const float4 pm = ld4(pq + p * ldpq + c);
-    float4 dP, dQ;
-    dP.x = ax - (hx * qx + cf * (fx * dbx + hx * (pm.x - mean.x)));
-    dP.y = ay - (hy * qy + cf * (fy * dby + hy * (pm.y - mean.y)));
-    dP.z = az - (hz * qz + cf * (fz * dbz + hz * (pm.z - mean.z)));
-    dP.w = aw - (hw * qw + cf * (fw * dbw + hw * (pm.w - mean.w)));
-    const float4 ap = ld4(a + p * Co + c), sp = ld4(s1 + p * Co + c);
-    dQ.x = ap.x - (kf * fx * dbx + hx * (sp.x - kf * mean.x));
-    dQ.y = ap.y - (kf * fy * dby + hy * (sp.y - kf * mean.y));
-    dQ.z = ap.z - (kf * fz * dbz + hz * (sp.z - kf * mean.z));
-    dQ.w = ap.w - (kf * fw * dbw + hw * (sp.w - kf * mean.w));
-    st4(dpq + p * lddpq + c, dP);
-    st4(dpq + p * lddpq + Co + c, dQ);
-  }
-}
-
 inline int lanes_per_point(int Co) {
   int lpp = 1;
   while (lpp < (Co >> 2) && lpp < 64) lpp <<= 1;
@@ -1251,36 +1157,6 @@ static int edgeconv_bwd_scatter_groups(const float* a, const uint8_t* arg, const
                                        int64_t ldpq, const int32_t* rev_off, const int32_t* rev_ent, const float* coef,
                                        const double* red, int B, int N, int k, int Co, int groups, int64_t coef_stride,
                                        int64_t red_stride, float* dpq, int64_t lddpq, void* stream);
-
-// Opt-in unordered (float-atomic) form of the scatter: 1 if SUG_EDGECONV_BWD_UNORDERED=1 and the shape is the LDS-resident one
-int sug_edgeconv_bwd_src_supported(int N, int k, int Co) {
-  static const int on = getenv("SUG_EDGECONV_BWD_UNORDERED") ? atoi(getenv("SUG_EDGECONV_BWD_UNORDERED")) : 0;
-  const size_t sh = ((size_t)2 * N * 18 + N) * sizeof(float);
-  return on && k == 20 && Co % 16 == 0 && sh <= 158 * 1024;
-}
-
-int sug_edgeconv_bwd_src_groups(const float* a, const uint8_t* arg, const float* s1, const float* pq, int64_t ldpq,
-                                const int32_t* idx, const float* coef, const double* red, int B, int N, int k, int Co,
-                                int groups, int64_t coef_stride, int64_t red_stride, float* dpq, int64_t lddpq, void* stream) {
-  SUG_REQUIRE(a && arg && s1 && pq && idx && coef && red && dpq, "sug_edgeconv_bwd_src: null pointer");
-  SUG_REQUIRE(B > 0 && N > 0 && k == 20 && Co > 0 && Co % 16 == 0, "sug_edgeconv_bwd_src: bad shape");
-  SUG_REQUIRE(groups >= 1 && B % groups == 0, "sug_edgeconv_bwd_src: B=%d does not split into %d groups", B, groups);
-  SUG_REQUIRE(ldpq >= 2 * Co && ldpq % 4 == 0 && lddpq >= 2 * Co && lddpq % 4 == 0, "sug_edgeconv_bwd_src: bad row strides");
-  SUG_REQUIRE(((uintptr_t)a % 16) == 0 && ((uintptr_t)pq % 16) == 0 && ((uintptr_t)arg % 4) == 0 && ((uintptr_t)dpq % 16) == 0 &&
-              ((uintptr_t)s1 % 16) == 0 && ((uintptr_t)coef % 16) == 0 && ((uintptr_t)idx % 16) == 0,
-              "sug_edgeconv_bwd_src: operands must be 16-byte aligned");
-  const int Bg = B / groups;
-  const float invM = (float)(1.0 / ((double)Bg * N * k));
-  const size_t sh = ((size_t)2 * N * 18 + N) * sizeof(float);
-  SUG_REQUIRE(sh <= 158 * 1024, "sug_edgeconv_bwd_src: N=%d does not fit the LDS accumulators", N);
-  static SugLdsOptIn note;
-  if (int rc = sug_allow_dynamic_lds(note, &edgeconv_bwd_src_kernel<16, 20>, 158 * 1024, "sug_edgeconv_bwd_src")) return rc;
-  hipLaunchKernelGGL((edgeconv_bwd_src_kernel<16, 20>), dim3(B * (Co / 16)), dim3(1024), sh, (hipStream_t)stream, a, arg, s1, pq,
-                     ldpq, idx, coef, red, B, N, Co, invM, Bg, coef_stride, red_stride, dpq, lddpq);
-  SUG_LAUNCH_CHECK("sug_edgeconv_bwd_src");
-  return SUG_OK;
-}
-
 
 extern "C" int sug_edgeconv_bwd_scatter(const float* a, const uint8_t* arg, const float* s1,
                                         const float* pq, int64_t ldpq, const int32_t* rev_off,

@@ -30,10 +30,6 @@ int sug_edgeconv_bwd_scatter_groups(const float* a, const uint8_t* arg, const fl
                                     const int32_t* rev_off, const int32_t* rev_ent, const float* coef, const double* red,
                                     int B, int N, int k, int Co, int groups, int64_t coef_stride, int64_t red_stride,
                                     float* dpq, int64_t lddpq, void* stream);
-int sug_edgeconv_bwd_src_supported(int N, int k, int Co);
-int sug_edgeconv_bwd_src_groups(const float* a, const uint8_t* arg, const float* s1, const float* pq, int64_t ldpq,
-                                const int32_t* idx, const float* coef, const double* red, int B, int N, int k, int Co,
-                                int groups, int64_t coef_stride, int64_t red_stride, float* dpq, int64_t lddpq, void* stream);
 #define LAYER_REQUIRE(cond, ...) do { if (!(cond)) { sug_set_error(__VA_ARGS__); return SUG_ERR_ARG; } } while (0)
 #define LAYER_TRY(call) do { const int rc_ = (call); if (rc_ != SUG_OK) return rc_; } while (0)
 
@@ -68,9 +64,7 @@ extern "C" int sug_edgeconv_layer_bwd(const float* gout, int64_t ldg, const floa
   LAYER_REQUIRE(red && a && rev_off && rev_ent, "sug_edgeconv_layer_bwd: null pointer");
   const int Bg = B / groups;
   const int64_t rows = (int64_t)Bg * N;
-  // SUG_EDGECONV_BWD_UNORDERED=1 (opt-in, not bit-reproducible): source-direction scatter with LDS float atomics, no reverse lists
-  const bool unordered = sug_edgeconv_bwd_src_supported(N, k, Co) != 0;
-  if (!unordered) LAYER_TRY(sug_knn_reverse(idx, B, N, k, rev_off, rev_ent, stream));
+  LAYER_TRY(sug_knn_reverse(idx, B, N, k, rev_off, rev_ent, stream));
   int grouped = 1;
   if (groups > 1) {
     grouped = sug_bwd_reduce_groups(gout, ldg, z, coef, rows, Co, groups, slope, a, red, ws, (ihipStream_t*)stream);
@@ -84,12 +78,6 @@ extern "C" int sug_edgeconv_layer_bwd(const float* gout, int64_t ldg, const floa
   }
   // eval mode: the statistics are constants, the scatter must see zero BN sums (red + groups*2Co: a
   // caller-zeroed spare row, shared by all groups)
-  if (unordered) {
-    LAYER_TRY(sug_edgeconv_bwd_src_groups(a, arg, s1, pq, ldpq, idx, coef, training ? red : red + (int64_t)groups * 2 * Co, B, N, k,
-                                          Co, groups, (int64_t)5 * Co, training ? (int64_t)2 * Co : 0, dpq, lddpq, stream));
-    if (dgb) LAYER_TRY(sug_fold_groups(red, groups, 2 * Co, dgb, stream));
-    return SUG_OK;
-  }
   LAYER_TRY(sug_edgeconv_bwd_scatter_groups(a, arg, s1, pq, ldpq, rev_off, rev_ent, coef,
                                             training ? red : red + (int64_t)groups * 2 * Co, B, N, k, Co, groups,
                                             (int64_t)5 * Co, training ? (int64_t)2 * Co : 0, dpq, lddpq, stream));

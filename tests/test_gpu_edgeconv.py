@@ -361,50 +361,3 @@ def test_edgeconv_large_offset(C, Co):
     err = float((out - ref).abs().max())
     print('max deviation from the fp64 layer: %.3e' % err)
     assert err < 5e-3, err                  # input rounding: ulp(100) = 7.6e-6 against a spread of ~0.05
-
-
-def test_unordered_backward_option_matches_the_ordered_default():
-    """SUG_EDGECONV_BWD_UNORDERED=1 (opt-in, csrc/edgeconv.hip edgeconv_bwd_src_kernel: source-direction scatter with LDS
-    float atomics, no reverse lists) computes the same gradient as the default ordered kernel up to the order of the
-    additions -- checked in a child process (the switch is read once per process), on a graph with hub points and
-    duplicate-heavy lists -- and the default stays bit-reproducible while the opt-in form need not be."""
-    import os
-    import subprocess
-    import sys
-    import tempfile
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = r'''
-import sys, torch
-sys.path.insert(0, %r)
-from sug_amd import ops
-from sug_amd.model.model_utils import conv_2d
-out = sys.argv[1]
-res = {}
-for C, Co, B in ((64, 64, 8), (64, 128, 8), (128, 256, 4), (3, 64, 8)):
-    torch.manual_seed(C + Co)
-    pts = torch.rand(B, 1024, 3, device='cuda') * 2 - 1
-    pts[:, 900:] = pts[:, 899:900]                      # 124 duplicates of one point: a hub with a long reverse list
-    x = (pts if C == 3 else torch.tanh(pts @ torch.randn(3, C, device='cuda'))).contiguous().requires_grad_(True)
-    idx = ops.knn(x.detach(), 20)
-    layer = conv_2d(2 * C, Co, 1, activation='leakyrelu', bias=False).cuda().train()
-    with ops.bn_groups(2):
-        y = layer.edge_rows(x, idx)
-    g = torch.randn(y.shape, device='cuda', generator=torch.Generator(device='cuda').manual_seed(1))
-    grads = torch.autograd.grad(y, [x] + list(layer.parameters()), g)
-    res['%%d_%%d' %% (C, Co)] = [t.cpu() for t in grads]
-torch.save(res, out)
-''' % root
-    outs = {}
-    with tempfile.TemporaryDirectory() as d:
-        for tag, val in (('ordered', '0'), ('unordered', '1'), ('ordered2', '0')):
-            f = os.path.join(d, tag + '.pt')
-            env = dict(os.environ, SUG_EDGECONV_BWD_UNORDERED=val)
-            r = subprocess.run([sys.executable, '-c', code, f], env=env, capture_output=True, text=True, timeout=600)
-            assert r.returncode == 0, r.stderr[-2000:]
-            outs[tag] = torch.load(f)
-    for key in outs['ordered']:
-        for a, b, c in zip(outs['ordered'][key], outs['unordered'][key], outs['ordered2'][key]):
-            assert torch.equal(a, c), 'the default (ordered) backward must be bit-reproducible: ' + key
-            err = float((a.double() - b.double()).norm() / a.double().norm().clamp_min(1e-30))
-            assert err <= 2e-6, (key, err)
-    print('unordered vs ordered EdgeConv backward: equal to 2e-6 relative L2 on', sorted(outs['ordered']))
