@@ -577,6 +577,7 @@ def main():
     prof, ops.PROFILE = ({} if graph_mode else ops.PROFILE), None
     eager_ms = None
     exact_ms = None
+    graph_kernel_ms = graph_launches = None
     child_events = None
     if graph_mode and not args.plain:
         # kernel durations INSIDE the measured launch mode: the device kernels' own timestamps (torch.profiler = roctracer,
@@ -589,6 +590,12 @@ def main():
         if exact_ms is not None and not any('knn_pc_kernel' in k for k in exact_ms):
             exact_ms = None                                      # the tracer did not see inside the graph launches
         child_events = child['events']
+        if exact_ms is not None:
+            # step-level accounting in the measured launch mode: device time of ALL kernels of a replayed step (their own
+            # timestamps) against the step's wall time -- the difference is launch gaps / dependency bubbles inside the graph
+            nrep = max(args.profile_steps, 1)
+            graph_kernel_ms = sum(sum(v) for v in exact_ms.values()) / nrep
+            graph_launches = sum(len(v) for v in exact_ms.values()) / nrep
     collectives = None
     if (world > 1 or args.segmented) and graph_mode and getattr(trainer, 'segmented', False):
         # per-collective milliseconds (events on the compute stream around the eager RCCL calls between the graph replays)
@@ -802,6 +809,7 @@ def main():
                                      'gradient-bucket all-reduces, bucket 1 in flight under the encoder backward)' if (graph_mode and (world > 1 or args.segmented)) else
                                      'hipGraph replay of the whole step' if graph_mode else 'eager'),
                           'eager_ms_per_step': eager_ms,
+                          'graph_kernel_ms_per_step': graph_kernel_ms, 'graph_launches_per_step': graph_launches,
                           'share_prefix': share_prefix_on, 'pair_domains': pair_domains_on,
                           'tuned_gemms': tuned, 'geo_weights': 'mean2one', 'sem_weights': 'mean2one',
                           'weight_gradients': ('outputs below 128x128: own split-K MFMA kernels (sug_linear_dw); 128x128 and wider: batched '

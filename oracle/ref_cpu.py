@@ -598,6 +598,17 @@ def prob_weights_soft(pred_s, pred_t, label_s, label_t, label_weight, weighting=
     return distance2weights(d, weighting).reshape(1, -1)
 
 
+def entropy_weights(pred_s, pred_t, weighting='exp_inverse'):
+    """entropy_weights / entropy_dis, model/mmd.py:155-166, with cal_probs2entropy and kl_divergence_distance,
+    dataset_splitter.py:234-245: symmetric KL (scipy kl_div, element-wise) between the prediction entropies
+    -(p log(p + 1e-30)).sum(1) of paired samples -> distance2weights -> [1, m].  (The reference runs for weighting 'none' /
+    'mean2one' on probability inputs only; its other weightings raise inside distance2weights.)"""
+    ent = lambda p_: -(p_ * torch.log(p_ + 1e-30)).sum(1)
+    es, et = ent(pred_s.detach()), ent(pred_t.detach())
+    d = _kl_div(es, et) * 0.5 + _kl_div(et, es) * 0.5
+    return distance2weights(d, weighting).reshape(1, -1)
+
+
 def chamfer_weights(pc_s, pc_t, weighting='mean2one'):
     """geometric_weights, model/mmd.py:107-131 + cd_distance :169-175.  PARITY UNPINNED:
     ChamferDistance is third-party (github.com/otaheri/chamfer_distance, unpinned, absent);
@@ -624,6 +635,8 @@ def mmd_cal(label_s, feat_s, label_t, feat_t, args, data_s=None, data_t=None):
     if data_s is not None and (args.get('GEO_WEIGHTS') or args.get('SEM_WEIGHTS')):
         if args.get('GEO_WEIGHTS'):
             w = chamfer_weights(data_s, data_t, args['GEO_WEIGHTS'])
+        elif args.get('ENTROPY_WEIGHTS'):                       # cal_sample_weights prefers it over SEM_WEIGHTS, :47
+            w = entropy_weights(data_s, data_t, args['ENTROPY_WEIGHTS'])
         else:
             w = prob_weights_soft(data_s, data_t, label_s, label_t, args['LABEL_WEIGHT'], args['SEM_WEIGHTS'])
     name = args['NAME']

@@ -36,6 +36,8 @@ def cal_sample_weights(data_s, data_t, args, label_s=None, label_t=None, KPC=Fal
     """model/mmd.py:44-53."""
     if args.get("GEO_WEIGHTS", None):
         return geometric_weights(data_s, data_t, weighting=args["GEO_WEIGHTS"], KPC=KPC)
+    elif args.get("ENTROPY_WEIGHTS", None):
+        return entropy_weights(data_s, data_t, weighting=args["ENTROPY_WEIGHTS"])
     elif args.get("SEM_WEIGHTS", None):
         return prob_weights_soft(data_s, data_t, label_s, label_t, args["LABEL_WEIGHT"], args["SEM_WEIGHTS"])
     raise RuntimeError("Not suppprted weighting opperation")
@@ -107,6 +109,26 @@ def _kl_div(x, y):
     return x * torch.log(x / y) - x + y
 
 
+def cal_probs2entropy(probs):
+    """dataset_splitter.py:234-241: -(p log(p + 1e-30)).sum(1) of the rows of probs [m, C]."""
+    return -(probs * torch.log(probs + 1e-30)).sum(1)
+
+
+def entropy_dis(pred_s, pred_t):
+    """model/mmd.py:161-166: symmetric KL (dataset_splitter.py:244-245, scipy kl_div element-wise) between the
+    prediction entropies of paired source / target samples -> [m]."""
+    es, et = cal_probs2entropy(pred_s.detach()), cal_probs2entropy(pred_t.detach())
+    return _kl_div(es, et) * 0.5 + _kl_div(et, es) * 0.5
+
+
+def entropy_weights(pred_s, pred_t, weighting="exp_inverse"):
+    """model/mmd.py:155-158, on the device (the reference returns a CPU tensor): [1, m] weights from entropy_dis.  As in the
+    reference the inputs must be PROBABILITIES (logits put a negative number under the log: NaN there and here); the
+    reference itself runs only for weighting 'none' / 'mean2one' -- its 'exp_inverse' / 'naive_inverse' build Python lists
+    that distance2weights then fails to reshape; here they follow their evident formulas -- and 'hist' raises in both."""
+    return distance2weights(distances=entropy_dis(pred_s, pred_t), method=weighting).reshape(1, -1)
+
+
 def prob_weights_soft(pred_s, pred_t, label_s, label_t, label_weight, weighting="mean2one"):
     """model/mmd.py:134-148, on the device."""
     assert label_weight < 1, "For Entropy, Label weight should be less than one"
@@ -134,6 +156,11 @@ def distance2weights(distances, method="naive_inverse"):
     elif method == "mean2one":
         scale_ = (1 / distances.mean()).type(torch.int)
         weights = distances * scale_
+    elif method == "hist":
+        # model/mmd.py:186-193 assigns into a Python list with a tuple of index arrays: a TypeError in the reference on
+        # every input; there is no behaviour to mirror
+        raise TypeError("distance2weights('hist'): list indices must be integers or slices, not tuple "
+                        "(the reference's own failure, model/mmd.py:193)")
     else:
         raise RuntimeError("Not supported weighting method %s" % method)
     return weights.reshape(-1, 1).squeeze()

@@ -690,9 +690,39 @@ def gen_eval_cls():
     save('eval_cls.npz', **out)
 
 
+def gen_entropy():
+    """ENTROPY_WEIGHTS (model/mmd.py:47-48, :155-166; dataset_splitter.py:234-245): per-sample weights = symmetric KL between
+    the prediction ENTROPIES of paired source / target samples.  What the reference can actually run: weighting 'none' and
+    'mean2one' on PROBABILITY inputs (raw logits give NaN through log of a negative number; 'exp_inverse' -- its default --,
+    'naive_inverse' and 'hist' raise inside distance2weights).  Reached through mmd_cal only together with SEM_WEIGHTS
+    (:28 tests GEO / SEM, :47 prefers ENTROPY)."""
+    g = torch.Generator().manual_seed(61)
+    m = 8
+    ps, pt = torch.softmax(torch.randn(m, 10, generator=g) * 2, 1), torch.softmax(torch.randn(m, 10, generator=g) * 2, 1)
+    ls, lt = torch.randint(0, 10, (m,), generator=g), torch.randint(0, 10, (m,), generator=g)
+    fs, ft = torch.randn(m, 256, generator=g), torch.randn(m, 256, generator=g) + 0.1
+    out = {'ps': ps, 'pt': pt, 'ls': ls, 'lt': lt, 'fs': fs, 'ft': ft}
+    for w in ('none', 'mean2one'):
+        out['w_' + w] = r_mmd.entropy_weights(ps, pt, weighting=w).float()
+        same(O.entropy_weights(ps, pt, w), out['w_' + w], 'entropy_weights ' + w, 1e-6)
+        args = {'NAME': 'SOFT_MMD', 'LABEL_SCALE': 5, 'SEM_WEIGHTS': 'mean2one', 'ENTROPY_WEIGHTS': w, 'LABEL_WEIGHT': 0.5}
+        out['mmd_' + w] = r_mmd.mmd_cal(ls, fs, lt, ft, args, data_s=ps, data_t=pt)
+        same(O.mmd_cal(ls, fs, lt, ft, args, ps, pt), out['mmd_' + w], 'mmd_cal ENTROPY_WEIGHTS ' + w, 1e-5)
+    raised = []
+    for w in ('exp_inverse', 'naive_inverse', 'hist'):
+        try:
+            r_mmd.entropy_weights(ps, pt, weighting=w)
+            raised.append(w + ':ok')
+        except Exception as e:
+            raised.append(w + ':' + type(e).__name__)
+    out['reference_raises'] = np.array(raised)
+    print('reference behaviour of the other weightings:', raised)
+    save('entropy.npz', **out)
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['ops', 'mmd', 'pointnet_cls', 'dgcnn', 'pointnet', 'pointnet2', 'ptran', 'step', 'focal', 'ptran2048',
-                             'pointnet2_b4', 'pointnet2_cls', 'dgcnn_cls', 'step_seeds', 'eval']
+                             'pointnet2_b4', 'pointnet2_cls', 'dgcnn_cls', 'step_seeds', 'eval', 'entropy']
     if 'ops' in which:
         gen_ops()
     if 'mmd' in which:
@@ -721,6 +751,8 @@ if __name__ == '__main__':
         gen_pointnet2_cls()
     if 'dgcnn_cls' in which:
         gen_dgcnn_cls()
+    if 'entropy' in which:
+        gen_entropy()
     if 'eval' in which:                 # eval-mode forwards (utils/eval_utils.py:5-88) after one train-mode forward
         gen_eval('DGCNN', 2, 1024, 51, 'eval_dgcnn.npz')
         gen_eval('Pointnet', 4, 1024, 52, 'eval_pointnet.npz')

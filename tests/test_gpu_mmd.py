@@ -91,3 +91,17 @@ def test_sda_prob_weights_kernel_vs_oracle(m, meth):
     got = mmd.prob_weights_soft(ps.cuda(), pt.cuda(), ls.cuda(), lt.cuda(), 0.5, meth)
     assert got.shape == want.shape
     torch.testing.assert_close(got.cpu(), want, rtol=2e-4, atol=1e-7)
+
+
+def test_mmd_cal_with_entropy_weights_matches_reference():
+    """mmd_cal(..., args with ENTROPY_WEIGHTS) on the device == the reference's value (tests/golden/entropy.npz):
+    cal_sample_weights prefers ENTROPY_WEIGHTS over SEM_WEIGHTS (model/mmd.py:44-53)."""
+    from conftest import load_golden
+    from sug_amd.model import mmd
+    G = load_golden('entropy.npz')
+    c = lambda k: G[k].cuda()
+    for w in ('none', 'mean2one'):
+        args = {'NAME': 'SOFT_MMD', 'LABEL_SCALE': 5, 'SEM_WEIGHTS': 'mean2one', 'ENTROPY_WEIGHTS': w, 'LABEL_WEIGHT': 0.5}
+        v = mmd.mmd_cal(c('ls'), c('fs'), c('lt'), c('ft'), args, data_s=c('ps'), data_t=c('pt'))
+        assert abs(float(v) - float(G['mmd_' + w])) <= 1e-4 * max(1.0, abs(float(G['mmd_' + w]))), (w, float(v), float(G['mmd_' + w]))
+        torch.testing.assert_close(mmd.entropy_weights(c('ps'), c('pt'), w).cpu(), G['w_' + w], rtol=1e-4, atol=2e-7)      # (x log(x/y) - x + y of nearby entropies cancels: 6e-8 absolute between scipy and torch)

@@ -264,3 +264,21 @@ def test_oracle_dropout_with_a_given_mask_is_torch_dropout():
     assert torch.equal(O._drop(y, 0.4, True, keep), want)
     assert 0.55 < float(keep.float().mean()) < 0.65
     assert torch.equal(O._drop(y, 0.4, False, keep), y)
+
+
+def test_entropy_weights_oracle_and_mirror_vs_golden():
+    """ENTROPY_WEIGHTS (model/mmd.py:47-48, :155-166): oracle and host mirror (pure torch, device-agnostic) reproduce what the
+    reference can run ('none', 'mean2one' on probability inputs); 'hist' raises as it does there."""
+    from sug_amd.model import mmd
+    G = load_golden('entropy.npz')
+    assert G['reference_raises'] == ['exp_inverse:AttributeError', 'naive_inverse:AttributeError', 'hist:TypeError']
+    for w in ('none', 'mean2one'):
+        torch.testing.assert_close(O.entropy_weights(G['ps'], G['pt'], w), G['w_' + w], rtol=1e-4, atol=2e-7)      # (x log(x/y) - x + y of nearby entropies cancels: 6e-8 absolute between scipy and torch)
+        torch.testing.assert_close(mmd.entropy_weights(G['ps'], G['pt'], w), G['w_' + w], rtol=1e-4, atol=2e-7)      # (x log(x/y) - x + y of nearby entropies cancels: 6e-8 absolute between scipy and torch)
+        args = {'NAME': 'SOFT_MMD', 'LABEL_SCALE': 5, 'SEM_WEIGHTS': 'mean2one', 'ENTROPY_WEIGHTS': w, 'LABEL_WEIGHT': 0.5}
+        torch.testing.assert_close(O.mmd_cal(G['ls'], G['fs'], G['lt'], G['ft'], args, G['ps'], G['pt']), G['mmd_' + w],
+                                   rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(mmd.cal_sample_weights(G['ps'], G['pt'], args, G['ls'], G['lt']), G['w_' + w], rtol=1e-4, atol=2e-7)      # (x log(x/y) - x + y of nearby entropies cancels: 6e-8 absolute between scipy and torch)
+    with pytest.raises(TypeError):
+        mmd.entropy_weights(G['ps'], G['pt'], 'hist')
+    assert torch.isnan(mmd.entropy_weights(torch.randn(4, 10), torch.randn(4, 10), 'none')).any()      # logits: NaN, as there
