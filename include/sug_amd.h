@@ -515,6 +515,17 @@ int sug_pointmlp_max_layer_fwd(const float* x, int64_t ldx, int64_t rows, int K,
                                float eps, float momentum, float slope, float* running_mean, float* running_var,
                                float* zext, int32_t* arg, float* coef, float* out, int64_t ldo, float* ws,
                                void* stream);
+/* The same layer fed with the PRE-activation rows y [rows, K] of the layer in front (round 5; model/pointnet2_utils.py:
+ * 193-207, layers i and i+1 of a set-abstraction MLP): that layer's BatchNorm + (Leaky)ReLU -- xcoef [groups][5][K] as
+ * sug_col_stats_bn / sug_bn_finalize write it (rows 0 / 1 = scale / shift), slope xslope -- is applied to the x operand on
+ * its way into LDS.  zout [rows, ldz] (may be null): the activated rows z = act(scale * y + shift), written once, for a
+ * backward (sug_pointmlp_max_bwd_sparse takes z as its x) or for a caller that needs z itself.  Replaces
+ * sug_affine_act on [rows, K] + this kernel's read of its output. */
+int sug_pointmlp_max_layer_fwd_xf(const float* y, int64_t ldy, int64_t rows, int K, const float* xcoef, float xslope,
+                                  float* zout, int64_t ldz, const float* w, const float* bias, const float* gamma,
+                                  const float* beta, int Co, int seg, int groups, int training, float eps, float momentum,
+                                  float slope, float* running_mean, float* running_var, float* zext, int32_t* arg,
+                                  float* coef, float* out, int64_t ldo, float* ws, void* stream);
 /* Backward, the terms that follow the winning rows n*(s,c) = s*seg + arg[s,c], with
  * a[s,c] = scale[c] * gout[s,c] * act' (sug_edgeconv_bwd_reduce on the [rows/seg, Co] tensors):
  *   dx[n*(s,c), :] += a[s,c] * w[c,:]   (dx holds the dense BatchNorm-statistics term -(x.A + v) or zeros)

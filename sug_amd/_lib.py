@@ -106,6 +106,8 @@ SIGNATURES = {
     'sug_pointmlp_max_fwd': [_vp, _i64, _i64, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
     'sug_pointmlp_max_layer_fwd': [_vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _vp,
                                    _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
+    'sug_pointmlp_max_layer_fwd_xf': [_vp, _i64, _i64, _i32, _vp, _f32, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32,
+                                      _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
     'sug_pointmlp_max_bwd_sparse': [_vp, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp],
     'sug_mmd_rbf': [_vp, _i64, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp],
     'sug_chamfer': [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],

@@ -25,11 +25,16 @@
 namespace {
 using namespace sug_tile;
 
-template <int CP>
+// XF (round 5): the rows of x are PRE-activation outputs of the previous layer; its BatchNorm + (Leaky)ReLU -- per input
+// channel scale / shift `xcoef` [2][CP] and slope `xslope` -- is applied to every tile on its way from the load registers to
+// LDS, and (zout != nullptr, first channel block only) the activated rows are written out once for the backward.  The
+// previous layer's separate BatchNorm pass (read y, write z) and this kernel's read of z collapse into one read of y.
+template <int CP, bool XF = false>
 __global__ __launch_bounds__(256, 2) void pointmlp_max_kernel(
     const float* __restrict__ x, int64_t ldx, int R, const float* __restrict__ W,
     const float* __restrict__ bias, const float* __restrict__ gamma, int Co, int L, int rows_per_wg, int nrb,
-    float* __restrict__ zext, int32_t* __restrict__ arg, float* __restrict__ ws, int pivoted, int parts) {
+    float* __restrict__ zext, int32_t* __restrict__ arg, float* __restrict__ ws, int pivoted, int parts,
+    const float* __restrict__ xcoef = nullptr, float xslope = 0.f, float* __restrict__ zout = nullptr, int64_t ldz = 0) {
   // parts > 1 (small grids, pointmlp_max_fwd): a segment of L rows is split over `parts` workgroups of rows_per_wg = L / parts
   // rows; each writes its sign-folded partial extreme + row to the scratch behind the statistics rows of ws
   // ([nrb][Co] floats, then [nrb][Co] ints) and pointmlp_max_combine_kernel picks the first extreme in part order.
@@ -71,6 +76,45 @@ __global__ __launch_bounds__(256, 2) void pointmlp_max_kernel(
       bq[4 * g + 3] = h ? hi.w : hi.z;
     }
   }
+  // XF: scale / shift of the 8 input features this thread stages (chunk c8 = threadIdx.x % (CP / 8) of every row it loads)
+  float xsc[8], xsh[8];
+  if constexpr (XF) {
+    const int c8 = (int)threadIdx.x % (CP / 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      xsc[e] = xcoef[c8 * 8 + e];
+      xsh[e] = xcoef[CP + c8 * 8 + e];
+    }
+  }
+  auto xf1 = [&](float v, float sc, float sh) {
+    const float t = fmaf(v, sc, sh);
+    return t > 0.f ? t : xslope * t;
+  };
+  // activate the tile a thread holds in registers (rows row0 + item / CH of this workgroup) and, for the first channel
+  // block, write the activated rows out
+  float* zb = (XF && zout != nullptr && cb == 0) ? zout + (int64_t)row_begin * ldz : nullptr;
+  auto xform = [&](TileRegs<CP>& t, int row0, int nrows_) {
+    if constexpr (XF) {
+      constexpr int CH = CP / 8;
+#pragma unroll
+      for (int u = 0; u < TileRegs<CP>::NV; ++u) {
+        float4 a = t.lo[u], b = t.hi[u];
+        a.x = xf1(a.x, xsc[0], xsh[0]); a.y = xf1(a.y, xsc[1], xsh[1]); a.z = xf1(a.z, xsc[2], xsh[2]); a.w = xf1(a.w, xsc[3], xsh[3]);
+        b.x = xf1(b.x, xsc[4], xsh[4]); b.y = xf1(b.y, xsc[5], xsh[5]); b.z = xf1(b.z, xsc[6], xsh[6]); b.w = xf1(b.w, xsc[7], xsh[7]);
+        t.lo[u] = a;
+        t.hi[u] = b;
+        if (zb != nullptr) {
+          const int item = (int)threadIdx.x + u * 256;
+          const int r = row0 + item / CH;
+          if (r < nrows_) {
+            float* d = zb + (int64_t)r * ldz + (item % CH) * 8;
+            *reinterpret_cast<float4*>(d) = a;
+            *reinterpret_cast<float4*>(d + 4) = b;
+          }
+        }
+      }
+    }
+  };
   const float sgn = gamma[col] >= 0.f ? 1.f : -1.f;
   // The sign of gamma is folded into the weights and the bias: the accumulator then holds sgn * y EXACTLY (negation commutes
   // with every rounding of the fma chain), the running extreme is a plain maximum, and the BatchNorm sums are taken of
@@ -84,7 +128,11 @@ __global__ __launch_bounds__(256, 2) void pointmlp_max_kernel(
   if (pivoted) {
     float d = 0.f;
 #pragma unroll
-    for (int e = 0; e < HALF; ++e) d = fmaf(x[2 * e + h], bq[e], d);
+    for (int e = 0; e < HALF; ++e) {
+      float xv = x[2 * e + h];
+      if constexpr (XF) xv = xf1(xv, xcoef[2 * e + h], xcoef[CP + 2 * e + h]);
+      d = fmaf(xv, bq[e], d);
+    }
     pvt = __fadd_rn(d + __shfl_xor(d, 32), bj);          // sgn * (pivot of y)
     if (rb == 0 && h == 0) ws[SUG_PIVOT_OFFSET(Co) + col] = sgn * pvt;
   }
@@ -158,6 +206,7 @@ __global__ __launch_bounds__(256, 2) void pointmlp_max_kernel(
   {
     TileRegs<CP> tra, trb;
     tile_load<CP>(tra, xb, ldx, nrows, 0);
+    xform(tra, 0, nrows);
     tile_store<CP, false>(tra, tbuf(0), nullptr, nrows, 0);
     __syncthreads();
     if (ntile > 1) tile_load<CP>(trb, xb, ldx, nrows, TJ);
@@ -176,7 +225,10 @@ __global__ __launch_bounds__(256, 2) void pointmlp_max_kernel(
         acc_cur = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, bq[4 * g + 3], acc_cur, 0, 0, 0);
       }
     }
-    if (ntile > 1) tile_store<CP, false>(trb, tbuf(1), nullptr, nrows, TJ);
+    if (ntile > 1) {
+      xform(trb, TJ, nrows);
+      tile_store<CP, false>(trb, tbuf(1), nullptr, nrows, TJ);
+    }
     __syncthreads();
     if (ntile > 3) tile_load<CP>(trb, xb, ldx, nrows, 3 * TJ);
     // iteration t: MFMA chain of tile t+1 || epilogue of tile t; registers of tile t+2 -> LDS; global
@@ -185,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void pointmlp_max_kernel(
       f32x16 acc_next; \
       step(acc_cur, acc_next, tbuf((T) + 1) + cj * RS + h * HALF, (T)); \
       if ((((T) + 1) * TJ) % L == 0 || (T) + 1 == ntile) flush((T)); \
-      if ((T) + 2 < ntile) tile_store<CP, false>(TR, tbuf((T) + 2), nullptr, nrows, ((T) + 2) * TJ); \
+      if ((T) + 2 < ntile) { xform(TR, ((T) + 2) * TJ, nrows); tile_store<CP, false>(TR, tbuf((T) + 2), nullptr, nrows, ((T) + 2) * TJ); } \
       __syncthreads(); \
       if ((T) + 4 < ntile) tile_load<CP>(TR, xb, ldx, nrows, ((T) + 4) * TJ); \
       acc_cur = acc_next; \
@@ -624,17 +676,17 @@ static int pointmlp_rows_per_wg(int64_t rows, int L) {
 
 static int pointmlp_max_fwd(const float* x, int64_t ldx, int64_t rows, int K, const float* w, const float* bias,
                             const float* gamma, int Co, int seg, float* zext, int32_t* arg, float* ws, int* nblk,
-                            void* stream, int pivoted);
+                            void* stream, int pivoted, const float* xcoef, float xslope, float* zout, int64_t ldz);
 
 extern "C" int sug_pointmlp_max_fwd(const float* x, int64_t ldx, int64_t rows, int K, const float* w, const float* bias,
                                     const float* gamma, int Co, int seg, float* zext, int32_t* arg, float* ws,
                                     int* nblk, void* stream) {
-  return pointmlp_max_fwd(x, ldx, rows, K, w, bias, gamma, Co, seg, zext, arg, ws, nblk, stream, 0);   // plain sums
+  return pointmlp_max_fwd(x, ldx, rows, K, w, bias, gamma, Co, seg, zext, arg, ws, nblk, stream, 0, nullptr, 0.f, nullptr, 0);   // plain sums
 }
 
 static int pointmlp_max_fwd(const float* x, int64_t ldx, int64_t rows, int K, const float* w, const float* bias,
                             const float* gamma, int Co, int seg, float* zext, int32_t* arg, float* ws, int* nblk,
-                            void* stream, int pivoted) {
+                            void* stream, int pivoted, const float* xcoef, float xslope, float* zout, int64_t ldz) {
   SUG_REQUIRE(x && w && gamma && zext && arg && ws && nblk, "sug_pointmlp_max_fwd: null pointer");
   SUG_REQUIRE(K == 64 || K == 128, "sug_pointmlp_max_fwd: K=%d (64 or 128 input channels)", K);
   SUG_REQUIRE(Co > 0 && Co % 128 == 0, "sug_pointmlp_max_fwd: Co=%d must be a multiple of 128", Co);
@@ -662,14 +714,22 @@ static int pointmlp_max_fwd(const float* x, int64_t ldx, int64_t rows, int K, co
   }
   const int grid = nrb * (Co / 128);
   hipStream_t st = (hipStream_t)stream;
-  if (K == 128) {
+  if (xcoef) {
+    SUG_REQUIRE(!zout || (ldz >= K && ldz % 4 == 0 && ((uintptr_t)zout % 16) == 0), "sug_pointmlp_max_fwd: bad zout / ldz");
+    if (K == 128)
+      hipLaunchKernelGGL((pointmlp_max_kernel<128, true>), dim3(grid), dim3(256), (size_t)3 * TJ * (128 + 4) * sizeof(float), st, x,
+                         ldx, (int)rows, w, bias, gamma, Co, seg, rpw, nrb, zext, arg, ws, pivoted, parts, xcoef, xslope, zout, ldz);
+    else
+      hipLaunchKernelGGL((pointmlp_max_kernel<64, true>), dim3(grid), dim3(256), (size_t)3 * TJ * (64 + 4) * sizeof(float), st, x,
+                         ldx, (int)rows, w, bias, gamma, Co, seg, rpw, nrb, zext, arg, ws, pivoted, parts, xcoef, xslope, zout, ldz);
+  } else if (K == 128) {
     const size_t sh = (size_t)3 * TJ * (128 + 4) * sizeof(float);
     hipLaunchKernelGGL((pointmlp_max_kernel<128>), dim3(grid), dim3(256), sh, st, x, ldx, (int)rows, w, bias, gamma, Co,
-                       seg, rpw, nrb, zext, arg, ws, pivoted, parts);
+                       seg, rpw, nrb, zext, arg, ws, pivoted, parts, nullptr, 0.f, nullptr, (int64_t)0);
   } else {
     const size_t sh = (size_t)3 * TJ * (64 + 4) * sizeof(float);
     hipLaunchKernelGGL((pointmlp_max_kernel<64>), dim3(grid), dim3(256), sh, st, x, ldx, (int)rows, w, bias, gamma, Co,
-                       seg, rpw, nrb, zext, arg, ws, pivoted, parts);
+                       seg, rpw, nrb, zext, arg, ws, pivoted, parts, nullptr, 0.f, nullptr, (int64_t)0);
   }
   SUG_LAUNCH_CHECK("sug_pointmlp_max_fwd");
   if (parts > 1) {
@@ -704,11 +764,39 @@ extern "C" int sug_rows_gemm(const float* x, int64_t ldx, int64_t rows, int K, c
   return SUG_OK;
 }
 
+static int pointmlp_max_layer(const float* x, int64_t ldx, int64_t rows, int K, const float* w,
+                              const float* bias, const float* gamma, const float* beta, int Co, int seg,
+                              int groups, int training, float eps, float momentum, float slope,
+                              float* running_mean, float* running_var, float* zext, int32_t* arg,
+                              float* coef, float* out, int64_t ldo, float* ws, void* stream, const float* xcoef, float xslope,
+                              float* zout, int64_t ldz);
+
 extern "C" int sug_pointmlp_max_layer_fwd(const float* x, int64_t ldx, int64_t rows, int K, const float* w,
                                           const float* bias, const float* gamma, const float* beta, int Co, int seg,
                                           int groups, int training, float eps, float momentum, float slope,
                                           float* running_mean, float* running_var, float* zext, int32_t* arg,
                                           float* coef, float* out, int64_t ldo, float* ws, void* stream) {
+  return pointmlp_max_layer(x, ldx, rows, K, w, bias, gamma, beta, Co, seg, groups, training, eps, momentum, slope, running_mean,
+                            running_var, zext, arg, coef, out, ldo, ws, stream, nullptr, 0.f, nullptr, 0);
+}
+
+extern "C" int sug_pointmlp_max_layer_fwd_xf(const float* y, int64_t ldy, int64_t rows, int K, const float* xcoef, float xslope,
+                                             float* zout, int64_t ldz, const float* w, const float* bias, const float* gamma,
+                                             const float* beta, int Co, int seg, int groups, int training, float eps,
+                                             float momentum, float slope, float* running_mean, float* running_var,
+                                             float* zext, int32_t* arg, float* coef, float* out, int64_t ldo, float* ws,
+                                             void* stream) {
+  SUG_REQUIRE(xcoef, "sug_pointmlp_max_layer_fwd_xf: null input coefficients");
+  return pointmlp_max_layer(y, ldy, rows, K, w, bias, gamma, beta, Co, seg, groups, training, eps, momentum, slope, running_mean,
+                            running_var, zext, arg, coef, out, ldo, ws, stream, xcoef, xslope, zout, ldz);
+}
+
+static int pointmlp_max_layer(const float* x, int64_t ldx, int64_t rows, int K, const float* w,
+                              const float* bias, const float* gamma, const float* beta, int Co, int seg,
+                              int groups, int training, float eps, float momentum, float slope,
+                              float* running_mean, float* running_var, float* zext, int32_t* arg,
+                              float* coef, float* out, int64_t ldo, float* ws, void* stream, const float* xcoef, float xslope,
+                              float* zout, int64_t ldz) {
   SUG_REQUIRE(groups >= 1 && rows > 0 && rows % ((int64_t)groups * seg) == 0,
               "sug_pointmlp_max_layer_fwd: %lld rows do not split into %d groups of whole segments", (long long)rows, groups);
   SUG_REQUIRE(beta && coef && out && ldo >= Co, "sug_pointmlp_max_layer_fwd: null pointer / bad ldo");
@@ -716,8 +804,10 @@ extern "C" int sug_pointmlp_max_layer_fwd(const float* x, int64_t ldx, int64_t r
   for (int g = 0; g < groups; ++g) {
     float* cg = coef + (int64_t)g * 5 * Co;
     int nblk = 0;
+    // (input transform: group g's scale | shift rows of the previous layer's coefficient block [groups][5][K])
     int rc = pointmlp_max_fwd(x + g * rg * ldx, ldx, rg, K, w, bias, gamma, Co, seg, zext + g * sg * Co,
-                              arg + g * sg * Co, ws, &nblk, stream, 1);
+                              arg + g * sg * Co, ws, &nblk, stream, 1, xcoef ? xcoef + (int64_t)g * 5 * K : nullptr, xslope,
+                              zout ? zout + g * rg * ldz : nullptr, ldz);
     if (rc != SUG_OK) return rc;
     if (training) {
       rc = sug_stats_finalize(ws, nblk, Co, gamma, beta, (double)rg, eps, momentum, running_mean, running_var, cg,

@@ -136,6 +136,20 @@ class PointNetSetAbstraction(nn.Module):
             if i < first:
                 continue
             w = conv.weight.view(conv.weight.shape[0], -1)
+            if i == last - 1 and ops.SA_MID_FUSED and g.is_cuda and \
+                    ops.pointmlp_max_supported(w.shape[0], self.mlp_convs[last].out_channels, g.shape[2]):
+                # middle layer + last layer: the middle layer's BatchNorm + ReLU is applied inside the fused last-layer
+                # kernel (ops.bn_act_pointmlp_max): no separate pass over [B,S,ns,C], z written once and only if needed
+                tail_on = tail_grad or not adapt           # (node pass: the last layer runs for its BatchNorm buffers only)
+                y1 = ops.linear_rows(g, w, conv.bias)
+                cl = self.mlp_convs[last]
+                out, z = ops.bn_act_pointmlp_max(y1, self.mlp_bns[i], 0.0, cl.weight.view(cl.weight.shape[0], -1), cl.bias,
+                                                 self.mlp_bns[last], 0.0, g.shape[2], want_z=(adapt and i == 1),
+                                                 last_grad=tail_on)
+                out = out.view(g.shape[0], g.shape[1], -1)
+                if adapt and i == 1:
+                    node = z
+                break
             with torch.set_grad_enabled(torch.is_grad_enabled() and (tail_grad or not adapt or i <= 1)):
                 if i == last and ops.pointmlp_max_supported(g.shape[-1], w.shape[0], g.shape[2]):
                     # last layer + max over the group in one kernel: [B,S,ns,C'] is never written

@@ -608,18 +608,24 @@ class _BNActRows(torch.autograd.Function):
     def backward(ctx, gout):
         y2, coef = ctx.saved_tensors
         rows, C, slope, training, shape, G = ctx.meta
-        dev = gout.device
-        g2 = gout.reshape(rows, C)
-        if g2.stride(1) != 1:
-            g2 = g2.contiguous()
-        a = torch.empty(rows, C, dtype=torch.float32, device=dev)
-        red = torch.empty(G, 2 * C, dtype=torch.float64, device=dev)
-        ws = torch.empty(STATS_BLOCKS * 2 * C, dtype=torch.float32, device=dev)
-        dy = torch.empty(rows, C, dtype=torch.float32, device=dev) if training else a
-        rf = torch.empty(2 * C, dtype=torch.float32, device=dev)
-        check(lib().sug_bn_act_rows_bwd(_p(g2), g2.stride(0), _p(y2), C, _p(coef), rows, C, G, 1 if training else 0,
-                                        slope, _p(a), _p(red), _p(dy), _p(ws), _p(rf), _st()), 'sug_bn_act_rows_bwd')
-        return dy.view(shape), rf[C:], rf[:C], None, None, None, None, None, None, None
+        dy, dgamma, dbeta = _bn_act_rows_backward(gout, y2, coef, rows, C, slope, training, G)
+        return dy.view(shape), dgamma, dbeta, None, None, None, None, None, None, None
+
+
+def _bn_act_rows_backward(gout, y2, coef, rows, C, slope, training, G):
+    """Gradient of act(BatchNorm(y)) over rows (exact train-mode statistics terms): -> (dy [rows, C], dgamma, dbeta)."""
+    dev = gout.device
+    g2 = gout.reshape(rows, C)
+    if g2.stride(1) != 1:
+        g2 = g2.contiguous()
+    a = torch.empty(rows, C, dtype=torch.float32, device=dev)
+    red = torch.empty(G, 2 * C, dtype=torch.float64, device=dev)
+    ws = torch.empty(STATS_BLOCKS * 2 * C, dtype=torch.float32, device=dev)
+    dy = torch.empty(rows, C, dtype=torch.float32, device=dev) if training else a
+    rf = torch.empty(2 * C, dtype=torch.float32, device=dev)
+    check(lib().sug_bn_act_rows_bwd(_p(g2), g2.stride(0), _p(y2), C, _p(coef), rows, C, G, 1 if training else 0,
+                                    slope, _p(a), _p(red), _p(dy), _p(ws), _p(rf), _st()), 'sug_bn_act_rows_bwd')
+    return dy, rf[C:], rf[:C]
 
 
 class _SAFirstLayer(torch.autograd.Function):
@@ -1371,6 +1377,13 @@ class _PointMLPMax(torch.autograd.Function):
     def backward(ctx, gout):
         x2, w2, b1, zext, arg, coef = ctx.saved_tensors
         rows, K, Co, seg, G, slope, training, xshape, wshape = ctx.meta
+        dx, dw, db, dgamma, dbeta = _pointmlp_max_backward(gout, x2, w2, b1, zext, arg, coef, rows, K, Co, seg, G, slope, training)
+        return dx.view(xshape), dw.view(wshape), db, dgamma, dbeta, None, None, None, None, None, None, None, None
+
+
+def _pointmlp_max_backward(gout, x2, w2, b1, zext, arg, coef, rows, K, Co, seg, G, slope, training):
+    """Backward of the fused per-point MLP + max layer (see _PointMLPMax): -> (dx [rows, K], dw [Co, K], db, dgamma, dbeta)."""
+    if True:
         dev = gout.device
         S = rows // seg
         rg, sg = rows // G, S // G
@@ -1420,7 +1433,7 @@ class _PointMLPMax(torch.autograd.Function):
         if b1 is not None:
             # a bias in front of train-mode BatchNorm has zero gradient identically
             db = torch.zeros_like(b1) if training else a.sum(dim=0)
-        return dx.view(xshape), dw.view(wshape), db, rf[Co:], rf[:Co], None, None, None, None, None, None, None, None
+        return dx, dw, db, rf[Co:], rf[:Co]
 
 
 def pointmlp_max(x, weight, bias, bn, slope, seg):
@@ -1431,6 +1444,105 @@ def pointmlp_max(x, weight, bias, bn, slope, seg):
                              slope, bn.eps, bn.momentum, seg, BN_GROUPS)
     _record_bn(bn)
     return out
+
+
+# The middle layer of a set-abstraction MLP folded into the fused last layer (round 5): the middle layer's BatchNorm + ReLU is
+# applied by sug_pointmlp_max_layer_fwd_xf to its x operand on the way into LDS, the activated tensor z is written once as a
+# side output (only when a backward or the SA-node features need it) -- instead of a separate pass that reads y and writes z
+# followed by the last layer's read of z.  SUG_SA_MID_FUSED=0 restores the separate BatchNorm pass (A/B).
+SA_MID_FUSED = _os.environ.get('SUG_SA_MID_FUSED', '1') != '0'
+
+
+class _BNActPointMLPMax(torch.autograd.Function):
+    """(max over `seg` rows of act2(BN2(z . W^T + b)), z) with z = act1(BN1(y)) formed inside the kernel from the
+    pre-activation rows y [rows, K] of the previous layer (pointnet2_utils.py:193-207: mlp_bns[i] / relu of layer i, conv /
+    bn / relu / max of layer i + 1).  Outputs: out [rows/seg, Co] and z [rows, K] (None unless wanted).  Backward = the two
+    layers' backward kernels unchanged: _pointmlp_max_backward on (z, gout), the gradient arriving at z added, then
+    _bn_act_rows_backward through BN1."""
+
+    @staticmethod
+    def forward(ctx, y, g1, be1, rm1, rv1, slope1, eps1, mom1, weight, bias, g2, be2, rm2, rv2, slope2, eps2, mom2,
+                training, seg, G, want_z, last_grad, grad_on):
+        _need_gpu(y, weight, g1, g2)
+        K = y.shape[-1]
+        y2 = y.reshape(-1, K)
+        if y2.stride(1) != 1 or y2.stride(0) != K or y2.data_ptr() % 16:
+            y2 = y2.contiguous()
+        rows, Co = y2.shape[0], weight.shape[0]
+        if rows % (G * seg):
+            raise RuntimeError('bn_act_pointmlp_max: %d rows do not split into %d groups of %d-row segments' % (rows, G, seg))
+        S, rg = rows // seg, rows // G
+        dev = y.device
+        L = lib()
+        g1c, be1c = g1.detach().contiguous(), be1.detach().contiguous()
+        ws = torch.empty(STATS_BLOCKS * 2 * max(K, Co), dtype=torch.float32, device=dev)
+        if training:
+            coef1 = torch.empty(G, 5, K, dtype=torch.float32, device=dev)
+            for i in range(G):
+                yi = y2[i * rg:(i + 1) * rg]
+                check(L.sug_col_stats_bn(_p(yi), K, rg, K, _p(g1c), _p(be1c), eps1, mom1, _p(rm1), _p(rv1), _p(coef1[i]), _p(ws),
+                                         _st()), 'sug_col_stats_bn')
+        else:
+            coef1 = eval_coef(g1c, be1c, rm1, rv1, eps1).unsqueeze(0).repeat(G, 1, 1).contiguous()
+        need1 = grad_on and any(ctx.needs_input_grad[i] for i in (0, 1, 2))
+        need2 = grad_on and last_grad and (need1 or any(ctx.needs_input_grad[i] for i in (8, 9, 10, 11)))
+        z = torch.empty(rows, K, dtype=torch.float32, device=dev) if (want_z or need2) else None
+        w2 = weight.detach().reshape(Co, K).contiguous()
+        b1 = None if bias is None else bias.detach().contiguous()
+        g2c, be2c = g2.detach().contiguous(), be2.detach().contiguous()
+        zext = torch.empty(S, Co, dtype=torch.float32, device=dev)
+        arg = torch.empty(S, Co, dtype=torch.int32, device=dev)
+        out = torch.empty(S, Co, dtype=torch.float32, device=dev)
+        if training:
+            coef2 = torch.empty(G, 5, Co, dtype=torch.float32, device=dev)
+        else:
+            coef2 = eval_coef(g2c, be2c, rm2, rv2, eps2).unsqueeze(0).repeat(G, 1, 1).contiguous()
+        check(_timed('pointmlp_max_K%d_Co%d' % (K, Co), {'B': rows, 'N': seg, 'k': K, 'Co': Co},
+                     lambda: L.sug_pointmlp_max_layer_fwd_xf(_p(y2), K, rows, K, _p(coef1), float(slope1), _p(z), K, _p(w2), _p(b1),
+                                                             _p(g2c), _p(be2c), Co, seg, G, 1 if training else 0, eps2, mom2,
+                                                             float(slope2), _p(rm2), _p(rv2), _p(zext), _p(arg), _p(coef2),
+                                                             _p(out), Co, _p(ws), _st())),
+              'sug_pointmlp_max_layer_fwd_xf')
+        ctx.need1, ctx.need2 = need1, need2
+        if need1 or need2:
+            ctx.save_for_backward(y2, coef1, z, w2, b1, zext, arg, coef2)
+            ctx.meta = (rows, K, Co, seg, G, float(slope1), float(slope2), bool(training), tuple(y.shape), tuple(weight.shape))
+        if not last_grad:
+            ctx.mark_non_differentiable(out)
+        ctx.set_materialize_grads(False)
+        if z is None:
+            return out, None
+        return out, z.view(y.shape)
+
+    @staticmethod
+    def backward(ctx, gout, gz):
+        y2, coef1, z, w2, b1, zext, arg, coef2 = ctx.saved_tensors
+        rows, K, Co, seg, G, slope1, slope2, training, yshape, wshape = ctx.meta
+        dz = dw = db = dg2 = db2 = None
+        if ctx.need2 and gout is not None:
+            dz, dw, db, dg2, db2 = _pointmlp_max_backward(gout, z, w2, b1, zext, arg, coef2, rows, K, Co, seg, G, slope2, training)
+            dw = dw.view(wshape)
+        if gz is not None:                                    # the SA-node features' gradient arrives at z too
+            gz2 = gz.reshape(rows, K)
+            dz = gz2 if dz is None else dz.add_(gz2)
+        dy = dg1 = db1 = None
+        if ctx.need1 and dz is not None:
+            dy, dg1, db1 = _bn_act_rows_backward(dz, y2, coef1, rows, K, slope1, training, G)
+            dy = dy.view(yshape)
+        return (dy, dg1, db1, None, None, None, None, None, dw, db, dg2, db2) + (None,) * 11
+
+
+def bn_act_pointmlp_max(y, bn1, slope1, weight, bias, bn2, slope2, seg, want_z=False, last_grad=True):
+    """y [..., K] = pre-activation rows of the layer in front -> (max over `seg`-row segments of act2(bn2(z.W^T + b)), z or
+    None) with z = act1(bn1(y)) never read back from memory by the last layer (see _BNActPointMLPMax)."""
+    _count_bn_call(bn1)
+    _count_bn_call(bn2)
+    out, z = _BNActPointMLPMax.apply(y, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, slope1, bn1.eps, bn1.momentum,
+                                     weight, bias, bn2.weight, bn2.bias, bn2.running_mean, bn2.running_var, slope2, bn2.eps,
+                                     bn2.momentum, bn1.training, seg, BN_GROUPS, want_z, last_grad, torch.is_grad_enabled())
+    _record_bn(bn1)
+    _record_bn(bn2)
+    return out, z
 
 
 # Step-scoped cache of 16-bit copies of weights / biases (opt-in: SUGStep sets a dict before the forwards of a step and

@@ -152,3 +152,73 @@ def test_sa_first_forms_are_equally_accurate_against_fp64():
     e_pq, e_geo, e_ref = e(y_pq), e(y_geo), e(ref32)
     print('max |y - fp64| on the passing entries: P - Q %.2e, geometric %.2e, reference composition in fp32 %.2e' % (e_pq, e_geo, e_ref))
     assert e_geo <= 2.0 * e_ref + 1e-7 and e_pq <= 2.0 * e_ref + 1e-7
+
+
+@pytest.mark.parametrize('cfg', ['sa1_adapt', 'sa1_adapt_node_pass', 'sa2', 'sa2_eval'])
+def test_middle_layer_folded_into_the_fused_last_layer_matches_separate_passes(cfg):
+    """Round 5 (ops.bn_act_pointmlp_max, sug_pointmlp_max_layer_fwd_xf): the middle SA-MLP layer's BatchNorm + ReLU applied
+    inside the fused last-layer kernel == the separate BatchNorm pass + fused last layer (SUG_SA_MID_FUSED=0): outputs, the
+    SA-node features (adapt), every gradient and every BatchNorm buffer; paired domain groups; the node-pass form (last layer
+    without autograd) and eval mode."""
+    from sug_amd import ops
+    from sug_amd.model.pointnet2_utils import PointNetSetAbstraction
+    sa1 = cfg.startswith('sa1')
+    B, N = 4, 1024 if sa1 else 512
+    gen = torch.Generator().manual_seed(len(cfg))
+    xyz = torch.rand(B, N, 3, generator=gen).cuda()
+    pts = None if sa1 else (torch.randn(B, N, 128, generator=gen) * 0.5).cuda()
+    adapt = sa1
+    tail_grad = cfg != 'sa1_adapt_node_pass'
+    train = cfg != 'sa2_eval'
+
+    def run(fused):
+        torch.manual_seed(1)
+        sa = (PointNetSetAbstraction(256, 0.2, 32, 3, [64, 64, 128], False) if sa1
+              else PointNetSetAbstraction(64, 0.4, 64, 128 + 3, [128, 128, 256], False)).cuda().train(train)
+        with torch.no_grad():
+            for bn in sa.mlp_bns:
+                C = bn.num_features
+                bn.weight.copy_(torch.linspace(-1.0, 1.5, C))
+                bn.bias.copy_(torch.linspace(-0.3, 0.3, C))
+                bn.running_mean.copy_(torch.linspace(-0.2, 0.2, C))
+                bn.running_var.copy_(torch.linspace(0.5, 1.5, C))
+        p = None if pts is None else pts.clone().requires_grad_(True)
+        keep, ops.SA_MID_FUSED = ops.SA_MID_FUSED, fused
+        try:
+            torch.manual_seed(5)                       # FPS start draw
+            with ops.bn_groups(2):
+                r = sa.rows(xyz, p, adapt=adapt, tail_grad=tail_grad) if adapt else sa.rows(xyz, p)
+        finally:
+            ops.SA_MID_FUSED = keep
+        outs = list(r[1:])
+        gg = torch.Generator(device='cuda').manual_seed(2)
+        loss = 0
+        for o in outs:
+            if o.requires_grad:
+                loss = loss + (o * torch.randn(o.shape, device='cuda', generator=gg)).sum()
+        grads = {}
+        if torch.is_tensor(loss):
+            loss.backward()
+            grads = {k: v.grad.clone() for k, v in sa.named_parameters() if v.grad is not None}
+            if p is not None and p.grad is not None:
+                grads['points'] = p.grad.clone()
+        bufs = {k: v.clone() for k, v in sa.named_buffers()}
+        return [o.detach() for o in outs], grads, bufs
+
+    o1, g1, b1 = run(True)
+    o0, g0, b0 = run(False)
+    assert len(o1) == len(o0) == (2 if adapt else 1)
+    for a, b in zip(o1, o0):
+        assert a.shape == b.shape
+        assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max())), cfg
+    assert set(g1) == set(g0), (sorted(g1), sorted(g0))
+    if train and cfg != 'sa2_eval':
+        assert g1, 'no gradients?'
+    if cfg == 'sa1_adapt_node_pass':
+        assert not any(k.startswith(('mlp_convs.2', 'mlp_bns.2')) for k in g1)      # the last layer ran without autograd
+    gmax = max([float(v.norm()) for v in g0.values()] + [1e-30])
+    for k in g0:
+        d = float((g1[k] - g0[k]).norm()) / max(float(g0[k].norm()), 1e-3 * gmax)
+        assert d <= 2e-4, (cfg, k, d)
+    for k in b0:
+        assert float((b1[k].double() - b0[k].double()).abs().max()) <= 1e-5 * max(1.0, float(b0[k].double().abs().max())), (cfg, k)
