@@ -328,7 +328,7 @@ class Pointnet_g(nn.Module):
         y = self._prefix(x, loc)
         y, node_fea, node_off = self.conv3.rows(y, loc)
         with torch.set_grad_enabled(torch.is_grad_enabled() and feat_grad):
-            y = bn_module(self.bn1, self.conv5.rows_max(self.conv4.rows(y)))
+            y = bn_module(self.bn1, self.conv5.rows_max_after(self.conv4, y))
         node_fea = node_fea.transpose(1, 2).unsqueeze(-1)
         node_off = node_off.transpose(1, 2)
         if node:

@@ -33,7 +33,7 @@ class Pointnet_cls(nn.Module):
         y = torch.bmm(y, self.trans_net1.rows(y))
         y = self.conv2.rows(self.conv1.rows(y))
         y = torch.bmm(y, self.trans_net2.rows(y))
-        y = self.conv5.rows_max(self.conv4.rows(self.conv3.rows(y)))
+        y = self.conv5.rows_max_after(self.conv4, self.conv3.rows(y))
         mid_feature = y
         y = self.dropout1(self.mlp1(y))
         y = self.dropout2(self.mlp2(y))

@@ -72,6 +72,19 @@ class conv_2d(nn.Module):
     def forward(self, x):
         return self.rows(x.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
 
+    def rows_max_after(self, prev, x):
+        """self.rows_max(prev.rows(x)) for two conv_2d layers in a row (Model.py:272-279, model_utils.py:70-79,
+        model_pointnet.py:44-48): `prev`'s BatchNorm + activation is applied inside this layer's fused kernel
+        (ops.bn_act_pointmlp_max) -- no separate pass over prev's [B,N,C] output."""
+        B, N, _ = x.shape
+        Wp, W = prev.weight2d(), self.weight2d()
+        if ops.SA_MID_FUSED and x.is_cuda and self.activation in _ACT_SLOPE and prev.activation in _ACT_SLOPE and \
+                OWN_BN(self.conv[1]) and OWN_BN(prev.conv[1]) and ops.pointmlp_max_supported(Wp.shape[0], W.shape[0], N):
+            y = ops.linear_rows(x, Wp, prev.conv[0].bias)
+            return ops.bn_act_pointmlp_max(y, prev.conv[1], _ACT_SLOPE[prev.activation], W, self.conv[0].bias, self.conv[1],
+                                           _ACT_SLOPE[self.activation], N)[0]
+        return self.rows_max(prev.rows(x))
+
     def rows_max(self, x):
         """x [B,N,Cin] -> [B,Cout] = max over the N points of act(bn(conv(x))): the layer and the
         reduction in one kernel, the [B,N,Cout] tensor is never written (sug_pointmlp_max_*;
@@ -156,7 +169,7 @@ class transform_net(nn.Module):
 
     def rows(self, x):
         """x [B,N,C] -> [B,K,K]."""
-        y = self.conv2d3.rows_max(self.conv2d2.rows(self.conv2d1.rows(x)))
+        y = self.conv2d3.rows_max_after(self.conv2d2, self.conv2d1.rows(x))
         y = self.fc3(self.fc2(self.fc1(y)))
         y = y + torch.eye(self.K, device=y.device, dtype=y.dtype).view(1, self.K * self.K)
         return y.view(-1, self.K, self.K)

@@ -1013,6 +1013,7 @@ def _count_bn_call(bn, n=None):
 # `with record_bn_stats() as rec:` collects (module, batch-statistics coefficients) of every train-mode BatchNorm op inside.
 BN_RECORD = None
 _LAST_COEF = None
+_LAST_COEF_PAIR = (None, None)
 
 
 @contextlib.contextmanager
@@ -1503,6 +1504,8 @@ class _BNActPointMLPMax(torch.autograd.Function):
                                                              float(slope2), _p(rm2), _p(rv2), _p(zext), _p(arg), _p(coef2),
                                                              _p(out), Co, _p(ws), _st())),
               'sug_pointmlp_max_layer_fwd_xf')
+        global _LAST_COEF_PAIR
+        _LAST_COEF_PAIR = (coef1, coef2)
         ctx.need1, ctx.need2 = need1, need2
         if need1 or need2:
             ctx.save_for_backward(y2, coef1, z, w2, b1, zext, arg, coef2)
@@ -1540,8 +1543,10 @@ def bn_act_pointmlp_max(y, bn1, slope1, weight, bias, bn2, slope2, seg, want_z=F
     out, z = _BNActPointMLPMax.apply(y, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, slope1, bn1.eps, bn1.momentum,
                                      weight, bias, bn2.weight, bn2.bias, bn2.running_mean, bn2.running_var, slope2, bn2.eps,
                                      bn2.momentum, bn1.training, seg, BN_GROUPS, want_z, last_grad, torch.is_grad_enabled())
-    _record_bn(bn1)
-    _record_bn(bn2)
+    if BN_RECORD is not None:                      # a shared prefix replays these running-statistics updates (record_bn_stats)
+        for bn, coef in zip((bn1, bn2), _LAST_COEF_PAIR):
+            if bn.training and bn.track_running_stats:
+                BN_RECORD.append((bn, coef))
     return out, z
 
 
