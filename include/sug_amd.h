@@ -181,6 +181,12 @@ int sug_col_stats_bn(const float* y, int64_t ldy, int64_t rows, int C, const flo
                      float eps, float momentum, float* running_mean, float* running_var, float* coef,
                      float* ws, void* stream);
 
+/* sug_col_stats_bn for `groups` equal consecutive row blocks of y [rows, C] (the domain groups of a paired batch): coef
+ * [groups][5][C], running buffers updated in group order; one launch pair for all groups where the layout allows. */
+int sug_col_stats_bn_grouped(const float* y, int64_t ldy, int64_t rows, int C, int groups, const float* gamma,
+                             const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                             float* coef, float* ws, void* stream);
+
 /* Replay of the running-statistics update for G more train-mode forwards over batches whose
  * statistics are already in coef [G,5,C] (rows 2 and 4 of each group), in group order, with
  * sug_bn_finalize's arithmetic: what nn.BatchNorm would do when the encoder prefix is evaluated

@@ -118,6 +118,24 @@ extern "C" int sug_bn_act_rows_fwd(const float* y, int64_t ldy, int64_t rows, in
   return SUG_OK;
 }
 
+extern "C" int sug_col_stats_bn_grouped(const float* y, int64_t ldy, int64_t rows, int C, int groups, const float* gamma,
+                                        const float* beta, float eps, float momentum, float* running_mean,
+                                        float* running_var, float* coef, float* ws, void* stream) {
+  LAYER_REQUIRE(groups >= 1 && rows > 0 && rows % groups == 0, "sug_col_stats_bn_grouped: %lld rows do not split into %d groups",
+                (long long)rows, groups);
+  LAYER_REQUIRE(y && gamma && beta && coef && ws, "sug_col_stats_bn_grouped: null pointer");
+  const int64_t rg = rows / groups;
+  if (groups > 1 && ldy == C) {                  // every group's statistics in one launch pair
+    const int rc = sug_col_stats_bn_groups(y, ldy, rg, C, groups, gamma, beta, eps, momentum, running_mean, running_var, coef, ws,
+                                           (ihipStream_t*)stream);
+    if (rc <= 0) return rc;
+  }
+  for (int g = 0; g < groups; ++g)
+    LAYER_TRY(sug_col_stats_bn(y + g * rg * ldy, ldy, rg, C, gamma, beta, eps, momentum, running_mean, running_var,
+                               coef + (int64_t)g * 5 * C, ws, stream));
+  return SUG_OK;
+}
+
 extern "C" int sug_bn_act_rows_bwd(const float* gout, int64_t ldg, const float* y, int64_t ldy, const float* coef,
                                    int64_t rows, int C, int groups, int training, float slope, float* a,
                                    double* red, float* dy, float* ws, float* dgb, void* stream) {

@@ -1479,10 +1479,8 @@ class _BNActPointMLPMax(torch.autograd.Function):
         ws = torch.empty(STATS_BLOCKS * 2 * max(K, Co), dtype=torch.float32, device=dev)
         if training:
             coef1 = torch.empty(G, 5, K, dtype=torch.float32, device=dev)
-            for i in range(G):
-                yi = y2[i * rg:(i + 1) * rg]
-                check(L.sug_col_stats_bn(_p(yi), K, rg, K, _p(g1c), _p(be1c), eps1, mom1, _p(rm1), _p(rv1), _p(coef1[i]), _p(ws),
-                                         _st()), 'sug_col_stats_bn')
+            check(L.sug_col_stats_bn_grouped(_p(y2), K, rows, K, G, _p(g1c), _p(be1c), eps1, mom1, _p(rm1), _p(rv1), _p(coef1),
+                                             _p(ws), _st()), 'sug_col_stats_bn_grouped')
         else:
             coef1 = eval_coef(g1c, be1c, rm1, rv1, eps1).unsqueeze(0).repeat(G, 1, 1).contiguous()
         need1 = grad_on and any(ctx.needs_input_grad[i] for i in (0, 1, 2))
