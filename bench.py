@@ -116,6 +116,26 @@ def pmc_traffic(name, shape):
     return None
 
 
+def measured_copy_gbps(dev, mib=1024, iters=10):
+    """What this box's HBM actually sustains (report the achievable rate beside the 8 TB/s vendor peak): a device-to-
+    device copy of `mib` MiB, read + write counted, HIP events around `iters` back-to-back copies."""
+    n = mib * 1024 * 1024 // 4
+    a = torch.empty(n, dtype=torch.float32, device=dev)
+    b = torch.empty_like(a)
+    a.fill_(1.0)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    del a, b
+    return 2.0 * n * 4 / (ms * 1e-3) / 1e9
+
+
 def hold_gpu(ms):
     """Occupy the current stream for about `ms` milliseconds (a spin kernel), so that everything enqueued meanwhile queues
     up behind it and then runs back to back."""
@@ -769,6 +789,11 @@ def main():
             else:
                 roofline['traffic_note'] = 'no PMC passes on file for this kernel version (profiles/pmc_traffic_%s.json)' % kernel_source_hash(dom)
         if roofline is not None:
+            try:
+                roofline['hbm_copy_gbps_measured'] = round(measured_copy_gbps(dev), 1)
+                roofline['hbm_note'] = 'device-to-device copy of 1 GiB on this box (read + write) beside the %.0f GB/s vendor peak the fractions use' % HBM_PEAK_GBS
+            except RuntimeError:
+                pass
             import bench_work
             roofline['step'] = bench_work.step_roofline(args.model, B, N, 1e3 * dt / args.steps, single_pass=args.single_pass,
                                                         fp16=args.fp16 and args.model == 'PTran', n_params=n_params,

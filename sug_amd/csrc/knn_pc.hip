@@ -216,6 +216,15 @@ __global__ __launch_bounds__(128 * PW, 2) void knn_pc_kernel(const float* __rest
         acc0[0] = arow[0]; acc1[0] = bq0[0] + bq1[0];
         mid();
 #else
+#ifdef SUG_KNN_ABL_SYMM
+        // timing experiment (round 5; wrong results): the ceiling of a block-pair form that scores each
+        // off-diagonal 64 x 32 tile once -- tiles whose candidates all precede this wave's queries skip the MFMA chain, as if
+        // their scores arrived transposed from the wave that owns the mirrored tile (the exchange itself costs nothing here)
+        if (t * TJ + TJ <= q0 + wv * 64) {
+          acc0[0] = arow[0]; acc1[0] = bq0[0] + bq1[0];
+          mid();
+        } else
+#endif
 #pragma unroll
         for (int g = 0; g < HALF / 4; ++g) {
           if (g == HALF / 8) mid();             // (empty in the product: see SUG_KNN_STAGE_MID below)

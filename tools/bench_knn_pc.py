@@ -48,6 +48,10 @@ if __name__ == '__main__':
                     ('no staging only', NC + ['-DSUG_KNN_ABL_NOSTAGE'])]
     if len(sys.argv) > 1 and sys.argv[1] == 'ab':             # careful A/B of two builds: interleaved rounds, median and minimum
         variants = [('product', []), ('staging inside the chain', ['-DSUG_KNN_STAGE_MID'])]
+    if len(sys.argv) > 1 and sys.argv[1] == 'symm':           # ceiling of a symmetric (block-pair) form: interleaved A/B
+        variants = [('product', []), ('mirrored tiles skip their MFMA chain (ceiling)', ['-DSUG_KNN_ABL_SYMM']),
+                    ('no MFMA at all', ['-DSUG_KNN_ABL_NOMFMA'])]
+        sys.argv[1] = 'ab'
     if len(sys.argv) > 1 and sys.argv[1] == 'seed':
         # Upper bound of threshold seeding: the consumer's threshold starts at the ORACLE value (the exact
         # K-th best score of every query, computed here with torch), and the candidates that pass the scan are counted.
