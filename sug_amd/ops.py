@@ -1384,57 +1384,56 @@ class _PointMLPMax(torch.autograd.Function):
 
 def _pointmlp_max_backward(gout, x2, w2, b1, zext, arg, coef, rows, K, Co, seg, G, slope, training):
     """Backward of the fused per-point MLP + max layer (see _PointMLPMax): -> (dx [rows, K], dw [Co, K], db, dgamma, dbeta)."""
-    if True:
-        dev = gout.device
-        S = rows // seg
-        rg, sg = rows // G, S // G
-        gout = gout.reshape(S, Co)
-        if gout.stride(1) != 1 or gout.stride(0) % 4 or gout.data_ptr() % 16:
-            gout = gout.contiguous()        # e.g. a column slice of a [.., 3 + C] gradient: the float4 kernels need aligned rows
-        a = torch.empty(S, Co, dtype=torch.float32, device=dev)
-        red = torch.empty(G, 2 * Co, dtype=torch.float64, device=dev)
-        ws = torch.empty(STATS_BLOCKS * 2 * Co, dtype=torch.float32, device=dev)
-        dx = torch.empty(rows, K, dtype=torch.float32, device=dev) if training else \
-            torch.zeros(rows, K, dtype=torch.float32, device=dev)
-        dw = torch.zeros(Co, K, dtype=torch.float32, device=dev)
-        dws = torch.empty(Co, K, dtype=torch.float32, device=dev)
-        wsp = torch.empty(int(lib().sug_pointmlp_max_bwd_workspace(rg, K, Co, seg)), dtype=torch.float32, device=dev)
-        L = lib()
-        f32 = dict(dtype=torch.float32, device=dev)
-        kbk2, negA, negv = torch.empty(2, Co, **f32), torch.empty(K, K, **f32), torch.empty(K, **f32)
-        nkb, nwk = torch.empty(Co, **f32), torch.empty(Co, K, **f32)
-        xtx, sx = torch.empty(K, K, **f32), torch.empty(K, **f32)
-        wsx = torch.empty(int(L.sug_linear_dw_workspace(rg, K, K)), **f32) if training else None
-        for gi in range(G):
-            xg = x2[gi * rg:(gi + 1) * rg]
-            zg, ag, cg = zext[gi * sg:(gi + 1) * sg], a[gi * sg:(gi + 1) * sg], coef[gi]
-            gg = gout[gi * sg:(gi + 1) * sg]
-            check(L.sug_edgeconv_bwd_reduce(_p(gg), gg.stride(0), _p(zg), _p(cg), sg, Co, slope, _p(ag), _p(red[gi]), _p(ws),
-                                            _st()), 'sug_edgeconv_bwd_reduce')
-            dxg = dx[gi * rg:(gi + 1) * rg]
-            if training:
-                # dy = a_full - (scale/M)(dbeta + xhat*dgamma) = a_full - k1 - k2*y over ALL rows, y = x.W^T + b:
-                # the coefficients kb, k2 and the operands of -A, -v from one launch (sug_pointmlp_max_bwd_coef)
-                check(L.sug_pointmlp_max_bwd_coef(_p(cg), _p(red[gi]), _p(b1), _p(w2), rg, K, Co, _p(kbk2[0]), _p(kbk2[1]),
-                                                  _p(nkb), _p(nwk), _st()), 'sug_pointmlp_max_bwd_coef')
-                torch.mm(nwk.t(), w2, out=negA)                         # -A = -(W^T diag(k2) W)   [K,K]
-                torch.mv(w2.t(), nkb, out=negv)                         # -v = -(kb . W)           [K]
-                check(L.sug_linear_dw_bias(_p(xg), xg.stride(0), _p(xg), xg.stride(0), rg, K, K, _p(xtx), _p(sx), _p(wsx),
-                                           _st()), 'sug_linear_dw_bias')        # X^T X and the column sums of x
-                # -(x.A + v): alpha = beta = 1 keeps the library's bias epilogue (any other alpha first expands
-                # the bias into dx: a full extra pass)
-                torch.addmm(negv, xg, negA, out=dxg)
-            check(L.sug_pointmlp_max_bwd_sparse(_p(ag), _p(arg[gi * sg:(gi + 1) * sg]), _p(xg), xg.stride(0), _p(w2), rg, K,
-                                                Co, seg, _p(dxg), K, _p(dws), _p(wsp), _st()),
-                  'sug_pointmlp_max_bwd_sparse')
-            check(L.sug_pointmlp_max_bwd_dwfix(_p(dw), _p(dws), _p(kbk2[0]), _p(kbk2[1]), _p(w2), _p(xtx), _p(sx), K, Co,
-                                               1 if training else 0, _st()), 'sug_pointmlp_max_bwd_dwfix')
-        rf = red[0].float() if G == 1 else red.sum(0, dtype=torch.float32)
-        db = None
-        if b1 is not None:
-            # a bias in front of train-mode BatchNorm has zero gradient identically
-            db = torch.zeros_like(b1) if training else a.sum(dim=0)
-        return dx, dw, db, rf[Co:], rf[:Co]
+    dev = gout.device
+    S = rows // seg
+    rg, sg = rows // G, S // G
+    gout = gout.reshape(S, Co)
+    if gout.stride(1) != 1 or gout.stride(0) % 4 or gout.data_ptr() % 16:
+        gout = gout.contiguous()        # e.g. a column slice of a [.., 3 + C] gradient: the float4 kernels need aligned rows
+    a = torch.empty(S, Co, dtype=torch.float32, device=dev)
+    red = torch.empty(G, 2 * Co, dtype=torch.float64, device=dev)
+    ws = torch.empty(STATS_BLOCKS * 2 * Co, dtype=torch.float32, device=dev)
+    dx = torch.empty(rows, K, dtype=torch.float32, device=dev) if training else \
+        torch.zeros(rows, K, dtype=torch.float32, device=dev)
+    dw = torch.zeros(Co, K, dtype=torch.float32, device=dev)
+    dws = torch.empty(Co, K, dtype=torch.float32, device=dev)
+    wsp = torch.empty(int(lib().sug_pointmlp_max_bwd_workspace(rg, K, Co, seg)), dtype=torch.float32, device=dev)
+    L = lib()
+    f32 = dict(dtype=torch.float32, device=dev)
+    kbk2, negA, negv = torch.empty(2, Co, **f32), torch.empty(K, K, **f32), torch.empty(K, **f32)
+    nkb, nwk = torch.empty(Co, **f32), torch.empty(Co, K, **f32)
+    xtx, sx = torch.empty(K, K, **f32), torch.empty(K, **f32)
+    wsx = torch.empty(int(L.sug_linear_dw_workspace(rg, K, K)), **f32) if training else None
+    for gi in range(G):
+        xg = x2[gi * rg:(gi + 1) * rg]
+        zg, ag, cg = zext[gi * sg:(gi + 1) * sg], a[gi * sg:(gi + 1) * sg], coef[gi]
+        gg = gout[gi * sg:(gi + 1) * sg]
+        check(L.sug_edgeconv_bwd_reduce(_p(gg), gg.stride(0), _p(zg), _p(cg), sg, Co, slope, _p(ag), _p(red[gi]), _p(ws),
+                                        _st()), 'sug_edgeconv_bwd_reduce')
+        dxg = dx[gi * rg:(gi + 1) * rg]
+        if training:
+            # dy = a_full - (scale/M)(dbeta + xhat*dgamma) = a_full - k1 - k2*y over ALL rows, y = x.W^T + b:
+            # the coefficients kb, k2 and the operands of -A, -v from one launch (sug_pointmlp_max_bwd_coef)
+            check(L.sug_pointmlp_max_bwd_coef(_p(cg), _p(red[gi]), _p(b1), _p(w2), rg, K, Co, _p(kbk2[0]), _p(kbk2[1]),
+                                              _p(nkb), _p(nwk), _st()), 'sug_pointmlp_max_bwd_coef')
+            torch.mm(nwk.t(), w2, out=negA)                         # -A = -(W^T diag(k2) W)   [K,K]
+            torch.mv(w2.t(), nkb, out=negv)                         # -v = -(kb . W)           [K]
+            check(L.sug_linear_dw_bias(_p(xg), xg.stride(0), _p(xg), xg.stride(0), rg, K, K, _p(xtx), _p(sx), _p(wsx),
+                                       _st()), 'sug_linear_dw_bias')        # X^T X and the column sums of x
+            # -(x.A + v): alpha = beta = 1 keeps the library's bias epilogue (any other alpha first expands
+            # the bias into dx: a full extra pass)
+            torch.addmm(negv, xg, negA, out=dxg)
+        check(L.sug_pointmlp_max_bwd_sparse(_p(ag), _p(arg[gi * sg:(gi + 1) * sg]), _p(xg), xg.stride(0), _p(w2), rg, K,
+                                            Co, seg, _p(dxg), K, _p(dws), _p(wsp), _st()),
+              'sug_pointmlp_max_bwd_sparse')
+        check(L.sug_pointmlp_max_bwd_dwfix(_p(dw), _p(dws), _p(kbk2[0]), _p(kbk2[1]), _p(w2), _p(xtx), _p(sx), K, Co,
+                                           1 if training else 0, _st()), 'sug_pointmlp_max_bwd_dwfix')
+    rf = red[0].float() if G == 1 else red.sum(0, dtype=torch.float32)
+    db = None
+    if b1 is not None:
+        # a bias in front of train-mode BatchNorm has zero gradient identically
+        db = torch.zeros_like(b1) if training else a.sum(dim=0)
+    return dx, dw, db, rf[Co:], rf[:Co]
 
 
 def pointmlp_max(x, weight, bias, bn, slope, seg):
