@@ -44,7 +44,7 @@ extern "C" {
 
 const char* sug_last_error(void);
 /* ABI version of the loaded library (bumped when a signature changes; 3: sug_adam_step_capturable gained lr_dev,
- * round-3 entry points; 4: sug_chamfer / sug_node_offset_bwd became reproducible -- sug_chamfer takes a workspace; 5: sug_ce_pair_* take ignore_index, lse has 2M + 1 entries).  A binding checks sug_abi_version() == SUG_ABI_VERSION of the header it was written against. */
+ * round-3 entry points; 4: sug_chamfer / sug_node_offset_bwd became reproducible -- sug_chamfer takes a workspace; 5: sug_ce_pair_* take ignore_index, lse has 2M + 1 entries; sug_pointmlp_max_layer_fwd_xf and sug_col_stats_bn_grouped added).  A binding checks sug_abi_version() == SUG_ABI_VERSION of the header it was written against. */
 #define SUG_ABI_VERSION 5
 int sug_abi_version(void);
 
