@@ -253,3 +253,37 @@ def test_single_pass_is_faster_than_two_pass_on_config2_shape():
         ms[single] = (time.perf_counter() - t0) * 100.0
     print('two-pass %.3f ms, single-pass %.3f ms per step' % (ms[False], ms[True]))
     assert ms[True] < ms[False]
+
+
+def test_single_pass_graph_soak_200_back_to_back_replays():
+    """200 replays of the captured single-pass step issued back to back with lr = 0 and re-seeded FPS starts: every replay
+    returns the planning step's losses (the soak the two-pass graph has in tests/test_gpu_graph.py); then 60 training replays
+    of the same graph lower the classification loss."""
+    from sug_amd.train_step import SUGStep
+    data, lab, data_t, lab_t = [t.cuda() for t in _batch(8, 1024, seed=43)]
+    net = _net('DGCNN')
+    tr = SUGStep(net, lr=0.0, weight_decay=5e-5, use_graph=True, methods=bench.BENCH_METHODS, single_pass=True)
+    torch.manual_seed(21)
+    first = [float(v) for v in tr.step(data, lab, data_t, lab_t)]
+    outs = []
+    for _ in range(200):
+        torch.manual_seed(21)
+        l = tr.step(data, lab, data_t, lab_t)
+        outs.append(torch.stack([v.clone() for v in l]))
+    torch.cuda.synchronize()
+    vals = torch.stack(outs).cpu()
+    want = torch.tensor(first)
+    bad = ((vals - want).abs() > 1e-5 * want.abs().clamp(min=1.0)).any(dim=1)
+    assert len(tr._graphs) == 1 and not bool(bad.any()), (bad.nonzero().flatten().tolist()[:10], vals[bad][:3].tolist(), first)
+    for o in (tr.optimizer_g, tr.optimizer_c, tr.optimizer_dis):
+        for g in o.param_groups:
+            g['lr'] = 1e-3
+    outs = []
+    for _ in range(60):
+        l = tr.step(data, lab, data_t, lab_t)
+        outs.append(torch.stack([v.clone() for v in l]))
+    torch.cuda.synchronize()
+    vals = torch.stack(outs).cpu()
+    assert len(tr._graphs) == 1 and bool(torch.isfinite(vals).all())
+    assert float(vals[-1, 0]) < 0.6 * first[0], (first, vals[-1].tolist())
+    assert all(bool(torch.isfinite(p).all()) for p in net.parameters())
