@@ -724,8 +724,8 @@ def main():
             gc.enable()
         trainer.pair_domains, trainer.share_prefix = keep
     # The opt-in single-pass step (SUGStep(single_pass=True)): one encoder evaluation per domain feeds heads and
-    # attention layers.  Reported BESIDE the headline, never as it: it differs from the reference's step in two documented
-    # ways (one FPS start draw, BatchNorm running statistics of the encoder updated once).
+    # attention layers.  Reported BESIDE the headline, never as it: it differs from the reference's step in one documented
+    # way (one FPS start draw per sampling stage instead of two).
     single_ms = None
     if args.caller_steps > 0 and not args.plain and world == 1 and not args.segmented and graph_mode and not args.single_pass:
         tr1 = SUGStep(model, lr=1e-3, weight_decay=5e-5, share_prefix=not args.no_share_prefix, use_graph=True,
@@ -856,8 +856,8 @@ def main():
                           'single_pass_ms_per_step': single_ms,
                           'single_pass_clouds_per_sec': None if single_ms is None else world * 2 * B / (single_ms * 1e-3),
                           'single_pass_note': 'opt-in SUGStep(single_pass=True), SURVEY 8 f2: one encoder evaluation per domain feeds '
-                                              'heads and attention layers; same losses / gradients as the two-pass step with tied FPS '
-                                              'starts, BatchNorm running statistics of the encoder updated once per step; NOT the headline',
+                                              'heads and attention layers; same losses / gradients / BatchNorm buffers as the two-pass step whose '
+                                              'node pass draws the semantic pass\'s FPS starts (one draw per stage instead of two); NOT the headline',
                           'clouds_per_step': world * 2 * B,
                           'other_workloads': others,
                           **({'fp16_linears': 'k-expanded and per-point 512-wide linears of the transformer blocks'}

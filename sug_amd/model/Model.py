@@ -497,6 +497,47 @@ class Net_MDA(nn.Module):
     # (model/Model.py:505-509) tests node_adaptation_* first and would return the attention branch alone for this flag
     # combination -- which none of its callers passes; set `dual_output_on_both_flags = False` for that literal behaviour.
     dual_output_on_both_flags = True
+    # The dual-output call applies the encoder's BatchNorm running-statistics update of the pass TWICE (default), so that the
+    # buffers end where the reference's two calls leave them when the second call draws the first one's FPS starts: a
+    # train-mode pass maps every running buffer r -> a r + c (a = (1 - momentum)^groups, c from the batch statistics), the
+    # second call of the reference repeats exactly that map on the same batch, and a r1 + c = r1 + a (r1 - r0) needs only
+    # the buffers before (r0) and after (r1) the one pass that is run.  num_batches_tracked likewise.  False: updated once.
+    dual_updates_bn_twice = True
+
+    def _bn_twice_begin(self):
+        """Before the single encoder pass of a dual-output call: copies of every BatchNorm running buffer of the encoder and of
+        the batch counters (multi-tensor launches, independent of the backbone)."""
+        if not (self.dual_updates_bn_twice and self.training):
+            return None
+        plan = getattr(self, '_bn_twice_plan', None)
+        if plan is None:
+            bns = [m for m in self.g.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm) and m.track_running_stats
+                   and m.momentum is not None]
+            # (.data views: the second update must not bump the version counters autograd checks -- torch's own batch_norm
+            # node keeps a reference to the running buffers it was given, for its eval-mode backward; a train-mode backward
+            # never reads them, and the reference's second forward call changes them under the first call's graph as well)
+            plan = self._bn_twice_plan = (
+                [b.data for m in bns for b in (m.running_mean, m.running_var)], [float(m.momentum) for m in bns for _ in (0, 1)],
+                [m.num_batches_tracked.data for m in bns if m.num_batches_tracked is not None])
+        bufs, moms, nbt = plan
+        if not bufs or not bufs[0].is_cuda:
+            return None
+        G = ops.BN_GROUPS
+        alphas = [(1.0 - m) ** G for m in moms]
+        return bufs, alphas, torch._foreach_add(bufs, 0.0), nbt, (torch._foreach_add(nbt, 0) if nbt else [])
+
+    @staticmethod
+    def _bn_twice_end(snap):
+        """r2 = a r1 + c with c = r1 - a r0, written as r1 + a (r1 - r0): a BatchNorm the pass did not run (r1 == r0) keeps
+        its buffers bit for bit."""
+        if snap is None:
+            return
+        bufs, alphas, r0, nbt, n0 = snap
+        d = torch._foreach_sub(bufs, r0)
+        torch._foreach_mul_(d, alphas)
+        torch._foreach_add_(bufs, d)
+        if nbt:
+            torch._foreach_add_(nbt, torch._foreach_sub(nbt, n0))
 
     def forward(self, x, constant=1, adaptation=False, node_vis=False, mid_feat=False, node_adaptation_s=False,
                 node_adaptation_t=False, semantic_adaption=False):
@@ -509,6 +550,10 @@ class Net_MDA(nn.Module):
             x, feat_ori, node_idx = self.g(x, node=True, feat_grad=False)       # the pooled feature is not used
         elif only_feat and self._g_skips_node():
             x, feat_ori, node_idx = self.g(x, node=True, need_node=False)       # the node features are not used
+        elif dual:
+            snap = self._bn_twice_begin()
+            x, feat_ori, node_idx = self.g(x, node=True)
+            self._bn_twice_end(snap)
         else:
             x, feat_ori, node_idx = self.g(x, node=True)
         batch_size = (feat_ori if feat_ori is not None else x).size(0)
@@ -520,8 +565,9 @@ class Net_MDA(nn.Module):
             # what train_dg_single_gpu.py:260-264 + :309-310 obtain from TWO calls on the same batch.  In train mode the
             # second call recomputes the first one's encoder bit for bit when its FPS start draw is the same (BatchNorm
             # uses batch statistics, dropout sits in the heads only), so the values and -- one graph instead of two equal
-            # ones -- the gradients are those of the two-call form with tied draws.  Documented differences: ONE FPS
-            # start draw per sampling stage instead of two, BatchNorm running statistics of the encoder updated once.
+            # ones -- the gradients are those of the two-call form with tied draws.  Documented difference: ONE FPS
+            # start draw per sampling stage instead of two (the encoder's BatchNorm running statistics receive the pass's
+            # update twice, as from the two calls: dual_updates_bn_twice).
             att = self.attention_s if node_adaptation_s else self.attention_t
             node = att(feat_ori.contiguous().view(batch_size, -1))
             if adaptation:
@@ -608,6 +654,10 @@ class Net_MDA(nn.Module):
         return out
 
     def _forward_pair(self, x_pair, node_adaptation, paired_out, queue, B, B2, dual=False):
+        snap = None
+        if dual:
+            with ops.bn_groups(2):
+                snap = self._bn_twice_begin()
         with ops.bn_groups(2), ops.start_queue(queue), ops.deferred_bn_counts():
             if dual:
                 x, feat_ori, _ = self.g(x_pair, node=True)                      # heads AND attention layers read this pass
@@ -617,6 +667,7 @@ class Net_MDA(nn.Module):
                 x, feat_ori, _ = self.g(x_pair, node=True, need_node=False)     # only the pooled feature is used
             else:
                 x, feat_ori, _ = self.g(x_pair, node=True)
+        self._bn_twice_end(snap)        # (after deferred_bn_counts has applied this pass's counter increments)
         cuts = getattr(self, '_cuts', None)
         if cuts is not None:            # SUGStep's two-phase backward cuts the graph at the encoder's outputs
             if dual:

@@ -243,8 +243,8 @@ class SUGStep:
         self.model = model
         # ONE encoder evaluation per domain feeds the heads and the attention layers, instead of the
         # semantic + node pass of train_dg_single_gpu.py:260-264, :309-310.  Same losses and gradients as the two-pass step
-        # whose node pass draws the FPS starts of its semantic pass; differences: one start draw per sampling stage and
-        # step instead of two, the encoder's BatchNorm running statistics move once per step instead of twice.
+        # whose node pass draws the FPS starts of its semantic pass, BatchNorm running statistics included (the pass's update
+        # is applied twice, Net_MDA.dual_updates_bn_twice); the one difference: one start draw per sampling stage instead of two.
         self.single_pass = bool(single_pass)
         self.base_lr, self.lr_scaler = float(lr), float(lr_scaler)
         # source and target batch go through the encoder as one 2B-cloud batch with per-domain

@@ -4,9 +4,9 @@ AND the attention layers; train_dg_single_gpu.py:260-264 + :309-310 run the enco
   * values: the single-pass losses == oracle.sug_losses with the node passes' FPS starts TIED to the semantic passes'
     (starts = [s_s, s_t, s_s, s_t]) within 1e-4, for all four backbones;
   * gradients: == the HIP two-pass step with tied starts (one graph instead of two equal ones: summation order only);
-  * the documented behavioural differences are asserted, not just described: ONE FPS start draw per sampling stage
-    (CPU generator state), the encoder's BatchNorm running statistics move once per domain (== the oracle after its two
-    semantic forwards alone, num_batches_tracked 2 instead of 4);
+  * the one documented behavioural difference is asserted, not just described: ONE FPS start draw per sampling stage (CPU
+    generator state); the encoder's BatchNorm running statistics and counters end where the tied two-pass step leaves them
+    (the pass's update applied twice, Net_MDA.dual_updates_bn_twice);
   * Net_MDA.forward(semantic_adaption=True, node_adaptation_s=True) returns the five outputs of the two calls;
   * hipGraph replay of the single-pass step == its eager twin.
 """
@@ -143,51 +143,82 @@ def test_single_pass_losses_match_oracle_with_tied_starts_and_gradients_match_tw
     assert worst[1] <= 5e-2, worst
 
 
-@pytest.mark.parametrize('model_name', ['DGCNN', 'Pointnet2'])
-def test_single_pass_documented_differences_bn_buffers_and_fps_draws(model_name):
-    """The two behavioural differences to the two-pass step: (1) the encoder's BatchNorm running statistics are updated
-    once per domain -- they equal the oracle's buffers after its two SEMANTIC forwards alone, num_batches_tracked = 2
-    where the two-pass step has 4; (2) the CPU generator is advanced by ONE draw per sampling stage and domain."""
+@pytest.mark.parametrize('model_name', ['DGCNN', 'Pointnet2', 'Pointnet', 'PTran'])
+def test_single_pass_one_fps_draw_and_bn_buffers_of_the_tied_two_pass_step(model_name):
+    """What the single-pass step changes and what it does not: (1) the CPU generator advances by ONE draw per sampling stage
+    and domain (the two-pass step: two) -- the one documented difference; (2) the encoder's BatchNorm running statistics and
+    batch counters end where the TWO-pass step leaves them when its node pass draws the semantic pass's starts: the pass's
+    update r -> a r + c is applied twice (Net_MDA.dual_updates_bn_twice), buffers equal to 2e-6, counters equal; with the
+    switch off they equal the oracle's buffers after its two semantic forwards alone (counters 2 instead of 4)."""
+    from sug_amd import ops
     from sug_amd.train_step import SUGStep
     N = N_OF[model_name]
     batch = _batch(B, N, seed=29)
     data, lab, data_t, lab_t = [t.cuda() for t in batch]
-    stages = [N] if model_name == 'DGCNN' else [N, 512]
-    out = {}
+    stages = {'DGCNN': [N], 'Pointnet': [N], 'Pointnet2': [N, 512], 'PTran': [N, 256, 64, 16]}[model_name]
+    # ---- (1) draws from the CPU generator
     for single in (True, False):
         net = _net(model_name)
         tr = SUGStep(net, lr=0.0, methods=bench.BENCH_METHODS, single_pass=single)
         torch.manual_seed(77)
         lc, lg, ls = tr.losses(data, lab, data_t, lab_t)
-        (lc + lg + ls).backward()
         state = torch.get_rng_state().clone()
         # the reference's draw order: per forward call, its sampling stages in order (point_utils.py:17, pointnet2_utils.py:72)
         torch.manual_seed(77)
-        starts = []
         for _ in range(2 if single else 4):            # forward calls that draw: (sem-s, sem-t) or (sem-s, sem-t, node-s, node-t)
-            starts.append([torch.randint(0, n, (B,), dtype=torch.long) for n in stages])
+            [torch.randint(0, n, (B,), dtype=torch.long) for n in stages]
         assert torch.equal(state, torch.get_rng_state()), 'CPU generator consumed differently (single_pass=%s)' % single
-        out[single] = (net, starts)
-    net1, starts1 = out[True]
-    net2, _ = out[False]
-    nbt = [k for k in net1.state_dict() if k.startswith('g.') and k.endswith('num_batches_tracked')]
-    used = [k for k in nbt if int(net2.state_dict()[k]) > 0]
+        del lc, lg, ls
+        if hasattr(net.g, 'clear_prefix_cache'):
+            net.g.clear_prefix_cache()
+    # ---- (2) buffers under tied starts: single pass (update applied twice) vs the two-pass step, and with the switch off
+    nets = {}
+    for tag, single, twice in (('single', True, True), ('two', False, True), ('single_once', True, False)):
+        net = _net(model_name)
+        net.dual_updates_bn_twice = twice
+        tr = SUGStep(net, lr=0.0, methods=bench.BENCH_METHODS, single_pass=single)
+        prov = TiedStarts(B)
+        ops.START_PROVIDER = prov
+        try:
+            tr.losses(data, lab, data_t, lab_t)
+        finally:
+            ops.START_PROVIDER = None
+        nets[tag] = (net, prov)
+        if hasattr(net.g, 'clear_prefix_cache'):
+            net.g.clear_prefix_cache()
+    sd1, sd2, sd0 = (nets[t][0].state_dict() for t in ('single', 'two', 'single_once'))
+    nbt = [k for k in sd1 if k.startswith('g.') and k.endswith('num_batches_tracked')]
+    used = [k for k in nbt if int(sd2[k]) > 0]
     assert used
-    for k in used:
-        assert int(net1.state_dict()[k]) == 2 and int(net2.state_dict()[k]) == 4, (k, int(net1.state_dict()[k]), int(net2.state_dict()[k]))
-    # buffers after the single-pass step == oracle buffers after the semantic forward of each domain (same starts)
-    p = _oracle_params(model_name)
-    spec = lambda st: [st[0]] if model_name == 'DGCNN' else tuple(st)
-    with torch.no_grad():
-        O.net_mda(p, model_name, batch[0], True, spec(starts1[0]), semantic_adaption=True)
-        O.net_mda(p, model_name, batch[2], True, spec(starts1[1]), semantic_adaption=True)
-    sd = net1.state_dict()
+    for k in nbt:
+        assert int(sd1[k]) == int(sd2[k]), (k, int(sd1[k]), int(sd2[k]))
+        assert int(sd2[k]) in (0, 4) and int(sd0[k]) == int(sd2[k]) // 2, (k, int(sd0[k]), int(sd2[k]))
     worst = 0.0
-    for k in sd:
+    for k in sd1:
+        if k.startswith('g.') and k.endswith(('running_mean', 'running_var')):
+            a, b = sd1[k].double(), sd2[k].double()
+            if k.rsplit('.', 1)[0] + '.num_batches_tracked' not in used:
+                assert torch.equal(sd1[k], sd2[k]), 'a BatchNorm the pass never ran must keep its buffers bit for bit: ' + k
+                continue
+            worst = max(worst, float((a - b).abs().max()) / max(1.0, float(b.abs().max())))
+    print(model_name, 'encoder running statistics, single pass (update applied twice) vs tied two-pass step: worst rel %.2e' % worst)
+    assert worst <= 2e-6, worst
+    # the attention layers' and heads' buffers are touched once per step in both forms
+    for k in sd1:
+        if k.startswith('attention') and k.endswith(('running_mean', 'running_var')):
+            assert float((sd1[k] - sd2[k]).abs().max()) <= 1e-5 * max(1.0, float(sd2[k].abs().max())), k
+    # switch off: one update per domain == the oracle after its two semantic forwards
+    p = _oracle_params(model_name)
+    s = nets['single_once'][1].spec(model_name, N)
+    kw = {}
+    with torch.no_grad():
+        O.net_mda(p, model_name, batch[0], True, s, semantic_adaption=True)
+        O.net_mda(p, model_name, batch[2], True, s, semantic_adaption=True)
+    worst = 0.0
+    for k in sd0:
         if k.startswith('g.') and k.endswith(('running_mean', 'running_var')) and k.rsplit('.', 1)[0] + '.num_batches_tracked' in used:
-            d = float((sd[k].cpu() - p[k]).abs().max())
-            worst = max(worst, d / max(1.0, float(p[k].abs().max())))
-    print(model_name, 'running statistics vs oracle after one forward per domain: worst rel %.2e' % worst)
+            worst = max(worst, float((sd0[k].cpu() - p[k]).abs().max()) / max(1.0, float(p[k].abs().max())))
+    print(model_name, 'dual_updates_bn_twice = False: running statistics vs oracle after one forward per domain: worst rel %.2e' % worst)
     assert worst <= 1e-4, worst
 
 
