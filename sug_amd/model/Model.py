@@ -509,17 +509,18 @@ class Net_MDA(nn.Module):
         the batch counters (multi-tensor launches, independent of the backbone)."""
         if not (self.dual_updates_bn_twice and self.training):
             return None
-        plan = getattr(self, '_bn_twice_plan', None)
-        if plan is None:
-            bns = [m for m in self.g.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm) and m.track_running_stats
-                   and m.momentum is not None]
-            # (.data views: the second update must not bump the version counters autograd checks -- torch's own batch_norm
-            # node keeps a reference to the running buffers it was given, for its eval-mode backward; a train-mode backward
-            # never reads them, and the reference's second forward call changes them under the first call's graph as well)
-            plan = self._bn_twice_plan = (
-                [b.data for m in bns for b in (m.running_mean, m.running_var)], [float(m.momentum) for m in bns for _ in (0, 1)],
-                [m.num_batches_tracked.data for m in bns if m.num_batches_tracked is not None])
-        bufs, moms, nbt = plan
+        bns = getattr(self, '_bn_twice_modules', None)
+        if bns is None:
+            # (the MODULES are cached, not their tensors: .to() / load_state_dict may replace a buffer's storage, and
+            # copy.deepcopy maps cached module references onto the copy's own modules)
+            bns = self._bn_twice_modules = [m for m in self.g.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm)
+                                            and m.track_running_stats and m.momentum is not None]
+        # .data views: the second update must not bump the version counters autograd checks -- torch's own batch_norm node
+        # keeps a reference to the running buffers it was given, for its eval-mode backward; a train-mode backward never reads
+        # them, and the reference's second forward call changes them under the first call's graph as well
+        bufs = [b.data for m in bns for b in (m.running_mean, m.running_var)]
+        moms = [float(m.momentum) for m in bns for _ in (0, 1)]
+        nbt = [m.num_batches_tracked.data for m in bns if m.num_batches_tracked is not None]
         if not bufs or not bufs[0].is_cuda:
             return None
         G = ops.BN_GROUPS
