@@ -196,6 +196,36 @@ def kernel_timestamps_in_child(args, want_events=False):
     return res
 
 
+def segmented_rehearsal(args):
+    """The MULTI-rank launch form on this one GPU: a child `bench.py --segmented` (five captured graph segments with the four
+    RCCL collectives between them, on a one-rank process group) -> {'ms_per_step', 'collectives'} or None.  No multi-GPU
+    node is needed for it, and it bounds what the launch form itself costs against the whole-step graph of the headline
+    (link time comes on top on a real node)."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--segmented', '--model', args.model, '--batch', str(args.batch),
+           '--npoints', str(args.npoints), '--warmup', '5', '--steps', '40', '--no-cpu-baseline', '--no-other-workloads',
+           '--caller-steps', '0', '--profile-steps', '3']
+    for flag, on in (('--fp16', args.fp16), ('--no-tuned-gemms', args.no_tuned_gemms)):
+        if on:
+            cmd.append(flag)
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT',
+                                                               'GROUP_RANK', 'ROLE_RANK', 'LOCAL_WORLD_SIZE', 'TORCHELASTIC_RUN_ID')}
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    try:
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        lines = [l for l in r.stdout.decode().splitlines() if l.startswith('{')]
+        if r.returncode != 0 or not lines:
+            print('bench.py: segmented rehearsal failed (rc %s)' % r.returncode, file=sys.stderr)
+            return None
+        d = json.loads(lines[-1])
+        return {'ms_per_step': d['ms_per_step'], 'launch': d['config']['launch'], 'collectives': d['config']['collectives'],
+                'note': 'the multi-rank launch form on ONE rank (RCCL group of size 1): what the five graph segments and four '
+                        'collective calls cost against the whole-step graph; no link time'}
+    except Exception as e:
+        print('bench.py: segmented rehearsal skipped (%s)' % str(e).splitlines()[0], file=sys.stderr)
+        return None
+
+
 def kernel_table(profs, exact=None):
     """{name: [(ev0, ev1, shape), ...]} -> {name: launches, avg / total ms, GB/s, TFLOP/s, bound, frac}."""
     kern = {}
@@ -814,6 +844,10 @@ def main():
                     others.append(other_workload(nm, b_, n_, f16, dev))
                 except RuntimeError as e:
                     others.append({'workload': '%s N=%d batch=%d' % (nm, n_, b_), 'error': str(e).splitlines()[0][:200]})
+        seg1 = None
+        if world == 1 and not args.plain and not args.segmented and not args.no_other_workloads and args.model == 'DGCNN' \
+                and not args.single_pass:
+            seg1 = segmented_rehearsal(args)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_record(args.model, args.cpu_batch, N, args.cpu_steps)
@@ -860,6 +894,7 @@ def main():
                                               'node pass draws the semantic pass\'s FPS starts (one draw per stage instead of two); NOT the headline',
                           'clouds_per_step': world * 2 * B,
                           'other_workloads': others,
+                          'segmented_one_rank_rccl': seg1,
                           **({'fp16_linears': 'k-expanded and per-point 512-wide linears of the transformer blocks'}
                              if (args.fp16 and args.model == 'PTran') else {})},
                'roofline': roofline, 'cpu_baseline': cpu, 'losses': loss_vals,
