@@ -42,7 +42,7 @@ def _oracle_losses(B, N=1024, wseed=5, sseed=21):
     return _ORACLE[key]
 
 
-def _trainer(B, use_graph, tuned, wseed=5, lr=0.0, model_name='DGCNN'):
+def _trainer(B, use_graph, tuned, wseed=5, lr=0.0, model_name='DGCNN', single_pass=False):
     from sug_amd.model.Model import Net_MDA
     from sug_amd.train_step import SUGStep
     net = Net_MDA(model_name)
@@ -55,7 +55,8 @@ def _trainer(B, use_graph, tuned, wseed=5, lr=0.0, model_name='DGCNN'):
         enable_tuned_gemms()
     # lr = 0: Adam leaves the weights where they are, so the planning step, the captured step and every replay see
     # the same weights and each of them can be held against the one oracle evaluation
-    return SUGStep(net.cuda().train(), lr=lr, weight_decay=5e-5, use_graph=use_graph, methods=bench.BENCH_METHODS)
+    return SUGStep(net.cuda().train(), lr=lr, weight_decay=5e-5, use_graph=use_graph, methods=bench.BENCH_METHODS,
+                   single_pass=single_pass)
 
 
 def _untune():
@@ -106,6 +107,38 @@ def test_benched_configuration_b32_graph_tuned_matches_oracle():
     finally:
         _untune()
     print('gpu', got, 'oracle', want)
+    for step in got:
+        for a, b in zip(step, want):
+            assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), (got, want)
+
+
+def test_benched_configuration_b32_single_pass_graph_tuned_matches_oracle_with_tied_starts():
+    """`bench.py`'s config.single_pass_ms_per_step configuration (DGCNN, 32 clouds per domain, hipGraph replay, tuned GEMMs,
+    SUGStep(single_pass=True)) except dropout: planning step, captured step and a replay against oracle.sug_losses whose
+    node passes draw the semantic passes' FPS starts, at 1e-4.  The step makes ONE draw of 2B starts per sampling stage
+    (source clouds first), which is the tie handed to the oracle."""
+    from sug_amd.model.Model import Net_MDA
+    B, N = 32, 1024
+    batch = _batch(B, N)
+    data, lab, data_t, lab_t = [t.cuda() for t in batch]
+    torch.manual_seed(21)
+    d = torch.randint(0, N, (2 * B,), dtype=torch.long)
+    s_s, s_t = [d[:B]], [d[B:]]
+    p = O.as_params(O.fill_params({k: tuple(v.shape) for k, v in Net_MDA('DGCNN').state_dict().items()}, 5))
+    with torch.no_grad():
+        want = [float(v) for v in O.sug_losses(p, 'DGCNN', batch[0], batch[1], batch[2], batch[3],
+                                               dict(bench.BENCH_METHODS['GEO_MMD'][0]), dict(bench.BENCH_METHODS['SEM_MMD'][0]),
+                                               drop_p=0.0, starts=[s_s, s_t, s_s, s_t])]
+    try:
+        tr = _trainer(B, True, True, single_pass=True)
+        got = []
+        for _ in range(3):
+            torch.manual_seed(21)
+            got.append([float(v) for v in tr.step(data, lab, data_t, lab_t)])
+        assert len(tr._graphs) == 1 and next(iter(tr._graphs.values()))['graph'] is not None
+    finally:
+        _untune()
+    print('single pass gpu', got, 'oracle (tied starts)', want)
     for step in got:
         for a, b in zip(step, want):
             assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), (got, want)
