@@ -212,6 +212,11 @@ def segmented_rehearsal(args):
                                                                'GROUP_RANK', 'ROLE_RANK', 'LOCAL_WORLD_SIZE', 'TORCHELASTIC_RUN_ID')}
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     try:
+        import socket
+        sk = socket.socket()
+        sk.bind(('127.0.0.1', 0))                    # a free rendezvous port for the one-rank group
+        env['MASTER_ADDR'], env['MASTER_PORT'] = '127.0.0.1', str(sk.getsockname()[1])
+        sk.close()
         r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
         lines = [l for l in r.stdout.decode().splitlines() if l.startswith('{')]
         if r.returncode != 0 or not lines:
