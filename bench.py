@@ -217,7 +217,7 @@ def segmented_rehearsal(args):
         sk.bind(('127.0.0.1', 0))                    # a free rendezvous port for the one-rank group
         env['MASTER_ADDR'], env['MASTER_PORT'] = '127.0.0.1', str(sk.getsockname()[1])
         sk.close()
-        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)     # ~20 s when healthy
         lines = [l for l in r.stdout.decode().splitlines() if l.startswith('{')]
         if r.returncode != 0 or not lines:
             print('bench.py: segmented rehearsal failed (rc %s)' % r.returncode, file=sys.stderr)
