@@ -180,7 +180,7 @@ def kernel_timestamps_in_child(args, want_events=False):
                                                                'GROUP_RANK', 'ROLE_RANK', 'LOCAL_WORLD_SIZE', 'TORCHELASTIC_RUN_ID')}
     res = {'exact': None, 'events': None}
     try:
-        r = subprocess.run(cmd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=600)
+        r = subprocess.run(cmd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=180)
         if r.returncode != 0:
             print('bench.py: kernel-timestamp child failed (rc %s); HIP-event timings stand' % r.returncode, file=sys.stderr)
         if os.path.exists(out):
