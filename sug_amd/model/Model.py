@@ -27,8 +27,11 @@ class _PrefixEntry:
     second forward on the SAME batch with the SAME weights may reuse.  `alive` turns False as soon as a backward pass
     reaches the cached tensors: their autograd graph is consumed then, and a later forward must recompute."""
 
-    def __init__(self, tensors, extra=None, source=None):
+    def __init__(self, tensors, extra=None, source=None, live=None, provider=None):
         self.tensors, self.extra = tensors, extra
+        # call-graph mode (sug_amd.call_graphs): the tensors are hidden outputs of a replayed forward graph; `live` says
+        # whether that replay is still the current one and its backward has not run, `provider` is the graph instance
+        self._live, self.provider = live, provider
         # identity of the input batch: (data_ptr, _version, shape) alone is NOT tensor identity -- the caching allocator
         # hands a freed batch's address to the next one with _version 0 again (ADVICE r3) -- so a hit also requires the
         # very same tensor object; a weak reference, the entry must not keep the batch alive
@@ -44,9 +47,64 @@ class _PrefixEntry:
     def alive(self):
         return self._flag[0]
 
+    # copy.deepcopy(model) (train_dg_single_gpu.py:364) and pickling meet the cache inside the encoder: the cached tensors
+    # are autograd non-leaves (not copyable) and belong to the original's graph -- the copy gets a dead, empty entry
+    def __deepcopy__(self, memo):
+        return _dead_prefix_entry()
+
+    def __reduce__(self):
+        return (_dead_prefix_entry, ())
+
+    def servable(self):
+        """Could this entry still serve its batch?"""
+        return self._flag[0] and self._source is not None and self._source() is not None and (self._live is None or self._live())
+
     def serves(self, x):
         """True if this entry was computed from the tensor object `x` and its autograd graph is still unconsumed."""
-        return self._flag[0] and self._source is not None and self._source() is x
+        return self._flag[0] and self._source is not None and self._source() is x and (self._live is None or self._live())
+
+
+class _PrefixSharing:
+    """Helpers shared by the encoders that cache a prefix (DGCNN, Pointnet_g, PTran_g): the cache key, a look-up by input
+    tensor and the installation of an entry computed elsewhere (sug_amd.call_graphs: the prefix of a replayed forward graph)."""
+
+    def _prefix_params(self):
+        raise NotImplementedError
+
+    def _prefix_key(self, x):
+        ver = sum(p._version for p in self._prefix_params())
+        return (x.data_ptr(), x._version, tuple(x.shape), torch.is_grad_enabled(), ver, ops.BN_GROUPS)
+
+    def find_prefix(self, x):
+        """The live cache entry computed from the tensor object `x` under the current weights, or None."""
+        hit = self._prefix_cache.get(self._prefix_key(x))
+        return hit if (hit is not None and hit.serves(x)) else None
+
+    def last_prefix(self, x):
+        """The entry a forward on `x` has just stored (whatever its liveness)."""
+        return self._prefix_cache.get(self._prefix_key(x))
+
+    def _prune_prefix_cache(self):
+        """Before an insertion: entries that can no longer serve (graph consumed, batch gone, replay superseded) go; the
+        cache never grows beyond a few live batches."""
+        if len(self._prefix_cache) >= 4:
+            self._prefix_cache = {k: e for k, e in self._prefix_cache.items() if e.servable()}
+            if len(self._prefix_cache) >= 8:
+                self._prefix_cache.clear()
+
+    def install_prefix(self, x, tensors, extra, live=None, provider=None):
+        self._prune_prefix_cache()
+        e = self._prefix_cache[self._prefix_key(x)] = _PrefixEntry(tuple(tensors), extra, source=x, live=live, provider=provider)
+        return e
+
+    def clear_prefix_cache(self):
+        self._prefix_cache = {}
+
+
+def _dead_prefix_entry():
+    e = _PrefixEntry.__new__(_PrefixEntry)
+    e.tensors, e.extra, e._source, e._flag, e._live, e.provider = (), None, None, [False], None, None
+    return e
 
 
 def _sharing_on(flag, training):
@@ -102,7 +160,7 @@ def grad_reverse(x, lambd=1.0):
     return x.view_as(x)
 
 
-class DGCNN(nn.Module):
+class DGCNN(nn.Module, _PrefixSharing):
     """EdgeConv encoder with the SA-node module (model/Model.py:54-121)."""
 
     def __init__(self):
@@ -127,8 +185,8 @@ class DGCNN(nn.Module):
         self.share_prefix = 'auto'
         self._prefix_cache = {}
 
-    def clear_prefix_cache(self):
-        self._prefix_cache = {}
+    def _prefix_params(self):
+        return [p for m in (self.conv1, self.conv2) for p in m.parameters()]
 
     def _prefix(self, x, loc, nb, out1=None):
         """kNN + conv1, kNN + conv2.  out1: where conv1's activations should be written (a column
@@ -136,8 +194,7 @@ class DGCNN(nn.Module):
         if not _sharing_on(self.share_prefix, self.training):
             x1 = self.conv1.edge_rows(loc, nb(loc, 0), out=out1)
             return x1, self.conv2.edge_rows(x1, nb(x1, 1))
-        ver = sum(p._version for m in (self.conv1, self.conv2) for p in m.parameters())
-        key = (x.data_ptr(), x._version, tuple(x.shape), torch.is_grad_enabled(), ver, ops.BN_GROUPS)
+        key = self._prefix_key(x)
         hit = self._prefix_cache.get(key)
         if hit is not None and hit.serves(x):
             x1, x2 = hit.tensors
@@ -147,8 +204,7 @@ class DGCNN(nn.Module):
             return x1, x2
         x1, st1 = self.conv1.edge_rows(loc, nb(loc, 0), return_stats=True, out=out1)
         x2, st2 = self.conv2.edge_rows(x1, nb(x1, 1), return_stats=True)
-        if len(self._prefix_cache) >= 4:            # a step has two inputs; never grow unbounded
-            self._prefix_cache.clear()
+        self._prune_prefix_cache()                  # a step has two inputs; never grow unbounded
         self._prefix_cache[key] = _PrefixEntry((x1, x2), (st1, st2), source=x)
         return x1, x2
 
@@ -272,7 +328,7 @@ class Pointnet2_g(nn.Module):
         return feat, node_fea
 
 
-class Pointnet_g(nn.Module):
+class Pointnet_g(nn.Module, _PrefixSharing):
     """PointNet encoder with the SA-node module (model/Model.py:235-283)."""
 
     def __init__(self):
@@ -292,11 +348,11 @@ class Pointnet_g(nn.Module):
         self.share_prefix = 'auto'
         self._prefix_cache = {}
 
-    def clear_prefix_cache(self):
-        self._prefix_cache = {}
-
     def _prefix_modules(self):
         return (self.trans_net1, self.conv1, self.conv2, self.trans_net2)
+
+    def _prefix_params(self):
+        return [p for mod in self._prefix_modules() for p in mod.parameters()]
 
     def _prefix(self, x, loc):
         def run():
@@ -305,16 +361,14 @@ class Pointnet_g(nn.Module):
             return torch.bmm(y, self.trans_net2.rows(y))
         if not (_sharing_on(self.share_prefix, self.training) and x.is_cuda):
             return run()
-        ver = sum(p._version for mod in self._prefix_modules() for p in mod.parameters())
-        key = (x.data_ptr(), x._version, tuple(x.shape), torch.is_grad_enabled(), ver, ops.BN_GROUPS)
+        key = self._prefix_key(x)
         hit = self._prefix_cache.get(key)
         if hit is not None and hit.serves(x):
             ops.replay_bn_stats(hit.extra)
             return hit.tensors[0]
         with ops.record_bn_stats() as rec:
             y = run()
-        if len(self._prefix_cache) >= 4:
-            self._prefix_cache.clear()
+        self._prune_prefix_cache()
         self._prefix_cache[key] = _PrefixEntry((y,), rec, source=x)
         return y
 
@@ -348,7 +402,7 @@ class TransitionDown(nn.Module):
         return self.sa(xyz, points)
 
 
-class PTran_g(nn.Module):
+class PTran_g(nn.Module, _PrefixSharing):
     """Point Transformer encoder (model/Model.py:295-337): 5 transformer blocks, 4 transition-down
     stages (FPS to 256/64/16/4 points -- the schedule is fixed to npoints=1024 as in the reference
     even for N=2048 -- kNN-16 grouping, 2-layer MLP, max)."""
@@ -376,8 +430,12 @@ class PTran_g(nn.Module):
         self.share_prefix = 'auto'
         self._prefix_cache = {}
 
-    def clear_prefix_cache(self):
-        self._prefix_cache = {}
+    def _prefix_params(self):
+        return [p for m in (self.fc1, self.transformer1) for p in m.parameters()]
+
+    def _prefix_key(self, x):
+        ver = sum(p._version for p in self._prefix_params())
+        return (x.data_ptr(), x._version, tuple(x.shape), torch.is_grad_enabled(), ver)
 
     def _lift(self, x_):
         """fc1 (Linear 3->32, ReLU, Linear 32->32) on the [B,N,3] rows; on the GPU through ops.linear_rows: its
@@ -388,12 +446,10 @@ class PTran_g(nn.Module):
     def _prefix(self, x, x_, xyz):
         if not _sharing_on(self.share_prefix, self.training):
             return self.transformer1(xyz, self._lift(x_))[0]
-        ver = sum(p._version for m in (self.fc1, self.transformer1) for p in m.parameters())
-        key = (x.data_ptr(), x._version, tuple(x.shape), torch.is_grad_enabled(), ver)
+        key = self._prefix_key(x)
         hit = self._prefix_cache.get(key)
         if hit is None or not hit.serves(x):
-            if len(self._prefix_cache) >= 4:
-                self._prefix_cache.clear()
+            self._prune_prefix_cache()
             hit = self._prefix_cache[key] = _PrefixEntry((self.transformer1(xyz, self._lift(x_))[0],), source=x)
         return hit.tensors[0]
 
@@ -540,9 +596,28 @@ class Net_MDA(nn.Module):
         if nbt:
             torch._foreach_add_(nbt, torch._foreach_sub(nbt, n0))
 
+    # Per-call hipGraph replay (sug_amd.call_graphs): a training loop that calls `model(...)` four times a
+    # step, as train_dg_single_gpu.py:260-310 does, is host-bound when every kernel is launched from Python (~480 launches
+    # in 8 ms against 6.8 ms of kernels).  With call_graphs on, the first train-mode call of a (flags, shape) combination runs
+    # eagerly, the second is captured -- forward and backward, each as one hipGraph -- and later calls replay: same
+    # kernels, same arithmetic, same CPU-generator draws (bit-identical losses and parameters, tests/test_gpu_call_graphs.py),
+    # two launches per call.  'auto' (default): on for train-mode calls with autograd enabled on one process; False: off.
+    call_graphs = 'auto'
+
     def forward(self, x, constant=1, adaptation=False, node_vis=False, mid_feat=False, node_adaptation_s=False,
                 node_adaptation_t=False, semantic_adaption=False):
         _check_input(x)
+        flags = (constant, bool(adaptation), bool(node_vis), bool(mid_feat), bool(node_adaptation_s), bool(node_adaptation_t),
+                 bool(semantic_adaption))
+        if self.call_graphs and self.training and torch.is_grad_enabled():
+            from .. import call_graphs as _cg
+            mgr = _cg.manager_for(self)
+            if mgr is not None:
+                return mgr.call(x, flags)
+        return self._forward_impl(x, *flags)
+
+    def _forward_impl(self, x, constant=1, adaptation=False, node_vis=False, mid_feat=False, node_adaptation_s=False,
+                      node_adaptation_t=False, semantic_adaption=False):
         dual = self.dual_output_on_both_flags and semantic_adaption and (node_adaptation_s or node_adaptation_t) \
             and not (node_vis or mid_feat)
         only_node = (node_adaptation_s or node_adaptation_t) and not (node_vis or mid_feat or dual)

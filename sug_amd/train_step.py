@@ -191,49 +191,7 @@ class GradReducer:
         self.flats = self.members = self.handles = None
 
 
-class _StartFeeder:
-    """FPS start indices for a replayable step: drawn from the CPU default generator in call
-    order with the same (B, N) sequence as an eager step (so the random stream is the
-    reference's), but delivered through one static device buffer."""
-
-    def __init__(self, device):
-        self.device = device
-        self.plan = []          # (B, N) per farthest_point_sample call of one step
-        self.host = self.dev = None
-        self.cursor = 0
-
-    def record(self, B, N):     # provider during the eager planning step
-        self.plan.append((B, N))
-        return torch.randint(0, N, (B,), dtype=torch.long)
-
-    def build(self):
-        total = sum(b for b, _ in self.plan)
-        # two pinned staging buffers, used alternately: the host must not overwrite one while its
-        # asynchronous copy to the device may still be pending (replays are not synchronised)
-        self.host = [torch.empty(total, dtype=torch.int32).pin_memory() for _ in range(2)]
-        self.done = [None, None]
-        self.turn = 0
-        self.dev = torch.zeros(total, dtype=torch.int32, device=self.device)
-
-    def refill(self):           # before every replay
-        h = self.host[self.turn]
-        if self.done[self.turn] is not None:
-            self.done[self.turn].synchronize()
-        off = 0
-        for B, N in self.plan:
-            h[off:off + B] = torch.randint(0, N, (B,), dtype=torch.long).to(torch.int32)
-            off += B
-        self.dev.copy_(h, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        self.done[self.turn] = ev
-        self.turn ^= 1
-
-    def provide(self, B, N):    # provider during capture
-        off = sum(b for b, _ in self.plan[:self.cursor])
-        assert self.plan[self.cursor] == (B, N), 'step structure changed between planning and capture'
-        self.cursor += 1
-        return self.dev[off:off + B]
+from .call_graphs import StartFeeder as _StartFeeder      # FPS start draws of a replayable step (moved there in round 6)
 
 
 class SUGStep:

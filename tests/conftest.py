@@ -53,3 +53,17 @@ def mmd_golden():
 @pytest.fixture(scope='session')
 def dev():
     return torch.device('cuda:0')
+
+
+@pytest.fixture(autouse=True)
+def _eager_net_mda_calls():
+    """The model-level tests pin the call-by-call EAGER form of Net_MDA.forward (many of them spy on ops.knn or feed FPS
+    starts through ops.START_PROVIDER, which a replayed call graph never reaches).  The per-call hipGraph replay
+    (sug_amd.call_graphs, on by default in the product) is held against exactly that eager form, bit for bit, by
+    tests/test_gpu_call_graphs.py, which switches it on for itself."""
+    from sug_amd.model.Model import Net_MDA
+    keep, Net_MDA.call_graphs = Net_MDA.call_graphs, False
+    try:
+        yield
+    finally:
+        Net_MDA.call_graphs = keep
