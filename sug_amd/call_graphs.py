@@ -12,8 +12,9 @@ module keeps the caller's code unchanged and removes the host from the picture:
     is: copy the batch into the static input, refill the FPS starts (same CPU-generator draws, in call order, through a
     pinned double buffer), replay;
   * an `autograd.Function` stands in for the call in the caller's autograd graph: its backward stages the incoming
-    gradients, replays the backward graph and ACCUMULATES the parameter gradients inside that graph into a flat buffer whose
-    views are the parameters' `.grad` -- no `AccumulateGrad` node, no `at::add` per parameter and call;
+    gradients, replays the backward graph and hands the parameter gradients to `.grad` itself -- the first contribution
+    since the caller's zero_grad() IS the static gradient tensor (no copy), later ones are added in one multi-tensor launch:
+    no `AccumulateGrad` node, no `at::add` per parameter and call;
   * two calls on the same batch share the encoder prefix as the eager form does (`share_prefix = 'auto'`): the first call's
     graph exposes the prefix tensors as hidden outputs of its Function, the second call's graph was captured reading them in
     place, its backward hands the prefix gradients to the first call's backward through autograd;
@@ -171,8 +172,6 @@ class CallGraphs:
         self._model = weakref.ref(model)
         self.keys = {}
         self.sig = None
-        self.G = None
-        self.gview = {}
         self.token = None
         self.stats = {'eager': 0, 'captured': 0, 'replayed': 0, 'refused': 0}
 
@@ -197,19 +196,11 @@ class CallGraphs:
         self._modules = list(model.modules())
         self._slots = [(m, n, q) for m in self._modules for n, q in m._parameters.items() if q is not None]
         self.sig = self._signature(model)
-        self.G, self.gview = None, {}
         self.token = None
 
-    def _grad_buffer(self, dev):
-        if self.G is None:
-            req = [p for p in self._params if p.requires_grad]
-            offs, n = [], 0
-            for p in req:
-                offs.append(n)
-                n += (p.numel() + 63) // 64 * 64          # 256-byte aligned views
-            self.G = torch.zeros(max(n, 1), dtype=torch.float32, device=dev)
-            self.gview = {id(p): self.G[o:o + p.numel()].view_as(p) for p, o in zip(req, offs)}
-            self._req = req
+    def _prepare(self, dev):
+        if self.token is None:
+            self._req = [p for p in self._params if p.requires_grad]
             self.token = torch.zeros((), dtype=torch.float32, device=dev, requires_grad=True)
 
     # ------------------------------------------------------------------ the call
@@ -302,7 +293,7 @@ class CallGraphs:
     # ------------------------------------------------------------------ capture
     def _capture(self, model, ks, x, flags, dep):
         dev = x.device
-        self._grad_buffer(dev)
+        self._prepare(dev)
         g = model.g
         inst = _Instance(self, ks, dep)
         inst.x = x.detach().clone()
@@ -351,15 +342,10 @@ class CallGraphs:
         inst.gdirty = [False] * len(diff)
         params = self._req
         inst.graph_b = torch.cuda.CUDAGraph()
-        _dbg = os.environ.get('SUG_CG_DEBUG', '')
-        with torch.cuda.graph(inst.graph_b, pool=(None if 'ownpool' in _dbg else inst.graph_f.pool()),
-                              capture_error_mode=('global' if 'global' in _dbg else 'thread_local')):
+        with torch.cuda.graph(inst.graph_b, pool=inst.graph_f.pool(), capture_error_mode='thread_local'):
             grads = torch.autograd.grad(diff, [alias[id(q)] for q in params] + leaves, inst.gouts, allow_unused=True)
-            used = [(p, gr) for p, gr in zip(params, grads[:len(params)]) if gr is not None]
-            if used and 'noadd' not in _dbg:
-                torch._foreach_add_([self.gview[id(p)] for p, _ in used], [gr for _, gr in used])
-        inst._static_grads = [gr for _, gr in used]                 # (keep the captured tensors' memory out of the pool's free list)
-        inst.used = [(p, self.gview[id(p)]) for p, _ in used]
+        # static gradient tensors of the parameters this call reaches (kept referenced: their memory stays out of the pool)
+        inst.used = [(q, gr) for q, gr in zip(params, grads[:len(params)]) if gr is not None]
         inst.leaf_grads = tuple(grads[len(params):])
         inst.outs = [t.detach() for t in outs]
         inst.prefix_static = tuple(t.detach() for t in pref)
@@ -370,8 +356,14 @@ class CallGraphs:
     def _replay(self, model, inst, x, entry):
         inst.generation += 1
         inst.busy = True
-        if x.data_ptr() != inst.x.data_ptr():
-            inst.x.copy_(x, non_blocking=True)
+        # A parameter whose .grad still IS one of this instance's static gradient tensors (the caller has not reset it since
+        # this instance's previous backward: gradient accumulation over several steps) keeps its value in a copy -- the
+        # static tensor shares the instance's memory pool with the forward's temporaries and is overwritten by the replays.
+        for p, gr in inst.used:
+            g = p.grad
+            if g is not None and g.data_ptr() == gr.data_ptr():
+                p.grad = g.clone()
+        inst.x.copy_(x, non_blocking=True)
         inst.feeder.refill()
         inst.graph_f.replay()
         self.stats['replayed'] += 1
@@ -399,21 +391,24 @@ class CallGraphs:
             torch._foreach_zero_(zero)
         if dst:
             torch._foreach_copy_(dst, src)
-        # the parameters' .grad are views of the flat buffer the backward graphs accumulate into; a parameter whose .grad
-        # the caller has reset (optimizer.zero_grad()) starts from zero again
-        need_zero = []
-        for p, v in inst.used:
+        for p, gr in inst.used:         # (as in _replay: a second backward through a retained graph)
             g = p.grad
-            if g is v:
-                continue
-            if g is None:
-                need_zero.append(v)
-            elif g.data_ptr() != v.data_ptr():
-                v.copy_(g)                      # a gradient from elsewhere (eager calls of the same step): keep accumulating
-            p.grad = v
-        if need_zero:
-            torch._foreach_zero_(need_zero)
+            if g is not None and g.data_ptr() == gr.data_ptr():
+                p.grad = g.clone()
         inst.graph_b.replay()
+        # .grad semantics without AccumulateGrad nodes: the first contribution since the caller's zero_grad() becomes the
+        # parameter's .grad as it is (the static tensor, no copy, no zero fill), later ones are added to it in one multi-tensor
+        # launch -- in the order autograd runs the calls' backwards, i.e. the order eager accumulation adds them in.
+        dst, src = [], []
+        for p, gr in inst.used:
+            g = p.grad
+            if g is None:
+                p.grad = gr
+            else:
+                dst.append(g)
+                src.append(gr)
+        if dst:
+            torch._foreach_add_(dst, src)
 
 
 def manager_for(model):

@@ -27,30 +27,14 @@
 //              give the lists of the exact consumer bit for bit (tests/golden/knn_pc_hashes.json).
 // One barrier per tile hands tile t's scores to the consumers while the producers work on tile
 // t+1.  No candidate ring, no compaction, no merge.
-// LDS: tiles 3 x 32 x (C+4) + score tiles 2 x PW x 64 x 36 floats = 100 / 125 KB (C = 64 / 128, PW = 4) or 63 KB (C = 64, PW = 2).
-// Workgroup = 64 PW queries of one cloud; the workgroups of a cloud share an XCD (one L2).
+// LDS: tiles 3 x 32 x (C+4) + score tiles 2 x QB x 36 floats = 100 / 125 KB (C = 64 / 128, QB = 256 queries) or 63 KB (C = 64, QB = 128).
+// Workgroup = QB queries of one cloud; the workgroups of a cloud share an XCD (one L2).
 //
 // FLOPs N^2*(2C+3) per cloud on the matrix pipe (157 TFLOP/s); algorithmic bytes 4*C*N + 4*N*k.
 #include <float.h>
 #include "common.h"
 #include "mfma_tile.h"
 
-#if defined(SUG_KNN_ABL_SEED) || defined(SUG_KNN_ABL_COUNT)
-// Ablation builds only (tools/bench_knn_pc.py seed): an ORACLE threshold per query ([B, N] scores: the exact K-th best score,
-// computed by the caller) seeds the consumer's threshold before the first tile -- the upper bound of what any threshold
-// seeding can save; and a counter of the candidates that pass the scan (accepted candidates per query).
-__device__ const float* g_knn_seed = nullptr;
-__device__ unsigned long long g_knn_accepted = 0ull;
-extern "C" int sug_knn_abl_set_seed(const float* seed) {
-  return hipMemcpyToSymbol(HIP_SYMBOL(g_knn_seed), &seed, sizeof(seed)) == hipSuccess ? 0 : -1;
-}
-extern "C" long long sug_knn_abl_accepted(int reset) {
-  unsigned long long v = 0ull, z = 0ull;
-  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_knn_accepted), sizeof(v)) != hipSuccess) return -1;
-  if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_knn_accepted), &z, sizeof(z)) != hipSuccess) return -1;
-  return (long long)v;
-}
-#endif
 
 namespace {
 using namespace sug_tile;
@@ -116,20 +100,27 @@ __device__ __forceinline__ float exact_norm(const float* __restrict__ r) {
   }
 }
 
-// PW: producer waves = consumer waves per workgroup.  PW = 4 (product): 256 queries, 512 threads, one workgroup per CU
-// (100 / 125 KB of LDS).  PW = 2 (small batches: see launch_pc): 128 queries, 256 threads, 63 KB of LDS at C <= 64 -- two
-// workgroups per CU with independent barrier phases.
-template <int CP, int K, int PW>
-__global__ __launch_bounds__(128 * PW, 2) void knn_pc_kernel(const float* __restrict__ x, int64_t ldx, int B, int N,
-                                                             int k, int32_t* __restrict__ idx, int force) {
+// NP producer waves, NC consumer waves per workgroup; the workgroup serves QB = 64 NC queries, a producer wave scores
+// QP = QB / NP of them (64: two 32-query column blocks sharing the A operand; 32: one).
+//   NP = NC = 4 (product): 256 queries, 512 threads, one workgroup per CU (100 / 125 KB of LDS);
+//   NP = NC = 2 (small batches: see launch_pc): 128 queries, 256 threads;
+//   NP = 4, NC = 2 (round 6, small batches at C >= 64): 128 queries, 384 threads -- a 128-query workgroup per CU leaves two
+//     of the four SIMDs without a producer when NP = 2 (the matrix pipe of half the chip idle, 109 us of MFMA chains per
+//     launch at C = 128 on the other half); four producers of 32 queries put a chain on every SIMD.
+// (Which waves of the workgroup take which role makes no difference: consumers first, in the middle or last measured within 1 us.)
+template <int CP, int K, int NP, int NC>
+__global__ __launch_bounds__(64 * (NP + NC), 2) void knn_pc_kernel(const float* __restrict__ x, int64_t ldx, int B, int N,
+                                                                   int k, int32_t* __restrict__ idx, int force) {
   constexpr int RS = CP + 4;
   constexpr int HALF = CP / 2;
-  constexpr int NTP = 64 * PW;                                          // producer threads
-  constexpr int QB = 64 * PW;                                           // queries per workgroup
+  constexpr int NTP = 64 * NP;                                          // producer threads
+  constexpr int QB = 64 * NC;                                           // queries per workgroup
+  constexpr int QP = QB / NP;                                           // queries per producer wave
+  static_assert(QP == 32 || QP == 64, "a producer wave scores one or two 32-query column blocks");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* s_tile = reinterpret_cast<float*>(smem);                       // [3][TJ][RS]
   float* s_norm = s_tile + 3 * TJ * RS;                                 // [3][TJ] (+pad)
-  float* s_score = s_norm + 4 * TJ;                                     // [2][PW][64][SROW]
+  float* s_score = s_norm + 4 * TJ;                                     // [2][QB][SROW]
 
   const int nq = (N + QB - 1) / QB;
   int b, qb;
@@ -142,8 +133,11 @@ __global__ __launch_bounds__(128 * PW, 2) void knn_pc_kernel(const float* __rest
     qb = blockIdx.x % nq;
   }
   const float* xb = x + (int64_t)b * N * ldx;
-  const bool producer = threadIdx.x < NTP;
-  const int lane = threadIdx.x & 63, wv = (threadIdx.x >> 6) & (PW - 1);   // wv: producer / consumer pair index
+  const int wave = (int)(threadIdx.x >> 6);
+  const bool producer = wave < NP;
+  const int lane = threadIdx.x & 63;
+  const int wv = producer ? wave : wave - NP;                           // index among the producer / the consumer waves
+  const int ptid = (int)threadIdx.x;                                    // producer thread number (staging)
   const int qj = lane & 31, h = lane >> 5;
   const int q0 = qb * QB;
 
@@ -163,10 +157,10 @@ __global__ __launch_bounds__(128 * PW, 2) void knn_pc_kernel(const float* __rest
     // multiplication per candidate.  (Until round 3 the query tiles were staged through the tile buffers: 4 PW + 1
     // barriers and 2 PW dependent load -> store -> read steps, 10 us of the kernel.)
     TileRegs<CP, NTP> tr;
-    tile_load<CP, NTP>(tr, xb, ldx, N, 0);       // candidate tile 0: in flight under the query loads
+    tile_load<CP, NTP>(tr, xb, ldx, N, 0, ptid);       // candidate tile 0: in flight under the query loads
     float bq0[HALF], bq1[HALF];
     {
-      const int r0 = min(q0 + wv * 64 + qj, N - 1), r1 = min(q0 + wv * 64 + 32 + qj, N - 1);   // (rows past N: results unused)
+      const int r0 = min(q0 + wv * QP + qj, N - 1), r1 = min(q0 + wv * QP + 32 + qj, N - 1);   // (rows past N: results unused; QP = 32: r1 unused)
       const float* p0 = xb + (int64_t)r0 * ldx;
       const float* p1 = xb + (int64_t)r1 * ldx;
       if constexpr (CP == 4) {
@@ -199,102 +193,59 @@ __global__ __launch_bounds__(128 * PW, 2) void knn_pc_kernel(const float* __rest
       f32x16 acc0, acc1;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-      // the two column blocks share the A operand; their chains alternate on the matrix pipe
-#ifdef SUG_KNN_ABL_NOMFMA                        // timing experiments only (tools/bench_knn_pc.py): wrong results
-      if constexpr (CP < 0) {
-#else
+      // QP = 64: the two column blocks share the A operand; their chains alternate on the matrix pipe
       if constexpr (CP == 4) {
-#endif
         const float2 a2 = *reinterpret_cast<const float2*>(arow);
         acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.x, bq0[0], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.x, bq1[0], acc1, 0, 0, 0);
+        if constexpr (QP == 64) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.x, bq1[0], acc1, 0, 0, 0);
         acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.y, bq0[1], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.y, bq1[1], acc1, 0, 0, 0);
+        if constexpr (QP == 64) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.y, bq1[1], acc1, 0, 0, 0);
         mid();
       } else {
-#ifdef SUG_KNN_ABL_NOMFMA
-        acc0[0] = arow[0]; acc1[0] = bq0[0] + bq1[0];
-        mid();
-#else
-#ifdef SUG_KNN_ABL_SYMM
-        // timing experiment (round 5; wrong results): the ceiling of a block-pair form that scores each
-        // off-diagonal 64 x 32 tile once -- tiles whose candidates all precede this wave's queries skip the MFMA chain, as if
-        // their scores arrived transposed from the wave that owns the mirrored tile (the exchange itself costs nothing here)
-        if (t * TJ + TJ <= q0 + wv * 64) {
-          acc0[0] = arow[0]; acc1[0] = bq0[0] + bq1[0];
-          mid();
-        } else
-#endif
 #pragma unroll
         for (int g = 0; g < HALF / 4; ++g) {
-          if (g == HALF / 8) mid();             // (empty in the product: see SUG_KNN_STAGE_MID below)
-#ifdef SUG_KNN_ABL_NOAREAD
-          const float4 a4 = make_float4(bq0[g], bq1[g], bq0[g + 1], bq1[g + 1]);
-#else
+          if (g == HALF / 8) mid();             // (empty in the product; tools/ubench/knn_pc_ablations.patch: staging inside the chain)
           const float4 a4 = *reinterpret_cast<const float4*>(arow + 4 * g);
-#endif
           acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, bq0[breg(4 * g + 0)], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, bq1[breg(4 * g + 0)], acc1, 0, 0, 0);
+          if constexpr (QP == 64) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, bq1[breg(4 * g + 0)], acc1, 0, 0, 0);
           acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, bq0[breg(4 * g + 1)], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, bq1[breg(4 * g + 1)], acc1, 0, 0, 0);
+          if constexpr (QP == 64) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, bq1[breg(4 * g + 1)], acc1, 0, 0, 0);
           acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, bq0[breg(4 * g + 2)], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, bq1[breg(4 * g + 2)], acc1, 0, 0, 0);
+          if constexpr (QP == 64) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, bq1[breg(4 * g + 2)], acc1, 0, 0, 0);
           acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, bq0[breg(4 * g + 3)], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, bq1[breg(4 * g + 3)], acc1, 0, 0, 0);
+          if constexpr (QP == 64) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, bq1[breg(4 * g + 3)], acc1, 0, 0, 0);
         }
-#endif
       }
       // S^T tile: lane = query column, registers 4g..4g+3 = candidate rows 8g + 4h .. +3: one b128 per g
-      float* d0 = s_score + ((buf * PW + wv) * 64 + qj) * SROW + 4 * h;
-      float* d1 = d0 + 32 * SROW;
-#ifdef SUG_KNN_ABL_NOSCOREWRITE
-      if (acc0[0] + acc1[0] + acc0[15] + acc1[15] == 12345.f) d0[0] = 1.f;
-      return;
-#endif
+      float* d0 = s_score + ((buf * QB + wv * QP) + qj) * SROW + 4 * h;
 #pragma unroll
       for (int g = 0; g < 4; ++g)
         *reinterpret_cast<float4*>(d0 + 8 * g) = make_float4(acc0[4 * g], acc0[4 * g + 1], acc0[4 * g + 2], acc0[4 * g + 3]);
+      if constexpr (QP == 64) {
+        float* d1 = d0 + 32 * SROW;
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
-        *reinterpret_cast<float4*>(d1 + 8 * g) = make_float4(acc1[4 * g], acc1[4 * g + 1], acc1[4 * g + 2], acc1[4 * g + 3]);
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<float4*>(d1 + 8 * g) = make_float4(acc1[4 * g], acc1[4 * g + 1], acc1[4 * g + 2], acc1[4 * g + 3]);
+      }
     };
 
     // pipeline: iteration t = scores of tile t+1 (consumers are on tile t); registers of tile t+2 -> LDS;
     // the global loads of tile t+3 are in flight for a whole iteration
-    tile_store<CP, true, NTP>(tr, tbuf(0), nbuf(0), N, 0);
-    if (ntile > 1) tile_load<CP, NTP>(tr, xb, ldx, N, TJ);
+    tile_store<CP, true, NTP>(tr, tbuf(0), nbuf(0), N, 0, ptid);
+    if (ntile > 1) tile_load<CP, NTP>(tr, xb, ldx, N, TJ, ptid);
     __syncthreads();
     produce(0, 0, [] {});
-    if (ntile > 1) tile_store<CP, true, NTP>(tr, tbuf(1), nbuf(1), N, TJ);
-    if (ntile > 2) tile_load<CP, NTP>(tr, xb, ldx, N, 2 * TJ);
+    if (ntile > 1) tile_store<CP, true, NTP>(tr, tbuf(1), nbuf(1), N, TJ, ptid);
+    if (ntile > 2) tile_load<CP, NTP>(tr, xb, ldx, N, 2 * TJ, ptid);
     __syncthreads();
     for (int t = 0; t < ntile; ++t) {
-#ifdef SUG_KNN_SERIAL
-      // experiment (tools/bench_knn_pc.py): the MFMA chain of tile t+1 only after the selection of tile t instead of
-      // next to it -- the two share the SIMD's FMA lanes, but alternating them measured 7 us slower (138 vs 131 at C=64)
-      if (t + 2 < ntile) tile_store<CP, true, NTP>(tr, tbuf(t + 2), nbuf(t + 2), N, (t + 2) * TJ);
-      if (t + 3 < ntile) tile_load<CP, NTP>(tr, xb, ldx, N, (t + 3) * TJ);
-      __syncthreads();
-      if (t + 1 < ntile) produce(t + 1, (t + 1) & 1, [] {});
-      __syncthreads();
-#else
       auto stage = [&] {
-#ifndef SUG_KNN_ABL_NOSTAGE
-        if (t + 2 < ntile) tile_store<CP, true, NTP>(tr, tbuf(t + 2), nbuf(t + 2), N, (t + 2) * TJ);
-        if (t + 3 < ntile) tile_load<CP, NTP>(tr, xb, ldx, N, (t + 3) * TJ);
-#endif
+        if (t + 2 < ntile) tile_store<CP, true, NTP>(tr, tbuf(t + 2), nbuf(t + 2), N, (t + 2) * TJ, ptid);
+        if (t + 3 < ntile) tile_load<CP, NTP>(tr, xb, ldx, N, (t + 3) * TJ, ptid);
       };
-#ifdef SUG_KNN_STAGE_MID                        // (A/B, tools/bench_knn_pc.py: the staging in the middle of the chain instead
-      // of behind it measured within 1 % -- VALU between dependent MFMAs costs about what the idle tail does)
-      if (t + 1 < ntile) produce(t + 1, (t + 1) & 1, stage); else stage();
-#else
       if (t + 1 < ntile) produce(t + 1, (t + 1) & 1, [] {});
       stage();
-#endif
-#ifndef SUG_KNN_ABL_NOBARRIER
       __syncthreads();
-#endif
-#endif
     }
   } else {
     __builtin_amdgcn_s_setprio(1);     // the selection waves are the second-dispatched half of the workgroup: static priority (-5 us at C=3)
@@ -315,13 +266,6 @@ __global__ __launch_bounds__(128 * PW, 2) void knn_pc_kernel(const float* __rest
     const unsigned FXMAX = (1u << (31 - idb)) - 2u;
     float scale = 1.f, inv_scale = 1.f;
     float thr = -FLT_MAX;                      // candidates with score >= thr may still enter the list
-#ifdef SUG_KNN_ABL_SEED
-    if (g_knn_seed != nullptr && q < N) thr = g_knn_seed[(int64_t)b * N + q];
-    const float seed_thr = thr;
-#endif
-#ifdef SUG_KNN_ABL_COUNT
-    unsigned acc_count = 0u;
-#endif
 
     // score of candidate slot c of the current tile: pairwise_distance = -xx - inner - xx^T, inner = -2*dot
     // (model_utils.py:179-181); the same three roundings wherever it is evaluated
@@ -330,13 +274,7 @@ __global__ __launch_bounds__(128 * PW, 2) void knn_pc_kernel(const float* __rest
     __syncthreads();                            // pipeline fill: tile 0 staged
     __syncthreads();                            // tile 0 scored
     for (int t = 0; t < ntile; ++t) {
-#ifdef SUG_KNN_ABL_NOCONS
-#ifndef SUG_KNN_ABL_NOBARRIER
-      __syncthreads();
-#endif
-      continue;
-#endif
-      const float* srow = s_score + (((t & 1) * PW + wv) * 64 + lane) * SROW;
+      const float* srow = s_score + (((t & 1) * QB + wv * 64) + lane) * SROW;
       const float* nrm = nbuf(t);
       // pass 1: which of the 32 candidates can still enter (thr: from the (K+2)-th key as of the previous tile:
       // stale by at most one tile, never too high; rows past N score -inf and never pass).  Candidate c -> bit 31-c.
@@ -359,9 +297,6 @@ __global__ __launch_bounds__(128 * PW, 2) void knn_pc_kernel(const float* __rest
           smin = fminf(smin, sw >= thr ? sw : INFINITY);
         }
         float R = (smin < 0.f && smin > -FLT_MAX) ? -smin : 1.f;            // no finite negative score: any range will do
-#ifdef SUG_KNN_ABL_SEED
-        if (seed_thr > -FLT_MAX && seed_thr < 0.f) R = -seed_thr * 1.01f;   // every accepted d lies below the seed
-#endif
         scale = (float)FXMAX / R;
         inv_scale = R / (float)FXMAX;
         if (!(scale < FLT_MAX) || !(inv_scale > 0.f)) { scale = 1.f; inv_scale = 1.f; }
@@ -389,13 +324,7 @@ __global__ __launch_bounds__(128 * PW, 2) void knn_pc_kernel(const float* __rest
       // pass 2: the marked candidates in ascending index order, one per lane per iteration (all lanes in
       // lockstep); iterations = the largest number of marked candidates of any lane: a wave-wide maximum built
       // bit by bit from ballots (scalar unit only; a shuffle tree would cost six LDS round trips per tile)
-#ifdef SUG_KNN_ABL_NOINSERT
-      if (t > 0) mask = 0u;
-#endif
       const int pc = __popc(mask);
-#ifdef SUG_KNN_ABL_COUNT
-      acc_count += (unsigned)pc;
-#endif
       unsigned long long cand = ~0ull;
       int nit = 0;
 #pragma unroll
@@ -450,23 +379,9 @@ __global__ __launch_bounds__(128 * PW, 2) void knn_pc_kernel(const float* __rest
       // margin (+3, 2e-6 relative) covers the roundings of d*scale, of scale and of this product (buckets < 2^21)
       const int lk = L[KP - 1];
       thr = lk == EMPTY ? -FLT_MAX : -((float)((lk >> idb) + 3) * inv_scale * 1.000002f);
-#ifdef SUG_KNN_ABL_SEED
-      thr = fmaxf(thr, seed_thr);                // never looser than the seed
-#endif
-#ifdef SUG_KNN_SERIAL
-      __syncthreads();
-#endif
       __syncthreads();
     }
 
-#ifdef SUG_KNN_ABL_COUNT
-    {
-      unsigned long long tot = (unsigned long long)(q < N ? acc_count : 0u);
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
-      if (lane == 0) atomicAdd(&g_knn_accepted, tot);
-    }
-#endif
     // ---- result.  Buckets (key >> idb) order the candidates as their exact scores do, except inside a bucket.
     bool amb = false;
 #pragma unroll
@@ -483,8 +398,8 @@ __global__ __launch_bounds__(128 * PW, 2) void knn_pc_kernel(const float* __rest
     }
     if (__ballot(amb) != 0ull) {
       // scratch: this wave's two score rows blocks (no other wave touches them; the producers are done)
-      int* s_keys = reinterpret_cast<int*>(s_score + ((0 * PW + wv) * 64) * SROW);      // [64][KP]
-      float* s_fv = s_score + ((1 * PW + wv) * 64) * SROW;                               // [K][64]
+      int* s_keys = reinterpret_cast<int*>(s_score + (0 * QB + wv * 64) * SROW);        // [64][KP]
+      float* s_fv = s_score + (1 * QB + wv * 64) * SROW;                                 // [K][64]
 #pragma unroll
       for (int t = 0; t < KP; ++t) s_keys[lane * KP + t] = L[t];
       // (a) exact re-rank of the K+2 candidates of one query at a time: lane u = candidate u
@@ -540,32 +455,38 @@ __global__ __launch_bounds__(128 * PW, 2) void knn_pc_kernel(const float* __rest
   }
 }
 
-template <int CP, int K, int PW>
-int launch_pc_pw(const float* x, int64_t ldx, int B, int N, int k, int32_t* idx, hipStream_t st) {
+template <int CP, int K, int NP, int NC>
+int launch_pc_form(const float* x, int64_t ldx, int B, int N, int k, int32_t* idx, hipStream_t st) {
   constexpr int RS = CP + 4;
-  const size_t sh = (size_t)(3 * TJ * RS + 4 * TJ + 2 * PW * 64 * SROW) * sizeof(float);
+  constexpr int QB = 64 * NC;
+  const size_t sh = (size_t)(3 * TJ * RS + 4 * TJ + 2 * QB * SROW) * sizeof(float);
   static SugLdsOptIn note;
-  if (int rc = sug_allow_dynamic_lds(note, &knn_pc_kernel<CP, K, PW>, (int)sh, "sug_knn(mfma, producer/consumer)")) return rc;
-  dim3 grid(sug_divup(N, 64 * PW) * B);
+  if (int rc = sug_allow_dynamic_lds(note, &knn_pc_kernel<CP, K, NP, NC>, (int)sh, "sug_knn(mfma, producer/consumer)")) return rc;
+  dim3 grid(sug_divup(N, QB) * B);
   const char* fe = getenv("SUG_KNN_FORCE");      // test knob: 1 = exact re-rank for every query, 2 = exact rescan
-  hipLaunchKernelGGL((knn_pc_kernel<CP, K, PW>), grid, dim3(128 * PW), sh, st, x, ldx, B, N, k, idx, fe ? atoi(fe) : 0);
+  hipLaunchKernelGGL((knn_pc_kernel<CP, K, NP, NC>), grid, dim3(64 * (NP + NC)), sh, st, x, ldx, B, N, k, idx, fe ? atoi(fe) : 0);
   SUG_LAUNCH_CHECK("sug_knn(mfma, producer/consumer)");
   return SUG_OK;
 }
 
 template <int CP, int K>
 int launch_pc(const float* x, int64_t ldx, int B, int N, int k, int32_t* idx, hipStream_t st) {
-  // 256-query workgroups (PW = 4, one per CU) when they fill the chip; 128-query workgroups (PW = 2; two per CU at C <= 64) when
-  // the 256-query grid would leave half of the CUs idle -- 32 clouds of 1024 points are 128 workgroups on 256 CUs.  Measured
-  // (tools/bench_knn_pw.py, us per launch at C = 3 / 64 / 128): 32 clouds PW = 4: 61 / 119 / 181, PW = 2: 55 / 92 / 157;
-  // 64 clouds PW = 4: 71 / 133 / 190, PW = 2: 77 / 157 / -- (every workgroup stages all candidate tiles, so two per CU
-  // double that work and halve the waves behind each barrier).  Same lists either way.  SUG_KNN_PW=2|4 forces a form.
+  // 256-query workgroups (NP = NC = 4, one per CU) when they fill the chip; 128-query workgroups when the 256-query grid would
+  // leave half of the CUs idle -- 32 clouds of 1024 points are 128 workgroups on 256 CUs: NC = 2 selection waves with NP = 2
+  // producers of 64 queries (C = 3: the matrix pipe has four MFMAs per tile to do) or NP = 4 producers of 32 queries (C >= 64:
+  // a chain on every SIMD).  Measured (tools/bench_knn_pw.py, us per launch at C = 3 / 64 / 128): 32 clouds 4+4: 61 / 119 / 181,
+  // 2+2: 55 / 92 / 157, 4+2 (round 6): -- / 88 / 122 (64-query workgroups of 2+1 waves: the same 88 / 123); 64 clouds 4+4: 71 / 133 / 190,
+  // 2+2: 77 / 157 / 303, 4+2: -- / 135 / 235 (every workgroup stages all candidate tiles, so two per CU double that work and
+  // halve the waves behind each barrier).  Same lists in every form.  SUG_KNN_PW=44|22|42 forces one.
   static const int forced = getenv("SUG_KNN_PW") ? atoi(getenv("SUG_KNN_PW")) : 0;
   const int ncu = sug_cu_count();
   const int64_t grid4 = (int64_t)B * sug_divup(N, 256);
-  const bool two = forced == 2 || (forced != 4 && 2 * grid4 <= ncu);
-  if (two) return launch_pc_pw<CP, K, 2>(x, ldx, B, N, k, idx, st);
-  return launch_pc_pw<CP, K, 4>(x, ldx, B, N, k, idx, st);
+  const bool small = 2 * grid4 <= ncu;
+  const int form = (forced == 4 || forced == 44) ? 44 : (forced == 2 || forced == 22) ? 22 : forced == 42 ? 42
+                   : !small ? 44 : (CP >= 64 ? 42 : 22);
+  if (form == 22) return launch_pc_form<CP, K, 2, 2>(x, ldx, B, N, k, idx, st);
+  if (form == 42) return launch_pc_form<CP, K, 4, 2>(x, ldx, B, N, k, idx, st);
+  return launch_pc_form<CP, K, 4, 4>(x, ldx, B, N, k, idx, st);
 }
 
 template <int K>

@@ -24,22 +24,22 @@ struct TileRegs {
 };
 
 // rows [row0, row0+32) of xb (row stride ldx); rows >= N read row N-1 (their norm is stored as +inf by tile_store: such a
-// candidate never scores, and the scores of such a query are never used).  NT threads.
+// candidate never scores, and the scores of such a query are never used).  NT threads, numbered by `tid` (0 .. NT-1).
 template <int CP, int NT = 256>
 __device__ __forceinline__ void tile_load(TileRegs<CP, NT>& t, const float* __restrict__ xb, int64_t ldx,
-                                          int N, int row0) {
+                                          int N, int row0, int tid = (int)threadIdx.x) {
   // The loads carry no guards and their values no select on r < N: with `ok ? loaded : 0` the compiler sinks the load
   // into a branch on ok and waits for it on the spot (s_waitcnt vmcnt(0) right behind the global_load) -- the prefetch
   // of tile t+3 then cost its full latency in every iteration of knn_pc_kernel (10-13 us per launch until round 3).
   if constexpr (CP == 4) {
-    const int r = min(row0 + (int)(threadIdx.x & (TJ - 1)), N - 1);
+    const int r = min(row0 + (tid & (TJ - 1)), N - 1);
     const float* p = xb + (int64_t)r * ldx;
     t.lo[0] = make_float4(p[0], p[1], p[2], 0.f);
   } else {
     constexpr int CH = CP / 8;                 // chunks per row
 #pragma unroll
     for (int u = 0; u < TileRegs<CP, NT>::NV; ++u) {
-      const int item = (int)threadIdx.x + u * NT;
+      const int item = tid + u * NT;
       const int r = min(row0 + item / CH, N - 1), c8 = item % CH;
       const float4* p = reinterpret_cast<const float4*>(xb + (int64_t)r * ldx + c8 * 8);
       t.lo[u] = p[0];
@@ -51,11 +51,11 @@ __device__ __forceinline__ void tile_load(TileRegs<CP, NT>& t, const float* __re
 // Register -> LDS half: de-interleave; with NORM also the row norms |x_j|^2 (rows >= N: +inf).
 template <int CP, bool NORM = true, int NT = 256>
 __device__ __forceinline__ void tile_store(const TileRegs<CP, NT>& t, float* __restrict__ s_tile,
-                                           float* __restrict__ s_norm, int N, int row0) {
+                                           float* __restrict__ s_norm, int N, int row0, int tid = (int)threadIdx.x) {
   constexpr int RS = CP + 4;
   if constexpr (CP == 4) {
-    if (threadIdx.x < TJ) {
-      const int r = threadIdx.x;
+    if (tid < TJ) {
+      const int r = tid;
       const float4 p = t.lo[0];
       float* d = s_tile + r * RS;
       d[0] = p.x; d[1] = p.z;        // even features 0,2
@@ -67,7 +67,7 @@ __device__ __forceinline__ void tile_store(const TileRegs<CP, NT>& t, float* __r
     constexpr int HALF = CP / 2;
 #pragma unroll
     for (int u = 0; u < TileRegs<CP, NT>::NV; ++u) {
-      const int item = (int)threadIdx.x + u * NT;
+      const int item = tid + u * NT;
       const int r = item / CH, c8 = item % CH;
       const float4 a = t.lo[u], b = t.hi[u];
       float* d = s_tile + r * RS;

@@ -263,6 +263,11 @@ class Pointnet2_g(nn.Module):
         """Point counts of the farthest_point_sample calls of one forward, in call order."""
         return [N, self.sa1.npoint]
 
+    def can_plan_geometry(self):
+        """Does plan_geometry cover this configuration (it returns None otherwise, without drawing a start)?"""
+        return not (self.normal_channel or self.sa1.group_all or self.sa2.group_all) and \
+            all(sa.takes_index_path() for sa in (self.sa1, self.sa2))
+
     def plan_geometry(self, xyz, passes, groups=1):
         """Sampling and grouping indices of `passes` forwards over the same batch xyz [B,3,N,1], in one set of launches
         (not in the reference; used by SUGStep: the semantic and the node pass of a step).  FPS and ball query read the

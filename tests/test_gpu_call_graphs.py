@@ -179,7 +179,9 @@ def test_deepcopy_and_eval_are_untouched():
         before = dict(mgr.stats)
         net.eval()
         with torch.no_grad():
+            torch.manual_seed(9)            # (the SA-node module draws its FPS start in eval mode as well)
             e1 = net(data, semantic_adaption=True)
+            torch.manual_seed(9)
             e2 = twin.eval()(data, semantic_adaption=True)
         assert dict(mgr.stats) == before
         for u, v in zip(e1, e2):

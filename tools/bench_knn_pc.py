@@ -1,11 +1,24 @@
 """Diagnostic: where does knn_pc_kernel's time go?  Builds ablation variants of knn_pc.hip on the GPU box (timing only:
-their results are wrong) and times them next to the product build.  usage: python tools/bench_knn_pc.py"""
-import ctypes, os, subprocess, sys, tempfile
+their results are wrong) and times them next to the product build.  The ablation switches (-DSUG_KNN_ABL_*, SUG_KNN_SERIAL,
+SUG_KNN_STAGE_MID) are NOT in the product source since round 6: tools/ubench/knn_pc_ablations.patch adds them to a scratch
+copy of sug_amd/csrc, which is what this script compiles.  usage: python tools/bench_knn_pc.py"""
+import ctypes, os, shutil, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 
-SRC = os.path.join(ROOT, 'sug_amd', 'csrc')
+def _ablation_sources():
+    """A scratch copy of the repository's sources with the ablation patch applied to knn_pc.hip."""
+    top = os.path.join(tempfile.gettempdir(), 'sug_knn_ablation_src')
+    shutil.rmtree(top, ignore_errors=True)
+    os.makedirs(os.path.join(top, 'sug_amd'))
+    shutil.copytree(os.path.join(ROOT, 'sug_amd', 'csrc'), os.path.join(top, 'sug_amd', 'csrc'),
+                    ignore=shutil.ignore_patterns('*.o', '*.so'))
+    subprocess.run(['patch', '-p1', '-s', '-i', os.path.join(ROOT, 'tools', 'ubench', 'knn_pc_ablations.patch')], cwd=top, check=True)
+    return os.path.join(top, 'sug_amd', 'csrc')
+
+
+SRC = _ablation_sources()
 FLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-ffp-contract=off', '-shared', '-I' + os.path.join(ROOT, 'include')]
 
 

@@ -1,4 +1,4 @@
-"""knn_pc_kernel: 256-query workgroups (one per CU) against 128-query workgroups (two per CU), us per launch at the C2 shapes.
+"""knn_pc_kernel forms (producer + consumer waves per workgroup: 4+4 = 256 queries, 2+2 and 4+2 = 128 queries), us per launch at the C2 shapes.
 The form is chosen per process (SUG_KNN_PW is read once), so each form runs in a child process.  usage: python tools/bench_knn_pw.py [CLOUDS]"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,6 +16,6 @@ for C in (3, 64, 128):
     b.record(); torch.cuda.synchronize()
     print('C=%%3d %%7.1f us  checksum %%d' %% (C, a.elapsed_time(b) / 20 * 1e3, int(idx.long().sum())))
 ''' % ROOT
-for pw in ('4', '2'):
+for pw in (os.environ.get('FORMS') or '44,22,42').split(','):
     print('SUG_KNN_PW=' + pw, flush=True)
     subprocess.run([sys.executable, '-c', CHILD] + sys.argv[1:2], env=dict(os.environ, SUG_KNN_PW=pw), check=True)
