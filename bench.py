@@ -904,6 +904,33 @@ def main():
                              if (args.fp16 and args.model == 'PTran') else {})},
                'roofline': roofline, 'cpu_baseline': cpu, 'losses': loss_vals,
                'kernels': {k: {kk: (round(vv, 5) if isinstance(vv, float) else vv) for kk, vv in v.items() if kk != 'flops'} for k, v in kern.items()}}
+        # the driver's parser keeps scalars and drops nested objects -- the per-config and step-level numbers
+        # again as flat keys beside the objects they summarise
+        cfg = out['config']
+        for tag, rec in zip(('c1', 'c3', 'c5'), others or ()):
+            if rec and 'error' not in rec:
+                cfg['%s_ms_per_step' % tag] = rec.get('ms_per_step')
+                cfg['%s_clouds_per_sec' % tag] = rec.get('clouds_per_sec')
+                cfg['%s_single_pass_ms_per_step' % tag] = rec.get('single_pass_ms_per_step')
+                sr = rec.get('step_roofline') or {}
+                cfg['%s_step_frac_mfma' % tag] = sr.get('frac_mfma')
+                cfg['%s_step_frac_hbm' % tag] = sr.get('frac_hbm')
+                cb = rec.get('cpu_baseline') or {}
+                cfg['%s_cpu_clouds_per_sec' % tag] = cb.get('value')
+        if seg1:
+            cfg['segmented_one_rank_rccl_ms'] = seg1.get('ms_per_step')
+        if roofline is not None:
+            st_ = roofline.get('step') or {}
+            roofline['step_frac_mfma'] = st_.get('frac_mfma')
+            roofline['step_frac_hbm'] = st_.get('frac_hbm')
+            roofline['step_gflop'] = st_.get('gflop')
+            roofline['step_gbytes'] = st_.get('gbytes')
+            fam_ = roofline.get('family') or {}
+            roofline['family_frac'] = fam_.get('frac')
+            for kn, tag in (('knn_C3', 'knn_C3'), ('knn_C64', 'knn_C64'), ('knn_C128', 'knn_C128')):
+                if kn in kern:
+                    roofline['%s_us' % tag] = round(1e3 * kern[kn]['avg_ms'], 2)
+                    roofline['%s_frac' % tag] = kern[kn].get('frac')
         print(json.dumps(out))
     if world > 1 or args.segmented:
         dist.barrier()

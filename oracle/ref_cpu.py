@@ -548,8 +548,9 @@ def mix_rbf_kernel(X, Y, sigmas=SIGMAS):
     return K[:m, :m], K[:m, m:], K[m:, m:]
 
 
-def mmd2_biased(K_XX, K_XY, K_YY, w=None):
-    """_mmd2(const_diagonal=False, biased=True), model/mmd.py:274-312."""
+def mmd2_biased(K_XX, K_XY, K_YY, w=None, biased=True):
+    """_mmd2(const_diagonal=False), model/mmd.py:274-312: the biased estimator (:300-303, the one every caller of the
+    reference uses) or, biased=False, the unbiased one (:304-308: the diagonal of K_XX / K_YY left out, m(m-1) pairs)."""
     m = K_XX.size(0)
     dX, dY = torch.diag(K_XX), torch.diag(K_YY)
     sxx = (K_XX.sum(dim=1) - dX).sum()
@@ -557,12 +558,14 @@ def mmd2_biased(K_XX, K_XY, K_YY, w=None):
     col = K_XY.sum(dim=0)
     if w is not None:
         col = w.reshape(-1).to(col.device) * col
+    if not biased:
+        return sxx / (m * (m - 1)) + syy / (m * (m - 1)) - 2.0 * col.sum() / (m * m)
     return (sxx + dX.sum()) / (m * m) + (syy + dY.sum()) / (m * m) - 2.0 * col.sum() / (m * m)
 
 
-def mix_rbf_mmd2(X, Y, sigmas=SIGMAS, sample_weights=None):
+def mix_rbf_mmd2(X, Y, sigmas=SIGMAS, sample_weights=None, biased=True):
     """mix_rbf_mmd2, model/mmd.py:257-260."""
-    return mmd2_biased(*mix_rbf_kernel(X, Y, sigmas), w=sample_weights)
+    return mmd2_biased(*mix_rbf_kernel(X, Y, sigmas), w=sample_weights, biased=biased)
 
 
 def distance2weights(d, method):
@@ -582,8 +585,12 @@ def distance2weights(d, method):
 
 
 def _kl_div(x, y):
-    """scipy.special.kl_div for strictly positive inputs: x log(x/y) - x + y."""
-    return x * torch.log(x / y) - x + y
+    """scipy.special.kl_div, all three branches: x log(x/y) - x + y for x, y > 0; y for x == 0, y >= 0; +inf otherwise
+    (e.g. y == 0 < x: a saturated softmax row has an fp32 entropy of exactly -0.0)."""
+    inf = torch.full_like(x, float('inf'))
+    main = x * torch.log(x / y) - x + y
+    out = torch.where((x > 0) & (y > 0), main, torch.where((x == 0) & (y >= 0), y, inf))
+    return torch.where(torch.isnan(x) | torch.isnan(y), x + y, out)           # (NaN in, NaN out -- scipy's first branch)
 
 
 def prob_weights_soft(pred_s, pred_t, label_s, label_t, label_weight, weighting='mean2one'):

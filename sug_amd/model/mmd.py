@@ -43,6 +43,16 @@ def cal_sample_weights(data_s, data_t, args, label_s=None, label_t=None, KPC=Fal
     raise RuntimeError("Not suppprted weighting opperation")
 
 
+def sda_weights_of(args, pred_s, pred_t, label_s, label_t):
+    """The SDA weights of one semantic MMD term from (gathered) logits and labels, with mmd_cal's own rules: weights only
+    if GEO_WEIGHTS or SEM_WEIGHTS is set (model/mmd.py:28), and then cal_sample_weights' precedence GEO > ENTROPY > SEM
+    (:44-53).  The batch-sharded steps of SUGStep call this, so that every launch form weights a term the way
+    mmd_cal(..., data_s=pred_s, data_t=pred_t) does."""
+    if not (args.get("GEO_WEIGHTS", None) or args.get("SEM_WEIGHTS", None)):
+        return None
+    return cal_sample_weights(pred_s, pred_t, args, label_s=label_s, label_t=label_t)
+
+
 def soft_mmd(label_s, feat_s, label_t, feat_t, label_weight, sample_weights=None):
     """model/mmd.py:56-66: MMD on [features | one-hot(label) * label_weight]."""
     m = feat_s.shape[0]
@@ -105,8 +115,14 @@ def normalized(vec):
 
 
 def _kl_div(x, y):
-    # scipy.special.kl_div for positive inputs (dataset_splitter.py:244-245 uses it both ways)
-    return x * torch.log(x / y) - x + y
+    """scipy.special.kl_div (dataset_splitter.py:244-245 uses it both ways), all three branches: x log(x/y) - x + y for
+    x, y > 0; y for x == 0, y >= 0; +inf otherwise.  A saturated softmax row has an fp32 entropy of exactly -0.0: the
+    reference then reports an infinite distance for that pair, where the plain formula gives NaN (golden
+    entropy.npz, keys ps1 / w1_*)."""
+    inf = torch.full_like(x, float('inf'))
+    main = x * torch.log(x / y) - x + y
+    out = torch.where((x > 0) & (y > 0), main, torch.where((x == 0) & (y >= 0), y, inf))
+    return torch.where(torch.isnan(x) | torch.isnan(y), x + y, out)           # (NaN in, NaN out -- scipy's first branch)
 
 
 def cal_probs2entropy(probs):
@@ -167,8 +183,6 @@ def distance2weights(distances, method="naive_inverse"):
 
 
 def mix_rbf_mmd2(X, Y, sigma_list, biased=True, sample_weights=None):
-    """model/mmd.py:257-260 (biased estimator; the only one the reference's callers use)."""
+    """model/mmd.py:257-260 with _mmd2, :274-312: biased (the estimator every caller of the reference uses) or unbiased."""
     assert X.size(0) == Y.size(0)
-    if not biased:
-        raise NotImplementedError("only the biased estimator is on the hot path")
-    return ops.mix_rbf_mmd2_rows(torch.cat((X, Y), 0), X.size(0), sample_weights, sigma_list)
+    return ops.mix_rbf_mmd2_rows(torch.cat((X, Y), 0), X.size(0), sample_weights, sigma_list, biased=biased)

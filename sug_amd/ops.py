@@ -2019,19 +2019,35 @@ def _neg_gammas(sigmas, device):
 
 class _MixRbfMMD2(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, Z, m, w, sigmas):
+    def forward(ctx, Z, m, w, sigmas, biased=True):
         _need_gpu(Z)
         Zc = Z if (Z.stride(1) == 1 and Z.stride(0) >= Z.shape[1]) else Z.contiguous()
         D = Zc.shape[1]
         dev = Z.device
         ng = _neg_gammas(sigmas, dev)
-        sums = torch.empty(3, dtype=torch.float64, device=dev)
-        val = torch.empty((), dtype=torch.float32, device=dev)
         need = ctx.needs_input_grad[0]
         wt = torch.empty(2 * m, 2 * m, dtype=torch.float32, device=dev) if need else None
         wc = w.detach().reshape(-1).to(device=dev, dtype=torch.float32).contiguous() if w is not None else None
-        check(lib().sug_mmd_rbf_value(_p(Zc), Zc.stride(0), m, D, _p(wc), _p(ng), len(sigmas), _p(sums), _p(wt), _p(val),
-                                      _st()), 'sug_mmd_rbf_value')
+        if biased:
+            sums = torch.empty(3, dtype=torch.float64, device=dev)
+            val = torch.empty((), dtype=torch.float32, device=dev)
+            check(lib().sug_mmd_rbf_value(_p(Zc), Zc.stride(0), m, D, _p(wc), _p(ng), len(sigmas), _p(sums), _p(wt), _p(val),
+                                          _st()), 'sug_mmd_rbf_value')
+        else:
+            # _mmd2(biased=False), model/mmd.py:304-308 (no caller in the reference; off the hot path: a few torch ops on
+            # the kernel's sums): the diagonals of K_XX / K_YY -- exactly len(sigmas) each, e_ii is identically 0 there and
+            # here -- leave the sums, the within-domain pairs are averaged over m (m - 1).  The kernel's gradient weights
+            # carry 2 / m^2 for those pairs (their diagonal is already zero): rescaled by m / (m - 1).
+            if m < 2:
+                raise RuntimeError('mix_rbf_mmd2(biased=False) needs at least two samples per domain')
+            sums = torch.zeros(3, dtype=torch.float64, device=dev)
+            check(lib().sug_mmd_rbf(_p(Zc), Zc.stride(0), m, D, _p(wc), _p(ng), len(sigmas), _p(sums), _p(wt), _st()), 'sug_mmd_rbf')
+            diag = float(len(sigmas) * m)
+            val = (((sums[0] - diag) + (sums[1] - diag)) / float(m * (m - 1)) - 2.0 * sums[2] / float(m * m)).to(torch.float32)
+            if need:
+                r = float(m) / float(m - 1)
+                wt[:m, :m] *= r
+                wt[m:, m:] *= r
         if need:
             ctx.save_for_backward(Zc, wt)
         return val
@@ -2044,12 +2060,12 @@ class _MixRbfMMD2(torch.autograd.Function):
         dZ = torch.empty(M2, D, dtype=torch.float32, device=Z.device)
         check(lib().sug_mmd_rbf_bwd(_p(Z), Z.stride(0), _p(wt), M2 // 2, D, _p(gs), _p(dZ), D, _st()),
               'sug_mmd_rbf_bwd')
-        return dZ, None, None, None
+        return dZ, None, None, None, None
 
 
-def mix_rbf_mmd2_rows(Z, m, sample_weights=None, sigmas=SIGMA_LIST):
-    """Z = cat(X, Y) [2m, D] -> biased MMD^2 (0-d tensor)."""
-    return _MixRbfMMD2.apply(Z, m, sample_weights, tuple(sigmas))
+def mix_rbf_mmd2_rows(Z, m, sample_weights=None, sigmas=SIGMA_LIST, biased=True):
+    """Z = cat(X, Y) [2m, D] -> MMD^2 (0-d tensor): the biased estimator (model/mmd.py:300-303) or the unbiased one (:304-308)."""
+    return _MixRbfMMD2.apply(Z, m, sample_weights, tuple(sigmas), bool(biased))
 
 
 class _MixRbfMMD2Sharded(torch.autograd.Function):

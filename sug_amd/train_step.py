@@ -330,9 +330,7 @@ class SUGStep:
             self.world)
         terms = []
         for (fs, ft, gs, gt, gps, gpt) in ((s1, t1, g_s1, g_t1, g_p1s, g_p1t), (s2, t2, g_s2, g_t2, g_p2s, g_p2t)):
-            w = None
-            if sem.get('SEM_WEIGHTS'):
-                w = mmd.prob_weights_soft(gps, gpt, label_g, label_tg, sem['LABEL_WEIGHT'], sem['SEM_WEIGHTS'])
+            w = mmd.sda_weights_of(sem, gps, gpt, label_g, label_tg)      # mmd_cal's rules (GEO > ENTROPY > SEM)
             terms.append(mmd.soft_mmd_sharded(label, fs, label_t, ft, label_g, gs, label_tg, gt,
                                               float(sem['LABEL_SCALE']), row0, w, self.world))
         return loss_geo, (0.5 * M_['MMD_WEIGHT'] * sem['SEM_SCALE']) * (terms[0] + terms[1])
@@ -640,8 +638,7 @@ class SUGStep:
             w_geo = mmd.distance2weights(g[12].reshape(-1), geo['GEO_WEIGHTS']).reshape(1, -1) if geo.get('GEO_WEIGHTS') else None
             specs = [(node_s, node_t, fn_s, fn_t, float(geo['LABEL_SCALE']), w_geo)]
             for fs, ft, gs, gt, gps, gpt in ((f_s1, f_t1, g_s1, g_t1, g_p1s, g_p1t), (f_s2, f_t2, g_s2, g_t2, g_p2s, g_p2t)):
-                w = mmd.prob_weights_soft(gps, gpt, label_g, label_tg, sem['LABEL_WEIGHT'], sem['SEM_WEIGHTS']) \
-                    if sem.get('SEM_WEIGHTS') else None
+                w = mmd.sda_weights_of(sem, gps, gpt, label_g, label_tg)  # mmd_cal's rules (GEO > ENTROPY > SEM)
                 specs.append((fs, ft, gs, gt, float(sem['LABEL_SCALE']), w))
             for i, (fs, ft, gs, gt, lsc, w) in enumerate(specs):
                 Zloc = ops.mmd_assemble(fs, ft, label, label_t, lsc)

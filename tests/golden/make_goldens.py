@@ -321,7 +321,9 @@ def gen_model(name, B, N, seed, fname):
 
 
 def gen_pointnet_cls():
-    """Config 1 plumbing: train_source.py's Pointnet_cls forward + CE loss."""
+    """Config 1 as train_source.py runs it (:76-97 model + criterion + optim.Adam(model.parameters()), :113-131 the step):
+    Pointnet_cls forward + CE loss + backward + ONE Adam update (lr 1e-3, weight decay 5e-5), then the loss of a second
+    forward on the same batch.  Round 6: gradients, BatchNorm buffers and the post-step parameters are part of the fixture."""
     seed = 31
     g = torch.Generator().manual_seed(seed)
     x = O.synth_clouds(8, 1024, g)
@@ -330,11 +332,26 @@ def gen_pointnet_cls():
     p0 = _load(net, seed)
     _no_dropout(net)
     net.train()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=5e-5)
     y = net(x)
-    loss = torch.nn.functional.cross_entropy(y, lab)
     o = O.pointnet_cls({k: v.clone() for k, v in p0.items()}, x, True)
     same(o, y, 'pointnet_cls', 2e-6)
-    save('pointnet_cls.npz', x=x, label=lab, y=y, loss=loss, seed=seed)
+    rec = _cls_record(net, y, lab)              # CE, zero_grad, backward; gradient norms / probe dots / BN buffer sums
+    p = O.as_params(p0)
+    torch.nn.functional.cross_entropy(O.pointnet_cls(p, x, True), lab).backward()
+    for k, gn in zip(rec['grad_names'], rec['grad_norm']):
+        assert abs(p[k].grad.norm().item() - gn) <= 2e-4 * max(1.0, gn), (k, p[k].grad.norm().item(), gn)
+    opt.step()
+    opt.zero_grad()
+    pnames = [k for k, _ in net.named_parameters()]
+    post = dict(net.named_parameters())
+    rec['param_names'] = np.array(pnames)
+    rec['param_sum'] = np.array([post[k].detach().double().sum().item() for k in pnames])
+    rec['param_dot'] = np.array([(post[k].detach() * _probe(post[k].shape, 'p' + k)).double().sum().item() for k in pnames])
+    rec['param_delta_norm'] = np.array([(post[k].detach() - p0[k]).double().norm().item() for k in pnames])
+    y2 = net(x)
+    rec['loss2'] = torch.nn.functional.cross_entropy(y2, lab).detach()
+    save('pointnet_cls.npz', x=x, label=lab, y=y, seed=seed, **rec)
 
 
 def _cls_record(net, y, lab):
@@ -447,6 +464,14 @@ def gen_mmd():
         out[tag + '_hard'], out[tag + '_maxhard'] = v_hard, v_max
         out[tag + '_soft_gx'], out[tag + '_soft_gy'] = gx, gy
         same(O.mix_rbf_mmd2(X, Y), v_plain, 'mmd plain', 1e-6)
+        # the unbiased estimator (_mmd2(biased=False), model/mmd.py:304-308; round 6): value and gradient
+        v_unb = r_mmd.mix_rbf_mmd2(X, Y, r_mmd.sigma_list, biased=False)
+        v_unb_w = r_mmd.mix_rbf_mmd2(X, Y, r_mmd.sigma_list, biased=False, sample_weights=w)
+        ugx, ugy = torch.autograd.grad(v_unb_w, (X, Y))
+        out[tag + '_unbiased'], out[tag + '_unbiased_weighted'] = v_unb, v_unb_w
+        out[tag + '_unbiased_gx'], out[tag + '_unbiased_gy'] = ugx, ugy
+        same(O.mix_rbf_mmd2(X, Y, biased=False), v_unb, 'mmd unbiased', 1e-6)
+        same(O.mix_rbf_mmd2(X, Y, sample_weights=w, biased=False), v_unb_w, 'mmd unbiased weighted', 1e-6)
         same(O.mix_rbf_mmd2(X, Y, sample_weights=w), v_w, 'mmd weighted', 1e-6)
         same(O.soft_mmd(ls, X, lt, Y, lsc, w), v_soft, 'soft mmd', 1e-6)
         same(O.mmd_cal(ls, X, ls.clone(), Y, {'NAME': 'HARD_MMD'}), v_hard, 'hard mmd', 1e-6)
@@ -708,6 +733,20 @@ def gen_entropy():
         args = {'NAME': 'SOFT_MMD', 'LABEL_SCALE': 5, 'SEM_WEIGHTS': 'mean2one', 'ENTROPY_WEIGHTS': w, 'LABEL_WEIGHT': 0.5}
         out['mmd_' + w] = r_mmd.mmd_cal(ls, fs, lt, ft, args, data_s=ps, data_t=pt)
         same(O.mmd_cal(ls, fs, lt, ft, args, ps, pt), out['mmd_' + w], 'mmd_cal ENTROPY_WEIGHTS ' + w, 1e-5)
+    # a saturated (one-hot) probability row: its entropy is exactly 0; scipy's kl_div(0, y) = y and kl_div(y, 0) = +inf, so
+    # the reference's distance of that pair is +inf ('none'), and 'mean2one' (1 / mean = 0, truncated) multiplies it by 0:
+    # NaN in that slot, 0 elsewhere -- recorded as the reference produces it (the naive x log(x/y) gives NaN for both)
+    ps1 = ps.clone()
+    ps1[2] = torch.nn.functional.one_hot(torch.tensor(4), 10).float()
+    out['ps1'] = ps1
+    for w in ('none', 'mean2one'):
+        out['w1_' + w] = r_mmd.entropy_weights(ps1, pt, weighting=w).float()
+        got = O.entropy_weights(ps1, pt, w).reshape(-1)
+        ref = out['w1_' + w].reshape(-1)
+        fin = torch.isfinite(ref)
+        assert torch.equal(torch.isnan(got), torch.isnan(ref)) and torch.equal(torch.isinf(got), torch.isinf(ref)), (w, got, ref)
+        same(got[fin], ref[fin], 'entropy_weights (one-hot row) ' + w, 1e-6)
+    print('one-hot row: none ->', out['w1_none'].reshape(-1)[:4].tolist(), ' mean2one ->', out['w1_mean2one'].reshape(-1)[:4].tolist())
     raised = []
     for w in ('exp_inverse', 'naive_inverse', 'hist'):
         try:

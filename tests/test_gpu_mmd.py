@@ -105,3 +105,47 @@ def test_mmd_cal_with_entropy_weights_matches_reference():
         v = mmd.mmd_cal(c('ls'), c('fs'), c('lt'), c('ft'), args, data_s=c('ps'), data_t=c('pt'))
         assert abs(float(v) - float(G['mmd_' + w])) <= 1e-4 * max(1.0, abs(float(G['mmd_' + w]))), (w, float(v), float(G['mmd_' + w]))
         torch.testing.assert_close(mmd.entropy_weights(c('ps'), c('pt'), w).cpu(), G['w_' + w], rtol=1e-4, atol=2e-7)      # (x log(x/y) - x + y of nearby entropies cancels: 6e-8 absolute between scipy and torch)
+
+
+@pytest.mark.parametrize('tag', ['sem', 'geo', 'sem32'])
+def test_unbiased_estimator_vs_reference_golden(tag):
+    """mix_rbf_mmd2(biased=False) = _mmd2(biased=False), model/mmd.py:304-308 (round 6; raised NotImplementedError before):
+    value (plain and with sample weights) and gradient against the reference run in tests/golden/mmd.npz."""
+    from conftest import load_golden
+    from sug_amd.model import mmd
+    G = load_golden('mmd.npz')
+    X, Y = G[tag + '_X'].cuda().requires_grad_(True), G[tag + '_Y'].cuda().requires_grad_(True)
+    w = G[tag + '_w'].cuda()
+    v = mmd.mix_rbf_mmd2(X, Y, mmd.sigma_list, biased=False)
+    vw = mmd.mix_rbf_mmd2(X, Y, mmd.sigma_list, biased=False, sample_weights=w)
+    assert abs(float(v) - float(G[tag + '_unbiased'])) <= 1e-4 * max(1.0, abs(float(G[tag + '_unbiased'])))
+    assert abs(float(vw) - float(G[tag + '_unbiased_weighted'])) <= 1e-4 * max(1.0, abs(float(G[tag + '_unbiased_weighted'])))
+    vw.backward()
+    # the fp32 reference gradient is itself noise-limited by the exp(-5000 d^2) cancellation (see the biased test above):
+    # compared against the fp64 oracle, with the reference's own deviation from it as the yardstick
+    Xo, Yo = G[tag + '_X'].double().requires_grad_(True), G[tag + '_Y'].double().requires_grad_(True)
+    O.mix_rbf_mmd2(Xo, Yo, sample_weights=G[tag + '_w'].double(), biased=False).backward()
+    go = torch.cat((Xo.grad, Yo.grad), 0)
+    got = torch.cat((X.grad, Y.grad), 0).cpu().double()
+    ref = torch.cat((G[tag + '_unbiased_gx'], G[tag + '_unbiased_gy']), 0).double()
+    scale = float(go.abs().max())
+    err, ref_err = float((got - go).abs().max()), float((ref - go).abs().max())
+    assert err <= max(2e-4 * scale, 2.0 * ref_err), (err, ref_err, scale)
+    # and the biased / unbiased values differ by the diagonal terms exactly: 2 ns / m - (m-1)-pair renormalisation
+    vb = mmd.mix_rbf_mmd2(X.detach(), Y.detach(), mmd.sigma_list)
+    assert abs(float(vb) - float(G[tag + '_plain'])) <= 1e-4 * max(1.0, abs(float(G[tag + '_plain'])))
+
+
+def test_entropy_weights_of_a_saturated_row_follow_scipy_kl_div():
+    """A one-hot probability row has an fp32 entropy of exactly -0.0: scipy's kl_div (the reference's, dataset_splitter.py:244)
+    then gives +inf for that pair ('none'), and 'mean2one' turns it into NaN in that slot and 0 elsewhere -- recorded in
+    tests/golden/entropy.npz (ps1 / w1_*).  The plain x log(x/y) - x + y gave NaN for both."""
+    from conftest import load_golden
+    from sug_amd.model import mmd
+    G = load_golden('entropy.npz')
+    for w in ('none', 'mean2one'):
+        want = G['w1_' + w].reshape(-1)
+        for got in (mmd.entropy_weights(G['ps1'].cuda(), G['pt'].cuda(), w).cpu().reshape(-1), O.entropy_weights(G['ps1'], G['pt'], w).reshape(-1)):
+            assert torch.equal(torch.isnan(got), torch.isnan(want)) and torch.equal(torch.isinf(got), torch.isinf(want)), (w, got, want)
+            fin = torch.isfinite(want)
+            torch.testing.assert_close(got[fin], want[fin], rtol=1e-4, atol=2e-7)

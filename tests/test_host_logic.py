@@ -33,3 +33,36 @@ def test_graph_key_excludes_learning_rates():
     opt.param_groups[1]['weight_decay'] = 0.2
     assert opt.graph_key() != k0
     assert len(k0) == 3
+
+
+def test_sharded_steps_weight_a_term_the_way_mmd_cal_does():
+    """SUGStep's batch-sharded / segmented steps computed the semantic SDA weights with prob_weights_soft whenever
+    SEM_WEIGHTS was set and never looked at ENTROPY_WEIGHTS, which cal_sample_weights ranks first (model/mmd.py:44-53).  They
+    now go through mmd.sda_weights_of: mmd_cal's own rules.  (Pure torch on probability inputs: runs without a GPU.)"""
+    import inspect
+    from sug_amd import train_step
+    from sug_amd.model import mmd
+    g = torch.Generator().manual_seed(0)
+    ps, pt = torch.softmax(torch.randn(6, 10, generator=g), 1), torch.softmax(torch.randn(6, 10, generator=g), 1)
+    ls, lt = torch.randint(0, 10, (6,), generator=g), torch.randint(0, 10, (6,), generator=g)
+    both = {'NAME': 'SOFT_MMD', 'LABEL_SCALE': 5, 'SEM_WEIGHTS': 'mean2one', 'ENTROPY_WEIGHTS': 'none', 'LABEL_WEIGHT': 0.5}
+    w = mmd.sda_weights_of(both, ps, pt, ls, lt)
+    assert torch.equal(w, mmd.entropy_weights(ps, pt, 'none'))                 # ENTROPY ahead of SEM
+    assert mmd.sda_weights_of({'NAME': 'SOFT_MMD', 'ENTROPY_WEIGHTS': 'none'}, ps, pt, ls, lt) is None      # :28: GEO / SEM switch weights on
+    assert mmd.sda_weights_of({'NAME': 'SOFT_MMD'}, ps, pt, ls, lt) is None
+    src = inspect.getsource(train_step.SUGStep)
+    assert src.count('mmd.sda_weights_of(') == 2 and 'mmd.prob_weights_soft(' not in src
+
+
+def test_call_graph_manager_is_not_copied_or_pickled_with_the_model():
+    import copy
+    import pickle
+    from sug_amd import call_graphs
+    from sug_amd.model.Model import Net_MDA
+    net = Net_MDA('Pointnet')
+    mgr = call_graphs.manager_for(net)
+    assert mgr is not None and call_graphs.manager_for(net) is mgr
+    twin = copy.deepcopy(net)
+    assert twin.__dict__.get('_call_graph_mgr') is None
+    assert call_graphs.manager_for(twin) is not mgr
+    assert pickle.loads(pickle.dumps(mgr)) is None
