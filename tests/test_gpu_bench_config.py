@@ -225,3 +225,62 @@ def test_config5_fp16_step_at_full_per_gpu_share():
     print('config 5 first-step losses: fp16 vs fp32 deviation %.3e, fp16 run-to-run %.3e' % (dev, rep))
     assert dev <= 2e-2, out
     assert rep <= 2e-3, out
+
+
+# ---- round 6: configs 3 and 5 at their FULL per-GPU sizes against the oracle, not by properties only --------
+_FULL = {'Pointnet2': (64, 2048, 13), 'PTran': (16, 2048, 17)}          # model -> (clouds per domain, N, batch seed)
+
+
+def _fps_counts(model_name, N):
+    return {'Pointnet2': (N, 512), 'PTran': (N, 256, 64, 16)}[model_name]
+
+
+def _full_size_oracle(model_name, tied):
+    """oracle.sug_losses (forward only, dropout 0, fp32) at the benched size under bench.BENCH_METHODS.  tied=False: the four
+    passes draw their FPS starts from the CPU generator seeded 21, in the reference's call order (what the two-pass step
+    draws); tied=True: the node passes use the semantic passes' starts (what the single-pass step computes)."""
+    key = ('full', model_name, tied)
+    if key not in _ORACLE:
+        from sug_amd.model.Model import Net_MDA
+        B, N, bseed = _FULL[model_name]
+        p = O.as_params(O.fill_params({k: tuple(v.shape) for k, v in Net_MDA(model_name).state_dict().items()}, 5))
+        data, lab, data_t, lab_t = _batch(B, N, seed=bseed)
+        torch.manual_seed(21)
+        starts = None
+        if tied:
+            s_s = tuple(torch.randint(0, n, (B,), dtype=torch.long) for n in _fps_counts(model_name, N))
+            s_t = tuple(torch.randint(0, n, (B,), dtype=torch.long) for n in _fps_counts(model_name, N))
+            starts = [s_s, s_t, s_s, s_t]
+        with torch.no_grad():
+            v = O.sug_losses(p, model_name, data, lab, data_t, lab_t, dict(bench.BENCH_METHODS['GEO_MMD'][0]),
+                             dict(bench.BENCH_METHODS['SEM_MMD'][0]), drop_p=0.0, starts=starts)
+        _ORACLE[key] = [float(t) for t in v]
+    return _ORACLE[key]
+
+
+@pytest.mark.parametrize('model_name', ['Pointnet2', 'PTran'])
+@pytest.mark.parametrize('single_pass', [False, True])
+def test_configs_3_and_5_full_size_graph_tuned_match_oracle(model_name, single_pass):
+    """BASELINE config 3 (PointNet++, 64 clouds per domain, N = 2048) and config 5's per-GPU share (Point Transformer, 16 clouds
+    per domain, N = 2048, fp32 = the reference arithmetic) in the launch mode bench.py times -- hipGraph replay, tuned GEMM
+    table -- with dropout 0 and lr 0: the three losses of the planning step, the captured step and a replay against
+    oracle.sug_losses at 1e-4; the exact two-pass step (FPS starts drawn in the reference's call order) and the opt-in
+    single-pass step (oracle with the node passes' starts tied to the semantic passes')."""
+    B, N, bseed = _FULL[model_name]
+    want = _full_size_oracle(model_name, single_pass)
+    data, lab, data_t, lab_t = [t.cuda() for t in _batch(B, N, seed=bseed)]
+    try:
+        tr = _trainer(B, True, True, model_name=model_name, single_pass=single_pass)
+        got = []
+        for _ in range(3):
+            torch.manual_seed(21)
+            got.append([float(v) for v in tr.step(data, lab, data_t, lab_t)])
+        assert len(tr._graphs) == 1 and next(iter(tr._graphs.values()))['graph'] is not None
+        tr.drop_graphs()
+    finally:
+        _untune()
+        torch.cuda.empty_cache()
+    print(model_name, 'single-pass' if single_pass else 'two-pass', 'gpu', got, 'oracle', want)
+    for step in got:
+        for a, b in zip(step, want):
+            assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), (model_name, single_pass, got, want)

@@ -183,6 +183,40 @@ def test_pointnet_cls_config1():
     assert abs(loss.item() - float(G['loss'])) < 1e-4
 
 
+def test_pointnet_cls_config1_source_only_train_step():
+    """BASELINE config 1 as train_source.py:76-97, :113-131 runs it: Pointnet_cls -> CrossEntropyLoss -> backward -> ONE
+    optim.Adam(model.parameters(), lr 1e-3, weight decay 5e-5) update, against the reference run in
+    tests/golden/pointnet_cls.npz (round 6: gradients, BatchNorm buffers, post-step parameters, second-forward loss).
+    Adam's first update is lr * g / (|g| + eps): +-lr per element whatever the gradient's size, so an element whose
+    gradient is rounding noise may move the other way -- the per-tensor checks allow 1 % of the elements to do so; the
+    loss of the second forward (same batch, updated weights) holds 2e-3."""
+    G = load_golden('pointnet_cls.npz')
+    for own_adam in (False, True):
+        net = _cls_net('Pointnet_cls', G)
+        p0 = {k: v.detach().clone() for k, v in net.named_parameters()}
+        if own_adam:
+            from sug_amd.optim import Adam
+            opt = Adam(net.parameters(), lr=1e-3, weight_decay=5e-5)
+        else:
+            opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=5e-5)
+        x, lab = G['x'].cuda(), G['label'].cuda()
+        y = net(x)
+        _cls_check(net, G, y, 1e-4, 2e-3, dot_tol=2e-2)          # logits, CE, backward, gradients, BatchNorm buffers
+        opt.step()
+        opt.zero_grad()
+        post = dict(net.named_parameters())
+        lr = 1e-3
+        for k, want_sum, want_dn in zip(G['param_names'], G['param_sum'].tolist(), G['param_delta_norm'].tolist()):
+            n = post[k].numel()
+            dn = float((post[k].detach() - p0[k]).double().norm())
+            assert abs(dn - want_dn) <= 2e-2 * max(want_dn, lr), (k, dn, want_dn)
+            got_sum = float(post[k].detach().double().sum())
+            assert abs(got_sum - want_sum) <= 2 * lr * max(4.0, 0.01 * n) + 1e-5 * abs(want_sum), (k, got_sum, want_sum, n)
+        loss2 = torch.nn.functional.cross_entropy(net(x), lab)
+        assert abs(float(loss2) - float(G['loss2'])) <= 2e-3 * max(1.0, abs(float(G['loss2']))), (own_adam, float(loss2), float(G['loss2']))
+        assert float(loss2) < float(G['loss'])                   # the step went downhill, as in the reference run
+
+
 def _cls_net(cls, G):
     from sug_amd.model import model_pointnet as MP
     net = getattr(MP, cls)()
