@@ -305,6 +305,27 @@ def other_workload(model_name, B, N, fp16, dev, steps=10, warmup=3, profile_step
             sp_ms, _, _ = timed_windows(tr1)
             tr1.drop_graphs()
             tr1 = None
+        # the same workload the way train_dg_single_gpu.py:260-310 calls the API (four separate model(...) calls, replayed
+        # per call by sug_amd.call_graphs; SUGStep's own losses / backward / Adam launched eagerly around them)
+        caller_ms = None
+        try:
+            trc = SUGStep(model, lr=1e-3, weight_decay=5e-5, use_graph=False, methods=BENCH_METHODS, pair_domains=False,
+                          share_prefix=False)
+            if hasattr(model.g, 'share_prefix'):
+                model.g.share_prefix = 'auto'
+            for _ in range(4):          # step 1 eager (planning), step 2 captures the four calls, then replays
+                trc.step(*batch)
+            torch.cuda.synchronize()
+            caller_ms, _, _ = timed_windows(trc)
+            from sug_amd import call_graphs as _cg
+            _cg.drop(model)
+        except RuntimeError as e:
+            print('bench.py: caller form of %s failed: %s' % (model_name, str(e).splitlines()[0][:160]), file=sys.stderr)
+        trc = None
+        if hasattr(model.g, 'share_prefix'):        # back to the timed trainer's settings for the eager profile steps below
+            model.g.share_prefix = tr.share_prefix
+        for m_ in tr._split_layers:
+            m_.cache_weight_split = True
         tr.use_graph = False
         tr.fused_heads = False
         tr.step(*batch)
@@ -333,6 +354,7 @@ def other_workload(model_name, B, N, fp16, dev, steps=10, warmup=3, profile_step
         if sp_ms is not None:
             out['single_pass_ms_per_step'] = sp_ms
             out['single_pass_clouds_per_sec'] = 2 * B / (sp_ms * 1e-3)
+        out['unchanged_caller_ms_per_step'] = caller_ms
         if kern:
             dom = max(kern, key=lambda n: kern[n]['rank_ms'])
             kd = kern[dom]
@@ -912,6 +934,7 @@ def main():
                 cfg['%s_ms_per_step' % tag] = rec.get('ms_per_step')
                 cfg['%s_clouds_per_sec' % tag] = rec.get('clouds_per_sec')
                 cfg['%s_single_pass_ms_per_step' % tag] = rec.get('single_pass_ms_per_step')
+                cfg['%s_unchanged_caller_ms_per_step' % tag] = rec.get('unchanged_caller_ms_per_step')
                 sr = rec.get('step_roofline') or {}
                 cfg['%s_step_frac_mfma' % tag] = sr.get('frac_mfma')
                 cfg['%s_step_frac_hbm' % tag] = sr.get('frac_hbm')

@@ -258,9 +258,11 @@ extern "C" int sug_group_max_bwd(const float* g, const int32_t* arg, int B, int 
   static const int unordered = getenv("SUG_GROUP_MAX_UNORDERED") ? atoi(getenv("SUG_GROUP_MAX_UNORDERED")) : 0;
   const size_t sh = ((size_t)2 * 64 * (GMB_CH + 1) + (size_t)4 * N) * sizeof(int);
   bool ordered = S <= 64 && B <= 65535 && sh <= 150 * 1024 && !unordered;
-  if (ordered && sh > 64 * 1024) {      // more than the default dynamic-LDS limit: opt in; a device that refuses takes the atomic form
+  if (ordered && sh > 64 * 1024) {      // more than the default dynamic-LDS limit: opt in.  A device that refuses (none of the gfx950
+    // parts) FAILS the call, as sug_node_offset_bwd does: the summation order of a gradient must not depend on which kernel
+    // happened to hit a limit; SUG_GROUP_MAX_UNORDERED=1 selects the atomic form explicitly
     static SugLdsOptIn note;
-    if (sug_allow_dynamic_lds(note, &group_max_bwd_ordered_kernel, 150 * 1024, "sug_group_max_bwd") != SUG_OK) ordered = false;
+    if (int rc = sug_allow_dynamic_lds(note, &group_max_bwd_ordered_kernel, 150 * 1024, "sug_group_max_bwd")) return rc;
   }
   if (ordered) {      // fixed summation order; dfeat must arrive ZERO-FILLED in both forms (sug_amd.h: this one stores the touched
                       // entries, the atomic one adds -- on a zeroed buffer the same result, on any other an unspecified one)

@@ -570,12 +570,16 @@ class Net_MDA(nn.Module):
         the batch counters (multi-tensor launches, independent of the backbone)."""
         if not (self.dual_updates_bn_twice and self.training):
             return None
-        bns = getattr(self, '_bn_twice_modules', None)
-        if bns is None:
-            # (the MODULES are cached, not their tensors: .to() / load_state_dict may replace a buffer's storage, and
-            # copy.deepcopy maps cached module references onto the copy's own modules)
-            bns = self._bn_twice_modules = [m for m in self.g.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm)
-                                            and m.track_running_stats and m.momentum is not None]
+        # (rebuilt on every call: cheap next to an encoder pass, and module surgery after the first call -- convert_sync_batchnorm,
+        # a replaced sub-module -- is then seen; ADVICE r5.  ASSUMPTION of the extrapolation below: every BatchNorm the pass
+        # runs is run exactly ops.BN_GROUPS times, or not at all.)
+        allbn = [m for m in self.g.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm) and m.track_running_stats]
+        bns = [m for m in allbn if m.momentum is not None]
+        if len(bns) != len(allbn) and not getattr(self, '_bn_twice_warned', False):
+            import warnings
+            self._bn_twice_warned = True
+            warnings.warn('Net_MDA dual-output forward: BatchNorm layers with momentum=None (cumulative average) receive the '
+                          "pass's running-statistics update once, not twice as from the reference's two calls")
         # .data views: the second update must not bump the version counters autograd checks -- torch's own batch_norm node
         # keeps a reference to the running buffers it was given, for its eval-mode backward; a train-mode backward never reads
         # them, and the reference's second forward call changes them under the first call's graph as well

@@ -79,7 +79,8 @@ class conv_2d(nn.Module):
         B, N, _ = x.shape
         Wp, W = prev.weight2d(), self.weight2d()
         if ops.SA_MID_FUSED and x.is_cuda and self.activation in _ACT_SLOPE and prev.activation in _ACT_SLOPE and \
-                OWN_BN(self.conv[1]) and OWN_BN(prev.conv[1]) and ops.pointmlp_max_supported(Wp.shape[0], W.shape[0], N):
+                OWN_BN(self.conv[1]) and OWN_BN(prev.conv[1]) and prev.conv[1].training == self.conv[1].training and \
+                ops.pointmlp_max_supported(Wp.shape[0], W.shape[0], N):
             y = ops.linear_rows(x, Wp, prev.conv[0].bias)
             return ops.bn_act_pointmlp_max(y, prev.conv[1], _ACT_SLOPE[prev.activation], W, self.conv[0].bias, self.conv[1],
                                            _ACT_SLOPE[self.activation], N)[0]

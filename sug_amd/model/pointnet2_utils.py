@@ -136,7 +136,7 @@ class PointNetSetAbstraction(nn.Module):
             if i < first:
                 continue
             w = conv.weight.view(conv.weight.shape[0], -1)
-            if i == last - 1 and ops.SA_MID_FUSED and g.is_cuda and \
+            if i == last - 1 and ops.SA_MID_FUSED and g.is_cuda and self.mlp_bns[i].training == self.mlp_bns[last].training and \
                     ops.pointmlp_max_supported(w.shape[0], self.mlp_convs[last].out_channels, g.shape[2]):
                 # middle layer + last layer: the middle layer's BatchNorm + ReLU is applied inside the fused last-layer
                 # kernel (ops.bn_act_pointmlp_max): no separate pass over [B,S,ns,C], z written once and only if needed

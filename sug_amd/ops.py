@@ -1516,6 +1516,10 @@ class _BNActPointMLPMax(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout, gz):
+        if not (ctx.need1 or ctx.need2):
+            # nothing was saved: neither the input nor any parameter of the two layers takes a gradient (a gradient that
+            # still arrives at z -- want_z with the layers frozen -- has nowhere to go)
+            return (None,) * 23
         y2, coef1, z, w2, b1, zext, arg, coef2 = ctx.saved_tensors
         rows, K, Co, seg, G, slope1, slope2, training, yshape, wshape = ctx.meta
         dz = dw = db = dg2 = db2 = None
@@ -1535,6 +1539,11 @@ class _BNActPointMLPMax(torch.autograd.Function):
 def bn_act_pointmlp_max(y, bn1, slope1, weight, bias, bn2, slope2, seg, want_z=False, last_grad=True):
     """y [..., K] = pre-activation rows of the layer in front -> (max over `seg`-row segments of act2(bn2(z.W^T + b)), z or
     None) with z = act1(bn1(y)) never read back from memory by the last layer (see _BNActPointMLPMax)."""
+    if bn1.training != bn2.training:
+        # one `training` flag drives both BatchNorms of the fused pair (batch statistics + buffer update, or running
+        # statistics): a frozen BatchNorm beside a training one has no fused form (ADVICE r5) -- the callers
+        # (conv_2d.rows_max_after, PointNetSetAbstraction) compare the modes and take the layer-by-layer path
+        raise RuntimeError('bn_act_pointmlp_max: the two BatchNorm layers must be in the same mode (train / eval)')
     _count_bn_call(bn1)
     _count_bn_call(bn2)
     out, z = _BNActPointMLPMax.apply(y, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, slope1, bn1.eps, bn1.momentum,

@@ -22,6 +22,16 @@ torch.manual_seed(666)
 net = Net_MDA(model).to(dev).train()
 tr = SUGStep(net, use_graph=False, methods=BENCH_METHODS)
 tr.fused_heads = True                    # what the captured step runs
+if os.environ.get('CALLER') == '1':      # the unchanged-caller form (four separate model(...) calls), launched eagerly
+    from sug_amd.model.Model import Net_MDA as _N
+    _N.call_graphs = False
+    tr.pair_domains = tr.share_prefix = False
+    net.g.share_prefix = 'auto'
+    for m_ in tr._split_layers:
+        m_.cache_weight_split = False
+if os.environ.get('TUNED') == '1':
+    from sug_amd.tuning import enable_tuned_gemms
+    enable_tuned_gemms()
 data = synth(B, N, 666, dev)
 for _ in range(3):
     tr.step(*data)
