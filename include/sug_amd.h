@@ -44,8 +44,8 @@ extern "C" {
 
 const char* sug_last_error(void);
 /* ABI version of the loaded library (bumped when a signature changes; 3: sug_adam_step_capturable gained lr_dev,
- * round-3 entry points; 4: sug_chamfer / sug_node_offset_bwd became reproducible -- sug_chamfer takes a workspace; 5: sug_ce_pair_* take ignore_index, lse has 2M + 1 entries; sug_pointmlp_max_layer_fwd_xf and sug_col_stats_bn_grouped added).  A binding checks sug_abi_version() == SUG_ABI_VERSION of the header it was written against. */
-#define SUG_ABI_VERSION 5
+ * round-3 entry points; 4: sug_chamfer / sug_node_offset_bwd became reproducible -- sug_chamfer takes a workspace; 5: sug_ce_pair_* take ignore_index, lse has 2M + 1 entries; sug_pointmlp_max_layer_fwd_xf and sug_col_stats_bn_grouped added; 6: sug_ptran_fused_fwd / sug_ptran_fused_supported added, sug_group_max_bwd fails instead of changing its summation order when the LDS opt-in is refused).  A binding checks sug_abi_version() == SUG_ABI_VERSION of the header it was written against. */
+#define SUG_ABI_VERSION 6
 int sug_abi_version(void);
 
 /* ---- kNN graph ----------------------------------------------------------
@@ -587,6 +587,19 @@ int sug_ptran_attn_bwd(const float* g, const float* mixed, const void* logits, c
                        const int32_t* nbr, const float* mx, const float* sm, const int32_t* rev_off, const int32_t* rev_ent,
                        int B, int n, int k, int d, int dtype, float scale, void* dlogits, void* da, float* dv, float* db,
                        float* ws, void* stream);
+/* The fp16 forward of the vector attention as ONE kernel on the matrix cores (csrc/ptran_fused.hip; round 6): pos1, the three
+ * 512 x 512 linears of fc_delta[2] / fc_gamma[0] / fc_gamma[2] (v_mfma_f32_32x32x16_f16, activations resident in LDS, weights
+ * streamed from L2), U = (q - K_nbr) + delta, the softmax over the 16 neighbours and the weighted sum of V_nbr + delta --
+ * model/Ptran_transformer.py:39-44 in the 16-bit mode of BASELINE config 5.  w2 / b2 / wg1 / bg1 / wg2 / bg2: fp16 ([512,512]
+ * row-major = nn.Linear.weight, [512]); q / kf / vf / xyz / w1 / b1 fp32.  delta [B n 16, 512] fp16 is always written
+ * (the kernel reads it back for the weighted sum); save = 1 additionally writes T0, U, T1 and the logits (what
+ * sug_ptran_*_bwd read), save = 0 leaves those pointers unused (NULL allowed).  mixed / mx / sm [B n, 512] fp32 as
+ * sug_ptran_attn_fwd.  sug_ptran_fused_supported: 1 for d = 512, k = 16 and B*n a multiple of 8. */
+int sug_ptran_fused_supported(int B, int n, int k, int d);
+int sug_ptran_fused_fwd(const float* xyz, const int32_t* nbr, const float* q, const float* kf, const float* vf,
+                        const float* w1, const float* b1, const void* w2, const void* b2, const void* wg1, const void* bg1,
+                        const void* wg2, const void* bg2, int B, int n, int k, int d, float scale, int save, void* T0,
+                        void* delta, void* U, void* T1, void* Lg, float* mixed, float* mx, float* sm, void* stream);
 int64_t sug_ptran_colsum_workspace(int64_t rows);
 int sug_ptran_relu_bwd_db(void* G, const void* T1, int64_t rows, int d, int dtype, float* db, float* ws, void* stream);
 

@@ -63,6 +63,8 @@ SIGNATURES = {
     'sug_ptran_qk_fwd': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
     'sug_ptran_qk_bwd': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
     'sug_ptran_attn_fwd': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp],
+    'sug_ptran_fused_supported': [_i32, _i32, _i32, _i32],
+    'sug_ptran_fused_fwd': [_vp] * 13 + [_i32, _i32, _i32, _i32, _f32, _i32] + [_vp] * 9,
     'sug_ptran_attn_bwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp,
                            _vp, _vp, _vp],
     'sug_ptran_relu_bwd_db': [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp],
@@ -162,7 +164,7 @@ def lib():
         L.sug_last_error.argtypes = []
         L.sug_abi_version.restype = ctypes.c_int
         L.sug_abi_version.argtypes = []
-        if L.sug_abi_version() != 5:
+        if L.sug_abi_version() != 6:
             raise RuntimeError('sug_amd: ABI version mismatch, rebuild libsug_amd.so')
         _lib = L
     return _lib

@@ -1648,6 +1648,16 @@ def linear16(x, layer, lo, out32=True):
 
 
 # ----------------------------------------------------------------------------- Point Transformer attention
+# fp16 mode: the forward of a transformer block's vector attention as ONE MFMA kernel (sug_ptran_fused_fwd) instead of pos1 +
+# 3 library GEMMs + qk + attn.  Same values bit for bit (tests/test_gpu_ptran.py).  Measured at config 5's block-1 shape (1 M
+# k-expanded rows; tools/bench_ptran_fused.py, profiles/r06_ptran_fused_ab.txt): without a backward to feed 2.56 vs 3.21 ms --
+# nothing but delta is written --, with the four tensors a backward reads 3.11 vs 3.13 ms, and 19.73 vs 19.63 ms for the
+# whole config-5 step: one 130 KB workgroup per CU serialises its row passes (L2 gathers of K / V rows) with its MFMA chains,
+# the composition overlaps them across kernels at full occupancy.  Hence 'auto': the one-kernel form where no backward
+# follows (eval / no_grad forwards), the composition in training.  SUG_PTRAN_FUSED=1 / 0 forces one form.
+PTRAN_FUSED = {'1': True, '0': False}.get(_os.environ.get('SUG_PTRAN_FUSED', 'auto'), 'auto')
+
+
 class _PTranAttention(torch.autograd.Function):
     """Vector attention of one TransformerBlock (model/Ptran_transformer.py:39-44) from the projected
     q / K / V rows: pos-encoding MLP on the neighbour offsets, attention MLP on q - k + delta, softmax
@@ -1674,6 +1684,24 @@ class _PTranAttention(torch.autograd.Function):
         w1c, b1c = w1.detach().contiguous(), b1.detach().contiguous()
         wl = [cast_cached(t, lo, detach=True) for t in (w2, b2, wg1, bg1, wg2, bg2)]
         L_ = lib()
+        scale = 1.0 / (d ** 0.5)
+        need = any(ctx.needs_input_grad[i] for i in range(2, 13))
+        if (PTRAN_FUSED is True or (PTRAN_FUSED == 'auto' and not need)) and code == 1 and L_.sug_ptran_fused_supported(B, n, k, d):
+            # the whole fp16 forward as ONE kernel on the matrix cores (csrc/ptran_fused.hip): no library GEMM, no k-expanded
+            # tensor read back; T0 / U / T1 / logits are written (once) only when a backward will read them
+            delta = torch.empty(R, d, dtype=lo, device=dev)
+            T0, U, T1, Lg = ((torch.empty(R, d, dtype=lo, device=dev) for _ in range(4)) if need else (None,) * 4)
+            mixed = torch.empty(B, n, d, dtype=torch.float32, device=dev)
+            mx, sm = torch.empty_like(mixed), torch.empty_like(mixed)
+            shp = {'B': B, 'N': n, 'k': k, 'd': d, 'e': 2}
+            check(_timed('ptran_fused_fwd_n%d' % n, shp, lambda: L_.sug_ptran_fused_fwd(
+                _p(xyz), _p(nbr), _p(q), _p(kf), _p(vf), _p(w1c), _p(b1c), _p(wl[0]), _p(wl[1]), _p(wl[2]), _p(wl[3]), _p(wl[4]),
+                _p(wl[5]), B, n, k, d, scale, 1 if need else 0, _p(T0), _p(delta), _p(U), _p(T1), _p(Lg), _p(mixed), _p(mx), _p(sm),
+                _st())), 'sug_ptran_fused_fwd')
+            if need:
+                ctx.save_for_backward(xyz, nbr, vf, w1c, b1c, wl[0], wl[2], wl[4], T0, delta, U, T1, Lg, mx, sm, mixed)
+            ctx.meta = (B, n, k, d, code, scale)
+            return mixed
         T0 = torch.empty(R, d, dtype=lo, device=dev)
         check(L_.sug_ptran_pos1_fwd(_p(xyz), _p(nbr), _p(w1c), _p(b1c), B, n, k, d, code, _p(T0), _st()), 'sug_ptran_pos1_fwd')
         delta = torch.addmm(wl[1], T0, wl[0].t())
@@ -1685,7 +1713,6 @@ class _PTranAttention(torch.autograd.Function):
         Lg = torch.addmm(wl[5], T1, wl[4].t())
         mixed = torch.empty(B, n, d, dtype=torch.float32, device=dev)
         mx, sm = torch.empty_like(mixed), torch.empty_like(mixed)
-        scale = 1.0 / (d ** 0.5)
         check(_timed('ptran_attn_fwd_n%d' % n, shp, lambda: L_.sug_ptran_attn_fwd(_p(Lg), _p(delta), _p(vf), _p(nbr), B, n, k, d, code, scale,
                                                                           _p(mixed), _p(mx), _p(sm), _st())), 'sug_ptran_attn_fwd')
         ctx.save_for_backward(xyz, nbr, vf, w1c, b1c, wl[0], wl[2], wl[4], T0, delta, U, T1, Lg, mx, sm, mixed)

@@ -46,7 +46,7 @@ def test_ctypes_table_matches_header():
 def test_version_and_error_string():
     from sug_amd import _lib
     L = _lib.lib()
-    assert L.sug_abi_version() == 5
+    assert L.sug_abi_version() == 6
     # argument validation happens on the host before any launch: safe without a GPU
     rc = L.sug_knn(None, 3, 1, 8, 3, 4, None, None)
     assert rc == -1 and b'null' in L.sug_last_error()

@@ -85,3 +85,52 @@ def test_linear16_matches_fp32_linear_to_fp16_rounding():
     # 16-bit output for a following 16-bit GEMM
     y2 = ops.linear16(x, lin, torch.float16, out32=False)
     assert y2.dtype == torch.float16 and rel(y2.float(), y0) < 3e-3
+
+
+@pytest.mark.parametrize('B,n', [(2, 512), (1, 2048), (3, 16), (2, 64)])
+def test_one_kernel_fp16_forward_matches_the_composed_fp16_chain(B, n):
+    """Round 6 (BASELINE config 5: "fp16 with MFMA attention path"): sug_ptran_fused_fwd -- pos1, the three 512 x 512 linears
+    on v_mfma_f32_32x32x16_f16 with the activations resident in LDS, q - k + delta, softmax over the 16 neighbours, weighted
+    sum -- against the same fp16 chain composed of sug_ptran_pos1 / qk / attn and three library GEMMs (ops.PTRAN_FUSED = False).
+    Both round the k-expanded tensors to fp16 at the same points and accumulate in fp32; they differ by the order of the
+    GEMMs' partial sums only: outputs within 2e-3 (relative L2 3e-4), every saved tensor within fp16 rounding of the
+    other's, and -- the backward being the same code fed with those tensors -- gradients within 2e-3 relative L2."""
+    from sug_amd import ops
+    from sug_amd.model import Ptran_transformer as PT
+    blk = _block(64, 3)
+    g = torch.Generator().manual_seed(B * 1000 + n)
+    xyz = torch.rand(B, n, 3, generator=g).cuda()
+    feat = torch.randn(B, n, 64, generator=g).cuda()
+    probe = torch.randn(B, n, 64, generator=g).cuda()
+    assert ops.lib().sug_ptran_fused_supported(B, n, min(16, n), 512) == 1
+    res = {}
+    keep = ops.PTRAN_FUSED
+    try:
+        PT.GEMM_DTYPE = torch.float16
+        for fused in (True, False):
+            ops.PTRAN_FUSED = fused
+            res[fused] = _run(blk, xyz, feat, probe, True)
+        # without a backward (torch.no_grad): the kernel's save = 0 form, same values
+        ops.PTRAN_FUSED = True
+        with torch.no_grad():
+            o_ng = blk(xyz, feat)[0]
+    finally:
+        PT.GEMM_DTYPE, ops.PTRAN_FUSED = None, keep
+    rel = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-12))
+    (o1, gf1, gr1), (o0, gf0, gr0) = res[True], res[False]
+    assert torch.equal(o_ng, o1), 'save = 0 and save = 1 must give the same output'
+    assert rel(o1, o0) < 3e-4, rel(o1, o0)
+    torch.testing.assert_close(o1, o0, rtol=2e-3, atol=2e-3)
+    assert rel(gf1, gf0) < 2e-3, rel(gf1, gf0)
+    gmax = max(float(v.norm()) for v in gr0.values())
+    for k in gr0:
+        assert float((gr1[k] - gr0[k]).norm()) <= 2e-3 * float(gr0[k].norm()) + 1e-5 * gmax, (k, rel(gr1[k], gr0[k]))
+
+
+def test_one_kernel_forward_is_declined_where_it_does_not_apply():
+    """k < 16 (a level with fewer than 16 points) and point counts that are not whole octets take the composed chain."""
+    from sug_amd import ops
+    L = ops.lib()
+    assert L.sug_ptran_fused_supported(2, 4, 4, 512) == 0
+    assert L.sug_ptran_fused_supported(1, 20, 16, 512) == 0
+    assert L.sug_ptran_fused_supported(2, 2048, 16, 512) == 1

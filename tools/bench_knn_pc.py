@@ -14,6 +14,7 @@ def _ablation_sources():
     os.makedirs(os.path.join(top, 'sug_amd'))
     shutil.copytree(os.path.join(ROOT, 'sug_amd', 'csrc'), os.path.join(top, 'sug_amd', 'csrc'),
                     ignore=shutil.ignore_patterns('*.o', '*.so'))
+    shutil.copytree(os.path.join(ROOT, 'include'), os.path.join(top, 'include'))        # (common.h includes ../../include/sug_amd.h)
     subprocess.run(['patch', '-p1', '-s', '-i', os.path.join(ROOT, 'tools', 'ubench', 'knn_pc_ablations.patch')], cwd=top, check=True)
     return os.path.join(top, 'sug_amd', 'csrc')
 
