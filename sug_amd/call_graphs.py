@@ -317,7 +317,7 @@ class CallGraphs:
         try:
             for m_, n_, q in self._slots:
                 m_._parameters[n_] = alias[id(q)]
-            with torch.cuda.graph(inst.graph_f, capture_error_mode='thread_local'):
+            with ops.capture_guard(), torch.cuda.graph(inst.graph_f, capture_error_mode='thread_local'):
                 with ops.deferred_bn_counts():
                     out = model._forward_impl(inst.x, *flags)
             if inst.feeder.cursor != len(inst.feeder.plan):
@@ -342,7 +342,7 @@ class CallGraphs:
         inst.gdirty = [False] * len(diff)
         params = self._req
         inst.graph_b = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(inst.graph_b, pool=inst.graph_f.pool(), capture_error_mode='thread_local'):
+        with ops.capture_guard(), torch.cuda.graph(inst.graph_b, pool=inst.graph_f.pool(), capture_error_mode='thread_local'):
             grads = torch.autograd.grad(diff, [alias[id(q)] for q in params] + leaves, inst.gouts, allow_unused=True)
         # static gradient tensors of the parameters this call reaches (kept referenced: their memory stays out of the pool)
         inst.used = [(q, gr) for q, gr in zip(params, grads[:len(params)]) if gr is not None]

@@ -61,6 +61,29 @@ def run_parallel(fns):
     return outs
 
 
+@contextlib.contextmanager
+def capture_guard():
+    """Around every hipGraph capture of this package.  torch.cuda.graph no longer runs the garbage collector when a capture
+    starts (torch >= 2.9: `torch.compiler.config.force_cudagraph_gc` is off), so a dead Python cycle that owns HIP objects -- an
+    earlier trainer's captured graphs, tensors of a destroyed graph's private pool -- could be collected IN THE MIDDLE of a
+    capture: hipGraphExecDestroy / hipFree under a global-mode capture aborted the process (seen once in a full test run,
+    round 6: 'Fatal Python error: Aborted ... Garbage-collecting' inside a captured forward).  Collect before, keep the
+    collector off during, and drop the module-level tensor caches first (their tensors may live in an older graph's pool and
+    would otherwise be released by the first op of the capture that replaces them)."""
+    import gc
+    global _LAST_COEF, _LAST_COEF_PAIR
+    clear_rows_cache()
+    _LAST_COEF, _LAST_COEF_PAIR = None, (None, None)
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
+
+
 # Domain groups of a batch: with BN_GROUPS = G the batch dimension holds G equal contiguous parts
 # (Net_MDA.forward_pair: source clouds then target clouds) that the reference sends through the
 # network in G separate forward calls.  Everything per-cloud / per-row is oblivious to that; the

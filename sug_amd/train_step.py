@@ -515,7 +515,7 @@ class SUGStep:
                 st['graph'].enable_debug_mode()
             ops.START_PROVIDER = st['feeder'].provide
             try:
-                with torch.cuda.graph(st['graph']):
+                with ops.capture_guard(), torch.cuda.graph(st['graph']):
                     st['out'] = self._eager_step(*st['in'], epoch)
             finally:
                 ops.START_PROVIDER = None
@@ -793,7 +793,7 @@ class SUGStep:
                     g = torch.cuda.CUDAGraph()
                     # thread_local: the process group's watchdog thread queries events of finished collectives while
                     # we capture; in the default (global) mode such a call from ANOTHER thread invalidates the capture
-                    with torch.cuda.graph(g, pool=pool, capture_error_mode='thread_local'):
+                    with ops.capture_guard(), torch.cuda.graph(g, pool=pool, capture_error_mode='thread_local'):
                         fn(S)
                     pool = g.pool() if pool is None else pool
                     graphs.append(g)

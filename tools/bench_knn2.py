@@ -1,4 +1,4 @@
-"""Time sug_knn (current library) at the benchmark shapes (the round-1 kernels: tools/bench_knn.py)."""
+"""Time sug_knn (current library) at the benchmark shapes."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
