@@ -67,14 +67,15 @@ def capture_guard():
     starts (torch >= 2.9: `torch.compiler.config.force_cudagraph_gc` is off), so a dead Python cycle that owns HIP objects -- an
     earlier trainer's captured graphs, tensors of a destroyed graph's private pool -- could be collected IN THE MIDDLE of a
     capture: hipGraphExecDestroy / hipFree under a global-mode capture aborted the process (seen once in a full test run,
-    round 6: 'Fatal Python error: Aborted ... Garbage-collecting' inside a captured forward).  Collect before, keep the
-    collector off during, and drop the module-level tensor caches first (their tensors may live in an older graph's pool and
-    would otherwise be released by the first op of the capture that replaces them)."""
+    round 6: 'Fatal Python error: Aborted ... Garbage-collecting' inside a captured forward).  The collector stays OFF for the
+    duration of the capture (dead cycles wait for the next automatic collection outside it; a full collection here costs
+    ~0.1 s in a large process and a step is captured in up to six pieces), and the module-level tensor caches are dropped
+    first (their tensors may live in an older graph's pool and would otherwise be released -- by reference count, collector
+    or not -- by the first op of the capture that replaces them)."""
     import gc
     global _LAST_COEF, _LAST_COEF_PAIR
     clear_rows_cache()
     _LAST_COEF, _LAST_COEF_PAIR = None, (None, None)
-    gc.collect()
     was = gc.isenabled()
     gc.disable()
     try:
