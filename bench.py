@@ -330,18 +330,18 @@ def other_workload(model_name, B, N, fp16, dev, steps=10, warmup=3, profile_step
         tr.fused_heads = False
         tr.step(*batch)
         torch.cuda.synchronize()
-        keep_prof = (ops.PROFILE, ops.PROFILE_ONLY)
+        keep_prof = (ops.CTX.profile, ops.CTX.profile_only)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         tr.step(*batch)
         torch.cuda.synchronize()
         e_ms = 1e3 * (time.perf_counter() - t1)
-        ops.PROFILE_ONLY, ops.PROFILE = {'edgeconv', 'pointmlp', 'knn', 'ptran'}, {}
+        ops.CTX.profile_only, ops.CTX.profile = {'edgeconv', 'pointmlp', 'knn', 'ptran'}, {}
         for _ in range(profile_steps):
             hold_gpu(2.0 * e_ms)                 # kernels queue up behind the spin kernel: event pairs bracket kernels, not host gaps
             tr.step(*batch)
             torch.cuda.synchronize()
-        prof, (ops.PROFILE, ops.PROFILE_ONLY) = ops.PROFILE, keep_prof
+        prof, (ops.CTX.profile, ops.CTX.profile_only) = ops.CTX.profile, keep_prof
         kern = kernel_table(prof)
         out = {'workload': '%s, N=%d, batch=%d per domain, MSA+SDA losses on' % (BACKBONE.get(model_name, model_name), N, B)
                            + (', fp16 transformer linears' if fp16 else ''),
@@ -601,7 +601,7 @@ def main():
     # kernels of the dominant family are then timed inside the timed region itself.
     timed_family = {'DGCNN': {'knn'}, 'Pointnet': {'pointmlp'}, 'Pointnet2': {'pointmlp'}}.get(args.model, {'knn'})
     all_families = {'edgeconv', 'pointmlp', 'knn'}
-    ops.PROFILE_ONLY = set(timed_family)
+    ops.CTX.profile_only = set(timed_family)
     try:
         for i in range(max(args.warmup, 3 if trainer.use_graph else 1)):
             trainer.step(data, lab, data_t, lab_t)
@@ -629,13 +629,13 @@ def main():
                 trainer.step(data, lab, data_t, lab_t)
             sync()
             ems = 1e3 * (time.perf_counter() - t1) / 3
-            ops.PROFILE_ONLY, ops.PROFILE = set(all_families), {}
+            ops.CTX.profile_only, ops.CTX.profile = set(all_families), {}
             for _ in range(max(args.profile_steps, 1)):
                 hold_gpu(2.5 * ems)
                 trainer.step(data, lab, data_t, lab_t)
                 sync()
-            res['events'] = {k: [[a.elapsed_time(b), shp] for a, b, shp in v] for k, v in ops.PROFILE.items()}
-            ops.PROFILE, ops.PROFILE_ONLY = None, set(timed_family)
+            res['events'] = {k: [[a.elapsed_time(b), shp] for a, b, shp in v] for k, v in ops.CTX.profile.items()}
+            ops.CTX.profile, ops.CTX.profile_only = None, set(timed_family)
             trainer.use_graph = graph_mode
             with open(args.timestamps_child, 'w') as f:
                 json.dump(res, f)
@@ -655,14 +655,14 @@ def main():
     gc.collect()
     gc.freeze()
     if not graph_mode:
-        ops.PROFILE = {}
+        ops.CTX.profile = {}
     t0 = time.perf_counter()
     for _ in range(args.steps):
         losses = trainer.step(data, lab, data_t, lab_t)
     sync()
     dt = time.perf_counter() - t0
     loss_vals = [None if l is None else float(l) for l in losses]
-    prof, ops.PROFILE = ({} if graph_mode else ops.PROFILE), None
+    prof, ops.CTX.profile = ({} if graph_mode else ops.CTX.profile), None
     eager_ms = None
     exact_ms = None
     graph_kernel_ms = graph_launches = None
@@ -738,21 +738,21 @@ def main():
         # per-kernel event timings: a few more eager steps, each queued BEHIND a spin kernel that holds the GPU while the
         # host enqueues the whole step -- the kernels then run back to back and an event pair brackets the kernel alone
         # (launched live, an event pair also spans the host's gap to the next launch whenever the host is the slower side)
-        ops.PROFILE_ONLY, ops.PROFILE = set(all_families), {}
+        ops.CTX.profile_only, ops.CTX.profile = set(all_families), {}
         for _ in range(max(args.profile_steps, 1)):
             hold_gpu(2.5 * eager_ms)
             trainer.step(data, lab, data_t, lab_t)
             sync()
-        extra_prof, ops.PROFILE, ops.PROFILE_ONLY = ops.PROFILE, None, set(timed_family)
+        extra_prof, ops.CTX.profile, ops.CTX.profile_only = ops.CTX.profile, None, set(timed_family)
         # (no in-process profiler pass as a fall-back: if the child failed, the HIP-event readings of the queued steps stand)
     else:
         # the other hand-written layer kernels (EdgeConv layer calls, per-point MLP + max): a few extra steps
         # outside the timed region, for the `kernels` table only
-        ops.PROFILE_ONLY, ops.PROFILE = all_families - timed_family, {}
+        ops.CTX.profile_only, ops.CTX.profile = all_families - timed_family, {}
         for _ in range(5):
             trainer.step(data, lab, data_t, lab_t)
         sync()
-        extra_prof, ops.PROFILE, ops.PROFILE_ONLY = ops.PROFILE, None, set(timed_family)
+        extra_prof, ops.CTX.profile, ops.CTX.profile_only = ops.CTX.profile, None, set(timed_family)
     # The same workload the way train_dg_single_gpu.py:260-310 calls the API: four separate model(...)
     # calls per step, nothing shared between them (the headline uses the exact restructurings of
     # paired domains + shared prefix).

@@ -205,9 +205,9 @@ class CallGraphs:
 
     # ------------------------------------------------------------------ the call
     def _eligible(self, model, x):
-        if not (x.is_cuda and not x.requires_grad and ops.BN_GROUPS == 1 and ops.START_QUEUE is None and
-                ops.GEOMETRY_PLAN is None and ops.START_PROVIDER is None and ops.PROFILE is None and
-                getattr(ops, 'W16_CACHE', None) is None and ops.BN_RECORD is None):
+        if not (x.is_cuda and not x.requires_grad and ops.CTX.bn_groups == 1 and ops.CTX.start_queue is None and
+                ops.CTX.geometry_plan is None and ops.CTX.start_provider is None and ops.CTX.profile is None and
+                ops.CTX.w16_cache is None and ops.CTX.bn_record is None):
             return False
         if torch.cuda.is_current_stream_capturing():
             return False
@@ -218,7 +218,7 @@ class CallGraphs:
     def _key(self, model, x, flags):
         from .model import Ptran_transformer as PT
         g = model.g
-        return (flags, tuple(x.shape), x.device.index, ops.FUSED_HEADS, ops.PARALLEL_BRANCHES, PT.GEMM_DTYPE,
+        return (flags, tuple(x.shape), x.device.index, ops.CTX.fused_heads, ops.CTX.parallel_branches, PT.GEMM_DTYPE,
                 getattr(PT, 'PROJ_16BIT', None), getattr(g, 'share_prefix', None), model.dual_output_on_both_flags,
                 model.dual_updates_bn_twice)
 
@@ -257,7 +257,7 @@ class CallGraphs:
             try:
                 inst = self._capture(model, ks, x, flags, dep)
             except Exception as e:      # capture refused: this key stays eager, in this process
-                ops.START_PROVIDER = None
+                ops.CTX.start_provider = None
                 ks.eager_only, ks.why = True, '%s: %s' % (type(e).__name__, str(e).splitlines()[0] if str(e) else '')
                 self.stats['refused'] += 1
                 if os.environ.get('SUG_CALL_GRAPHS_STRICT') == '1':
@@ -275,11 +275,11 @@ class CallGraphs:
         if ks.plan is not None and ks.bwd_seen[0]:
             return model._forward_impl(x, *flags)
         feeder = StartFeeder(x.device)
-        ops.START_PROVIDER = feeder.record
+        ops.CTX.start_provider = feeder.record
         try:
             out = model._forward_impl(x, *flags)
         finally:
-            ops.START_PROVIDER = None
+            ops.CTX.start_provider = None
         ks.plan = feeder.plan
         # a capture of this key waits until one eager backward has run (every GEMM shape of the key has then been looked
         # up outside a capture): any output's gradient hook says the backward has started, and the next forward call
@@ -313,7 +313,7 @@ class CallGraphs:
         # captured gradient to them makes the engine synchronise the capture stream with the default stream, which
         # invalidates the capture (torch warns 'AccumulateGrad node's stream does not match'; hipStreamEndCapture crashed).
         alias = {id(q): q.detach().requires_grad_(q.requires_grad) for q in self._params}
-        ops.START_PROVIDER = inst.feeder.provide
+        ops.CTX.start_provider = inst.feeder.provide
         try:
             for m_, n_, q in self._slots:
                 m_._parameters[n_] = alias[id(q)]
@@ -329,7 +329,7 @@ class CallGraphs:
                     if dep is None and bool(getattr(g, 'share_prefix', False)) and all(t.requires_grad for t in e.tensors):
                         exported = e
         finally:
-            ops.START_PROVIDER = None
+            ops.CTX.start_provider = None
             for m_, n_, q in self._slots:
                 m_._parameters[n_] = q
         inst.single = isinstance(out, torch.Tensor)

@@ -73,7 +73,7 @@ class _PrefixSharing:
 
     def _prefix_key(self, x):
         ver = sum(p._version for p in self._prefix_params())
-        return (x.data_ptr(), x._version, tuple(x.shape), torch.is_grad_enabled(), ver, ops.BN_GROUPS)
+        return (x.data_ptr(), x._version, tuple(x.shape), torch.is_grad_enabled(), ver, ops.CTX.bn_groups)
 
     def find_prefix(self, x):
         """The live cache entry computed from the tensor object `x` under the current weights, or None."""
@@ -273,7 +273,7 @@ class Pointnet2_g(nn.Module):
         (not in the reference; used by SUGStep: the semantic and the node pass of a step).  FPS and ball query read the
         coordinates and the start draws only; the draws are made here, in the order the `passes` forwards would make them
         (per pass and domain group: sa1's, then sa2's -- pointnet2_utils.py:72), so the random stream is unchanged.
-        Returns a list of per-pass plans for ops.GEOMETRY_PLAN."""
+        Returns a list of per-pass plans for ops.CTX.geometry_plan."""
         if self.normal_channel or self.sa1.group_all or self.sa2.group_all:
             return None
         # only sample_and_group_idx consumes a plan: a layer that takes the grouped-tensor path (SUG_SA_FIRST=0, an
@@ -572,7 +572,7 @@ class Net_MDA(nn.Module):
             return None
         # (rebuilt on every call: cheap next to an encoder pass, and module surgery after the first call -- convert_sync_batchnorm,
         # a replaced sub-module -- is then seen; ADVICE r5.  ASSUMPTION of the extrapolation below: every BatchNorm the pass
-        # runs is run exactly ops.BN_GROUPS times, or not at all.)
+        # runs is run exactly ops.CTX.bn_groups times, or not at all.)
         allbn = [m for m in self.g.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm) and m.track_running_stats]
         bns = [m for m in allbn if m.momentum is not None]
         if len(bns) != len(allbn) and not getattr(self, '_bn_twice_warned', False):
@@ -588,7 +588,7 @@ class Net_MDA(nn.Module):
         nbt = [m.num_batches_tracked.data for m in bns if m.num_batches_tracked is not None]
         if not bufs or not bufs[0].is_cuda:
             return None
-        G = ops.BN_GROUPS
+        G = ops.CTX.bn_groups
         alphas = [(1.0 - m) ** G for m in moms]
         return bufs, alphas, torch._foreach_add(bufs, 0.0), nbt, (torch._foreach_add(nbt, 0) if nbt else [])
 
@@ -721,19 +721,19 @@ class Net_MDA(nn.Module):
             if not geom[1] or geom[0]() is not x_pair:
                 self._geometry = None
         plan = self.g.fps_plan(x_pair.size(2)) if hasattr(self.g, 'fps_plan') else [x_pair.size(2)]
-        if geometry is None and (ops.START_PROVIDER is None or len(plan) > 1):
+        if geometry is None and (ops.CTX.start_provider is None or len(plan) > 1):
             # CPU-generator draws in the reference's order: all FPS calls of the source forward, then all of the target
             # forward.  Under a graph's start feeder the same order is recorded / replayed (one device slice per draw), so a
             # captured step and its eager twin see the same starts; with ONE FPS call per forward a single draw of 2B
             # starts is the same stream and needs no concatenation.
             draws = [[ops.draw_group_start(B, n) for n in plan] for _ in range(2)]
             queue = [torch.cat((draws[0][c], draws[1][c])) for c in range(len(plan))]
-        keep_plan, ops.GEOMETRY_PLAN = ops.GEOMETRY_PLAN, (list(geometry) if geometry is not None else None)
+        keep_plan, ops.CTX.geometry_plan = ops.CTX.geometry_plan, (list(geometry) if geometry is not None else None)
         try:
             out = self._forward_pair(x_pair, node_adaptation, paired_out, queue, B, B2, dual)
-            left = len(ops.GEOMETRY_PLAN or ())
+            left = len(ops.CTX.geometry_plan or ())
         finally:
-            ops.GEOMETRY_PLAN = keep_plan
+            ops.CTX.geometry_plan = keep_plan
         if left:        # a planned entry nobody popped = a sampling stage that drew its start a second time
             raise RuntimeError('geometry plan of this pass was not consumed by the encoder (%d entries left)' % left)
         return out

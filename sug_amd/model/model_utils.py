@@ -23,15 +23,15 @@ def OWN_BN(bn):
 def bn_module(bn, y):
     """Apply a torch BatchNorm module per domain group (ops.bn_groups), i.e. as the separate
     forward calls of the reference would."""
-    if ops.BN_GROUPS == 1:
+    if ops.CTX.bn_groups == 1:
         return bn(y)
-    return torch.cat([bn(c) for c in y.chunk(ops.BN_GROUPS, dim=0)], dim=0)
+    return torch.cat([bn(c) for c in y.chunk(ops.CTX.bn_groups, dim=0)], dim=0)
 
 
 def _bn_rows(bn, y):
     """Train/eval BatchNorm of a [..., C] rows tensor with the module's parameters."""
-    if ops.BN_GROUPS > 1:
-        G = ops.BN_GROUPS
+    if ops.CTX.bn_groups > 1:
+        G = ops.CTX.bn_groups
         with ops.bn_groups(1):
             return torch.cat([_bn_rows(bn, c) for c in y.chunk(G, dim=0)], dim=0)
     shp = y.shape
@@ -147,8 +147,8 @@ class fc_layer(nn.Module):
         self.fc = nn.Sequential(*layers)
 
     def forward(self, x):
-        if ops.FUSED_HEADS and len(self.fc) == 3 and x.is_cuda and ops.ln_act_supported(x, self.fc[1]):
-            # LayerNorm + activation in one launch (two in the backward) instead of 2 + 4 (graph replay only: ops.FUSED_HEADS)
+        if ops.CTX.fused_heads and len(self.fc) == 3 and x.is_cuda and ops.ln_act_supported(x, self.fc[1]):
+            # LayerNorm + activation in one launch (two in the backward) instead of 2 + 4 (graph replay only: ops.CTX.fused_heads)
             slope = 0.0 if isinstance(self.ac, nn.ReLU) else self.ac.negative_slope
             return ops.ln_act(self.fc[0](x), self.fc[1], slope)
         return self.fc(x)
@@ -206,7 +206,7 @@ class adapt_layer_off(nn.Module):
         """fea [B,N,64], loc [B,N,3] -> (out [B,N,128], node_fea [B,num_node,64], node_off [B,num_node,3])."""
         B, N, _ = loc.shape
         S = self.num_node
-        plan = ops.GEOMETRY_PLAN
+        plan = ops.CTX.geometry_plan
         if plan:
             fidx, f_loc, gidx = plan.pop(0)    # computed up front for this pass (plan_geometry below)
             if fidx.shape != (B, S) or gidx.shape[:2] != (B, S):
@@ -239,12 +239,12 @@ class adapt_layer_off(nn.Module):
     def plan_geometry(self, loc, passes, groups=1):
         """The coordinate-only part of `passes` forwards over the same clouds loc [B,N,3] -- FPS start draws (in the order
         the forwards would make them), FPS, the sampled coordinates, the radius-0.3 ball query -- in one set of launches
-        (SUGStep: the semantic and the node pass of a step).  -> per pass [(fidx, f_loc, gidx)] for ops.GEOMETRY_PLAN."""
+        (SUGStep: the semantic and the node pass of a step).  -> per pass [(fidx, f_loc, gidx)] for ops.CTX.geometry_plan."""
         B, N, _ = loc.shape
         S = self.num_node
         starts = []
         for _ in range(passes):
-            if ops.START_PROVIDER is not None or groups == 1:
+            if ops.CTX.start_provider is not None or groups == 1:
                 starts.append(ops.draw_start(B, N))
             else:
                 starts.append(torch.cat([torch.randint(0, N, (B // groups,), dtype=torch.long) for _ in range(groups)]))

@@ -55,7 +55,7 @@ def sample_and_group_idx(npoint, radius, nsample, xyz):
     """The index half of sample_and_group (model/pointnet2_utils.py:107-124): same FPS start draw and kernels,
     -> new_xyz [B,S,3], idx [B,S,nsample] int32; the grouped tensor itself is not formed."""
     B, N, _ = xyz.shape
-    plan = ops.GEOMETRY_PLAN
+    plan = ops.CTX.geometry_plan
     if plan:
         new_xyz, idx = plan.pop(0)              # computed up front for this pass (Pointnet2_g.plan_geometry)
         if new_xyz.shape != (B, npoint, 3) or idx.shape != (B, npoint, nsample):
@@ -97,7 +97,7 @@ class PointNetSetAbstraction(nn.Module):
 
     def takes_index_path(self):
         """True if rows() runs its first MLP layer on the neighbour lists (sample_and_group_idx -- the only consumer of an
-        ops.GEOMETRY_PLAN) instead of forming the grouped tensor."""
+        ops.CTX.geometry_plan) instead of forming the grouped tensor."""
         return (not self.group_all) and len(self.mlp_convs) > 1 and \
             ops.sa_first_layer_supported(self.mlp_convs[0].out_channels)
 

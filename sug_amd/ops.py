@@ -12,6 +12,42 @@ import torch
 
 from ._lib import lib, check, STATS_BLOCKS
 
+class StepContext:
+    """The mutable state a forward / training step of this package scopes -- ONE object instead of a dozen module globals (round 6,
+    VERDICT r5 #9).  One process drives one GPU, so one context per process: SUGStep, Net_MDA.forward_pair, the call-graph manager
+    and bench.py set fields for the duration of a pass (always restoring the previous value), the ops read them.  The old
+    module-level names (`ops.BN_GROUPS`, `ops.START_PROVIDER`, `ops.PROFILE`, ...) remain as properties of the module that forward
+    to this object, so existing callers and tests keep working.
+
+      bn_groups          G equal contiguous parts of the batch (Net_MDA.forward_pair: source clouds, then target clouds) that the
+                         reference sends through the network in G separate forward calls: BatchNorm statistics and running-buffer
+                         updates per part, in order
+      start_queue        pre-drawn FPS starts of this forward (the reference's call order), consumed by draw_start
+      start_provider     None, or a callable (B, N) -> starts: a graph's start feeder (record / provide), a test's table
+      geometry_plan      FPS + ball-query results of this pass computed up front (Pointnet2_g.plan_geometry), popped in call order
+      profile            None, or {kernel name: [(event, event, shape)]}: bench.py's per-kernel HIP-event timings
+      profile_only       None, or the set of name prefixes that get events
+      parallel_branches  independent small-kernel chains on forked streams (opt-in; measured slower)
+      fused_heads        fused LayerNorm + activation in the FC heads (SUGStep switches it on for its own forwards)
+      w16_cache          step-scoped cache of 16-bit weight copies (Point Transformer, fp16 mode) or None
+      bn_record          None, or the list collecting (BatchNorm module, batch-statistics coefficients) of a shared prefix
+      pending_counts     None, or the deferred num_batches_tracked increments of this pass
+      last_coef, last_coef_pair   the batch-statistics coefficients of the most recent BatchNorm op(s), for bn_record"""
+    __slots__ = ('bn_groups', 'start_queue', 'start_provider', 'geometry_plan', 'profile', 'profile_only', 'parallel_branches',
+                 'fused_heads', 'w16_cache', 'bn_record', 'pending_counts', 'last_coef', 'last_coef_pair')
+
+    def __init__(self):
+        self.bn_groups = 1
+        self.start_queue = self.start_provider = self.geometry_plan = None
+        self.profile = self.profile_only = None
+        self.parallel_branches = False
+        self.fused_heads = False
+        self.w16_cache = self.bn_record = self.pending_counts = None
+        self.last_coef, self.last_coef_pair = None, (None, None)
+
+
+CTX = StepContext()
+
 SIGMA_LIST = (0.01, 0.1, 1, 10, 100)       # model/mmd.py:23
 
 
@@ -19,13 +55,10 @@ SIGMA_LIST = (0.01, 0.1, 1, 10, 100)       # model/mmd.py:23
 # PROFILE_ONLY (a set of name prefixes or None) restricts which kernels get events: every
 # event pair costs host time, and an eager step is host-bound.  While a hipGraph is being
 # captured the events are created `external` so that they become event-record nodes.
-PROFILE = None
-PROFILE_ONLY = None
 
 # FPS start indices: the reference draws torch.randint(0, N, (B,)) from the CPU default
 # generator once per farthest_point_sample call.  A provider (SUGStep's graph mode) may hand
 # out device-resident slices instead, filled from the same draws, so a step can be replayed.
-START_PROVIDER = None
 
 
 # Independent branches of a step (the two classifier heads, the two attention layers, the three MMD terms) are chains of
@@ -35,13 +68,12 @@ START_PROVIDER = None
 # forward, so the backward branches overlap too.  Launched eagerly from Python the extra event records only cost host
 # time, hence off by default.  (Measured on ROCm 7.2 / MI355X: also under graph replay it is a loss -- 5.35 vs 5.26 ms per
 # DGCNN step -- a cross-stream edge of a hipGraph costs more than the kernels it overlaps; SUG_PARALLEL_BRANCHES=1 opts in.)
-PARALLEL_BRANCHES = False
 _SIDE_STREAMS = {}
 
 
 def run_parallel(fns):
     """[f() for f in fns], the calls after the first on side streams forked from / joined to the current stream."""
-    if not PARALLEL_BRANCHES or len(fns) < 2 or not torch.cuda.is_available():
+    if not CTX.parallel_branches or len(fns) < 2 or not torch.cuda.is_available():
         return [f() for f in fns]
     main = torch.cuda.current_stream()
     dev = main.device_index
@@ -73,9 +105,8 @@ def capture_guard():
     first (their tensors may live in an older graph's pool and would otherwise be released -- by reference count, collector
     or not -- by the first op of the capture that replaces them)."""
     import gc
-    global _LAST_COEF, _LAST_COEF_PAIR
     clear_rows_cache()
-    _LAST_COEF, _LAST_COEF_PAIR = None, (None, None)
+    CTX.last_coef, CTX.last_coef_pair = None, (None, None)
     was = gc.isenabled()
     gc.disable()
     try:
@@ -90,32 +121,28 @@ def capture_guard():
 # network in G separate forward calls.  Everything per-cloud / per-row is oblivious to that; the
 # BatchNorm ops compute statistics and update the running buffers per part, in order, so the
 # result is the one of G separate calls.
-BN_GROUPS = 1
 
 
 @contextlib.contextmanager
 def bn_groups(g):
-    global BN_GROUPS
-    old, BN_GROUPS = BN_GROUPS, int(g)
+    old, CTX.bn_groups = CTX.bn_groups, int(g)
     try:
         yield
     finally:
-        BN_GROUPS = old
+        CTX.bn_groups = old
 
 
 # Pre-drawn FPS starts (Net_MDA.forward_pair draws them in the reference's call order: every
 # farthest_point_sample of the source forward, then those of the target forward).
-START_QUEUE = None
 
 
 @contextlib.contextmanager
 def start_queue(q):
-    global START_QUEUE
-    old, START_QUEUE = START_QUEUE, (list(q) if q is not None else None)
+    old, CTX.start_queue = CTX.start_queue, (list(q) if q is not None else None)
     try:
         yield
     finally:
-        START_QUEUE = old
+        CTX.start_queue = old
 
 
 # Geometry of several encoder passes over ONE batch, computed up front (Pointnet2_g.plan_geometry): farthest-point sampling and
@@ -123,18 +150,17 @@ def start_queue(q):
 # their launches (FPS is one workgroup per cloud and `npoint` dependent rounds: 128 clouds fill half of the chip for
 # 0.34 ms; both passes in one launch take the same 0.34 ms).  A list of (new_xyz, idx) per sample_and_group call, in call
 # order; pointnet2_utils.sample_and_group_idx pops from it.
-GEOMETRY_PLAN = None
 
 
 def draw_start(B, N):
-    if START_QUEUE:                 # draws made up front for this forward (Net_MDA.forward_pair: the reference's order)
-        t = START_QUEUE.pop(0)
+    if CTX.start_queue:                 # draws made up front for this forward (Net_MDA.forward_pair: the reference's order)
+        t = CTX.start_queue.pop(0)
         if t.numel() != B:
             raise RuntimeError('FPS start plan does not match the encoder (%d starts for %d clouds)' % (t.numel(), B))
         return t
-    if START_PROVIDER is not None:
-        return START_PROVIDER(B, N)
-    G = BN_GROUPS
+    if CTX.start_provider is not None:
+        return CTX.start_provider(B, N)
+    G = CTX.bn_groups
     if G > 1 and B % G == 0:        # one CPU-generator draw per reference forward call
         return torch.cat([torch.randint(0, N, (B // G,), dtype=torch.long) for _ in range(G)])
     return torch.randint(0, N, (B,), dtype=torch.long)
@@ -142,13 +168,13 @@ def draw_start(B, N):
 
 def draw_group_start(B, N):
     """One reference forward's draw (B clouds of one domain group), through the graph's start feeder when one is active."""
-    if START_PROVIDER is not None:
-        return START_PROVIDER(B, N)
+    if CTX.start_provider is not None:
+        return CTX.start_provider(B, N)
     return torch.randint(0, N, (B,), dtype=torch.long)
 
 
 def _timed(name, shape, call):
-    if PROFILE is None or (PROFILE_ONLY is not None and not name.startswith(tuple(PROFILE_ONLY))):
+    if CTX.profile is None or (CTX.profile_only is not None and not name.startswith(tuple(CTX.profile_only))):
         return call()
     if torch.cuda.is_current_stream_capturing():        # timing events cannot be captured on ROCm
         return call()
@@ -157,7 +183,7 @@ def _timed(name, shape, call):
     a.record()
     r = call()
     b.record()
-    PROFILE.setdefault(name, []).append((a, b, shape))
+    CTX.profile.setdefault(name, []).append((a, b, shape))
     return r
 
 
@@ -621,8 +647,7 @@ class _BNActRows(torch.autograd.Function):
         check(lib().sug_bn_act_rows_fwd(_p(y2), C, rows, C, G, _p(g), _p(b), 1 if training else 0, eps, momentum,
                                         float(slope), _p(running_mean), _p(running_var), _p(coef), _p(out), C,
                                         _p(stats), _p(ws), _st()), 'sug_bn_act_rows_fwd')
-        global _LAST_COEF
-        _LAST_COEF = coef
+        CTX.last_coef = coef
         if any(ctx.needs_input_grad[i] for i in (0, 1, 2)):
             ctx.save_for_backward(y2, coef)
             ctx.meta = (rows, C, float(slope), bool(training), tuple(y.shape), G)
@@ -769,7 +794,7 @@ SA_FIRST_GEO = _os.environ.get('SUG_SA_FIRST_GEO', '0') == '1'  # opt-in: y = Pf
 def sa_first_layer_geo(Pf, Px, Q, idx, xyz, cent, Wx, bias, bn):
     _count_bn_call(bn)
     return _SAFirstLayerGeo.apply(Pf, Px, Q, idx, xyz, cent, Wx, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                  bn.training, bn.eps, bn.momentum, BN_GROUPS)
+                                  bn.training, bn.eps, bn.momentum, CTX.bn_groups)
 
 
 SA_FIRST = _os.environ.get('SUG_SA_FIRST', '1') != '0'          # 0: grouped tensor + GEMM (the reference's arithmetic) instead
@@ -784,7 +809,7 @@ def sa_first_layer(P, Q, idx, bn):
     lists -> relu(bn(P[idx] - Q)) [B,S,ns,C] (train-mode statistics over each domain group's rows)."""
     _count_bn_call(bn)
     return _SAFirstLayer.apply(P, Q, idx, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, bn.eps,
-                               bn.momentum, BN_GROUPS)
+                               bn.momentum, CTX.bn_groups)
 
 
 class _LNAct(torch.autograd.Function):
@@ -819,7 +844,6 @@ class _LNAct(torch.autograd.Function):
 # The fused LayerNorm + activation of the FC heads saves 3 launches per layer on the GPU but costs more host time than
 # the native ops it replaces (a Python autograd.Function per call): worth it when the step is replayed from a hipGraph
 # (SUGStep(use_graph=True) switches it on), not when every launch is issued from Python.
-FUSED_HEADS = False
 
 
 def ln_act_supported(x, ln):
@@ -1000,20 +1024,18 @@ def heads_fused(heads, x):
 
 # num_batches_tracked increments: one tiny launch per BatchNorm call unless deferred; inside a
 # `deferred_bn_counts()` block they are collected and applied with one foreach add at the end.
-_PENDING_COUNTS = None
 
 
 @contextlib.contextmanager
 def deferred_bn_counts():
-    global _PENDING_COUNTS
-    if _PENDING_COUNTS is not None:          # nested: the outer block flushes
+    if CTX.pending_counts is not None:          # nested: the outer block flushes
         yield
         return
-    _PENDING_COUNTS = {}
+    CTX.pending_counts = {}
     try:
         yield
     finally:
-        pend, _PENDING_COUNTS = _PENDING_COUNTS, None
+        pend, CTX.pending_counts = CTX.pending_counts, None
         by_inc = {}
         for t, n in pend.values():
             by_inc.setdefault(n, []).append(t)
@@ -1023,11 +1045,11 @@ def deferred_bn_counts():
 
 def _count_bn_call(bn, n=None):
     if bn.training and bn.num_batches_tracked is not None:
-        n = BN_GROUPS if n is None else n
-        if _PENDING_COUNTS is not None:
+        n = CTX.bn_groups if n is None else n
+        if CTX.pending_counts is not None:
             t = bn.num_batches_tracked
-            old = _PENDING_COUNTS.get(id(t))
-            _PENDING_COUNTS[id(t)] = (t, n + (old[1] if old else 0))
+            old = CTX.pending_counts.get(id(t))
+            CTX.pending_counts[id(t)] = (t, n + (old[1] if old else 0))
         else:
             bn.num_batches_tracked.add_(n)
 
@@ -1035,24 +1057,20 @@ def _count_bn_call(bn, n=None):
 # A shared prefix (DGCNN / Point Transformer / PointNet encoders: the part of the semantic and of the node pass of a step that
 # is the same computation) is run once; the second pass only REPLAYS the running-statistics updates of its BatchNorm layers.
 # `with record_bn_stats() as rec:` collects (module, batch-statistics coefficients) of every train-mode BatchNorm op inside.
-BN_RECORD = None
-_LAST_COEF = None
-_LAST_COEF_PAIR = (None, None)
 
 
 @contextlib.contextmanager
 def record_bn_stats():
-    global BN_RECORD
-    prev, BN_RECORD = BN_RECORD, []
+    prev, CTX.bn_record = CTX.bn_record, []
     try:
-        yield BN_RECORD
+        yield CTX.bn_record
     finally:
-        BN_RECORD = prev
+        CTX.bn_record = prev
 
 
 def _record_bn(bn):
-    if BN_RECORD is not None and bn.training and bn.track_running_stats:
-        BN_RECORD.append((bn, _LAST_COEF))
+    if CTX.bn_record is not None and bn.training and bn.track_running_stats:
+        CTX.bn_record.append((bn, CTX.last_coef))
 
 
 def replay_bn_stats(rec):
@@ -1075,7 +1093,7 @@ def bn_act_rows(y, bn, slope):
     """bn: an nn.BatchNorm{1,2}d module whose parameters / running buffers are used."""
     _count_bn_call(bn)
     out = _BNActRows.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, slope, bn.eps,
-                           bn.momentum, BN_GROUPS)
+                           bn.momentum, CTX.bn_groups)
     _record_bn(bn)
     return out
 
@@ -1138,7 +1156,7 @@ def bn_update_stats(y, bn):
     y2 = y.detach().reshape(-1, C)
     if y2.stride(1) != 1:
         y2 = y2.contiguous()
-    rows, G = y2.shape[0], BN_GROUPS
+    rows, G = y2.shape[0], CTX.bn_groups
     if rows % G:
         raise RuntimeError('bn_update_stats: %d rows do not split into %d domain groups' % (rows, G))
     rg = rows // G
@@ -1157,7 +1175,7 @@ def bn_act_pool(y, bn, slope):
     """(max over points, mean over points) of act(bn(y)), y [B,N,C]."""
     _count_bn_call(bn)
     return _BNActPool.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, slope, bn.eps,
-                            bn.momentum, BN_GROUPS)
+                            bn.momentum, CTX.bn_groups)
 
 
 # ----------------------------------------------------------------------------- EdgeConv
@@ -1239,7 +1257,7 @@ def edgeconv_bn_act_max(pq, idx, gamma, beta, running_mean, running_var, trainin
                         out=None):
     """pq [B,N,2*Co] = x.[W1;W2-W1]^T, idx [B,N,k] -> (out [B,N,Co], coef [5,Co] = scale, shift,
     batch mean, rstd, unbiased batch variance; [G,5,Co] under bn_groups(G > 1))."""
-    return _EdgeConv.apply(pq, idx, gamma, beta, running_mean, running_var, training, slope, eps, momentum, BN_GROUPS,
+    return _EdgeConv.apply(pq, idx, gamma, beta, running_mean, running_var, training, slope, eps, momentum, CTX.bn_groups,
                            None if out is None else [out], torch.is_grad_enabled())
 
 
@@ -1344,7 +1362,7 @@ def edgeconv_fused(x, wcat, bias, idx, bn_weight, bn_bias, running_mean, running
                    momentum=0.1, out=None):
     """x [B,N,C] rows, wcat [2Co, C] = [W1 ; W2-W1], idx [B,N,k] -> (out [B,N,Co], coef) as edgeconv_bn_act_max."""
     return _EdgeConvFused.apply(x, wcat, bias, idx, bn_weight, bn_bias, running_mean, running_var, training, slope, eps,
-                                momentum, BN_GROUPS, None if out is None else [out], torch.is_grad_enabled())
+                                momentum, CTX.bn_groups, None if out is None else [out], torch.is_grad_enabled())
 
 
 # ----------------------------------------------------------------------------- per-point MLP + max
@@ -1391,8 +1409,7 @@ class _PointMLPMax(torch.autograd.Function):
                                                               float(slope), _p(running_mean), _p(running_var), _p(zext),
                                                               _p(arg), _p(coef), _p(out), Co, _p(ws), _st())),
               'sug_pointmlp_max_layer_fwd')
-        global _LAST_COEF
-        _LAST_COEF = coef
+        CTX.last_coef = coef
         if any(ctx.needs_input_grad[i] for i in (0, 1, 2, 3, 4)):
             ctx.save_for_backward(x2, w2, b1, zext, arg, coef)
             ctx.meta = (rows, K, Co, seg, G, float(slope), bool(training), tuple(x.shape), tuple(weight.shape))
@@ -1465,7 +1482,7 @@ def pointmlp_max(x, weight, bias, bn, slope, seg):
     module -> [rows/seg, Co] = max over each segment of LeakyReLU_slope(bn(x.W^T + b))."""
     _count_bn_call(bn)
     out = _PointMLPMax.apply(x, weight, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training,
-                             slope, bn.eps, bn.momentum, seg, BN_GROUPS)
+                             slope, bn.eps, bn.momentum, seg, CTX.bn_groups)
     _record_bn(bn)
     return out
 
@@ -1525,8 +1542,7 @@ class _BNActPointMLPMax(torch.autograd.Function):
                                                              float(slope2), _p(rm2), _p(rv2), _p(zext), _p(arg), _p(coef2),
                                                              _p(out), Co, _p(ws), _st())),
               'sug_pointmlp_max_layer_fwd_xf')
-        global _LAST_COEF_PAIR
-        _LAST_COEF_PAIR = (coef1, coef2)
+        CTX.last_coef_pair = (coef1, coef2)
         ctx.need1, ctx.need2 = need1, need2
         if need1 or need2:
             ctx.save_for_backward(y2, coef1, z, w2, b1, zext, arg, coef2)
@@ -1572,17 +1588,16 @@ def bn_act_pointmlp_max(y, bn1, slope1, weight, bias, bn2, slope2, seg, want_z=F
     _count_bn_call(bn2)
     out, z = _BNActPointMLPMax.apply(y, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, slope1, bn1.eps, bn1.momentum,
                                      weight, bias, bn2.weight, bn2.bias, bn2.running_mean, bn2.running_var, slope2, bn2.eps,
-                                     bn2.momentum, bn1.training, seg, BN_GROUPS, want_z, last_grad, torch.is_grad_enabled())
-    if BN_RECORD is not None:                      # a shared prefix replays these running-statistics updates (record_bn_stats)
-        for bn, coef in zip((bn1, bn2), _LAST_COEF_PAIR):
+                                     bn2.momentum, bn1.training, seg, CTX.bn_groups, want_z, last_grad, torch.is_grad_enabled())
+    if CTX.bn_record is not None:                      # a shared prefix replays these running-statistics updates (record_bn_stats)
+        for bn, coef in zip((bn1, bn2), CTX.last_coef_pair):
             if bn.training and bn.track_running_stats:
-                BN_RECORD.append((bn, coef))
+                CTX.bn_record.append((bn, coef))
     return out, z
 
 
 # Step-scoped cache of 16-bit copies of weights / biases (opt-in: SUGStep sets a dict before the forwards of a step and
 # drops it after them).  Without it every call re-casts its operands: ~280 tiny launches per step at config 5.
-W16_CACHE = None
 
 
 def cast_cached(p, lo, detach=False):
@@ -1590,13 +1605,13 @@ def cast_cached(p, lo, detach=False):
     (detach=False) stay in the autograd graph: the fp32 parameter receives the sum of their gradients."""
     if p is None:
         return None
-    if W16_CACHE is None:
+    if CTX.w16_cache is None:
         return (p.detach() if detach else p).to(lo)
     key = (id(p), lo, bool(detach) or not torch.is_grad_enabled())
-    hit = W16_CACHE.get(key)
+    hit = CTX.w16_cache.get(key)
     if hit is None or hit[0] != p._version:
         hit = (p._version, (p.detach() if key[2] else p).to(lo), p)
-        W16_CACHE[key] = hit
+        CTX.w16_cache[key] = hit
     return hit[1]
 
 
@@ -1797,7 +1812,7 @@ CALAYER_FUSED = _os.environ.get('SUG_CALAYER_FUSED', '1') != '0'    # A/B knob: 
 
 def calayer_supported(layers, x):
     """Can the CALayer modules `layers` (1 or 2: attention_s [, attention_t]) run through sug_calayer_* on x [len(layers)*M, C]?"""
-    if not (CALAYER_FUSED and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and BN_GROUPS == 1):
+    if not (CALAYER_FUSED and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and CTX.bn_groups == 1):
         return False
     if x.shape[0] % len(layers):
         return False
@@ -2340,7 +2355,7 @@ class _GateBN(torch.autograd.Function):
 
 def gate_bn_supported(x, bn):
     return GATE_BN_FUSED and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] <= 1024 and bn.affine and \
-        (bn.training or bn.track_running_stats) and bn.momentum is not None and BN_GROUPS == 1
+        (bn.training or bn.track_running_stats) and bn.momentum is not None and CTX.bn_groups == 1
 
 
 def gate_bn(x, z, bn):
@@ -2416,3 +2431,29 @@ def chamfer(a, b):
     ws = torch.empty(lib().sug_chamfer_workspace(B, N, M), dtype=torch.float32, device=a.device)
     check(lib().sug_chamfer(_p(a), _p(b), B, N, M, _p(out), _p(ws), _st()), 'sug_chamfer')
     return out
+
+
+# ----------------------------------------------------------------------------- the old module-level names of the context fields
+def _ctx_property(field):
+    return property(lambda self: getattr(CTX, field), lambda self, v: setattr(CTX, field, v))
+
+
+class _OpsModule(type(_os)):
+    """`ops.BN_GROUPS`, `ops.START_PROVIDER = f`, ... read and write CTX (see StepContext)."""
+    BN_GROUPS = _ctx_property('bn_groups')
+    START_QUEUE = _ctx_property('start_queue')
+    START_PROVIDER = _ctx_property('start_provider')
+    GEOMETRY_PLAN = _ctx_property('geometry_plan')
+    PROFILE_ONLY = _ctx_property('profile_only')
+    PROFILE = _ctx_property('profile')
+    PARALLEL_BRANCHES = _ctx_property('parallel_branches')
+    FUSED_HEADS = _ctx_property('fused_heads')
+    W16_CACHE = _ctx_property('w16_cache')
+    BN_RECORD = _ctx_property('bn_record')
+    _PENDING_COUNTS = _ctx_property('pending_counts')
+    _LAST_COEF_PAIR = _ctx_property('last_coef_pair')
+    _LAST_COEF = _ctx_property('last_coef')
+
+
+import sys as _sys
+_sys.modules[__name__].__class__ = _OpsModule

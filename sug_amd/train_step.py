@@ -497,11 +497,11 @@ class SUGStep:
                 self._graphs.pop(next(iter(self._graphs)))  # dicts keep insertion order; a hit re-inserts (below)
             st = {'feeder': _StartFeeder(data.device), 'graph': None, 'gens': None}
             self._graphs[key] = st
-            ops.START_PROVIDER = st['feeder'].record
+            ops.CTX.start_provider = st['feeder'].record
             try:
                 out = self._eager_step(data, label, data_t, label_t, epoch)
             finally:
-                ops.START_PROVIDER = None
+                ops.CTX.start_provider = None
             st['feeder'].build()
             return out
         self._graphs[key] = self._graphs.pop(key)           # most recently used last
@@ -513,12 +513,12 @@ class SUGStep:
             st['graph'] = torch.cuda.CUDAGraph()
             if os.environ.get('SUG_GRAPH_DUMP'):
                 st['graph'].enable_debug_mode()
-            ops.START_PROVIDER = st['feeder'].provide
+            ops.CTX.start_provider = st['feeder'].provide
             try:
                 with ops.capture_guard(), torch.cuda.graph(st['graph']):
                     st['out'] = self._eager_step(*st['in'], epoch)
             finally:
-                ops.START_PROVIDER = None
+                ops.CTX.start_provider = None
             st['gens'] = self._plan_generations()
             if os.environ.get('SUG_GRAPH_DUMP'):
                 st['graph'].debug_dump(os.environ['SUG_GRAPH_DUMP'])
@@ -572,9 +572,9 @@ class SUGStep:
 
         def seg_a(S):
             from .model import Ptran_transformer as _PT
-            ops.W16_CACHE = ops.w16_prefill(getattr(self, '_w16_plan', None) or []) if _PT.GEMM_DTYPE is not None else None
-            fused_before, ops.FUSED_HEADS = ops.FUSED_HEADS, (self.fused_heads or ops.FUSED_HEADS)
-            par_before, ops.PARALLEL_BRANCHES = ops.PARALLEL_BRANCHES, (self.parallel_branches or ops.PARALLEL_BRANCHES)
+            ops.CTX.w16_cache = ops.w16_prefill(getattr(self, '_w16_plan', None) or []) if _PT.GEMM_DTYPE is not None else None
+            fused_before, ops.CTX.fused_heads = ops.CTX.fused_heads, (self.fused_heads or ops.CTX.fused_heads)
+            par_before, ops.CTX.parallel_branches = ops.CTX.parallel_branches, (self.parallel_branches or ops.CTX.parallel_branches)
             try:
                 model._cuts = S['cuts'] = []
                 pair = torch.cat((data, data_t), dim=0)
@@ -604,11 +604,11 @@ class SUGStep:
                     S['packed'] = torch.cat(cols, dim=1)
             finally:
                 model._cuts = None
-                ops.FUSED_HEADS = fused_before
-                ops.PARALLEL_BRANCHES = par_before
-                if ops.W16_CACHE is not None:
-                    self._w16_plan = ops.w16_plan(ops.W16_CACHE)
-                ops.W16_CACHE = None
+                ops.CTX.fused_heads = fused_before
+                ops.CTX.parallel_branches = par_before
+                if ops.CTX.w16_cache is not None:
+                    self._w16_plan = ops.w16_plan(ops.CTX.w16_cache)
+                ops.CTX.w16_cache = None
 
         def col_gather(S):
             if not mmd_on:
@@ -770,11 +770,11 @@ class SUGStep:
         if st is None:
             st = {'feeder': _StartFeeder(data.device), 'graphs': None, 'gens': None, 'S': {}}
             self._graphs[key] = st
-            ops.START_PROVIDER = st['feeder'].record
+            ops.CTX.start_provider = st['feeder'].record
             try:
                 out = self._run_segments(self._segments(data, label, data_t, label_t, epoch), st['S'])
             finally:
-                ops.START_PROVIDER = None
+                ops.CTX.start_provider = None
             st['feeder'].build()
             st['S'] = {'static': st['S']['static']}         # keep only the collective buffers
             return out
@@ -787,7 +787,7 @@ class SUGStep:
             segs = self._segments(*st['in'], epoch)
             S = st['S']
             graphs, pool, err = [], None, None
-            ops.START_PROVIDER = st['feeder'].provide
+            ops.CTX.start_provider = st['feeder'].provide
             try:
                 for fn in segs['device']:
                     g = torch.cuda.CUDAGraph()
@@ -800,7 +800,7 @@ class SUGStep:
             except RuntimeError as e:                      # (reported below, after every rank has been heard)
                 err = e
             finally:
-                ops.START_PROVIDER = None
+                ops.CTX.start_provider = None
             # the ranks must agree before the first replay: a rank whose capture failed would otherwise meet the others'
             # all-gather with a different collective.  One flag all-reduce per capture (not per step).
             ok = torch.tensor([0.0 if err is not None else 1.0], device=data.device)
@@ -857,17 +857,17 @@ class SUGStep:
         from .model import Ptran_transformer as _PT
         # 16-bit weight copies shared by this step's forwards; from the second step on they are refreshed by one
         # multi-tensor copy into the first step's buffers
-        ops.W16_CACHE = ops.w16_prefill(getattr(self, '_w16_plan', None) or []) if _PT.GEMM_DTYPE is not None else None
-        fused_before, ops.FUSED_HEADS = ops.FUSED_HEADS, (self.fused_heads or ops.FUSED_HEADS)
-        par_before, ops.PARALLEL_BRANCHES = ops.PARALLEL_BRANCHES, (self.parallel_branches or ops.PARALLEL_BRANCHES)
+        ops.CTX.w16_cache = ops.w16_prefill(getattr(self, '_w16_plan', None) or []) if _PT.GEMM_DTYPE is not None else None
+        fused_before, ops.CTX.fused_heads = ops.CTX.fused_heads, (self.fused_heads or ops.CTX.fused_heads)
+        par_before, ops.CTX.parallel_branches = ops.CTX.parallel_branches, (self.parallel_branches or ops.CTX.parallel_branches)
         try:
             loss_cls, loss_geo, loss_sem = self.losses(data, label, data_t, label_t, mmd_on, combine=True)
         finally:
-            ops.FUSED_HEADS = fused_before
-            ops.PARALLEL_BRANCHES = par_before
-            if ops.W16_CACHE is not None:
-                self._w16_plan = ops.w16_plan(ops.W16_CACHE)
-            ops.W16_CACHE = None
+            ops.CTX.fused_heads = fused_before
+            ops.CTX.parallel_branches = par_before
+            if ops.CTX.w16_cache is not None:
+                self._w16_plan = ops.w16_plan(ops.CTX.w16_cache)
+            ops.CTX.w16_cache = None
         loss = getattr(self, '_total', None)             # set by losses() when the tail was combined in one launch
         self._total = None
         if loss is None:
