@@ -188,3 +188,58 @@ def test_deepcopy_and_eval_are_untouched():
             assert torch.equal(u, v)
     finally:
         Net_MDA.call_graphs = False
+
+
+def _grads(net):
+    return {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+
+
+def test_many_calls_in_flight_eval_interludes_and_new_shapes():
+    """What a real loop does besides the steady state: (a) SIX forwards of one kind before the single backward (more than the
+    four graph instances a key may hold: the surplus runs eagerly), (b) an eval-mode validation pass between training steps
+    (graphs untouched, reused afterwards), (c) a last batch of another size (a new key: eager once, then captured).  Losses,
+    BatchNorm buffers and the CPU generator's state equal the all-eager run bit for bit (no parameter update between the
+    steps: each is judged from the same weights); gradient norms to 1e-5: with THREE calls sharing one batch's prefix (two importers of one exporter) autograd adds the importers' prefix
+    gradients to each other before the exporter's backward graph adds its own, where the eager graph adds them one node at a
+    time -- another association of the same fp32 sums (the reference's pattern, one importer per prefix, is exact:
+    test_graphed_calls_equal_the_eager_caller_form_bit_for_bit)."""
+    from sug_amd.model.Model import Net_MDA
+    res = {}
+    for graphs in (False, True):
+        net, batches = _make('Pointnet', 4, 1024)
+        small = [t[:2].clone() for t in batches[1]]
+        torch.manual_seed(5)
+        log = []
+        try:
+            Net_MDA.call_graphs = 'auto' if graphs else False
+            for step in range(5):
+                data, label, data_t, label_t = batches[step % 2] if step != 3 else small       # step 3: the odd-sized batch
+                outs = [net(data if i % 2 == 0 else data_t, semantic_adaption=True) for i in range(6 if step >= 2 else 2)]
+                loss = sum(torch.nn.functional.cross_entropy(o[0], label if i % 2 == 0 else label_t) + o[2].square().mean()
+                           for i, o in enumerate(outs))
+                loss.backward()
+                log.append((float(loss), _state_hash(net), {k: float(v.double().norm()) for k, v in _grads(net).items()}))
+                net.zero_grad(set_to_none=True)           # (no parameter update: every step is judged from the same weights)
+                if step == 1:                           # validation interlude
+                    net.eval()
+                    with torch.no_grad():
+                        torch.manual_seed(77)
+                        log.append(float(net(data, semantic_adaption=True)[0].sum()))
+                    net.train()
+                    torch.manual_seed(6)
+        finally:
+            Net_MDA.call_graphs = False
+        res[graphs] = (log, torch.get_rng_state().clone())
+        if graphs:
+            st = net.__dict__['_call_graph_mgr'].stats
+            assert st['refused'] == 0 and st['captured'] >= 2 and st['replayed'] >= 4 and st['eager'] >= 2, st
+    for i, (a, b) in enumerate(zip(res[True][0], res[False][0])):
+        if isinstance(a, float):                            # the eval-mode interlude's output
+            assert a == b
+            continue
+        assert a[0] == b[0] and a[1] == b[1], (i, a[0], b[0])                  # loss, sha256(parameters + BatchNorm buffers)
+        assert a[2].keys() == b[2].keys()
+        gmax = max(abs(v) for v in b[2].values())
+        for k in a[2]:
+            assert abs(a[2][k] - b[2][k]) <= 1e-5 * abs(b[2][k]) + 1e-6 * gmax, (i, k, a[2][k], b[2][k])      # (gradient norms)
+    assert torch.equal(res[True][1], res[False][1])
