@@ -18,6 +18,43 @@ def _free_port():
     return p
 
 
+def _run_world(worker, world, attempts=3):
+    """Start `world` gloo ranks and collect one queue item per rank.  A rendezvous that fails for reasons outside
+    the code under test (the probed port taken again before rank 0 binds it) is retried on a fresh port; the
+    numerical assertions of the callers are never retried."""
+    import queue as _queue
+    ctx = mp.get_context('spawn')
+    last = None
+    for _ in range(attempts):
+        port = _free_port()
+        q = ctx.Queue()
+        procs = [ctx.Process(target=worker, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = []
+        try:
+            while len(res) < world:
+                try:
+                    res.append(q.get(timeout=2))
+                except _queue.Empty:
+                    if any(p.exitcode not in (None, 0) for p in procs):
+                        raise RuntimeError('a rank died: exit codes %s' % [p.exitcode for p in procs])
+            for p in procs:
+                p.join(timeout=60)
+            codes = [p.exitcode for p in procs]
+            if all(c == 0 for c in codes):
+                return res
+            last = RuntimeError('exit codes %s' % codes)
+        except RuntimeError as e:
+            last = e
+        finally:
+            for p in procs:
+                if p.is_alive():
+                    p.terminate()
+                p.join(timeout=10)
+    raise last
+
+
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -40,16 +77,7 @@ def _worker(rank, world, port, q):
 
 def test_sharded_mmd_and_grad_allreduce_match_single_process():
     world = 2
-    port = _free_port()
-    ctx = mp.get_context('spawn')
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    res = sorted(_run_world(_worker, world), key=lambda t: t[0])
     # single-process reference on the global batch
     torch.manual_seed(0)
     m, D = 6, 16
@@ -92,16 +120,7 @@ def test_packed_gather_equals_separate_gathers():
     """gather_rows_packed (one collective per step for the three MMD terms) returns the tensors and
     the gradients of one gather_rows_ddp per tensor."""
     world = 2
-    port = _free_port()
-    ctx = mp.get_context('spawn')
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_worker_packed, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=120) for _ in range(world)]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    res = _run_world(_worker_packed, world)
     assert all(ok for _, ok in res), res
 
 
@@ -138,16 +157,7 @@ def test_grad_reducer_overlapped_buckets_match_plain_average():
     cross-rank average in every .grad, through its learning step, overlapped steps and a change of
     the set of parameters that receive gradients."""
     world = 2
-    port = _free_port()
-    ctx = mp.get_context('spawn')
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_worker_reducer, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = dict(q.get(timeout=120) for _ in range(world))
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    res = dict(_run_world(_worker_reducer, world))
     # reference: both ranks' local gradients computed here, averaged
     torch.manual_seed(0)
     enc, head, extra, unused = torch.nn.Linear(8, 8), torch.nn.Linear(8, 4), torch.nn.Linear(8, 4), torch.nn.Linear(3, 3)
