@@ -44,8 +44,8 @@ extern "C" {
 
 const char* sug_last_error(void);
 /* ABI version of the loaded library (bumped when a signature changes; 3: sug_adam_step_capturable gained lr_dev,
- * round-3 entry points; 4: sug_chamfer / sug_node_offset_bwd became reproducible -- sug_chamfer takes a workspace; 5: sug_ce_pair_* take ignore_index, lse has 2M + 1 entries; sug_pointmlp_max_layer_fwd_xf and sug_col_stats_bn_grouped added; 6: sug_ptran_fused_fwd / sug_ptran_fused_supported added, sug_group_max_bwd fails instead of changing its summation order when the LDS opt-in is refused).  A binding checks sug_abi_version() == SUG_ABI_VERSION of the header it was written against. */
-#define SUG_ABI_VERSION 6
+ * round-3 entry points; 4: sug_chamfer / sug_node_offset_bwd became reproducible -- sug_chamfer takes a workspace; 5: sug_ce_pair_* take ignore_index, lse has 2M + 1 entries; sug_pointmlp_max_layer_fwd_xf and sug_col_stats_bn_grouped added; 6: sug_ptran_fused_fwd / sug_ptran_fused_supported added, sug_group_max_bwd fails instead of changing its summation order when the LDS opt-in is refused; 7: sug_adam_chain_step, sug_edge_weight_split_multi and sug_soft_mmd_multi_fwd / _bwd added).  A binding checks sug_abi_version() == SUG_ABI_VERSION of the header it was written against. */
+#define SUG_ABI_VERSION 7
 int sug_abi_version(void);
 
 /* ---- kNN graph ----------------------------------------------------------
@@ -343,6 +343,28 @@ int sug_adam_step_capturable(const int64_t* table, const int32_t* block_first, c
                              int T, const void* const* grads_host, double lr, double beta1, double beta2,
                              double eps, double weight_decay, int32_t* step_dev, float* scalars_dev,
                              const double* lr_dev, void* stream);
+
+/* The three optimizer steps of train_dg_single_gpu.py:333-335 in ONE update launch.  optimizer_dis and optimizer_g both
+ * own the encoder's parameters (:193-203), so a tensor carries an ordered list of up to SUG_ADAM_CHAIN_SLOTS
+ * (exp_avg, exp_avg_sq, bucket) slots; the updates of a tensor are applied one after the other on the value held in
+ * registers, each with exactly sug_adam_step's arithmetic: bit-identical to stepping the optimizers in that order, with
+ * the parameter and its gradient read and written once.  A bucket = one set of hyper-parameters + one step count
+ * (at most SUG_ADAM_CHAIN_BUCKETS).
+ * table: device int64 [T,8] = {param, numel, exp_avg0, exp_avg_sq0, exp_avg1, exp_avg_sq1,
+ *        nslots | bucket0 << 8 | bucket1 << 16, 0};  block_map: device int32 [blocks,2] = (tensor, chunk) per workgroup of
+ *        sug_adam_chain_chunk() elements, tensors in table order;  block_first_host: HOST int32 [T+1] prefix sum of the
+ *        tensors' workgroup counts;  grads_host: HOST array of T device pointers (null = skipped);
+ * hyper_host: HOST double [nbuckets,6] = {lr, beta1, beta2, eps, weight_decay, t} with t the step count the update
+ *        belongs to (1-based; read only when steps_dev is null);
+ * steps_dev / scalars_dev (both or neither): device int32 [nbuckets] advanced by the call and float [nbuckets,2] scratch,
+ *        for replay from a hipGraph (as sug_adam_step_capturable); lr_dev (may be null): device double [nbuckets]
+ *        overriding hyper_host's lr. */
+#define SUG_ADAM_CHAIN_SLOTS 2
+#define SUG_ADAM_CHAIN_BUCKETS 8
+int sug_adam_chain_chunk(void);
+int sug_adam_chain_step(const int64_t* table, const int32_t* block_map, const int32_t* block_first_host, int T,
+                        const void* const* grads_host, int nbuckets, const double* hyper_host, int32_t* steps_dev,
+                        float* scalars_dev, const double* lr_dev, void* stream);
 
 /* ---- SA-node module glue (adapt_layer_off, model/model_utils.py:103-128) --------------------
  * off[b,s,:] = mean_j tanh(proj[b,g_j,:] - proj[b,f,:]) * (loc[b,g_j,:] - loc[b,f,:]),
@@ -656,10 +678,30 @@ int sug_sda_prob_weights(const float* pred_s, int64_t lds, const float* pred_t, 
 int sug_mmd_assemble(const float* feat_s, int64_t lds, const float* feat_t, int64_t ldt, const int64_t* label_s,
                      const int64_t* label_t, int m, int D, int num_class, float label_scale, float* z, void* stream);
 
+/* Up to 4 soft-MMD terms of ONE batch (same m samples per domain, same labels; a SUG step has three:
+ * train_dg_single_gpu.py:300-322 -> mmd_cal -> soft_mmd, model/mmd.py:25-41, :56-66) with one launch per stage instead of
+ * one per stage and term: assemble (sug_mmd_assemble; it also clears sums), kernel sums + derivative weights
+ * (sug_mmd_rbf: each term through the kernel that call would choose), the n values; backward: sug_mmd_rbf_bwd of every
+ * term in one launch.  Per-term results are bit-identical to the single-term calls.  HOST arrays of n entries:
+ * feat_s / feat_t [m, D[i]] (row strides lds / ldt), label_scale, w (device [m] or null), z (device [2m, D[i] + num_class],
+ * written), wt (device [2m, 2m] written, or null: no backward).  sums: device double [3n] scratch; values: device float [n].
+ * Backward: gscale[i] = device scalar (upstream gradient of value i) or null (term skipped), dz[i] device
+ * [2m, D[i] + num_class] written entirely. */
+int sug_soft_mmd_multi_fwd(int n, const void* const* feat_s, const int64_t* lds, const void* const* feat_t,
+                           const int64_t* ldt, const int32_t* D, const float* label_scale, const int64_t* label_s,
+                           const int64_t* label_t, int m, int num_class, const void* const* w, const float* neg_gamma,
+                           int nsigma, void* const* z, void* const* wt, double* sums, float* values, void* stream);
+int sug_soft_mmd_multi_bwd(int n, const void* const* z, const int32_t* D, const void* const* wt,
+                           const void* const* gscale, int m, int num_class, void* const* dz, void* stream);
+
 /* The EdgeConv GEMM operand of a conv_2d weight W [Co, 2C] (get_graph_feature's cat(x_j - x_i, x_i) folded into
  * the weights, model/model_utils.py:188-210): backward = 0: in = W, out [2Co, C] = [W[:, :C] ; W[:, C:] - W[:, :C]];
  * backward = 1: in = d out [2Co, C], out = dW [Co, 2C]. */
 int sug_edge_weight_split(const float* in, int Co, int C, int backward, float* out, void* stream);
+/* The same for n <= 8 weights in ONE launch (the four EdgeConv layers of Model.py:54-121): HOST arrays of n device
+ * pointers and shapes; an entry whose in or out pointer is null is skipped (a layer without a gradient). */
+int sug_edge_weight_split_multi(const void* const* in_host, const int32_t* Co_host, const int32_t* C_host, int n,
+                                int backward, void* const* out_host, void* stream);
 
 /* Chamfer distance per cloud pair (SDA geometric weights; geometric_weights(),
  * model/mmd.py:107-131 -- third-party op in the reference, parity unpinned):

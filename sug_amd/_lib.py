@@ -77,9 +77,13 @@ SIGNATURES = {
     'sug_gate_bwd': [_vp, _vp, _vp, _i64, _vp, _vp, _vp],
     'sug_mmd_assemble': [_vp, _i64, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp],
     'sug_edge_weight_split': [_vp, _i32, _i32, _i32, _vp, _vp],
+    'sug_edge_weight_split_multi': [_vp, _vp, _vp, _i32, _i32, _vp, _vp],
+    'sug_soft_mmd_multi_fwd': [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
+    'sug_soft_mmd_multi_bwd': [_i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp],
     'sug_sda_prob_weights': [_vp, _i64, _vp, _i64, _vp, _vp, _i32, _i32, _f32, _i32, _vp, _vp],
     'sug_adam_step': [_vp, _vp, _vp, _i32, _vp, _f64, _f64, _f64, _f64, _f64, _f64, _f64, _vp],
     'sug_adam_step_capturable': [_vp, _vp, _vp, _i32, _vp, _f64, _f64, _f64, _f64, _f64, _vp, _vp, _vp, _vp],
+    'sug_adam_chain_step': [_vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
     'sug_linear_dw': [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp],
     'sug_linear_dw_fold': [_vp, _i32, _i64, _vp, _vp],
     'sug_sa_first_fwd': [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -160,11 +164,13 @@ def lib():
         L.sug_chamfer_workspace.argtypes = [_i32, _i32, _i32]
         L.sug_adam_chunk.restype = ctypes.c_int
         L.sug_adam_chunk.argtypes = []
+        L.sug_adam_chain_chunk.restype = ctypes.c_int
+        L.sug_adam_chain_chunk.argtypes = []
         L.sug_last_error.restype = ctypes.c_char_p
         L.sug_last_error.argtypes = []
         L.sug_abi_version.restype = ctypes.c_int
         L.sug_abi_version.argtypes = []
-        if L.sug_abi_version() != 6:
+        if L.sug_abi_version() != 7:
             raise RuntimeError('sug_amd: ABI version mismatch, rebuild libsug_amd.so')
         _lib = L
     return _lib

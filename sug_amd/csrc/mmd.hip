@@ -59,17 +59,17 @@ __device__ __forceinline__ void pair_epilogue(int li, int i, int j, int m, float
   }
 }
 
-__global__ __launch_bounds__(256) void mmd_rbf_kernel(const float* __restrict__ z, int64_t ldz, int m,
-                                                      int D, const float* __restrict__ w,
-                                                      const float* __restrict__ neg_gamma, int ns, int row0, int mloc,
-                                                      double* __restrict__ sums,
-                                                      float* __restrict__ wt) {
+__device__ __forceinline__ void mmd_rbf_body(const int bx, const int by, const float* __restrict__ z, int64_t ldz, int m,
+                                             int D, const float* __restrict__ w,
+                                             const float* __restrict__ neg_gamma, int ns, int row0, int mloc,
+                                             double* __restrict__ sums,
+                                             float* __restrict__ wt) {
   __shared__ float s_a[TI][DK + 1];
   __shared__ float s_b[TI][DK + 1];
   __shared__ double s_sum[256 / WAVE][3];          // per-wave partial sums, combined in wave order
   const int M2 = 2 * m;
   const int ti = threadIdx.x / TI, tj = threadIdx.x % TI;
-  const int i0 = blockIdx.y * TI, j0 = blockIdx.x * TI;        // i0: LOCAL row of the tile
+  const int i0 = by * TI, j0 = bx * TI;                        // i0: LOCAL row of the tile
   const int li = i0 + ti, j = j0 + tj;
   const int ML = 2 * mloc;
   const int i = li < ML ? global_row(li, m, row0, mloc) : M2;
@@ -113,15 +113,15 @@ __global__ __launch_bounds__(256) void mmd_rbf_kernel(const float* __restrict__ 
 // lanes of a pair split D (stride 16, straight from global / L2) and their partial chains are
 // combined by a fixed xor tree -- for i == j the three partial chains are identical lane by lane,
 // so e_ii is still exactly 0.  (2m/4)^2 workgroups instead of (2m/16)^2.
-__global__ __launch_bounds__(256) void mmd_rbf_small_kernel(const float* __restrict__ z, int64_t ldz, int m,
-                                                            int D, const float* __restrict__ w,
-                                                            const float* __restrict__ neg_gamma, int ns, int row0,
-                                                            int mloc, double* __restrict__ sums,
-                                                            float* __restrict__ wt) {
+__device__ __forceinline__ void mmd_rbf_small_body(const int bx, const int by, const float* __restrict__ z, int64_t ldz,
+                                                   int m, int D, const float* __restrict__ w,
+                                                   const float* __restrict__ neg_gamma, int ns, int row0,
+                                                   int mloc, double* __restrict__ sums,
+                                                   float* __restrict__ wt) {
   __shared__ double s_sum[256 / WAVE][3];          // per-wave partial sums, combined in wave order
   const int M2 = 2 * m;
   const int l16 = threadIdx.x & 15, pr = threadIdx.x >> 4;
-  const int li = blockIdx.y * 4 + (pr >> 2), j = blockIdx.x * 4 + (pr & 3);
+  const int li = by * 4 + (pr >> 2), j = bx * 4 + (pr & 3);
   const int i = li < 2 * mloc ? global_row(li, m, row0, mloc) : M2;
   __syncthreads();
   float g = 0.f, ni = 0.f, nj = 0.f;
@@ -169,6 +169,66 @@ __global__ __launch_bounds__(256) void mmd_rbf_small_kernel(const float* __restr
   // -munsafe-fp-atomics: hundreds of workgroups on three addresses)
   if (threadIdx.x < 3)
     unsafeAtomicAdd(&sums[threadIdx.x], ((s_sum[0][threadIdx.x] + s_sum[1][threadIdx.x]) + s_sum[2][threadIdx.x]) + s_sum[3][threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void mmd_rbf_kernel(const float* __restrict__ z, int64_t ldz, int m, int D,
+                                                      const float* __restrict__ w, const float* __restrict__ neg_gamma,
+                                                      int ns, int row0, int mloc, double* __restrict__ sums,
+                                                      float* __restrict__ wt) {
+  mmd_rbf_body(blockIdx.x, blockIdx.y, z, ldz, m, D, w, neg_gamma, ns, row0, mloc, sums, wt);
+}
+__global__ __launch_bounds__(256) void mmd_rbf_small_kernel(const float* __restrict__ z, int64_t ldz, int m, int D,
+                                                            const float* __restrict__ w, const float* __restrict__ neg_gamma,
+                                                            int ns, int row0, int mloc, double* __restrict__ sums,
+                                                            float* __restrict__ wt) {
+  mmd_rbf_small_body(blockIdx.x, blockIdx.y, z, ldz, m, D, w, neg_gamma, ns, row0, mloc, sums, wt);
+}
+
+// ---- several soft-MMD terms of one batch in one launch per stage (sug_soft_mmd_multi_*): a SUG step evaluates three
+// (node features, two heads' semantic features: train_dg_single_gpu.py:300-322) on the same m samples and labels; each
+// stage is a latency-bound launch of a few workgroups, so the three of a stage run side by side as blockIdx.z.
+#define SUG_MMD_MULTI 4
+struct MmdTerm {
+  const float* fs; const float* ft; int64_t lds, ldt;      // features [m, D] of the two domains
+  float* z; int D;                                           // assembled operand [2m, D + ncls] (row stride D + ncls)
+  float scale;                                               // label weight
+  const float* w; float* wt;                                 // SDA weights [m] or null; derivative weights [2m, 2m] or null
+  const float* gscale; float* dz;                            // backward: upstream gradient (device scalar), dZ [2m, D + ncls]
+  int small;
+};
+struct MmdMulti {
+  MmdTerm t[SUG_MMD_MULTI];
+};
+
+__global__ __launch_bounds__(256) void mmd_assemble_multi_kernel(MmdMulti a, int n, const int64_t* __restrict__ ls,
+                                                                 const int64_t* __restrict__ lt, int m, int ncls,
+                                                                 double* __restrict__ sums) {
+  if (blockIdx.x == 0 && blockIdx.y == 0 && (int)threadIdx.x < 3 * n) sums[threadIdx.x] = 0.0;   // the rbf launch follows in stream order
+  const MmdTerm& t = a.t[blockIdx.y];
+  const int row = blockIdx.x, D = t.D;
+  const float* src = row < m ? t.fs + (int64_t)row * t.lds : t.ft + (int64_t)(row - m) * t.ldt;
+  const int64_t lab = row < m ? ls[row] : lt[row - m];
+  float* dst = t.z + (int64_t)row * (D + ncls);
+  for (int c = threadIdx.x; c < D; c += 256) dst[c] = src[c];
+  for (int c = threadIdx.x; c < ncls; c += 256) dst[D + c] = (c == lab) ? t.scale : 0.f;
+}
+
+__global__ __launch_bounds__(256) void mmd_rbf_multi_kernel(MmdMulti a, int m, int ncls, const float* __restrict__ neg_gamma, int ns,
+                                                            double* __restrict__ sums) {
+  const MmdTerm& t = a.t[blockIdx.z];
+  const int Dz = t.D + ncls;
+  if (t.small) {
+    mmd_rbf_small_body(blockIdx.x, blockIdx.y, t.z, Dz, m, Dz, t.w, neg_gamma, ns, 0, m, sums + 3 * blockIdx.z, t.wt);
+  } else {
+    const int nb = (2 * m + TI - 1) / TI;                    // the launch is sized for the 4 x 4 tiles of the small form
+    if ((int)blockIdx.x >= nb || (int)blockIdx.y >= nb) return;
+    mmd_rbf_body(blockIdx.x, blockIdx.y, t.z, Dz, m, Dz, t.w, neg_gamma, ns, 0, m, sums + 3 * blockIdx.z, t.wt);
+  }
+}
+
+__global__ void mmd_value_multi_kernel(const double* __restrict__ sums, int n, double mm, float* __restrict__ out) {
+  const int i = threadIdx.x;
+  if (i < n) out[i] = (float)((sums[3 * i] + sums[3 * i + 1] - 2.0 * sums[3 * i + 2]) / mm);
 }
 
 // part[b][blockIdx.x] = sum over this workgroup's points i of min_j |a_i - b_j|^2   (one direction; called twice, then
@@ -234,16 +294,16 @@ __global__ __launch_bounds__(256) void chamfer_fold_kernel(const float* __restri
 // row i, see global_row) over all 2m columns j: workgroup = (64 columns of D) x 4 row groups; the Z
 // column panel goes through LDS in chunks of JT rows, wt rows are broadcast reads.
 constexpr int JT = 128;
-__global__ __launch_bounds__(256) void mmd_bwd_kernel(const float* __restrict__ z, int64_t ldz,
-                                                      const float* __restrict__ wt, int m, int D, int row0, int mloc,
-                                                      const float* __restrict__ gscale, float gmul,
-                                                      float* __restrict__ dz, int64_t lddz) {
+__device__ __forceinline__ void mmd_bwd_body(const int bx, const int by, const float* __restrict__ z, int64_t ldz,
+                                             const float* __restrict__ wt, int m, int D, int row0, int mloc,
+                                             const float* __restrict__ gscale, float gmul,
+                                             float* __restrict__ dz, int64_t lddz) {
   __shared__ float s_z[JT * 64];
   __shared__ __attribute__((aligned(16))) float s_w[JT * 32];       // wt panel, [j][local row]: a row group's 8 weights = 2 x b128
   const int M2 = 2 * m, ML = 2 * mloc;
   const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
-  const int d = blockIdx.x * 64 + c;
-  const int li0 = blockIdx.y * 32;                          // 32 local rows per workgroup, 8 per row group
+  const int d = bx * 64 + c;
+  const int li0 = by * 32;                          // 32 local rows per workgroup, 8 per row group
   float rs[8], acc[8];
 #pragma unroll
   for (int u = 0; u < 8; ++u) { rs[u] = 0.f; acc[u] = 0.f; }
@@ -281,6 +341,19 @@ __global__ __launch_bounds__(256) void mmd_bwd_kernel(const float* __restrict__ 
     const int i = global_row(li, m, row0, mloc);
     dz[(int64_t)li * lddz + d] = g2 * (rs[u] * z[(int64_t)i * ldz + d] - acc[u]);
   }
+}
+
+__global__ __launch_bounds__(256) void mmd_bwd_kernel(const float* __restrict__ z, int64_t ldz,
+                                                      const float* __restrict__ wt, int m, int D, int row0, int mloc,
+                                                      const float* __restrict__ gscale, float gmul,
+                                                      float* __restrict__ dz, int64_t lddz) {
+  mmd_bwd_body(blockIdx.x, blockIdx.y, z, ldz, wt, m, D, row0, mloc, gscale, gmul, dz, lddz);
+}
+__global__ __launch_bounds__(256) void mmd_bwd_multi_kernel(MmdMulti a, int m, int ncls) {
+  const MmdTerm& t = a.t[blockIdx.z];
+  const int Dz = t.D + ncls;
+  if ((int)blockIdx.x * 64 >= Dz) return;                    // the launch is sized for the widest term
+  mmd_bwd_body(blockIdx.x, blockIdx.y, t.z, Dz, t.wt, m, Dz, 0, m, t.gscale, 1.0f, t.dz, Dz);
 }
 
 // SDA sample weights from class probabilities (prob_weights_soft + distance2weights,
@@ -479,6 +552,30 @@ __global__ __launch_bounds__(256) void split_weight_kernel(const float* __restri
   }
 }
 
+// the same for up to SUG_SPLIT_MULTI weights in one launch (the four EdgeConv layers of the DGCNN encoder)
+#define SUG_SPLIT_MULTI 8
+struct SplitMultiArgs {
+  const float* in[SUG_SPLIT_MULTI];
+  float* out[SUG_SPLIT_MULTI];
+  int Co[SUG_SPLIT_MULTI], C[SUG_SPLIT_MULTI], first[SUG_SPLIT_MULTI + 1];
+};
+__global__ __launch_bounds__(256) void split_weight_multi_kernel(SplitMultiArgs a, int n, int backward) {
+  int t = 0;
+  while (t + 1 < n && (int)blockIdx.x >= a.first[t + 1]) ++t;
+  const float* __restrict__ in = a.in[t];
+  float* __restrict__ out = a.out[t];
+  const int Co = a.Co[t], C = a.C[t];
+  const int e = (blockIdx.x - a.first[t]) * 256 + threadIdx.x;
+  if (e >= 2 * Co * C) return;
+  if (!backward) {
+    const int r = e / C, c = e - r * C;
+    out[e] = r < Co ? in[(int64_t)r * 2 * C + c] : in[(int64_t)(r - Co) * 2 * C + C + c] - in[(int64_t)(r - Co) * 2 * C + c];
+  } else {
+    const int r = e / (2 * C), c = e - r * 2 * C;
+    out[e] = c < C ? in[(int64_t)r * C + c] - in[(int64_t)(Co + r) * C + c] : in[(int64_t)(Co + r) * C + c - C];
+  }
+}
+
 }  // namespace
 
 extern "C" int sug_mmd_assemble(const float* feat_s, int64_t lds, const float* feat_t, int64_t ldt, const int64_t* label_s,
@@ -498,5 +595,102 @@ extern "C" int sug_edge_weight_split(const float* in, int Co, int C, int backwar
   hipLaunchKernelGGL(split_weight_kernel, dim3(sug_divup(2 * Co * C, 256)), dim3(256), 0, (hipStream_t)stream, in, Co, C,
                      backward, out);
   SUG_LAUNCH_CHECK("sug_edge_weight_split");
+  return SUG_OK;
+}
+
+extern "C" int sug_edge_weight_split_multi(const void* const* in_host, const int32_t* Co_host, const int32_t* C_host, int n,
+                                           int backward, void* const* out_host, void* stream) {
+  SUG_REQUIRE(in_host && Co_host && C_host && out_host, "sug_edge_weight_split_multi: null pointer");
+  SUG_REQUIRE(n > 0 && n <= SUG_SPLIT_MULTI, "sug_edge_weight_split_multi: %d weights (1..%d)", n, SUG_SPLIT_MULTI);
+  SplitMultiArgs a;
+  int m = 0;
+  a.first[0] = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!in_host[i] || !out_host[i]) continue;                       // a weight without a gradient: skipped
+    SUG_REQUIRE(Co_host[i] > 0 && C_host[i] > 0 && (int64_t)Co_host[i] * C_host[i] < (1 << 26),
+                "sug_edge_weight_split_multi: bad shape of weight %d", i);
+    a.in[m] = (const float*)in_host[i];
+    a.out[m] = (float*)out_host[i];
+    a.Co[m] = Co_host[i];
+    a.C[m] = C_host[i];
+    a.first[m + 1] = a.first[m] + sug_divup(2 * Co_host[i] * C_host[i], 256);
+    ++m;
+  }
+  if (m == 0) return SUG_OK;
+  for (int i = m; i < SUG_SPLIT_MULTI; ++i) {
+    a.in[i] = nullptr;
+    a.out[i] = nullptr;
+    a.Co[i] = a.C[i] = 0;
+    a.first[i + 1] = a.first[m];
+  }
+  hipLaunchKernelGGL(split_weight_multi_kernel, dim3(a.first[m]), dim3(256), 0, (hipStream_t)stream, a, m, backward);
+  SUG_LAUNCH_CHECK("sug_edge_weight_split_multi");
+  return SUG_OK;
+}
+
+extern "C" int sug_soft_mmd_multi_fwd(int n, const void* const* feat_s, const int64_t* lds, const void* const* feat_t,
+                                      const int64_t* ldt, const int32_t* D, const float* label_scale, const int64_t* label_s,
+                                      const int64_t* label_t, int m, int num_class, const void* const* w,
+                                      const float* neg_gamma, int nsigma, void* const* z, void* const* wt, double* sums,
+                                      float* values, void* stream) {
+  SUG_REQUIRE(feat_s && lds && feat_t && ldt && D && label_scale && label_s && label_t && w && neg_gamma && z && wt && sums &&
+              values, "sug_soft_mmd_multi_fwd: null pointer");
+  SUG_REQUIRE(n >= 1 && n <= SUG_MMD_MULTI, "sug_soft_mmd_multi_fwd: %d terms (1..%d)", n, SUG_MMD_MULTI);
+  SUG_REQUIRE(m > 0 && m <= 16384 && num_class > 0 && num_class <= 256, "sug_soft_mmd_multi_fwd: bad shape m=%d classes=%d", m, num_class);
+  SUG_REQUIRE(nsigma >= 1 && nsigma <= 8, "sug_soft_mmd_multi_fwd: nsigma=%d", nsigma);
+  hipStream_t st = (hipStream_t)stream;
+  MmdMulti a;
+  bool any_small = false, any_big = false;
+  for (int i = 0; i < SUG_MMD_MULTI; ++i) {
+    const int k = i < n ? i : 0;
+    SUG_REQUIRE(feat_s[k] && feat_t[k] && z[k], "sug_soft_mmd_multi_fwd: null operand of term %d", k);
+    SUG_REQUIRE(D[k] > 0 && lds[k] >= D[k] && ldt[k] >= D[k], "sug_soft_mmd_multi_fwd: bad shape of term %d", k);
+    MmdTerm& t = a.t[i];
+    t.fs = (const float*)feat_s[k];
+    t.ft = (const float*)feat_t[k];
+    t.lds = lds[k];
+    t.ldt = ldt[k];
+    t.z = (float*)z[k];
+    t.D = D[k];
+    t.scale = label_scale[k];
+    t.w = (const float*)w[k];
+    t.wt = (float*)wt[k];
+    t.gscale = nullptr;
+    t.dz = nullptr;
+    t.small = (2 * m <= 128 && D[k] + num_class >= 256) ? 1 : 0;         // sug_mmd_rbf_rows' own choice
+    if (i < n) (t.small ? any_small : any_big) = true;
+  }
+  hipLaunchKernelGGL(mmd_assemble_multi_kernel, dim3(2 * m, n), dim3(256), 0, st, a, n, label_s, label_t, m, num_class, sums);
+  const int nb = any_small ? sug_divup(2 * m, 4) : sug_divup(2 * m, TI);
+  (void)any_big;
+  hipLaunchKernelGGL(mmd_rbf_multi_kernel, dim3(nb, nb, n), dim3(256), 0, st, a, m, num_class, neg_gamma, nsigma, sums);
+  hipLaunchKernelGGL(mmd_value_multi_kernel, dim3(1), dim3(64), 0, st, sums, n, (double)m * (double)m, values);
+  SUG_LAUNCH_CHECK("sug_soft_mmd_multi_fwd");
+  return SUG_OK;
+}
+
+extern "C" int sug_soft_mmd_multi_bwd(int n, const void* const* z, const int32_t* D, const void* const* wt,
+                                      const void* const* gscale, int m, int num_class, void* const* dz, void* stream) {
+  SUG_REQUIRE(z && D && wt && gscale && dz, "sug_soft_mmd_multi_bwd: null pointer");
+  SUG_REQUIRE(n >= 1 && n <= SUG_MMD_MULTI && m > 0 && num_class > 0, "sug_soft_mmd_multi_bwd: bad arguments");
+  MmdMulti a;
+  int na = 0, dmax = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!gscale[i] || !dz[i]) continue;                                   // a term without an upstream gradient: skipped
+    SUG_REQUIRE(z[i] && wt[i] && D[i] > 0, "sug_soft_mmd_multi_bwd: null operand of term %d", i);
+    MmdTerm& t = a.t[na++];
+    t = MmdTerm{};
+    t.z = (float*)z[i];
+    t.D = D[i];
+    t.wt = (float*)wt[i];
+    t.gscale = (const float*)gscale[i];
+    t.dz = (float*)dz[i];
+    if (D[i] + num_class > dmax) dmax = D[i] + num_class;
+  }
+  if (na == 0) return SUG_OK;
+  for (int i = na; i < SUG_MMD_MULTI; ++i) a.t[i] = a.t[0];
+  hipLaunchKernelGGL(mmd_bwd_multi_kernel, dim3(sug_divup(dmax, 64), sug_divup(2 * m, 32), na), dim3(256), 0,
+                     (hipStream_t)stream, a, m, num_class);
+  SUG_LAUNCH_CHECK("sug_soft_mmd_multi_bwd");
   return SUG_OK;
 }

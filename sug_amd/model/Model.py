@@ -14,7 +14,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
-from .model_utils import conv_2d, fc_layer, transform_net, adapt_layer_off, _bn_rows, bn_module
+from .model_utils import conv_2d, fc_layer, transform_net, adapt_layer_off, _bn_rows, bn_module, edge_wcats
 from .pointnet2_utils import PointNetSetAbstraction
 from . import PTran_utils
 from .Ptran_transformer import TransformerBlock
@@ -188,12 +188,12 @@ class DGCNN(nn.Module, _PrefixSharing):
     def _prefix_params(self):
         return [p for m in (self.conv1, self.conv2) for p in m.parameters()]
 
-    def _prefix(self, x, loc, nb, out1=None):
+    def _prefix(self, x, loc, nb, out1=None, wc=(None, None)):
         """kNN + conv1, kNN + conv2.  out1: where conv1's activations should be written (a column
         slice of the conv5 input buffer); a cache hit returns the tensors of the earlier pass instead."""
         if not _sharing_on(self.share_prefix, self.training):
-            x1 = self.conv1.edge_rows(loc, nb(loc, 0), out=out1)
-            return x1, self.conv2.edge_rows(x1, nb(x1, 1))
+            x1 = self.conv1.edge_rows(loc, nb(loc, 0), out=out1, wcat=wc[0])
+            return x1, self.conv2.edge_rows(x1, nb(x1, 1), wcat=wc[1])
         key = self._prefix_key(x)
         hit = self._prefix_cache.get(key)
         if hit is not None and hit.serves(x):
@@ -202,8 +202,8 @@ class DGCNN(nn.Module, _PrefixSharing):
             self.conv1.replay_bn_update(st1)
             self.conv2.replay_bn_update(st2)
             return x1, x2
-        x1, st1 = self.conv1.edge_rows(loc, nb(loc, 0), return_stats=True, out=out1)
-        x2, st2 = self.conv2.edge_rows(x1, nb(x1, 1), return_stats=True)
+        x1, st1 = self.conv1.edge_rows(loc, nb(loc, 0), return_stats=True, out=out1, wcat=wc[0])
+        x2, st2 = self.conv2.edge_rows(x1, nb(x1, 1), return_stats=True, wcat=wc[1])
         self._prune_prefix_cache()                  # a step has two inputs; never grow unbounded
         self._prefix_cache[key] = _PrefixEntry((x1, x2), (st1, st2), source=x)
         return x1, x2
@@ -226,12 +226,14 @@ class DGCNN(nn.Module, _PrefixSharing):
         # conv5 consumes cat(x1, x2, x3, x4): the EdgeConv layers write their activations straight
         # into the column slices of that [B,N,512] buffer instead of concatenating afterwards
         cat_in = torch.empty(B, N, 512, dtype=torch.float32, device=x.device)
-        x1, x2 = self._prefix(x, loc, nb, out1=cat_in[:, :, 0:64])   # [B,N,64], [B,N,64]
+        # the [W1 ; W2-W1] operands of the four EdgeConv layers in one launch (one more in the backward)
+        wc = edge_wcats((self.conv1, self.conv2, self.conv3, self.conv4))
+        x1, x2 = self._prefix(x, loc, nb, out1=cat_in[:, :, 0:64], wc=wc[:2])   # [B,N,64], [B,N,64]
         x_, node_fea, _ = self.node_fea_adapt.rows(x2, loc)           # [B,N,128], [B,64,64]
         with torch.set_grad_enabled(torch.is_grad_enabled() and feat_grad):
             x2 = ops.linear_rows(x_, self.conv1d.weight.squeeze(-1), self.conv1d.bias)
-            x3 = self.conv3.edge_rows(x2, nb(x2, 2), out=cat_in[:, :, 128:256])     # [B,N,128]
-            x4 = self.conv4.edge_rows(x3, nb(x3, 3), out=cat_in[:, :, 256:512])     # [B,N,256]
+            x3 = self.conv3.edge_rows(x2, nb(x2, 2), out=cat_in[:, :, 128:256], wcat=wc[2])     # [B,N,128]
+            x4 = self.conv4.edge_rows(x3, nb(x3, 3), out=cat_in[:, :, 256:512], wcat=wc[3])     # [B,N,256]
             x5 = ops.linear_rows(ops.assemble_rows(cat_in, (x1, x2, x3, x4)), self.conv5.weight.squeeze(-1))
             if feat_grad:
                 # bn5 -> leaky_relu(0.2) -> adaptive max | avg pool (Model.py:113-116), fused

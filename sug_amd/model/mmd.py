@@ -60,6 +60,21 @@ def soft_mmd(label_s, feat_s, label_t, feat_t, label_weight, sample_weights=None
     return ops.mix_rbf_mmd2_rows(Z, m, sample_weights, sigma_list)
 
 
+def soft_mmd_multi(label_s, label_t, terms):
+    """[mmd_cal(label_s, feat_s, label_t, feat_t, args, data_s, data_t) for (feat_s, feat_t, args, data_s, data_t) in terms]
+    for SOFT_MMD terms of one batch (model/mmd.py:25-41, :56-66; the three terms of train_dg_single_gpu.py:300-322): the
+    SDA weights per term as mmd_cal forms them, then every stage of the terms in one launch (ops.soft_mmd_multi)."""
+    packed = []
+    for feat_s, feat_t, args, data_s, data_t in terms:
+        if args["NAME"] != "SOFT_MMD":
+            raise RuntimeError("soft_mmd_multi: SOFT_MMD terms only")
+        w = None
+        if data_s is not None and (args.get("GEO_WEIGHTS", None) or args.get("SEM_WEIGHTS", None)):
+            w = cal_sample_weights(data_s, data_t, args, label_s=label_s, label_t=label_t)
+        packed.append((feat_s, feat_t, float(args["LABEL_SCALE"]), w))
+    return ops.soft_mmd_multi(label_s, label_t, packed, sigma_list)
+
+
 def soft_mmd_sharded(label_s, feat_s, label_t, feat_t, label_g, feat_g_s, label_tg, feat_g_t, label_weight, row0,
                      sample_weights=None, world=1):
     """soft_mmd of the GLOBAL batch from a rank's shard: feat_s / feat_t [mloc, D] are this

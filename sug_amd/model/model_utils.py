@@ -43,6 +43,26 @@ def _bn_rows(bn, y):
     return y2.view(shp)
 
 
+def edge_wcats(layers):
+    """The EdgeConv GEMM operands [W1 ; W2-W1] of conv_2d `layers`: a layer's cached split where it keeps one for the
+    step (cache_weight_split: same weights, same step -- a graph-attached copy also serves no_grad), all the others in
+    ONE launch forward and one backward (ops.edge_weight_split_multi) instead of one per layer."""
+    grad = torch.is_grad_enabled()
+    out, miss = [None] * len(layers), []
+    for i, l in enumerate(layers):
+        W = l.weight2d()
+        hit = l._wcat if l.cache_weight_split else None
+        if hit is not None and hit[0] == W._version and (hit[1] or not grad):
+            out[i] = hit[2]
+        else:
+            miss.append((i, l, W))
+    if miss:
+        for (i, l, W), wc in zip(miss, ops.edge_weight_split_multi([W for _, _, W in miss])):
+            out[i] = wc
+            l._wcat = (W._version, grad, wc) if l.cache_weight_split else None
+    return out
+
+
 class conv_2d(nn.Module):
     """1x1 Conv2d -> BatchNorm2d -> activation (model/model_utils.py:8-32)."""
 
@@ -96,7 +116,7 @@ class conv_2d(nn.Module):
             return ops.pointmlp_max(x, W, self.conv[0].bias, self.conv[1], _ACT_SLOPE[self.activation], N)
         return torch.max(self.rows(x), dim=1)[0]
 
-    def edge_rows(self, x, idx, return_stats=False, out=None):
+    def edge_rows(self, x, idx, return_stats=False, out=None, wcat=None):
         """Fused EdgeConv layer: max_k act(bn(W.[x_j - x_i ; x_i])) for x [B,N,C] rows and
         idx [B,N,k] (get_graph_feature + conv + max, model_utils.py:188-210, Model.py:88-94).
         W.[x_j-x_i; x_i] = W1.x_j + (W2-W1).x_i, so one [B*N,C]x[C,2Co] GEMM replaces the
@@ -105,13 +125,7 @@ class conv_2d(nn.Module):
         B, N, C = x.shape
         W = self.weight2d()
         assert W.shape[1] == 2 * C
-        grad = torch.is_grad_enabled()
-        hit = self._wcat if self.cache_weight_split else None
-        if hit is not None and hit[0] == W._version and (hit[1] or not grad):
-            Wcat = hit[2]                  # same weights, same step (a graph-attached copy also serves no_grad)
-        else:
-            Wcat = ops.edge_weight_split(W)                                 # [2Co, C] = [W1 ; W2-W1]
-            self._wcat = (W._version, grad, Wcat) if self.cache_weight_split else None
+        Wcat = wcat if wcat is not None else edge_wcats((self,))[0]       # [2Co, C] = [W1 ; W2-W1]
         bias = self.conv[0].bias
         bn = self.conv[1]
         ops._count_bn_call(bn)

@@ -2263,6 +2263,78 @@ def mmd_assemble(feat_s, feat_t, label_s, label_t, scale, num_class=10):
     return _AssembleZ.apply(feat_s, feat_t, label_s, label_t, scale, num_class)
 
 
+class _SoftMMDMulti(torch.autograd.Function):
+    """soft_mmd (model/mmd.py:56-66) of up to four (feat_s, feat_t) pairs of ONE batch -- same samples, same labels -- with one
+    launch per stage: assemble, kernel sums (+ derivative weights), values; one backward launch (sug_soft_mmd_multi_*).
+    Every term's value and gradient equal mmd_assemble + mix_rbf_mmd2_rows of that term bit for bit."""
+
+    @staticmethod
+    def forward(ctx, label_s, label_t, scales, ws, sigmas, num_class, *feats):
+        n = len(feats) // 2
+        _need_gpu(label_s, label_t, *feats)
+        m = feats[0].shape[0]
+        dev = feats[0].device
+        fs = [f if f.stride(1) == 1 else f.contiguous() for f in feats[0::2]]
+        ft = [f if f.stride(1) == 1 else f.contiguous() for f in feats[1::2]]
+        ls, lt = label_s.reshape(-1).long().contiguous(), label_t.reshape(-1).long().contiguous()
+        Ds = [f.shape[1] for f in fs]
+        need = [ctx.needs_input_grad[6 + 2 * i] or ctx.needs_input_grad[7 + 2 * i] for i in range(n)]
+        Z = [torch.empty(2 * m, D + num_class, dtype=torch.float32, device=dev) for D in Ds]
+        wt = [torch.empty(2 * m, 2 * m, dtype=torch.float32, device=dev) if nd else None for nd in need]
+        wc = [None if w is None else w.detach().reshape(-1).to(device=dev, dtype=torch.float32).contiguous() for w in ws]
+        for w in wc:
+            if w is not None and w.numel() != m:
+                raise RuntimeError('soft_mmd_multi: %d sample weights for %d samples' % (w.numel(), m))
+        sums = torch.empty(3 * n, dtype=torch.float64, device=dev)
+        vals = torch.empty(n, dtype=torch.float32, device=dev)
+        ng = _neg_gammas(sigmas, dev)
+        I64, I32, F32 = ctypes.c_int64 * n, ctypes.c_int32 * n, ctypes.c_float * n
+        check(lib().sug_soft_mmd_multi_fwd(n, _ptrs(fs), I64(*[f.stride(0) for f in fs]), _ptrs(ft), I64(*[f.stride(0) for f in ft]),
+                                           I32(*Ds), F32(*[float(v) for v in scales]), _p(ls), _p(lt), m, num_class, _ptrs(wc),
+                                           _p(ng), len(sigmas), _ptrs(Z), _ptrs(wt), _p(sums), _p(vals), _st()),
+              'sug_soft_mmd_multi_fwd')
+        ctx.meta = (n, m, num_class, Ds, need)
+        ctx.save_for_backward(*(Z + wt))
+        ctx.set_materialize_grads(False)
+        return tuple(vals.unbind(0))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        n, m, num_class, Ds, need = ctx.meta
+        saved = ctx.saved_tensors
+        Z, wt = saved[:n], saved[n:]
+        dev = Z[0].device
+        live = [need[i] and gs[i] is not None for i in range(n)]
+        gsc = [gs[i].detach().to(device=dev, dtype=torch.float32).reshape(1) if live[i] else None for i in range(n)]
+        dZ = [torch.empty(2 * m, Ds[i] + num_class, dtype=torch.float32, device=dev) if live[i] else None for i in range(n)]
+        if any(live):
+            check(lib().sug_soft_mmd_multi_bwd(n, _ptrs(Z), (ctypes.c_int32 * n)(*Ds), _ptrs(wt), _ptrs(gsc), m, num_class, _ptrs(dZ),
+                                               _st()), 'sug_soft_mmd_multi_bwd')
+        out = [None] * 6
+        for i in range(n):
+            D = Ds[i]
+            out += [dZ[i][:m, :D] if (live[i] and ctx.needs_input_grad[6 + 2 * i]) else None,
+                    dZ[i][m:, :D] if (live[i] and ctx.needs_input_grad[7 + 2 * i]) else None]
+        return tuple(out)
+
+
+def soft_mmd_multi(label_s, label_t, terms, sigmas=SIGMA_LIST, num_class=10):
+    """[soft MMD^2 of (feat_s, feat_t, label_weight, sample_weights) for each of `terms`] on one batch (label_s / label_t [m]
+    shared by the terms), at most four terms per launch set."""
+    terms = list(terms)
+    for fs, ft, _, _ in terms:
+        if fs.dtype != torch.float32 or ft.dtype != torch.float32 or fs.shape != ft.shape or fs.dim() != 2 \
+                or fs.shape[0] != terms[0][0].shape[0]:
+            raise RuntimeError('sug_amd.ops.soft_mmd_multi: fp32 [m, D] feature blocks, one m for all terms')
+    out = []
+    for i in range(0, len(terms), 4):
+        grp = terms[i:i + 4]
+        feats = [t for fs, ft, _, _ in grp for t in (fs, ft)]
+        out += list(_SoftMMDMulti.apply(label_s, label_t, tuple(float(g[2]) for g in grp), tuple(g[3] for g in grp), tuple(sigmas),
+                                        int(num_class), *feats))
+    return out
+
+
 def colsum(x2, sign=1.0):
     """fp32 column sums [C] of a [R, C] fp32 / fp16 matrix (sug_colsum: no memset, fixed order)."""
     _need_gpu(x2)
@@ -2397,6 +2469,51 @@ def edge_weight_split(W):
     if W.dtype != torch.float32 or W.dim() != 2 or W.shape[1] % 2:
         raise RuntimeError('sug_amd.ops.edge_weight_split: fp32 [Co, 2C] weight')
     return _EdgeWeightSplit.apply(W)
+
+
+class _EdgeWeightSplitMulti(torch.autograd.Function):
+    """_EdgeWeightSplit for several weights at once: one launch forward, one backward (sug_edge_weight_split_multi); a
+    split that received no gradient hands None to its weight."""
+
+    @staticmethod
+    def forward(ctx, *Ws):
+        _need_gpu(*Ws)
+        Ws = [W.contiguous() for W in Ws]
+        n = len(Ws)
+        ctx.shapes = [(W.shape[0], W.shape[1] // 2) for W in Ws]
+        outs = [torch.empty(2 * Co, C, dtype=torch.float32, device=W.device) for W, (Co, C) in zip(Ws, ctx.shapes)]
+        I32 = ctypes.c_int32 * n
+        check(lib().sug_edge_weight_split_multi(_ptrs(Ws), I32(*[s[0] for s in ctx.shapes]), I32(*[s[1] for s in ctx.shapes]), n, 0,
+                                                _ptrs(outs), _st()), 'sug_edge_weight_split_multi')
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        n = len(gs)
+        gs = [None if (g is None or not ctx.needs_input_grad[i]) else g.contiguous() for i, g in enumerate(gs)]
+        if all(g is None for g in gs):
+            return (None,) * n
+        dev = next(g for g in gs if g is not None).device
+        dWs = [None if g is None else torch.empty(Co, 2 * C, dtype=torch.float32, device=dev) for g, (Co, C) in zip(gs, ctx.shapes)]
+        I32 = ctypes.c_int32 * n
+        check(lib().sug_edge_weight_split_multi(_ptrs(gs), I32(*[s[0] for s in ctx.shapes]), I32(*[s[1] for s in ctx.shapes]), n, 1,
+                                                _ptrs(dWs), _st()), 'sug_edge_weight_split_multi')
+        return tuple(dWs)
+
+
+def edge_weight_split_multi(Ws):
+    """[edge_weight_split(W) for W in Ws] in one launch each way (at most 8 weights per launch)."""
+    Ws = list(Ws)
+    for W in Ws:
+        if W.dtype != torch.float32 or W.dim() != 2 or W.shape[1] % 2:
+            raise RuntimeError('sug_amd.ops.edge_weight_split_multi: fp32 [Co, 2C] weights')
+    if len(Ws) == 1:
+        return [_EdgeWeightSplit.apply(Ws[0])]
+    out = []
+    for i in range(0, len(Ws), 8):
+        out += list(_EdgeWeightSplitMulti.apply(*Ws[i:i + 8]))
+    return out
 
 
 _SDA_METHODS = {'none': 0, 'naive_inverse': 1, 'exp_inverse': 2, 'mean2one': 3}

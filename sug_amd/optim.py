@@ -126,15 +126,20 @@ class Adam(torch.optim.Adam):
         self._plan, self._plan_key = plan, key
         return plan
 
-    @torch.no_grad()
-    def step(self, closure=None):
-        if closure is not None:
-            raise RuntimeError('sug_amd.optim.Adam: closures are not supported')
+    def _ensure_plan(self):
+        """The update plan for the parameters that hold a gradient now (rebuilt when that set or a by-value
+        hyper-parameter changed); graph_capturable mode: the current learning rates are on the device afterwards."""
         key = (tuple(p.grad is not None for g in self.param_groups for p in g['params']),
                tuple(self._hyper(g)[1 if self._graph_capturable else 0:] for g in self.param_groups))
         if self._graph_capturable and not torch.cuda.is_current_stream_capturing():
             self.refresh_device_scalars()
-        plan = self._plan if (self._plan is not None and key == self._plan_key) else self._build(key)
+        return self._plan if (self._plan is not None and key == self._plan_key) else self._build(key)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if closure is not None:
+            raise RuntimeError('sug_amd.optim.Adam: closures are not supported')
+        plan = self._ensure_plan()
         L = lib()
         for b in plan:
             if not self._graph_capturable:
@@ -166,4 +171,123 @@ class Adam(torch.optim.Adam):
             # on p._version (conv_2d's [W1;W2-W1] cache, DGCNN's prefix cache, autograd's
             # saved-tensor checks) sees the update, as after an in-place torch op
             torch.autograd.graph.increment_version(b.params)
+        return None
+
+
+CHAIN_SLOTS, CHAIN_BUCKETS = 2, 8          # SUG_ADAM_CHAIN_SLOTS / SUG_ADAM_CHAIN_BUCKETS of include/sug_amd.h
+
+
+class AdamChain:
+    """`for o in optimizers: o.step()` for sug_amd.optim.Adam optimizers in ONE update launch (sug_adam_chain_step).
+
+    The reference steps optimizer_dis, optimizer_g and optimizer_c back to back (train_dg_single_gpu.py:333-335), and the
+    first two both own the encoder's parameters (:193-203): a parameter that sits in two optimizers gets both updates,
+    in the order given, on the value held in registers -- bit-identical to the sequential calls, one launch (plus one
+    one-thread-per-bucket prepare launch in graph_capturable mode) instead of three (six).  Every optimizer keeps its own
+    `state` (state_dict() / load_state_dict() / a later plain `o.step()` work as before); what the chain adds is a joint
+    pointer table, rebuilt whenever one of the optimizers rebuilt its plan.  Falls back to the sequential calls when the
+    optimizers do not fit (a parameter in more than CHAIN_SLOTS of them, more than CHAIN_BUCKETS hyper-parameter sets,
+    mixed graph_capturable modes or devices)."""
+
+    def __init__(self, optimizers):
+        self.optimizers = list(optimizers)
+        if not self.optimizers or not all(isinstance(o, Adam) for o in self.optimizers):
+            raise RuntimeError('sug_amd.optim.AdamChain: sug_amd.optim.Adam optimizers only')
+        self._joint = None
+        self._joint_gens = None
+        # bumped with every rebuild of the joint table: captured graphs hold raw pointers into it (see Adam.plan_generation)
+        self.plan_generation = 0
+
+    def _build(self, plans):
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('sug_amd.optim.AdamChain: the joint update plan changed while a hipGraph is being captured; '
+                               'run one eager step first')
+        self.plan_generation += 1
+        opts = self.optimizers
+        cap = opts[0]._graph_capturable
+        buckets = [b for plan in plans for b in plan]
+        devs = {b.table.device for b in buckets}
+        J = {'fallback': True}
+        self._joint = J
+        if any(o._graph_capturable != cap for o in opts) or len(devs) != 1 or not 0 < len(buckets) <= CHAIN_BUCKETS:
+            return J
+        dev = devs.pop()
+        order, slots = [], {}
+        for bi, b in enumerate(buckets):
+            for p in b.params:
+                if id(p) not in slots:
+                    slots[id(p)] = []
+                    order.append(p)
+                slots[id(p)].append(bi)
+        if any(len(v) > CHAIN_SLOTS or len(set(v)) != len(v) for v in slots.values()):
+            return J
+        owner = {}                                   # bucket index -> optimizer (the moments live in ITS state)
+        bi = 0
+        for o, plan in zip(opts, plans):
+            for _ in plan:
+                owner[bi] = o
+                bi += 1
+        chunk = lib().sug_adam_chain_chunk()
+        rows, first, bmap = [], [0], []
+        for t, p in enumerate(order):
+            row = [p.data_ptr(), p.numel(), 0, 0, 0, 0, 0, 0]
+            code = len(slots[id(p)])
+            for s, bk in enumerate(slots[id(p)]):
+                st = owner[bk].state[p]
+                row[2 + 2 * s], row[3 + 2 * s] = st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr()
+                code |= bk << (8 + 8 * s)
+            row[6] = code
+            rows.append(row)
+            nb = (p.numel() + chunk - 1) // chunk
+            bmap += [(t, c) for c in range(nb)]
+            first.append(first[-1] + nb)
+        J.update(fallback=False, params=order, buckets=buckets, capturable=cap, T=len(order),
+                 table=torch.tensor(rows, dtype=torch.int64).to(dev),
+                 block_map=torch.tensor(bmap, dtype=torch.int32).reshape(-1, 2).to(dev),
+                 first_host=(ctypes.c_int32 * len(first))(*first),
+                 hyper=(ctypes.c_double * (6 * len(buckets)))(), steps=None, scalars=None, lr=None)
+        if cap:
+            # the buckets' device scalars move into joint arrays and stay reachable through the optimizers' own buckets
+            # (views): refresh_device_scalars / _sync_steps_from_device / a plain o.step() keep working
+            J['steps'] = torch.cat([b.step_dev for b in buckets])
+            J['scalars'] = torch.zeros(2 * len(buckets), dtype=torch.float32, device=dev)
+            J['lr'] = torch.cat([b.lr_dev for b in buckets])
+            for i, b in enumerate(buckets):
+                b.step_dev, b.lr_dev, b.scalars = J['steps'][i:i + 1], J['lr'][i:i + 1], J['scalars'][2 * i:2 * i + 2]
+        return J
+
+    @torch.no_grad()
+    def step(self):
+        opts = self.optimizers
+        plans = [o._ensure_plan() for o in opts]
+        gens = tuple(o.plan_generation for o in opts)
+        J = self._joint if gens == self._joint_gens else None
+        if J is None:
+            J = self._build(plans)
+            self._joint_gens = gens
+        if J['fallback']:
+            for o in opts:
+                o.step()
+            return None
+        ptrs = []
+        for p in J['params']:
+            g = p.grad
+            if g.is_sparse or g.dtype != torch.float32:
+                raise RuntimeError('sug_amd.optim.Adam: dense fp32 gradients only')
+            if not g.is_contiguous():
+                g = p.grad = g.contiguous()
+            ptrs.append(g.data_ptr())
+        H = J['hyper']
+        for i, b in enumerate(J['buckets']):
+            if not J['capturable']:
+                b.step_val += 1
+                torch._foreach_add_(b.steps, 1.0)
+            H[6 * i:6 * i + 6] = list(b.hyper) + [float(b.step_val)]
+        T = J['T']
+        stream = torch._C._cuda_getCurrentRawStream(J['table'].device.index)
+        p_ = lambda t: None if t is None else t.data_ptr()
+        check(lib().sug_adam_chain_step(J['table'].data_ptr(), J['block_map'].data_ptr(), J['first_host'], T,
+                                        (ctypes.c_void_p * T)(*ptrs), len(J['buckets']), H, p_(J['steps']), p_(J['scalars']),
+                                        p_(J['lr']), ctypes.c_void_p(stream)), 'sug_adam_chain_step')
+        torch.autograd.graph.increment_version(J['params'])
         return None

@@ -243,6 +243,7 @@ class SUGStep:
         self._graphs = None
         self._total = None
         self._combine_tail = os.environ.get('SUG_FUSED_LOSS', '1') != '0'
+        self._mmd_multi = os.environ.get('SUG_MMD_MULTI', '1') != '0'   # the step's MMD terms stage by stage in one launch
         self.max_graphs = 4                             # captured steps kept (each owns a private memory pool)
         # segmented steps: {collective name: [(event before, event after), ...]} when a dict is assigned (bench.py
         # --gpus N reads it for config.collectives); None = no events
@@ -275,6 +276,12 @@ class SUGStep:
                                                {'params': model.attention_s.parameters()},
                                                {'params': model.attention_t.parameters()}],
                                               lr=lr * lr_scaler, weight_decay=weight_decay, **kw)
+        # the three steps of train_dg_single_gpu.py:333-335 (dis, g, c -- the encoder's parameters get two updates) in one
+        # launch, bit-identical to the calls in sequence (optim.AdamChain; SUG_ADAM_CHAIN=0: the three calls)
+        self._adam_chain = None
+        if own_adam and os.environ.get('SUG_ADAM_CHAIN', '1') != '0':
+            from .optim import AdamChain
+            self._adam_chain = AdamChain([self.optimizer_dis, self.optimizer_g, self.optimizer_c])
 
     # ------------------------------------------------------------------ learning-rate schedules
     def set_epoch(self, epoch, max_epoch_num):
@@ -418,11 +425,23 @@ class SUGStep:
         if pair is not None and geo.get('GEO_WEIGHTS') and not self.global_mmd and pair.shape[2] != 3:   # (N == 3: [m,3,3] rows would read as channel-first, mmd.py:110)
             rows = ops.cloud_rows(pair)                  # the encoder's own [2B,N,3] rows: no second transpose for Chamfer
             cs, ct = rows[:data.shape[0], :, :3], rows[data.shape[0]:, :, :3]
-        terms = [lambda: self._mmd(label, feat_node_s, label_t, feat_node_t, geo, cs, ct)]
-        if sem['SEM_SCALE'] > 0:
-            terms += [lambda: self._mmd(label, sem_s1, label_t, sem_t1, sem, pred_s1, pred_t1),
-                      lambda: self._mmd(label, sem_s2, label_t, sem_t2, sem, pred_s2, pred_t2)]
-        vals = ops.run_parallel(terms)
+        if self._mmd_multi and not self.global_mmd and not ops.CTX.parallel_branches and feat_node_s.is_cuda \
+                and geo['NAME'] == 'SOFT_MMD' and (sem['SEM_SCALE'] <= 0 or sem['NAME'] == 'SOFT_MMD') \
+                and feat_node_s.dim() == 2 and feat_node_s.shape == feat_node_t.shape \
+                and (sem['SEM_SCALE'] <= 0 or (sem_s1.dim() == 2 and sem_s1.shape == sem_t1.shape == sem_s2.shape == sem_t2.shape
+                                               and sem_s1.shape[0] == feat_node_s.shape[0])):
+            # the terms share the batch and its labels: every stage of the three in one launch (mmd.soft_mmd_multi; each
+            # term's value and gradient are those of its own mmd_cal call bit for bit)
+            tl = [(feat_node_s, feat_node_t, geo, cs, ct)]
+            if sem['SEM_SCALE'] > 0:
+                tl += [(sem_s1, sem_t1, sem, pred_s1, pred_t1), (sem_s2, sem_t2, sem, pred_s2, pred_t2)]
+            vals = mmd.soft_mmd_multi(label, label_t, tl)
+        else:
+            terms = [lambda: self._mmd(label, feat_node_s, label_t, feat_node_t, geo, cs, ct)]
+            if sem['SEM_SCALE'] > 0:
+                terms += [lambda: self._mmd(label, sem_s1, label_t, sem_t1, sem, pred_s1, pred_t1),
+                          lambda: self._mmd(label, sem_s2, label_t, sem_t2, sem, pred_s2, pred_t2)]
+            vals = ops.run_parallel(terms)
         if combine and self._combine_tail and loss_cls.is_cuda:
             # total and its two reported parts in one launch each way (ops.loss_combine): _eager_step takes the total
             wg, wsem = M['MMD_WEIGHT'] * geo['GEO_SCALE'], 0.5 * M['MMD_WEIGHT'] * sem['SEM_SCALE']
@@ -461,7 +480,15 @@ class SUGStep:
         return (mmd_on, self.single_pass, tuple(tuple(t.shape) for t in tensors), tuple(hyp))
 
     def _plan_generations(self):
-        return tuple(getattr(o, 'plan_generation', 0) for o in self._opts())
+        return tuple(getattr(o, 'plan_generation', 0) for o in self._opts() + (self._adam_chain,))
+
+    def _optimizers_step(self):
+        if self._adam_chain is not None:
+            self._adam_chain.step()
+        else:
+            self.optimizer_dis.step()
+            self.optimizer_g.step()
+            self.optimizer_c.step()
 
     def drop_graphs(self):
         """Forget every captured step (their private pools are released).  Called automatically when an optimizer's
@@ -732,9 +759,7 @@ class SUGStep:
                     n = p.numel()
                     p.grad = flat[off:off + n].view_as(p)
                     off += n
-            self.optimizer_dis.step()
-            self.optimizer_g.step()
-            self.optimizer_c.step()
+            self._optimizers_step()
             self.optimizer_g.zero_grad()
             self.optimizer_c.zero_grad()
             self.optimizer_dis.zero_grad()
@@ -889,9 +914,7 @@ class SUGStep:
             m._wcat = None
         if self.reducer is not None:
             self.reducer.finish()
-        self.optimizer_dis.step()
-        self.optimizer_g.step()
-        self.optimizer_c.step()
+        self._optimizers_step()
         self.optimizer_g.zero_grad()
         self.optimizer_c.zero_grad()
         self.optimizer_dis.zero_grad()

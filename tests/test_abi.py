@@ -35,7 +35,7 @@ def test_library_built_and_exports_header_symbols():
 
 def test_ctypes_table_matches_header():
     from sug_amd import _lib
-    names = [n for n in _declared() if n not in ('sug_last_error', 'sug_abi_version', 'sug_linear_dw_workspace', 'sug_adam_chunk',
+    names = [n for n in _declared() if n not in ('sug_last_error', 'sug_abi_version', 'sug_linear_dw_workspace', 'sug_adam_chunk', 'sug_adam_chain_chunk',
                                                'sug_pointmlp_max_bwd_workspace', 'sug_ptran_colsum_workspace', 'sug_colsum_workspace',
                                                'sug_chamfer_workspace', 'sug_scatter_rows_workspace')]
     assert sorted(_lib.SIGNATURES) == names
@@ -46,7 +46,7 @@ def test_ctypes_table_matches_header():
 def test_version_and_error_string():
     from sug_amd import _lib
     L = _lib.lib()
-    assert L.sug_abi_version() == 6
+    assert L.sug_abi_version() == 7
     # argument validation happens on the host before any launch: safe without a GPU
     rc = L.sug_knn(None, 3, 1, 8, 3, 4, None, None)
     assert rc == -1 and b'null' in L.sug_last_error()

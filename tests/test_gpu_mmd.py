@@ -149,3 +149,50 @@ def test_entropy_weights_of_a_saturated_row_follow_scipy_kl_div():
             assert torch.equal(torch.isnan(got), torch.isnan(want)) and torch.equal(torch.isinf(got), torch.isinf(want)), (w, got, want)
             fin = torch.isfinite(want)
             torch.testing.assert_close(got[fin], want[fin], rtol=1e-4, atol=2e-7)
+
+
+@pytest.mark.parametrize('m', [4, 32, 80])
+def test_soft_mmd_multi_equals_the_terms_one_by_one(m):
+    """mmd.soft_mmd_multi (one launch per stage for the step's three terms, sug_soft_mmd_multi_*) against mmd_cal per term:
+    values and gradients bit for bit; wide and narrow operands (both kernel forms in one launch), with and without SDA
+    weights, a term whose value is not used, a non-contiguous feature block."""
+    from sug_amd.model import mmd
+    g = torch.Generator().manual_seed(5 + m)
+    dev = 'cuda'
+    ls, lt = torch.randint(0, 10, (m,), generator=g).to(dev), torch.randint(0, 10, (m,), generator=g).to(dev)
+    geo = {'NAME': 'SOFT_MMD', 'LABEL_SCALE': 50.0, 'GEO_WEIGHTS': 'mean2one'}
+    sem = {'NAME': 'SOFT_MMD', 'LABEL_SCALE': 5.0, 'SEM_WEIGHTS': 'mean2one', 'LABEL_WEIGHT': 0.5}
+    plain = {'NAME': 'SOFT_MMD', 'LABEL_SCALE': 2.0}
+    pcs, pct = torch.rand(m, 3, 128, generator=g).to(dev), torch.rand(m, 3, 128, generator=g).to(dev)
+    logit = lambda: torch.randn(m, 10, generator=g).to(dev)
+    specs = [(4096, geo, pcs, pct), (256, sem, logit(), logit()), (100, sem, logit(), logit()), (37, plain, None, None)]
+
+    def leaves():
+        gg = torch.Generator().manual_seed(77)
+        out = []
+        for D, _, _, _ in specs:
+            fs = (0.3 * torch.randn(m, D, generator=gg)).to(dev).requires_grad_(True)
+            wide = (0.3 * torch.randn(m, 2 * D, generator=gg)).to(dev).requires_grad_(True)
+            out.append((fs, wide))
+        return out
+
+    coef = [1.0, 0.5, 0.0, 2.0]                      # term 2: value computed, no gradient flows into it
+    res = []
+    for multi in (False, True):
+        L = leaves()
+        feats = [(fs, wide[:, ::2]) for fs, wide in L]          # target blocks with a column stride of 2
+        if multi:
+            vals = mmd.soft_mmd_multi(ls, lt, [(fs, ft, cfg, ds, dt) for (fs, ft), (_, cfg, ds, dt) in zip(feats, specs)])
+        else:
+            vals = [mmd.mmd_cal(ls, fs, lt, ft, cfg, data_s=ds, data_t=dt) for (fs, ft), (_, cfg, ds, dt) in zip(feats, specs)]
+        total = sum(c * v for c, v in zip(coef, vals) if c != 0.0)
+        total.backward()
+        res.append(([v.detach().clone() for v in vals], [(fs.grad, wide.grad) for fs, wide in L]))
+    (va, ga), (vb, gb) = res
+    for a, b in zip(va, vb):
+        assert torch.equal(a, b), (a, b)
+    for i, ((a1, a2), (b1, b2)) in enumerate(zip(ga, gb)):
+        if coef[i] == 0.0:
+            assert b1 is None and b2 is None
+            continue
+        assert torch.equal(a1, b1) and torch.equal(a2, b2), i

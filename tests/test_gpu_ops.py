@@ -500,6 +500,20 @@ def test_small_assembly_kernels_match_their_torch_formulations():
     assert torch.equal(S, Sr)
     probe = torch.randn(48, 13, generator=g).to(dev)
     assert torch.equal(torch.autograd.grad((S * probe).sum(), W)[0], torch.autograd.grad((Sr * probe).sum(), W)[0])
+    # ... of several layers in one launch each way (the DGCNN encoder's four); a split that is not used hands no gradient
+    shapes = [(64, 3), (64, 64), (128, 64), (256, 128), (5, 7)]
+    Ws = [torch.randn(co, 2 * c, generator=g).to(dev).requires_grad_(True) for co, c in shapes]
+    Ss = ops.edge_weight_split_multi(Ws)
+    probes = [torch.randn(2 * co, c, generator=g).to(dev) for co, c in shapes]
+    used = [0, 1, 3, 4]
+    gm = torch.autograd.grad(sum((Ss[i] * probes[i]).sum() for i in used), Ws, allow_unused=True)
+    for i, (Wi, Si) in enumerate(zip(Ws, Ss)):
+        one = ops.edge_weight_split(Wi)
+        assert torch.equal(Si, one)
+        if i in used:
+            assert torch.equal(gm[i], torch.autograd.grad((one * probes[i]).sum(), Wi)[0])
+        else:
+            assert gm[i] is None
     # CALayer gate
     x = torch.randn(5, 4096, generator=g).to(dev).requires_grad_(True)
     z = (3 * torch.randn(5, 4096, generator=g)).to(dev).requires_grad_(True)
