@@ -44,7 +44,7 @@ extern "C" {
 
 const char* sug_last_error(void);
 /* ABI version of the loaded library (bumped when a signature changes; 3: sug_adam_step_capturable gained lr_dev,
- * round-3 entry points; 4: sug_chamfer / sug_node_offset_bwd became reproducible -- sug_chamfer takes a workspace; 5: sug_ce_pair_* take ignore_index, lse has 2M + 1 entries; sug_pointmlp_max_layer_fwd_xf and sug_col_stats_bn_grouped added; 6: sug_ptran_fused_fwd / sug_ptran_fused_supported added, sug_group_max_bwd fails instead of changing its summation order when the LDS opt-in is refused; 7: sug_adam_chain_step, sug_edge_weight_split_multi and sug_soft_mmd_multi_fwd / _bwd added).  A binding checks sug_abi_version() == SUG_ABI_VERSION of the header it was written against. */
+ * round-3 entry points; 4: sug_chamfer / sug_node_offset_bwd became reproducible -- sug_chamfer takes a workspace; 5: sug_ce_pair_* take ignore_index, lse has 2M + 1 entries; sug_pointmlp_max_layer_fwd_xf and sug_col_stats_bn_grouped added; 6: sug_ptran_fused_fwd / sug_ptran_fused_supported added, sug_group_max_bwd fails instead of changing its summation order when the LDS opt-in is refused; 7: sug_adam_chain_step, sug_edge_weight_split_multi, sug_soft_mmd_multi_fwd / _bwd, sug_sda_prob_weights_multi and sug_chamfer_weights added).  A binding checks sug_abi_version() == SUG_ABI_VERSION of the header it was written against. */
 #define SUG_ABI_VERSION 7
 int sug_abi_version(void);
 
@@ -671,6 +671,10 @@ int sug_mmd_rbf_rows_bwd(const float* z, int64_t ldz, const float* wt, int m, in
 int sug_sda_prob_weights(const float* pred_s, int64_t lds, const float* pred_t, int64_t ldt,
                          const int64_t* label_s, const int64_t* label_t, int m, int num_class,
                          float label_weight, int method, float* weights, void* stream);
+/* The same for the logits of n <= 4 heads on one batch (same labels), one launch: HOST arrays of n device pointers / strides. */
+int sug_sda_prob_weights_multi(int n, const void* const* pred_s, const int64_t* lds, const void* const* pred_t,
+                               const int64_t* ldt, const int64_t* label_s, const int64_t* label_t, int m, int num_class,
+                               float label_weight, int method, void* const* weights, void* stream);
 
 /* Z [2m, D+num_class] = [feat_s ; feat_t | one-hot(label) * label_scale]: the label-augmented operand of soft_mmd
  * (model/mmd.py:56-66, create_one_hot_labels utils/common_utils.py:161-164) in one launch; feat_* [m,D] with row
@@ -685,8 +689,8 @@ int sug_mmd_assemble(const float* feat_s, int64_t lds, const float* feat_t, int6
  * term in one launch.  Per-term results are bit-identical to the single-term calls.  HOST arrays of n entries:
  * feat_s / feat_t [m, D[i]] (row strides lds / ldt), label_scale, w (device [m] or null), z (device [2m, D[i] + num_class],
  * written), wt (device [2m, 2m] written, or null: no backward).  sums: device double [3n] scratch; values: device float [n].
- * Backward: gscale[i] = device scalar (upstream gradient of value i) or null (term skipped), dz[i] device
- * [2m, D[i] + num_class] written entirely. */
+ * Backward: gscale[i] = device scalar (upstream gradient of value i) or null (term skipped), dz[i] device [2m, D[i]]
+ * dense = the gradient of [feat_s ; feat_t] (the label columns of z are constants), written entirely. */
 int sug_soft_mmd_multi_fwd(int n, const void* const* feat_s, const int64_t* lds, const void* const* feat_t,
                            const int64_t* ldt, const int32_t* D, const float* label_scale, const int64_t* label_s,
                            const int64_t* label_t, int m, int num_class, const void* const* w, const float* neg_gamma,
@@ -710,6 +714,10 @@ int sug_edge_weight_split_multi(const void* const* in_host, const int32_t* Co_ho
  * of the workgroups, folded per cloud in block order (no float atomics: the value is reproducible run to run). */
 int64_t sug_chamfer_workspace(int B, int N, int M);
 int sug_chamfer(const float* a, const float* b, int B, int N, int M, float* out, float* ws, void* stream);
+/* sug_chamfer followed by distance2weights (model/mmd.py:178-202) in the fold's own launch: out[b] = the SDA geometric weight
+ * of pair b; method 1 naive_inverse, 2 exp_inverse, 3 mean2one (1 / mean truncated to an integer, :200).  Sums over the
+ * batch in fp64, fixed order. */
+int sug_chamfer_weights(const float* a, const float* b, int B, int N, int M, int method, float* out, float* ws, void* stream);
 
 /* ---- the scalar tail of a step ---------------------------------------------------------------------------
  * Cross entropy of both classifier heads on the source rows of the paired logits (train_dg_single_gpu.py:269-292 with

@@ -81,6 +81,7 @@ SIGNATURES = {
     'sug_soft_mmd_multi_fwd': [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
     'sug_soft_mmd_multi_bwd': [_i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp],
     'sug_sda_prob_weights': [_vp, _i64, _vp, _i64, _vp, _vp, _i32, _i32, _f32, _i32, _vp, _vp],
+    'sug_sda_prob_weights_multi': [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _i32, _vp, _vp],
     'sug_adam_step': [_vp, _vp, _vp, _i32, _vp, _f64, _f64, _f64, _f64, _f64, _f64, _f64, _vp],
     'sug_adam_step_capturable': [_vp, _vp, _vp, _i32, _vp, _f64, _f64, _f64, _f64, _f64, _vp, _vp, _vp, _vp],
     'sug_adam_chain_step': [_vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
@@ -118,6 +119,7 @@ SIGNATURES = {
     'sug_pointmlp_max_bwd_sparse': [_vp, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp],
     'sug_mmd_rbf': [_vp, _i64, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp],
     'sug_chamfer': [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
+    'sug_chamfer_weights': [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
     'sug_sa_first_geo_fwd': [_vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _f32, _f32,
                              _vp, _vp, _vp, _vp, _vp, _vp],
     'sug_sa_first_geo_bwd': [_vp, _vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp,

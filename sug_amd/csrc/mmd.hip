@@ -289,6 +289,38 @@ __global__ __launch_bounds__(256) void chamfer_fold_kernel(const float* __restri
   out[b] = sn * inv_n + sm * inv_m;
 }
 
+// chamfer_fold_kernel + distance2weights (model/mmd.py:178-202) for a batch that fits one workgroup's loop: the per-pair
+// distances, their fp64 sums in thread / wave order, then the weights -- the mean / reciprocal / cast / multiply launches of
+// the torch formulation in the fold's own launch.  method: 1 naive_inverse, 2 exp_inverse, 3 mean2one (1/mean truncated).
+__global__ __launch_bounds__(256) void chamfer_fold_weights_kernel(const float* __restrict__ pn, int nbn,
+                                                                   const float* __restrict__ pm, int nbm, int B, float inv_n,
+                                                                   float inv_m, int method, float* __restrict__ out) {
+  __shared__ double s_red[4][2];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  double dsum = 0.0, wsum = 0.0;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    float sn = 0.f, sm = 0.f;
+    for (int i = 0; i < nbn; ++i) sn += pn[(int64_t)b * nbn + i];
+    for (int i = 0; i < nbm; ++i) sm += pm[(int64_t)b * nbm + i];
+    const float dist = sn * inv_n + sm * inv_m;
+    out[b] = dist;
+    dsum += (double)dist;
+    wsum += method == 1 ? (double)(1.f / (dist + 1e-8f)) : (method == 2 ? (double)expf(-dist) : 0.0);
+  }
+  dsum = wave_sum_d(dsum);
+  wsum = wave_sum_d(wsum);
+  if (lane == 0) { s_red[wv][0] = dsum; s_red[wv][1] = wsum; }
+  __syncthreads();
+  const double td = ((s_red[0][0] + s_red[1][0]) + s_red[2][0]) + s_red[3][0];
+  const double tw = ((s_red[0][1] + s_red[1][1]) + s_red[2][1]) + s_red[3][1];
+  const float mean = (float)(td / (double)B);
+  const float scale = (float)(int)(1.f / mean);           // .type(torch.int): truncation
+  for (int b = threadIdx.x; b < B; b += 256) {            // every thread re-reads its own stores
+    const float dist = out[b];
+    out[b] = method == 1 ? (1.f / (dist + 1e-8f)) / (float)tw : (method == 2 ? expf(-dist) / (float)tw : dist * scale);
+  }
+}
+
 
 // dZ[li,:] = scale * 2 * (rowsum(wt)[li] * Z[i,:] - sum_j wt[li,j] Z[j,:]) for the local rows li (global
 // row i, see global_row) over all 2m columns j: workgroup = (64 columns of D) x 4 row groups; the Z
@@ -351,9 +383,10 @@ __global__ __launch_bounds__(256) void mmd_bwd_kernel(const float* __restrict__ 
 }
 __global__ __launch_bounds__(256) void mmd_bwd_multi_kernel(MmdMulti a, int m, int ncls) {
   const MmdTerm& t = a.t[blockIdx.z];
-  const int Dz = t.D + ncls;
-  if ((int)blockIdx.x * 64 >= Dz) return;                    // the launch is sized for the widest term
-  mmd_bwd_body(blockIdx.x, blockIdx.y, t.z, Dz, t.wt, m, Dz, 0, m, t.gscale, 1.0f, t.dz, Dz);
+  if ((int)blockIdx.x * 64 >= t.D) return;                   // the launch is sized for the widest term
+  // the feature columns only, dense [2m, D]: the label columns of Z are constants, and the two domains' gradients leave as
+  // adjacent contiguous row blocks (no strided-slice copies downstream)
+  mmd_bwd_body(blockIdx.x, blockIdx.y, t.z, t.D + ncls, t.wt, m, t.D, 0, m, t.gscale, 1.0f, t.dz, t.D);
 }
 
 // SDA sample weights from class probabilities (prob_weights_soft + distance2weights,
@@ -361,11 +394,11 @@ __global__ __launch_bounds__(256) void mmd_bwd_multi_kernel(MmdMulti a, int m, i
 //   a = [softmax(pred_s) | onehot(label_s) * lw] + 1e-8, normalised by its global sum (b likewise);
 //   dist_i = sum_c 0.5*kl(a,b) + 0.5*kl(b,a), kl(x,y) = x log(x/y) - x + y;
 //   method 0 none, 1 naive_inverse, 2 exp_inverse, 3 mean2one (1/mean truncated to an integer).
-__global__ __launch_bounds__(256) void sda_prob_weights_kernel(const float* __restrict__ ps, int64_t lds,
-                                                               const float* __restrict__ pt, int64_t ldt,
-                                                               const int64_t* __restrict__ ls,
-                                                               const int64_t* __restrict__ lt, int m, float lw,
-                                                               int method, float* __restrict__ out) {
+__device__ __forceinline__ void sda_prob_weights_body(const float* __restrict__ ps, int64_t lds,
+                                                      const float* __restrict__ pt, int64_t ldt,
+                                                      const int64_t* __restrict__ ls,
+                                                      const int64_t* __restrict__ lt, int m, float lw,
+                                                      int method, float* __restrict__ out) {
   constexpr int NC = 10;
   __shared__ double s_red[4][2];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -424,6 +457,27 @@ __global__ __launch_bounds__(256) void sda_prob_weights_kernel(const float* __re
     const float dist = out[i];
     out[i] = method == 1 ? (1.f / (dist + 1e-8f)) / (float)tw : (method == 2 ? expf(-dist) / (float)tw : dist * scale);
   }
+}
+
+__global__ __launch_bounds__(256) void sda_prob_weights_kernel(const float* __restrict__ ps, int64_t lds,
+                                                               const float* __restrict__ pt, int64_t ldt,
+                                                               const int64_t* __restrict__ ls,
+                                                               const int64_t* __restrict__ lt, int m, float lw,
+                                                               int method, float* __restrict__ out) {
+  sda_prob_weights_body(ps, lds, pt, ldt, ls, lt, m, lw, method, out);
+}
+
+// the weights of several heads' logits on one batch (same labels): one workgroup per head
+struct SdaMulti {
+  const float* ps[SUG_MMD_MULTI];
+  const float* pt[SUG_MMD_MULTI];
+  int64_t lds[SUG_MMD_MULTI], ldt[SUG_MMD_MULTI];
+  float* out[SUG_MMD_MULTI];
+};
+__global__ __launch_bounds__(256) void sda_prob_weights_multi_kernel(SdaMulti a, const int64_t* __restrict__ ls,
+                                                                     const int64_t* __restrict__ lt, int m, float lw, int method) {
+  const int t = blockIdx.x;
+  sda_prob_weights_body(a.ps[t], a.lds[t], a.pt[t], a.ldt[t], ls, lt, m, lw, method, a.out[t]);
 }
 
 }  // namespace
@@ -685,12 +739,51 @@ extern "C" int sug_soft_mmd_multi_bwd(int n, const void* const* z, const int32_t
     t.wt = (float*)wt[i];
     t.gscale = (const float*)gscale[i];
     t.dz = (float*)dz[i];
-    if (D[i] + num_class > dmax) dmax = D[i] + num_class;
+    if (D[i] > dmax) dmax = D[i];
   }
   if (na == 0) return SUG_OK;
   for (int i = na; i < SUG_MMD_MULTI; ++i) a.t[i] = a.t[0];
   hipLaunchKernelGGL(mmd_bwd_multi_kernel, dim3(sug_divup(dmax, 64), sug_divup(2 * m, 32), na), dim3(256), 0,
                      (hipStream_t)stream, a, m, num_class);
   SUG_LAUNCH_CHECK("sug_soft_mmd_multi_bwd");
+  return SUG_OK;
+}
+
+extern "C" int sug_sda_prob_weights_multi(int n, const void* const* pred_s, const int64_t* lds, const void* const* pred_t,
+                                          const int64_t* ldt, const int64_t* label_s, const int64_t* label_t, int m,
+                                          int num_class, float label_weight, int method, void* const* weights, void* stream) {
+  SUG_REQUIRE(pred_s && lds && pred_t && ldt && label_s && label_t && weights, "sug_sda_prob_weights_multi: null pointer");
+  SUG_REQUIRE(n >= 1 && n <= SUG_MMD_MULTI, "sug_sda_prob_weights_multi: %d heads (1..%d)", n, SUG_MMD_MULTI);
+  SUG_REQUIRE(m > 0 && num_class == 10, "sug_sda_prob_weights_multi: bad shape (10 classes)");
+  SUG_REQUIRE(method >= 0 && method <= 3, "sug_sda_prob_weights_multi: unknown weighting method");
+  SdaMulti a;
+  for (int i = 0; i < SUG_MMD_MULTI; ++i) {
+    const int k = i < n ? i : 0;
+    SUG_REQUIRE(pred_s[k] && pred_t[k] && weights[k] && lds[k] >= 10 && ldt[k] >= 10, "sug_sda_prob_weights_multi: bad operand %d", k);
+    a.ps[i] = (const float*)pred_s[k];
+    a.pt[i] = (const float*)pred_t[k];
+    a.lds[i] = lds[k];
+    a.ldt[i] = ldt[k];
+    a.out[i] = (float*)weights[k];
+  }
+  hipLaunchKernelGGL(sda_prob_weights_multi_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, a, label_s, label_t, m,
+                     label_weight, method);
+  SUG_LAUNCH_CHECK("sug_sda_prob_weights_multi");
+  return SUG_OK;
+}
+
+extern "C" int sug_chamfer_weights(const float* a, const float* b, int B, int N, int M, int method, float* out, float* ws,
+                                   void* stream) {
+  SUG_REQUIRE(a && b && out && ws, "sug_chamfer_weights: null pointer");
+  SUG_REQUIRE(B > 0 && N > 0 && M > 0 && N <= 5000 && M <= 5000 && B <= 65535, "sug_chamfer_weights: bad shape");
+  SUG_REQUIRE(method >= 1 && method <= 3, "sug_chamfer_weights: weighting method %d (1 naive_inverse, 2 exp_inverse, 3 mean2one)", method);
+  hipStream_t st = (hipStream_t)stream;
+  const int nbn = sug_divup(4 * N, 256), nbm = sug_divup(4 * M, 256);
+  float* pm = ws + (int64_t)B * nbn;
+  hipLaunchKernelGGL(chamfer_dir_kernel, dim3(nbn, B), dim3(256), (size_t)M * 4 * sizeof(float), st, a, b, N, M, ws);
+  hipLaunchKernelGGL(chamfer_dir_kernel, dim3(nbm, B), dim3(256), (size_t)N * 4 * sizeof(float), st, b, a, M, N, pm);
+  hipLaunchKernelGGL(chamfer_fold_weights_kernel, dim3(1), dim3(256), 0, st, ws, nbn, pm, nbm, B, 1.0f / (float)N,
+                     1.0f / (float)M, method, out);
+  SUG_LAUNCH_CHECK("sug_chamfer_weights");
   return SUG_OK;
 }

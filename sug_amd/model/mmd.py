@@ -64,14 +64,27 @@ def soft_mmd_multi(label_s, label_t, terms):
     """[mmd_cal(label_s, feat_s, label_t, feat_t, args, data_s, data_t) for (feat_s, feat_t, args, data_s, data_t) in terms]
     for SOFT_MMD terms of one batch (model/mmd.py:25-41, :56-66; the three terms of train_dg_single_gpu.py:300-322): the
     SDA weights per term as mmd_cal forms them, then every stage of the terms in one launch (ops.soft_mmd_multi)."""
-    packed = []
-    for feat_s, feat_t, args, data_s, data_t in terms:
+    terms = list(terms)
+    for _, _, args, _, _ in terms:
         if args["NAME"] != "SOFT_MMD":
             raise RuntimeError("soft_mmd_multi: SOFT_MMD terms only")
-        w = None
-        if data_s is not None and (args.get("GEO_WEIGHTS", None) or args.get("SEM_WEIGHTS", None)):
-            w = cal_sample_weights(data_s, data_t, args, label_s=label_s, label_t=label_t)
-        packed.append((feat_s, feat_t, float(args["LABEL_SCALE"]), w))
+    ws = [None] * len(terms)
+    # terms weighted from head logits by the same rule (cal_sample_weights' third branch): their weights in one launch
+    by_rule = {}
+    for i, (_, _, args, data_s, data_t) in enumerate(terms):
+        if data_s is None or not (args.get("GEO_WEIGHTS", None) or args.get("SEM_WEIGHTS", None)):
+            continue
+        if args.get("SEM_WEIGHTS", None) and not args.get("GEO_WEIGHTS", None) and not args.get("ENTROPY_WEIGHTS", None) \
+                and data_s.is_cuda and data_s.shape[-1] == 10:
+            by_rule.setdefault((float(args["LABEL_WEIGHT"]), args["SEM_WEIGHTS"]), []).append(i)
+        else:
+            ws[i] = cal_sample_weights(data_s, data_t, args, label_s=label_s, label_t=label_t)
+    for (lw, rule), idx in by_rule.items():
+        assert lw < 1, "For Entropy, Label weight should be less than one"
+        outs = ops.sda_prob_weights_multi([(terms[i][3], terms[i][4]) for i in idx], label_s, label_t, lw, rule)
+        for i, o in zip(idx, outs):
+            ws[i] = o.reshape(1, -1)
+    packed = [(fs, ft, float(args["LABEL_SCALE"]), w) for (fs, ft, args, _, _), w in zip(terms, ws)]
     return ops.soft_mmd_multi(label_s, label_t, packed, sigma_list)
 
 
@@ -102,6 +115,10 @@ def max_hard_mmd(label_s, feat_s, label_t, feat_t):
 def chamfer_distances(pc_s, pc_t):
     """Per-pair Chamfer distance [m] of paired clouds ([m,3,N(,1)] or [m,N,3]): cd_distance,
     model/mmd.py:169-175 (mean of dist1 + mean of dist2)."""
+    return ops.chamfer(*_chamfer_rows(pc_s, pc_t))
+
+
+def _chamfer_rows(pc_s, pc_t):
     assert pc_s.shape[0] == pc_t.shape[0]
     # the reference's own layout test (model/mmd.py:110): channel-first when dim 1 has 3 entries.  [m,N,3] rows with N == 3
     # are therefore read as channel-first, exactly as there; internal callers only pass rows when N != 3
@@ -110,7 +127,7 @@ def chamfer_distances(pc_s, pc_t):
         b = pc_t.reshape(pc_t.shape[0], 3, -1).transpose(1, 2)
     else:
         a, b = pc_s, pc_t
-    return ops.chamfer(a, b)
+    return a, b
 
 
 def geometric_weights(pc_s, pc_t, metric="chamfer_distance", weighting="none", KPC=False):
@@ -119,6 +136,9 @@ def geometric_weights(pc_s, pc_t, metric="chamfer_distance", weighting="none", K
     contract (parity unpinned, see oracle/ref_cpu.py:chamfer_weights)."""
     if metric != "chamfer_distance":
         raise RuntimeError("Currently Only Support CD distance")
+    if weighting in ("naive_inverse", "exp_inverse", "mean2one") and pc_s.is_cuda:
+        a, b = _chamfer_rows(pc_s, pc_t)
+        return ops.chamfer_weights(a, b, weighting).reshape(1, -1)      # the weighting in the distance's own fold launch
     distance = chamfer_distances(pc_s, pc_t)
     return distance2weights(distances=distance, method=weighting).reshape(1, -1)
 

@@ -2306,15 +2306,14 @@ class _SoftMMDMulti(torch.autograd.Function):
         dev = Z[0].device
         live = [need[i] and gs[i] is not None for i in range(n)]
         gsc = [gs[i].detach().to(device=dev, dtype=torch.float32).reshape(1) if live[i] else None for i in range(n)]
-        dZ = [torch.empty(2 * m, Ds[i] + num_class, dtype=torch.float32, device=dev) if live[i] else None for i in range(n)]
+        dZ = [torch.empty(2 * m, Ds[i], dtype=torch.float32, device=dev) if live[i] else None for i in range(n)]
         if any(live):
             check(lib().sug_soft_mmd_multi_bwd(n, _ptrs(Z), (ctypes.c_int32 * n)(*Ds), _ptrs(wt), _ptrs(gsc), m, num_class, _ptrs(dZ),
                                                _st()), 'sug_soft_mmd_multi_bwd')
         out = [None] * 6
         for i in range(n):
-            D = Ds[i]
-            out += [dZ[i][:m, :D] if (live[i] and ctx.needs_input_grad[6 + 2 * i]) else None,
-                    dZ[i][m:, :D] if (live[i] and ctx.needs_input_grad[7 + 2 * i]) else None]
+            out += [dZ[i][:m] if (live[i] and ctx.needs_input_grad[6 + 2 * i]) else None,
+                    dZ[i][m:] if (live[i] and ctx.needs_input_grad[7 + 2 * i]) else None]
         return tuple(out)
 
 
@@ -2538,6 +2537,31 @@ def sda_prob_weights(pred_s, pred_t, label_s, label_t, label_weight, method):
     return out
 
 
+def sda_prob_weights_multi(preds, label_s, label_t, label_weight, method):
+    """[sda_prob_weights(ps, pt, ...) for (ps, pt) in preds] in one launch (at most four heads; one batch, one set of labels)."""
+    preds = list(preds)
+    if len(preds) == 1:
+        return [sda_prob_weights(preds[0][0], preds[0][1], label_s, label_t, label_weight, method)]
+    if len(preds) > 4:
+        return sda_prob_weights_multi(preds[:4], label_s, label_t, label_weight, method) + \
+            sda_prob_weights_multi(preds[4:], label_s, label_t, label_weight, method)
+    if method not in _SDA_METHODS:
+        raise RuntimeError('Not supported weighting method %s' % method)
+    rows = lambda p: (lambda q: q if q.stride(1) == 1 else q.contiguous())(p.detach().reshape(-1, 10).float())
+    ps, pt = [rows(a) for a, _ in preds], [rows(b) for _, b in preds]
+    _need_gpu(label_s, label_t, *(ps + pt))
+    ls, lt = label_s.reshape(-1).long().contiguous(), label_t.reshape(-1).long().contiguous()
+    m, n = ps[0].shape[0], len(preds)
+    if any(t.shape[0] != m for t in ps + pt):
+        raise RuntimeError('sda_prob_weights_multi: one batch size for all heads')
+    outs = [torch.empty(m, dtype=torch.float32, device=ps[0].device) for _ in range(n)]
+    I64 = ctypes.c_int64 * n
+    check(lib().sug_sda_prob_weights_multi(n, _ptrs(ps), I64(*[t.stride(0) for t in ps]), _ptrs(pt), I64(*[t.stride(0) for t in pt]),
+                                           _p(ls), _p(lt), m, 10, float(label_weight), _SDA_METHODS[method], _ptrs(outs), _st()),
+          'sug_sda_prob_weights_multi')
+    return outs
+
+
 def chamfer(a, b):
     """a [B,N,3], b [B,M,3] -> [B]: mean_i min_j d + mean_j min_i d."""
     _need_gpu(a, b)
@@ -2547,6 +2571,21 @@ def chamfer(a, b):
     out = torch.empty(B, dtype=torch.float32, device=a.device)
     ws = torch.empty(lib().sug_chamfer_workspace(B, N, M), dtype=torch.float32, device=a.device)
     check(lib().sug_chamfer(_p(a), _p(b), B, N, M, _p(out), _p(ws), _st()), 'sug_chamfer')
+    return out
+
+
+def chamfer_weights(a, b, method):
+    """distance2weights(chamfer(a, b), method) [B] for method in naive_inverse / exp_inverse / mean2one, the weighting inside
+    the fold launch of the distance (sug_chamfer_weights)."""
+    _need_gpu(a, b)
+    if method not in ('naive_inverse', 'exp_inverse', 'mean2one'):
+        raise RuntimeError('Not supported weighting method %s' % method)
+    a, b = a.detach().contiguous(), b.detach().contiguous()
+    B, N, _ = a.shape
+    M = b.shape[1]
+    out = torch.empty(B, dtype=torch.float32, device=a.device)
+    ws = torch.empty(lib().sug_chamfer_workspace(B, N, M), dtype=torch.float32, device=a.device)
+    check(lib().sug_chamfer_weights(_p(a), _p(b), B, N, M, _SDA_METHODS[method], _p(out), _p(ws), _st()), 'sug_chamfer_weights')
     return out
 
 

@@ -196,3 +196,30 @@ def test_soft_mmd_multi_equals_the_terms_one_by_one(m):
             assert b1 is None and b2 is None
             continue
         assert torch.equal(a1, b1) and torch.equal(a2, b2), i
+
+
+@pytest.mark.parametrize('B', [1, 7, 64, 300])
+def test_fused_weight_launches_match_their_step_by_step_forms(B):
+    """sug_chamfer_weights (distance2weights inside the Chamfer fold launch) against distance2weights(chamfer(...)) and
+    sug_sda_prob_weights_multi (several heads, one launch) against the single-head kernel."""
+    from sug_amd import ops
+    from sug_amd.model import mmd
+    g = torch.Generator().manual_seed(B)
+    a, b = torch.rand(B, 200, 3, generator=g).cuda(), torch.rand(B, 173, 3, generator=g).cuda()
+    dist = ops.chamfer(a, b)
+    for method in ('naive_inverse', 'exp_inverse', 'mean2one'):
+        w = ops.chamfer_weights(a, b, method)
+        ref = mmd.distance2weights(dist, method).reshape(-1)
+        if method == 'mean2one':
+            assert torch.equal(w, ref)            # an integer scale: exact unless 1/mean sits on an integer
+        else:
+            torch.testing.assert_close(w, ref, rtol=1e-5, atol=1e-9)
+    # geometric_weights routes through it for channel-first clouds as well
+    w = mmd.geometric_weights(a.transpose(1, 2).contiguous(), b[:, :173].transpose(1, 2).contiguous(), weighting='mean2one')
+    assert torch.equal(w.reshape(-1), mmd.distance2weights(dist, 'mean2one').reshape(-1))
+    ls, lt = torch.randint(0, 10, (B,), generator=g).cuda(), torch.randint(0, 10, (B,), generator=g).cuda()
+    preds = [(torch.randn(B, 10, generator=g).cuda(), torch.randn(B, 20, generator=g).cuda()[:, ::2]) for _ in range(5)]
+    for method in ('none', 'naive_inverse', 'exp_inverse', 'mean2one'):
+        many = ops.sda_prob_weights_multi(preds, ls, lt, 0.5, method)
+        for (ps, pt), w in zip(preds, many):
+            assert torch.equal(w, ops.sda_prob_weights(ps, pt, ls, lt, 0.5, method))
