@@ -44,7 +44,7 @@ extern "C" {
 
 const char* sug_last_error(void);
 /* ABI version of the loaded library (bumped when a signature changes; 3: sug_adam_step_capturable gained lr_dev,
- * round-3 entry points; 4: sug_chamfer / sug_node_offset_bwd became reproducible -- sug_chamfer takes a workspace; 5: sug_ce_pair_* take ignore_index, lse has 2M + 1 entries; sug_pointmlp_max_layer_fwd_xf and sug_col_stats_bn_grouped added; 6: sug_ptran_fused_fwd / sug_ptran_fused_supported added, sug_group_max_bwd fails instead of changing its summation order when the LDS opt-in is refused; 7: sug_adam_chain_step, sug_edge_weight_split_multi, sug_soft_mmd_multi_fwd / _bwd, sug_sda_prob_weights_multi and sug_chamfer_weights added).  A binding checks sug_abi_version() == SUG_ABI_VERSION of the header it was written against. */
+ * round-3 entry points; 4: sug_chamfer / sug_node_offset_bwd became reproducible -- sug_chamfer takes a workspace; 5: sug_ce_pair_* take ignore_index, lse has 2M + 1 entries; sug_pointmlp_max_layer_fwd_xf and sug_col_stats_bn_grouped added; 6: sug_ptran_fused_fwd / sug_ptran_fused_supported added, sug_group_max_bwd fails instead of changing its summation order when the LDS opt-in is refused; 7: sug_adam_chain_step, sug_edge_weight_split_multi, sug_soft_mmd_multi_fwd / _bwd, sug_sda_prob_weights_multi and sug_chamfer_weights added, sug_bn_act_pool_* take the row stride ld_pool of the pooled outputs / their gradients).  A binding checks sug_abi_version() == SUG_ABI_VERSION of the header it was written against. */
 #define SUG_ABI_VERSION 7
 int sug_abi_version(void);
 
@@ -402,16 +402,18 @@ int sug_bn_bwd_apply(const float* a, const float* y, int64_t ldy, const float* c
                      const double* red, int64_t rows, int C, float* dy, int64_t lddy, void* stream);
 
 /* BatchNorm1d -> LeakyReLU(slope) -> max over N | mean over N  (model/Model.py:112-116),
- * one read of y [B,N,C]; coef from sug_bn_finalize.  out_max/out_mean [B,C], arg [B,C] = row of
- * the (first) maximum.  ws: workspace of 12*B*C floats (per-chunk partial max/sum/arg). */
+ * one read of y [B,N,C]; coef from sug_bn_finalize.  out_max/out_mean [B,C] with row stride ld_pool (ld_pool = 2C and
+ * out_mean = out_max + C: the two land in the torch.cat((max, mean), 1) of Model.py:116 directly), arg [B,C] dense =
+ * row of the (first) maximum.  ws: workspace of 12*B*C floats (per-chunk partial max/sum/arg). */
 int sug_bn_act_pool_fwd(const float* y, int64_t ldy, const float* coef, int B, int N, int C,
-                        float slope, float* out_max, float* out_mean, int32_t* arg, float* ws,
+                        float slope, float* out_max, float* out_mean, int64_t ld_pool, int32_t* arg, float* ws,
                         void* stream);
 /* Backward of the above including the BN statistics terms: dy [B,N,C] (row stride lddy),
  * red[0:C] = dbeta, red[C:2C] = dgamma (fp64).  train = 0: statistics are constants (eval mode).
+ * gmax / gmean [B,C] with row stride ld_pool (the two column halves of the gradient of the concatenated feature).
  * ws: SUG_STATS_BLOCKS*2*C floats. B <= SUG_STATS_BLOCKS/4. */
 int sug_bn_act_pool_bwd(const float* y, int64_t ldy, const float* coef, const float* gmax,
-                        const float* gmean, const int32_t* arg, int B, int N, int C, float slope,
+                        const float* gmean, int64_t ld_pool, const int32_t* arg, int B, int N, int C, float slope,
                         int train, double* red, float* ws, float* dy, int64_t lddy, void* stream);
 
 /* ---- layer-level entry points ---------------------------------------------------------------
@@ -504,10 +506,10 @@ int sug_bn_act_rows_bwd(const float* gout, int64_t ldg, const float* y, int64_t 
 int sug_bn_act_pool_layer_fwd(const float* y, int64_t ldy, int B, int N, int C, int groups,
                               const float* gamma, const float* beta, int training, float eps, float momentum,
                               float slope, float* running_mean, float* running_var, float* coef,
-                              float* out_max, float* out_mean, int32_t* arg, double* stats, float* ws_stats,
+                              float* out_max, float* out_mean, int64_t ld_pool, int32_t* arg, double* stats, float* ws_stats,
                               float* ws_pool, void* stream);
 int sug_bn_act_pool_layer_bwd(const float* y, int64_t ldy, const float* coef, const float* gmax,
-                              const float* gmean, const int32_t* arg, int B, int N, int C, int groups,
+                              const float* gmean, int64_t ld_pool, const int32_t* arg, int B, int N, int C, int groups,
                               float slope, int training, double* red, float* ws, float* dy, int64_t lddy,
                               float* dgb, void* stream);
 

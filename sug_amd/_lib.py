@@ -49,8 +49,8 @@ SIGNATURES = {
                             _vp, _vp, _vp],
     'sug_bn_act_rows_bwd': [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp],
     'sug_bn_act_pool_layer_fwd': [_vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _f32, _f32, _f32, _vp, _vp, _vp,
-                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-    'sug_bn_act_pool_layer_bwd': [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp,
+                                  _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp],
+    'sug_bn_act_pool_layer_bwd': [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp,
                                   _i64, _vp, _vp],
     'sug_fold_groups': [_vp, _i32, _i32, _vp, _vp],
     'sug_edgeconv_fwd_bn': [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp,
@@ -108,8 +108,8 @@ SIGNATURES = {
     'sug_interp3_cat_fwd': [_vp, _i64, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp],
     'sug_interp3_cat_bwd': [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
     'sug_bn_bwd_apply': [_vp, _vp, _i64, _vp, _vp, _i64, _i32, _vp, _i64, _vp],
-    'sug_bn_act_pool_fwd': [_vp, _i64, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp],
-    'sug_bn_act_pool_bwd': [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp, _i64, _vp],
+    'sug_bn_act_pool_fwd': [_vp, _i64, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _i64, _vp, _vp, _vp],
+    'sug_bn_act_pool_bwd': [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp, _i64, _vp],
     'sug_rows_gemm': [_vp, _i64, _i64, _i32, _vp, _vp, _i32, _vp, _i64, _vp],
     'sug_pointmlp_max_fwd': [_vp, _i64, _i64, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
     'sug_pointmlp_max_layer_fwd': [_vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _vp,

@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void pool_combine_kernel(const float* __restri
                                                            const float* __restrict__ psum,
                                                            const int32_t* __restrict__ parg, int B, int N,
                                                            int C, float* __restrict__ omax,
-                                                           float* __restrict__ omean,
+                                                           float* __restrict__ omean, int64_t ldp,
                                                            int32_t* __restrict__ arg) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= (int64_t)B * C) return;
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void pool_combine_kernel(const float* __restri
     sm += psum[o];
     if (pmax[o] > m) { m = pmax[o]; a = parg[o]; }
   }
-  omax[e] = m; omean[e] = sm / (float)N; arg[e] = a;
+  omax[(int64_t)b * ldp + c] = m; omean[(int64_t)b * ldp + c] = sm / (float)N; arg[e] = a;
 }
 
 // G[b,n,c] = act'(u) * (gmean[b,c]/N + gmax[b,c]*[n == arg[b,c]]);  partial sums of G and G*xhat
@@ -189,7 +189,7 @@ template <int VEC>
 __global__ __launch_bounds__(256) void pool_bwd_reduce_kernel(const float* __restrict__ y, int64_t ldy,
                                                               const float* __restrict__ coef,
                                                               const float* __restrict__ gmax,
-                                                              const float* __restrict__ gmean,
+                                                              const float* __restrict__ gmean, int64_t ldp,
                                                               const int32_t* __restrict__ arg, int N,
                                                               int C, float slope, float* __restrict__ ws) {
   constexpr int LX = 64 / VEC, LY = 256 / LX;
@@ -208,8 +208,8 @@ __global__ __launch_bounds__(256) void pool_bwd_reduce_kernel(const float* __res
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
       sc[v] = coef[c + v]; sh[v] = coef[C + c + v]; mean[v] = coef[2 * C + c + v]; rstd[v] = coef[3 * C + c + v];
-      gm[v] = gmean[(int64_t)b * C + c + v] / (float)N;
-      gx[v] = gmax[(int64_t)b * C + c + v];
+      gm[v] = gmean[(int64_t)b * ldp + c + v] / (float)N;
+      gx[v] = gmax[(int64_t)b * ldp + c + v];
       am[v] = arg[(int64_t)b * C + c + v];
     }
     const float* p = y + (int64_t)b * N * ldy + c;
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void pool_bwd_apply_kernel(const float* __rest
                                                              const float* __restrict__ coef,
                                                              const double* __restrict__ red,
                                                              const float* __restrict__ gmax,
-                                                             const float* __restrict__ gmean,
+                                                             const float* __restrict__ gmean, int64_t ldp,
                                                              const int32_t* __restrict__ arg, int B,
                                                              int N, int C, float slope, float invM,
                                                              float* __restrict__ dy, int64_t lddy) {
@@ -275,8 +275,8 @@ __global__ __launch_bounds__(256) void pool_bwd_apply_kernel(const float* __rest
     for (int v = 0; v < VEC; ++v) {
       const float sc = coef[c + v];
       const float u = fmaf(sc, val[v], coef[C + c + v]);
-      const float g = (u > 0.f ? 1.f : slope) * (gmean[(int64_t)b * C + c + v] / (float)N +
-                                                 (n == arg[(int64_t)b * C + c + v] ? gmax[(int64_t)b * C + c + v] : 0.f));
+      const float g = (u > 0.f ? 1.f : slope) * (gmean[(int64_t)b * ldp + c + v] / (float)N +
+                                                 (n == arg[(int64_t)b * C + c + v] ? gmax[(int64_t)b * ldp + c + v] : 0.f));
       const float xhat = (val[v] - coef[2 * C + c + v]) * coef[3 * C + c + v];
       out[v] = sc * (g - invM * ((float)red[c + v] + xhat * (float)red[C + c + v]));
     }
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void pool_bwd_apply_rows_kernel(const float* _
                                                                   const float* __restrict__ coef,
                                                                   const double* __restrict__ red,
                                                                   const float* __restrict__ gmax,
-                                                                  const float* __restrict__ gmean,
+                                                                  const float* __restrict__ gmean, int64_t ldp,
                                                                   const int32_t* __restrict__ arg, int N, int C,
                                                                   int rows_per_block, float slope, float invM,
                                                                   float* __restrict__ dy, int64_t lddy) {
@@ -313,8 +313,8 @@ __global__ __launch_bounds__(256) void pool_bwd_apply_rows_kernel(const float* _
     rs[v] = coef[3 * C + c + v];
     r0[v] = (float)red[c + v];
     r1[v] = (float)red[C + c + v];
-    gme[v] = gmean[(int64_t)b * C + c + v] / (float)N;
-    gmx[v] = gmax[(int64_t)b * C + c + v];
+    gme[v] = gmean[(int64_t)b * ldp + c + v] / (float)N;
+    gmx[v] = gmax[(int64_t)b * ldp + c + v];
     am[v] = arg[(int64_t)b * C + c + v];
   }
   const int n0 = blockIdx.x * rows_per_block;
@@ -509,10 +509,10 @@ static bool vec4_ok(const float* y, int64_t ld, int C) {
 }
 
 extern "C" int sug_bn_act_pool_fwd(const float* y, int64_t ldy, const float* coef, int B, int N, int C,
-                                   float slope, float* out_max, float* out_mean, int32_t* arg,
+                                   float slope, float* out_max, float* out_mean, int64_t ld_pool, int32_t* arg,
                                    float* ws, void* stream) {
   SUG_REQUIRE(y && coef && out_max && out_mean && arg && ws, "sug_bn_act_pool_fwd: null pointer");
-  SUG_REQUIRE(B > 0 && N > 0 && C > 0 && ldy >= C && B <= 65535, "sug_bn_act_pool_fwd: bad shape");
+  SUG_REQUIRE(B > 0 && N > 0 && C > 0 && ldy >= C && ld_pool >= C && B <= 65535, "sug_bn_act_pool_fwd: bad shape");
   hipStream_t st = (hipStream_t)stream;
   const size_t part = (size_t)B * NS * C;
   float* pmax = ws;
@@ -525,25 +525,25 @@ extern "C" int sug_bn_act_pool_fwd(const float* y, int64_t ldy, const float* coe
     hipLaunchKernelGGL((bn_act_pool_part_kernel<1>), grid, dim3(256), 0, st, y, ldy, coef, N, C, slope, pmax, psum, parg);
   SUG_LAUNCH_CHECK("sug_bn_act_pool_fwd");
   hipLaunchKernelGGL(pool_combine_kernel, dim3(sug_divup((int64_t)B * C, 256)), dim3(256), 0, st, pmax, psum, parg,
-                     B, N, C, out_max, out_mean, arg);
+                     B, N, C, out_max, out_mean, ld_pool, arg);
   SUG_LAUNCH_CHECK("sug_bn_act_pool_fwd(combine)");
   return SUG_OK;
 }
 
 extern "C" int sug_bn_act_pool_bwd(const float* y, int64_t ldy, const float* coef, const float* gmax,
-                                   const float* gmean, const int32_t* arg, int B, int N, int C,
+                                   const float* gmean, int64_t ld_pool, const int32_t* arg, int B, int N, int C,
                                    float slope, int train, double* red, float* ws, float* dy,
                                    int64_t lddy, void* stream) {
   SUG_REQUIRE(y && coef && gmax && gmean && arg && red && ws && dy, "sug_bn_act_pool_bwd: null pointer");
-  SUG_REQUIRE(B > 0 && N > 0 && C > 0 && ldy >= C && lddy >= C && B * NS <= SUG_STATS_BLOCKS,
+  SUG_REQUIRE(B > 0 && N > 0 && C > 0 && ldy >= C && lddy >= C && ld_pool >= C && B * NS <= SUG_STATS_BLOCKS,
               "sug_bn_act_pool_bwd: bad shape (B must be <= %d)", SUG_STATS_BLOCKS / NS);
   hipStream_t st = (hipStream_t)stream;
   const bool vec = vec4_ok(y, ldy, C) && vec4_ok(dy, lddy, C);
   dim3 grid(sug_divup(C, 64), B, NS);
   if (vec)
-    hipLaunchKernelGGL((pool_bwd_reduce_kernel<4>), grid, dim3(256), 0, st, y, ldy, coef, gmax, gmean, arg, N, C, slope, ws);
+    hipLaunchKernelGGL((pool_bwd_reduce_kernel<4>), grid, dim3(256), 0, st, y, ldy, coef, gmax, gmean, ld_pool, arg, N, C, slope, ws);
   else
-    hipLaunchKernelGGL((pool_bwd_reduce_kernel<1>), grid, dim3(256), 0, st, y, ldy, coef, gmax, gmean, arg, N, C, slope, ws);
+    hipLaunchKernelGGL((pool_bwd_reduce_kernel<1>), grid, dim3(256), 0, st, y, ldy, coef, gmax, gmean, ld_pool, arg, N, C, slope, ws);
   SUG_LAUNCH_CHECK("sug_bn_act_pool_bwd(reduce)");
   hipLaunchKernelGGL(reduce_rows_kernel, dim3(sug_divup(2 * C, 16)), dim3(256), 0, st, ws, B * NS, 2 * C, red);
   SUG_LAUNCH_CHECK("sug_bn_act_pool_bwd(combine)");
@@ -551,13 +551,13 @@ extern "C" int sug_bn_act_pool_bwd(const float* y, int64_t ldy, const float* coe
   if (vec && (C / 4) <= 256 && 256 % (C / 4) == 0 && B <= 65535) {
     const int rpb = 64 > 256 / (C / 4) ? 64 : 256 / (C / 4);
     hipLaunchKernelGGL(pool_bwd_apply_rows_kernel, dim3(sug_divup(N, rpb), B), dim3(256), 0, st, y, ldy, coef, red, gmax,
-                       gmean, arg, N, C, rpb, slope, invM, dy, lddy);
+                       gmean, ld_pool, arg, N, C, rpb, slope, invM, dy, lddy);
   } else if (vec)
     hipLaunchKernelGGL((pool_bwd_apply_kernel<4>), dim3(ew_grid((int64_t)B * N * C / 4)), dim3(256), 0, st, y, ldy,
-                       coef, red, gmax, gmean, arg, B, N, C, slope, invM, dy, lddy);
+                       coef, red, gmax, gmean, ld_pool, arg, B, N, C, slope, invM, dy, lddy);
   else
     hipLaunchKernelGGL((pool_bwd_apply_kernel<1>), dim3(ew_grid((int64_t)B * N * C)), dim3(256), 0, st, y, ldy, coef,
-                       red, gmax, gmean, arg, B, N, C, slope, invM, dy, lddy);
+                       red, gmax, gmean, ld_pool, arg, B, N, C, slope, invM, dy, lddy);
   SUG_LAUNCH_CHECK("sug_bn_act_pool_bwd(apply)");
   return SUG_OK;
 }

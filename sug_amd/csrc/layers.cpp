@@ -185,7 +185,7 @@ extern "C" int sug_bn_act_rows_bwd(const float* gout, int64_t ldg, const float* 
 extern "C" int sug_bn_act_pool_layer_fwd(const float* y, int64_t ldy, int B, int N, int C, int groups,
                                          const float* gamma, const float* beta, int training, float eps,
                                          float momentum, float slope, float* running_mean, float* running_var,
-                                         float* coef, float* out_max, float* out_mean, int32_t* arg, double* stats,
+                                         float* coef, float* out_max, float* out_mean, int64_t ld_pool, int32_t* arg, double* stats,
                                          float* ws_stats, float* ws_pool, void* stream) {
   LAYER_REQUIRE(groups >= 1 && B > 0 && B % groups == 0, "sug_bn_act_pool_layer_fwd: B=%d does not split into %d groups", B, groups);
   const int Bg = B / groups;
@@ -196,22 +196,22 @@ extern "C" int sug_bn_act_pool_layer_fwd(const float* y, int64_t ldy, int B, int
     if (training)
       LAYER_TRY(sug_col_stats_bn(yg, ldy, rg, C, gamma, beta, eps, momentum, running_mean, running_var, cg, ws_stats,
                                  stream));
-    LAYER_TRY(sug_bn_act_pool_fwd(yg, ldy, cg, Bg, N, C, slope, out_max + (int64_t)g * Bg * C, out_mean + (int64_t)g * Bg * C,
-                                  arg + (int64_t)g * Bg * C, ws_pool, stream));
+    LAYER_TRY(sug_bn_act_pool_fwd(yg, ldy, cg, Bg, N, C, slope, out_max + (int64_t)g * Bg * ld_pool, out_mean + (int64_t)g * Bg * ld_pool,
+                                  ld_pool, arg + (int64_t)g * Bg * C, ws_pool, stream));
   }
   return SUG_OK;
 }
 
 extern "C" int sug_bn_act_pool_layer_bwd(const float* y, int64_t ldy, const float* coef, const float* gmax,
-                                         const float* gmean, const int32_t* arg, int B, int N, int C, int groups,
+                                         const float* gmean, int64_t ld_pool, const int32_t* arg, int B, int N, int C, int groups,
                                          float slope, int training, double* red, float* ws, float* dy, int64_t lddy,
                                          float* dgb, void* stream) {
   LAYER_REQUIRE(groups >= 1 && B > 0 && B % groups == 0, "sug_bn_act_pool_layer_bwd: B=%d does not split into %d groups", B, groups);
   const int Bg = B / groups;
   const int64_t rg = (int64_t)Bg * N;
   for (int g = 0; g < groups; ++g)
-    LAYER_TRY(sug_bn_act_pool_bwd(y + g * rg * ldy, ldy, coef + (int64_t)g * 5 * C, gmax + (int64_t)g * Bg * C,
-                                  gmean + (int64_t)g * Bg * C, arg + (int64_t)g * Bg * C, Bg, N, C, slope, training,
+    LAYER_TRY(sug_bn_act_pool_bwd(y + g * rg * ldy, ldy, coef + (int64_t)g * 5 * C, gmax + (int64_t)g * Bg * ld_pool,
+                                  gmean + (int64_t)g * Bg * ld_pool, ld_pool, arg + (int64_t)g * Bg * C, Bg, N, C, slope, training,
                                   red + (int64_t)g * 2 * C, ws, dy + g * rg * lddy, lddy, stream));
   if (dgb) LAYER_TRY(sug_fold_groups(red, groups, 2 * C, dgb, stream));
   return SUG_OK;

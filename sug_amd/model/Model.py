@@ -237,7 +237,7 @@ class DGCNN(nn.Module, _PrefixSharing):
             x5 = ops.linear_rows(ops.assemble_rows(cat_in, (x1, x2, x3, x4)), self.conv5.weight.squeeze(-1))
             if feat_grad:
                 # bn5 -> leaky_relu(0.2) -> adaptive max | avg pool (Model.py:113-116), fused
-                feat = torch.cat(ops.bn_act_pool(x5, self.bn5, 0.2), 1)
+                feat = ops.bn_act_pool_cat(x5, self.bn5, 0.2)
             else:
                 ops.bn_update_stats(x5, self.bn5)        # the pooled feature is not used: buffers only
                 feat = None
@@ -754,7 +754,9 @@ class Net_MDA(nn.Module):
                 x, feat_ori, _ = self.g(x_pair, node=True, need_node=False)     # only the pooled feature is used
             else:
                 x, feat_ori, _ = self.g(x_pair, node=True)
-        self._bn_twice_end(snap)        # (after deferred_bn_counts has applied this pass's counter increments)
+        if snap is not None:
+            ops.flush_bn_counts()       # an enclosing deferred_bn_counts() block (SUGStep) still holds this pass's increments
+        self._bn_twice_end(snap)        # (after this pass's counter increments have been applied)
         cuts = getattr(self, '_cuts', None)
         if cuts is not None:            # SUGStep's two-phase backward cuts the graph at the encoder's outputs
             if dual:

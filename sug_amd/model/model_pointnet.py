@@ -109,5 +109,5 @@ class DGCNN(nn.Module):
         x3 = self.conv3.edge_rows(x2, nb(x2, 2), out=cat_in[:, :, 128:256])
         x4 = self.conv4.edge_rows(x3, nb(x3, 3), out=cat_in[:, :, 256:512])
         x5 = ops.linear_rows(ops.assemble_rows(cat_in, (x1, x2, x3, x4)), self.conv5.weight.squeeze(-1))
-        feat = torch.cat(ops.bn_act_pool(x5, self.bn5, 0.2), 1)       # bn5 -> leaky_relu(0.2) -> max | avg pool
+        feat = ops.bn_act_pool_cat(x5, self.bn5, 0.2)                  # bn5 -> leaky_relu(0.2) -> max | avg pool, concatenated
         return self.classifier(feat)

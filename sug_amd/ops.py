@@ -521,6 +521,7 @@ class _NodeOffset(torch.autograd.Function):
         check(lib().sug_node_offset_fwd(_p(proj), _p(loc), _p(fidx), _p(gidx), B, N, S, ns, _p(off), _p(nloc), _st()),
               'sug_node_offset_fwd')
         ctx.save_for_backward(proj, loc, fidx, gidx)
+        ctx.set_materialize_grads(False)
         return off, nloc
 
     @staticmethod
@@ -528,7 +529,10 @@ class _NodeOffset(torch.autograd.Function):
         proj, loc, fidx, gidx = ctx.saved_tensors
         B, N, _ = proj.shape
         S, ns = gidx.shape[1], gidx.shape[2]
-        g = (goff + gnloc).contiguous()                 # nloc = loc[f] + off
+        if goff is None and gnloc is None:
+            return None, None, None, None
+        # nloc = loc[f] + off; an output that took no part in the loss arrives as None (no zero fill + add for it)
+        g = (goff if gnloc is None else gnloc if goff is None else goff + gnloc).contiguous()
         dproj = torch.empty_like(proj)              # written (or zeroed) entirely by the entry point
         check(lib().sug_node_offset_bwd(_p(proj), _p(loc), _p(fidx), _p(gidx), _p(g), B, N, S, ns, _p(dproj), _st()),
               'sug_node_offset_bwd')
@@ -1035,12 +1039,17 @@ def deferred_bn_counts():
     try:
         yield
     finally:
-        pend, CTX.pending_counts = CTX.pending_counts, None
-        by_inc = {}
-        for t, n in pend.values():
-            by_inc.setdefault(n, []).append(t)
-        for n, ts in by_inc.items():
-            torch._foreach_add_(ts, n)
+        flush_bn_counts()
+        CTX.pending_counts = None
+
+
+def flush_bn_counts():
+    """Apply the counter increments collected so far by the enclosing deferred_bn_counts() block (one multi-tensor launch,
+    a scalar per counter); whoever reads num_batches_tracked inside such a block calls this first."""
+    pend = CTX.pending_counts
+    if pend:
+        torch._foreach_add_([t for t, _ in pend.values()], [n for _, n in pend.values()])
+        pend.clear()
 
 
 def _count_bn_call(bn, n=None):
@@ -1114,32 +1123,33 @@ class _BNActPool(torch.autograd.Function):
             coef = torch.empty(G, 5, C, dtype=torch.float32, device=dev)
         else:
             coef = eval_coef(g, b, running_mean, running_var, eps).unsqueeze(0).repeat(G, 1, 1)
-        omax = torch.empty(B, C, dtype=torch.float32, device=dev)
-        omean = torch.empty(B, C, dtype=torch.float32, device=dev)
+        pooled = torch.empty(B, 2 * C, dtype=torch.float32, device=dev)      # [max | mean]: torch.cat((max, mean), 1) in place
+        omax, omean = pooled[:, :C], pooled[:, C:]
         arg = torch.empty(B, C, dtype=torch.int32, device=dev)
         stats = torch.empty(2 * C, dtype=torch.float64, device=dev)
         wss = torch.empty(STATS_BLOCKS * 2 * C, dtype=torch.float32, device=dev)
         wsp = torch.empty(12 * (B // G) * C, dtype=torch.float32, device=dev)
         check(lib().sug_bn_act_pool_layer_fwd(_p(y), ld, B, N, C, G, _p(g), _p(b), 1 if training else 0, eps, momentum,
                                               float(slope), _p(running_mean), _p(running_var), _p(coef), _p(omax),
-                                              _p(omean), _p(arg), _p(stats), _p(wss), _p(wsp), _st()),
+                                              _p(omean), 2 * C, _p(arg), _p(stats), _p(wss), _p(wsp), _st()),
               'sug_bn_act_pool_layer_fwd')
         ctx.save_for_backward(y, coef, arg)
         ctx.meta = (B, N, C, ld, float(slope), bool(training), G)
-        ctx.mark_non_differentiable(arg)
-        return omax, omean
+        return pooled
 
     @staticmethod
-    def backward(ctx, gmax, gmean):
+    def backward(ctx, g):
         y, coef, arg = ctx.saved_tensors
         B, N, C, ld, slope, training, G = ctx.meta
         dev = y.device
-        gmax, gmean = gmax.contiguous(), gmean.contiguous()
+        if g.stride(1) != 1 or g.stride(0) < 2 * C:
+            g = g.contiguous()
+        gmax, gmean, ldp = g[:, :C], g[:, C:], g.stride(0)
         red = torch.empty(G, 2 * C, dtype=torch.float64, device=dev)
         ws = torch.empty(STATS_BLOCKS * 2 * C, dtype=torch.float32, device=dev)
         dy = torch.empty(B, N, C, dtype=torch.float32, device=dev)
         rf = torch.empty(2 * C, dtype=torch.float32, device=dev)
-        check(lib().sug_bn_act_pool_layer_bwd(_p(y), ld, _p(coef), _p(gmax), _p(gmean), _p(arg), B, N, C, G, slope,
+        check(lib().sug_bn_act_pool_layer_bwd(_p(y), ld, _p(coef), _p(gmax), _p(gmean), ldp, _p(arg), B, N, C, G, slope,
                                               1 if training else 0, _p(red), _p(ws), _p(dy), C, _p(rf), _st()),
               'sug_bn_act_pool_layer_bwd')
         return dy, rf[C:], rf[:C], None, None, None, None, None, None, None
@@ -1171,11 +1181,19 @@ def bn_update_stats(y, bn):
     _count_bn_call(bn)
 
 
-def bn_act_pool(y, bn, slope):
-    """(max over points, mean over points) of act(bn(y)), y [B,N,C]."""
+def bn_act_pool_cat(y, bn, slope):
+    """cat((max over points, mean over points), 1) [B, 2C] of act(bn(y)), y [B,N,C]: the kernels write the two halves of
+    the concatenated feature (Model.py:113-116) and read the two halves of its gradient in place."""
     _count_bn_call(bn)
     return _BNActPool.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, slope, bn.eps,
                             bn.momentum, CTX.bn_groups)
+
+
+def bn_act_pool(y, bn, slope):
+    """(max over points, mean over points) of act(bn(y)), y [B,N,C]."""
+    C = y.shape[-1]
+    pooled = bn_act_pool_cat(y, bn, slope)
+    return pooled[:, :C], pooled[:, C:]
 
 
 # ----------------------------------------------------------------------------- EdgeConv
@@ -1987,11 +2005,14 @@ class _LossCombine(torch.autograd.Function):
         ctx.meta = (float(wg), float(ws), v0 is not None, v1 is not None, v2 is not None)
         tot, geo, sem = out[0], out[1], out[2]
         ctx.mark_non_differentiable(geo, sem)
+        ctx.set_materialize_grads(False)          # no zero-filled scalars for the two reporting outputs (a launch each)
         return tot, geo, sem
 
     @staticmethod
     def backward(ctx, g, _g1, _g2):
         wg, ws, h0, h1, h2 = ctx.meta
+        if g is None:
+            return None, None, None, None, None, None
         o = torch.empty(4, dtype=torch.float32, device=g.device)
         gs = g.detach().to(dtype=torch.float32).reshape(1)
         check(lib().sug_loss_combine_bwd(_p(gs), wg, ws, _p(o), _st()), 'sug_loss_combine_bwd')

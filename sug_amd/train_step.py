@@ -886,7 +886,8 @@ class SUGStep:
         fused_before, ops.CTX.fused_heads = ops.CTX.fused_heads, (self.fused_heads or ops.CTX.fused_heads)
         par_before, ops.CTX.parallel_branches = ops.CTX.parallel_branches, (self.parallel_branches or ops.CTX.parallel_branches)
         try:
-            loss_cls, loss_geo, loss_sem = self.losses(data, label, data_t, label_t, mmd_on, combine=True)
+            with ops.deferred_bn_counts():            # every num_batches_tracked increment of the step's forwards: one launch
+                loss_cls, loss_geo, loss_sem = self.losses(data, label, data_t, label_t, mmd_on, combine=True)
         finally:
             ops.CTX.fused_heads = fused_before
             ops.CTX.parallel_branches = par_before

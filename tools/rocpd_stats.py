@@ -2,7 +2,8 @@
 usage: python tools/rocpd_stats.py results.db [steps_total] [skip_steps] [csv_out] [marker_regex] [markers_per_step]
 
 Steps are delimited by a MARKER kernel that every training step launches a fixed number of times (default: the Adam
-update, `adam_kernel`, 3 launches per step = optimizer_dis, optimizer_g, optimizer_c, the last kernels of a step): a step
+update: `adam_chain_kernel`, one launch per step since round 6, or `adam_kernel`, 3 launches per step = optimizer_dis,
+optimizer_g, optimizer_c, in older trees / with SUG_ADAM_CHAIN=0 -- the last kernels of a step): a step
 is everything after the previous step's last marker up to and including its own.  The last `steps_total - skip_steps`
 complete steps are summarised, so `calls_per_step` is integral for every kernel the steps launch identically.  (Round 4
 divided the row count by `steps_total`; a step whose kernels are captured into a hipGraph instead of executed has no
@@ -12,9 +13,11 @@ import sqlite3, collections, re, sys
 db = sqlite3.connect(sys.argv[1])
 steps_total = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 skip = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-marker = re.compile(sys.argv[5] if len(sys.argv) > 5 else r'adam_kernel')
-per_step = int(sys.argv[6]) if len(sys.argv) > 6 else 3
 rows = list(db.execute("select name, start, end from kernels order by start"))
+# since round 6 the three updates are ONE launch (adam_chain_kernel, optim.AdamChain); SUG_ADAM_CHAIN=0 runs bring back 3 x adam_kernel
+chained = any('adam_chain_kernel' in r[0] for r in rows)
+marker = re.compile(sys.argv[5] if len(sys.argv) > 5 else (r'adam_chain_kernel' if chained else r'adam_kernel'))
+per_step = int(sys.argv[6]) if len(sys.argv) > 6 else (1 if chained else 3)
 
 if steps_total > 1:
     marks = [i for i, r in enumerate(rows) if marker.search(r[0])]
