@@ -15,6 +15,7 @@ import torch.nn.functional as F
 
 from .. import ops
 from .model_utils import conv_2d, fc_layer, transform_net, adapt_layer_off, _bn_rows, bn_module, edge_wcats
+from . import model_utils as _mu
 from .pointnet2_utils import PointNetSetAbstraction
 from . import PTran_utils
 from .Ptran_transformer import TransformerBlock
@@ -389,7 +390,15 @@ class Pointnet_g(nn.Module, _PrefixSharing):
         y = self._prefix(x, loc)
         y, node_fea, node_off = self.conv3.rows(y, loc)
         with torch.set_grad_enabled(torch.is_grad_enabled() and feat_grad):
-            y = bn_module(self.bn1, self.conv5.rows_max_after(self.conv4, y))
+            y = self.conv5.rows_max_after(self.conv4, y)
+            bn = self.bn1
+            if y.is_cuda and y.dtype == torch.float32 and _mu.OWN_BN(bn) and bn.track_running_stats and bn.momentum is not None \
+                    and bn.affine:
+                # BatchNorm1d over the B pooled rows, per domain group, in the library's own kernels (three launches each
+                # way instead of torch's three per group + cat + counter)
+                y = ops.bn_act_rows(y, bn, 1.0)
+            else:
+                y = bn_module(bn, y)
         node_fea = node_fea.transpose(1, 2).unsqueeze(-1)
         node_off = node_off.transpose(1, 2)
         if node:

@@ -1454,7 +1454,10 @@ def _pointmlp_max_backward(gout, x2, w2, b1, zext, arg, coef, rows, K, Co, seg, 
     ws = torch.empty(STATS_BLOCKS * 2 * Co, dtype=torch.float32, device=dev)
     dx = torch.empty(rows, K, dtype=torch.float32, device=dev) if training else \
         torch.zeros(rows, K, dtype=torch.float32, device=dev)
-    dw = torch.zeros(Co, K, dtype=torch.float32, device=dev)
+    # dw (accumulated over the groups) and the identically-zero bias gradient of a train-mode layer: ONE zero fill
+    zdb = Co if (b1 is not None and training) else 0
+    zbuf = torch.zeros(Co * K + zdb, dtype=torch.float32, device=dev)
+    dw = zbuf[:Co * K].view(Co, K)
     dws = torch.empty(Co, K, dtype=torch.float32, device=dev)
     wsp = torch.empty(int(lib().sug_pointmlp_max_bwd_workspace(rg, K, Co, seg)), dtype=torch.float32, device=dev)
     L = lib()
@@ -1487,11 +1490,12 @@ def _pointmlp_max_backward(gout, x2, w2, b1, zext, arg, coef, rows, K, Co, seg, 
               'sug_pointmlp_max_bwd_sparse')
         check(L.sug_pointmlp_max_bwd_dwfix(_p(dw), _p(dws), _p(kbk2[0]), _p(kbk2[1]), _p(w2), _p(xtx), _p(sx), K, Co,
                                            1 if training else 0, _st()), 'sug_pointmlp_max_bwd_dwfix')
-    rf = red[0].float() if G == 1 else red.sum(0, dtype=torch.float32)
+    rf = torch.empty(2 * Co, dtype=torch.float32, device=dev)
+    check(L.sug_fold_groups(_p(red), G, 2 * Co, _p(rf), _st()), 'sug_fold_groups')      # dbeta | dgamma over the groups, in group order
     db = None
     if b1 is not None:
         # a bias in front of train-mode BatchNorm has zero gradient identically
-        db = torch.zeros_like(b1) if training else a.sum(dim=0)
+        db = zbuf[Co * K:].view_as(b1) if training else a.sum(dim=0)
     return dx, dw, db, rf[Co:], rf[:Co]
 
 
