@@ -44,7 +44,7 @@ extern "C" {
 
 const char* sug_last_error(void);
 /* ABI version of the loaded library (bumped when a signature changes; 3: sug_adam_step_capturable gained lr_dev,
- * round-3 entry points; 4: sug_chamfer / sug_node_offset_bwd became reproducible -- sug_chamfer takes a workspace; 5: sug_ce_pair_* take ignore_index, lse has 2M + 1 entries; sug_pointmlp_max_layer_fwd_xf and sug_col_stats_bn_grouped added; 6: sug_ptran_fused_fwd / sug_ptran_fused_supported added, sug_group_max_bwd fails instead of changing its summation order when the LDS opt-in is refused; 7: sug_adam_chain_step, sug_edge_weight_split_multi, sug_soft_mmd_multi_fwd / _bwd, sug_sda_prob_weights_multi and sug_chamfer_weights added, sug_bn_act_pool_* take the row stride ld_pool of the pooled outputs / their gradients).  A binding checks sug_abi_version() == SUG_ABI_VERSION of the header it was written against. */
+ * round-3 entry points; 4: sug_chamfer / sug_node_offset_bwd became reproducible -- sug_chamfer takes a workspace; 5: sug_ce_pair_* take ignore_index, lse has 2M + 1 entries; sug_pointmlp_max_layer_fwd_xf and sug_col_stats_bn_grouped added; 6: sug_ptran_fused_fwd / sug_ptran_fused_supported added, sug_group_max_bwd fails instead of changing its summation order when the LDS opt-in is refused; 7: sug_adam_chain_step, sug_edge_weight_split_multi, sug_soft_mmd_multi_fwd / _bwd, sug_sda_prob_weights_multi, sug_chamfer_weights and sug_bn_replay_multi added, sug_bn_act_pool_* take the row stride ld_pool of the pooled outputs / their gradients).  A binding checks sug_abi_version() == SUG_ABI_VERSION of the header it was written against. */
 #define SUG_ABI_VERSION 7
 int sug_abi_version(void);
 
@@ -193,6 +193,9 @@ int sug_col_stats_bn_grouped(const float* y, int64_t ldy, int64_t rows, int C, i
  * again on the same batch (model/Model.py:88-92 run once per forward call). */
 int sug_bn_replay(const float* coef, int G, int C, float momentum, float* running_mean, float* running_var,
                   void* stream);
+/* The same for n <= 16 layers in one launch (HOST arrays of n entries; a layer must not appear twice). */
+int sug_bn_replay_multi(int n, const void* const* coef, const int32_t* G, const int32_t* C, const float* momentum,
+                        void* const* running_mean, void* const* running_var, void* stream);
 
 /* out[r,c] = act(scale[c]*z[r,c] + shift[c]), act = LeakyReLU(slope) (slope 0: ReLU,
  * slope 1: identity).  rows = B*N.  */

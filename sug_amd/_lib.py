@@ -58,6 +58,7 @@ SIGNATURES = {
     'sug_col_stats_bn': [_vp, _i64, _i64, _i32, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp],
     'sug_col_stats_bn_grouped': [_vp, _i64, _i64, _i32, _i32, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp],
     'sug_bn_replay': [_vp, _i32, _i32, _f32, _vp, _vp, _vp],
+    'sug_bn_replay_multi': [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     'sug_ptran_pos1_fwd': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
     'sug_ptran_pos1_bwd': [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
     'sug_ptran_qk_fwd': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp],

@@ -266,6 +266,36 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
   }
 }
 
+// reduce_partials_kernel for every domain group of a layer in one workgroup per 16 columns, plus the group-folded fp32
+// copy the parameter gradients want (sug_fold_groups' arithmetic: the groups' fp64 sums added in group order, then
+// rounded) -- the separate fold launch of every BatchNorm backward is gone.
+__global__ __launch_bounds__(256) void reduce_partials_fold_kernel(const float* __restrict__ ws, int nblk, int W, int groups,
+                                                                   double* __restrict__ out, float* __restrict__ folded) {
+  __shared__ double s_p[16][17];
+  const int cl = threadIdx.x & 15, p = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  double tot = 0.0;
+  for (int g = 0; g < groups; ++g) {
+    const float* wg = ws + (size_t)g * nblk * W;
+    double acc = 0.0;
+    if (c < W) {
+#pragma unroll 8
+      for (int b = p; b < nblk; b += 16) acc += (double)wg[(size_t)b * W + c];
+    }
+    __syncthreads();
+    s_p[p][cl] = acc;
+    __syncthreads();
+    if (p == 0 && c < W) {
+      double t = 0.0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) t += s_p[i][cl];
+      out[(size_t)g * W + c] = t;
+      tot += t;
+    }
+  }
+  if (p == 0 && c < W) folded[c] = (float)tot;
+}
+
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ stats,
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, int C,
@@ -420,6 +450,32 @@ __global__ __launch_bounds__(256) void bn_replay_kernel(const float* __restrict_
   }
   rmean[c] = m;
   rvar[c] = v;
+}
+
+// bn_replay_kernel for up to SUG_REPLAY_MULTI layers in one launch (the BatchNorm layers of a shared encoder prefix:
+// replay_bn_stats): blockIdx.y = layer.
+#define SUG_REPLAY_MULTI 16
+struct ReplayMulti {
+  const float* coef[SUG_REPLAY_MULTI];
+  float* rmean[SUG_REPLAY_MULTI];
+  float* rvar[SUG_REPLAY_MULTI];
+  int G[SUG_REPLAY_MULTI], C[SUG_REPLAY_MULTI];
+  float momentum[SUG_REPLAY_MULTI];
+};
+__global__ __launch_bounds__(256) void bn_replay_multi_kernel(ReplayMulti a) {
+  const int l = blockIdx.y, C = a.C[l], G = a.G[l];
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float momentum = a.momentum[l];
+  const float* coef = a.coef[l];
+  float m = a.rmean[l][c], v = a.rvar[l][c];
+  for (int g = 0; g < G; ++g) {
+    const float* cg = coef + (size_t)g * 5 * C;
+    m = (1.f - momentum) * m + momentum * cg[2 * C + c];
+    v = (1.f - momentum) * v + momentum * cg[4 * C + c];
+  }
+  a.rmean[l][c] = m;
+  a.rvar[l][c] = v;
 }
 
 __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ z, int64_t ldz,
@@ -1127,13 +1183,16 @@ int sug_affine_act_groups(const float* z, int64_t ldz, const float* coef, int64_
 }
 //   a = scale*G and the BatchNorm backward sums red [groups, 2C]
 int sug_bwd_reduce_groups(const float* gout, int64_t ldg, const float* z, const float* coef, int64_t rows, int Co,
-                          int groups, float slope, float* a, double* red, float* ws, hipStream_t st) {
-  // a == nullptr: sums only
+                          int groups, float slope, float* a, double* red, float* ws, hipStream_t st, float* dgb) {
+  // a == nullptr: sums only;  dgb (may be null): dbeta | dgamma [2Co] summed over the groups, fp32 (sug_fold_groups of red)
   const int grid = a ? launch_col_reduce<1>(gout, ldg, z, coef, rows, Co, slope, a, ws, st, groups)
                      : launch_col_reduce<2>(gout, ldg, z, coef, rows, Co, slope, nullptr, ws, st, groups);
   if (grid < 0) return 1;
   SUG_LAUNCH_CHECK("sug_edgeconv_bwd_reduce");
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(sug_divup(2 * Co, 16), groups), dim3(256), 0, st, ws, grid, 2 * Co, red);
+  if (dgb)
+    hipLaunchKernelGGL(reduce_partials_fold_kernel, dim3(sug_divup(2 * Co, 16)), dim3(256), 0, st, ws, grid, 2 * Co, groups, red, dgb);
+  else
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(sug_divup(2 * Co, 16), groups), dim3(256), 0, st, ws, grid, 2 * Co, red);
   SUG_LAUNCH_CHECK("sug_edgeconv_bwd_reduce(reduce)");
   return SUG_OK;
 }
@@ -1234,5 +1293,27 @@ static int edgeconv_bwd_scatter_groups(const float* a, const uint8_t* arg, const
       LAUNCH_SCATTER(4);
   }
   SUG_LAUNCH_CHECK("sug_edgeconv_bwd_scatter");
+  return SUG_OK;
+}
+
+extern "C" int sug_bn_replay_multi(int n, const void* const* coef, const int32_t* G, const int32_t* C, const float* momentum,
+                                   void* const* running_mean, void* const* running_var, void* stream) {
+  SUG_REQUIRE(coef && G && C && momentum && running_mean && running_var, "sug_bn_replay_multi: null pointer");
+  SUG_REQUIRE(n >= 1 && n <= SUG_REPLAY_MULTI, "sug_bn_replay_multi: %d layers (1..%d)", n, SUG_REPLAY_MULTI);
+  ReplayMulti a;
+  int cmax = 0;
+  for (int i = 0; i < SUG_REPLAY_MULTI; ++i) {
+    const int k = i < n ? i : 0;
+    SUG_REQUIRE(coef[k] && running_mean[k] && running_var[k] && G[k] >= 1 && C[k] >= 1, "sug_bn_replay_multi: bad layer %d", k);
+    a.coef[i] = (const float*)coef[k];
+    a.rmean[i] = (float*)running_mean[k];
+    a.rvar[i] = (float*)running_var[k];
+    a.G[i] = G[k];
+    a.C[i] = C[k];
+    a.momentum[i] = momentum[k];
+    if (i < n && C[k] > cmax) cmax = C[k];
+  }
+  hipLaunchKernelGGL(bn_replay_multi_kernel, dim3(sug_divup(cmax, 256), n), dim3(256), 0, (hipStream_t)stream, a);
+  SUG_LAUNCH_CHECK("sug_bn_replay_multi");
   return SUG_OK;
 }

@@ -18,7 +18,7 @@ int sug_col_stats_bn_groups(const float* y, int64_t ldy, int64_t rows, int C, in
 int sug_affine_act_groups(const float* z, int64_t ldz, const float* coef, int64_t rows, int groups, int C, float slope,
                           float* out, int64_t ldo, ihipStream_t* st);
 int sug_bwd_reduce_groups(const float* gout, int64_t ldg, const float* z, const float* coef, int64_t rows, int Co,
-                          int groups, float slope, float* a, double* red, float* ws, ihipStream_t* st);
+                          int groups, float slope, float* a, double* red, float* ws, ihipStream_t* st, float* dgb);
 int sug_bn_bwd_apply_groups(const float* a, int64_t lda, int from_g, float slope, const float* y, int64_t ldy,
                             const float* coef, const double* red, int64_t rows_g, int groups, int C, float* dy,
                             int64_t lddy, ihipStream_t* st);
@@ -66,8 +66,8 @@ extern "C" int sug_edgeconv_layer_bwd(const float* gout, int64_t ldg, const floa
   const int64_t rows = (int64_t)Bg * N;
   LAYER_TRY(sug_knn_reverse(idx, B, N, k, rev_off, rev_ent, stream));
   int grouped = 1;
-  if (groups > 1) {
-    grouped = sug_bwd_reduce_groups(gout, ldg, z, coef, rows, Co, groups, slope, a, red, ws, (ihipStream_t*)stream);
+  if (groups > 1) {      // (the grouped reduce also writes dgb: no fold launch afterwards)
+    grouped = sug_bwd_reduce_groups(gout, ldg, z, coef, rows, Co, groups, slope, a, red, ws, (ihipStream_t*)stream, dgb);
     if (grouped < 0) return grouped;
   }
   for (int g = 0; grouped != 0 && g < groups; ++g) {
@@ -81,7 +81,7 @@ extern "C" int sug_edgeconv_layer_bwd(const float* gout, int64_t ldg, const floa
   LAYER_TRY(sug_edgeconv_bwd_scatter_groups(a, arg, s1, pq, ldpq, rev_off, rev_ent, coef,
                                             training ? red : red + (int64_t)groups * 2 * Co, B, N, k, Co, groups,
                                             (int64_t)5 * Co, training ? (int64_t)2 * Co : 0, dpq, lddpq, stream));
-  if (dgb) LAYER_TRY(sug_fold_groups(red, groups, 2 * Co, dgb, stream));
+  if (dgb && grouped != 0) LAYER_TRY(sug_fold_groups(red, groups, 2 * Co, dgb, stream));
   return SUG_OK;
 }
 
@@ -148,18 +148,17 @@ extern "C" int sug_bn_act_rows_bwd(const float* gout, int64_t ldg, const float* 
   // from gout and y (5 passes over the layer instead of 6), all groups per launch
   if (training && ldg % 4 == 0 && C % 4 == 0 && ((uintptr_t)gout % 16) == 0 && ((uintptr_t)y % 16) == 0 &&
       ((uintptr_t)dy % 16) == 0 && ((uintptr_t)coef % 16) == 0) {
-    int rc = sug_bwd_reduce_groups(gout, ldg, y, coef, rg, C, groups, slope, nullptr, red, ws, st);
+    int rc = sug_bwd_reduce_groups(gout, ldg, y, coef, rg, C, groups, slope, nullptr, red, ws, st, dgb);
     if (rc < 0) return rc;
     if (rc == 0) {
       rc = sug_bn_bwd_apply_groups(gout, ldg, 1, slope, y, C, coef, red, rg, groups, C, dy, C, st);
       if (rc != 0) return rc < 0 ? rc : SUG_ERR_ARG;
-      if (dgb) LAYER_TRY(sug_fold_groups(red, groups, 2 * C, dgb, stream));
       return SUG_OK;
     }
   }
   bool reduced = false;
   if (groups > 1) {
-    const int rc = sug_bwd_reduce_groups(gout, ldg, y, coef, rg, C, groups, slope, a, red, ws, st);
+    const int rc = sug_bwd_reduce_groups(gout, ldg, y, coef, rg, C, groups, slope, a, red, ws, st, dgb);
     if (rc < 0) return rc;
     reduced = rc == 0;
   }
@@ -178,7 +177,7 @@ extern "C" int sug_bn_act_rows_bwd(const float* gout, int64_t ldg, const float* 
     if (training && !applied)
       LAYER_TRY(sug_bn_bwd_apply(a + g * rg * C, y + g * rg * C, C, cg, rd, rg, C, dy + g * rg * C, C, stream));
   }
-  if (dgb) LAYER_TRY(sug_fold_groups(red, groups, 2 * C, dgb, stream));
+  if (dgb && !reduced) LAYER_TRY(sug_fold_groups(red, groups, 2 * C, dgb, stream));
   return SUG_OK;
 }
 

@@ -200,8 +200,7 @@ class DGCNN(nn.Module, _PrefixSharing):
         if hit is not None and hit.serves(x):
             x1, x2 = hit.tensors
             st1, st2 = hit.extra
-            self.conv1.replay_bn_update(st1)
-            self.conv2.replay_bn_update(st2)
+            ops.replay_bn_stats([(self.conv1.conv[1], st1), (self.conv2.conv[1], st2)])     # both layers' updates, one launch
             return x1, x2
         x1, st1 = self.conv1.edge_rows(loc, nb(loc, 0), return_stats=True, out=out1, wcat=wc[0])
         x2, st2 = self.conv2.edge_rows(x1, nb(x1, 1), return_stats=True, wcat=wc[1])

@@ -1083,8 +1083,29 @@ def _record_bn(bn):
 
 
 def replay_bn_stats(rec):
-    for bn, coef in rec:
-        bn_replay(bn, coef)
+    """bn_replay for every (bn, coef) of a recorded prefix, in order; runs of distinct layers share one launch."""
+    rec = list(rec)
+    i = 0
+    while i < len(rec):
+        run, seen = [], set()
+        while i < len(rec) and len(run) < 16 and id(rec[i][0]) not in seen:     # a layer recorded twice: its updates stay in order
+            seen.add(id(rec[i][0]))
+            run.append(rec[i])
+            i += 1
+        if len(run) == 1:
+            bn_replay(*run[0])
+            continue
+        c3s = []
+        for _, coef in run:
+            c3 = coef if coef.dim() == 3 else coef.unsqueeze(0)
+            c3s.append(c3 if c3.is_contiguous() else c3.contiguous())
+        n = len(run)
+        I32, F32 = ctypes.c_int32 * n, ctypes.c_float * n
+        check(lib().sug_bn_replay_multi(n, _ptrs(c3s), I32(*[c.shape[0] for c in c3s]), I32(*[c.shape[2] for c in c3s]),
+                                        F32(*[float(bn.momentum) for bn, _ in run]), _ptrs([bn.running_mean for bn, _ in run]),
+                                        _ptrs([bn.running_var for bn, _ in run]), _st()), 'sug_bn_replay_multi')
+        for (bn, _), c3 in zip(run, c3s):
+            _count_bn_call(bn, c3.shape[0])
 
 
 def bn_replay(bn, coef):
