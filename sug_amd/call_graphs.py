@@ -207,7 +207,7 @@ class CallGraphs:
     def _eligible(self, model, x):
         if not (x.is_cuda and not x.requires_grad and ops.CTX.bn_groups == 1 and ops.CTX.start_queue is None and
                 ops.CTX.geometry_plan is None and ops.CTX.start_provider is None and ops.CTX.profile is None and
-                ops.CTX.w16_cache is None and ops.CTX.bn_record is None):
+                ops.CTX.bn_record is None):
             return False
         if torch.cuda.is_current_stream_capturing():
             return False
@@ -314,6 +314,12 @@ class CallGraphs:
         # invalidates the capture (torch warns 'AccumulateGrad node's stream does not match'; hipStreamEndCapture crashed).
         alias = {id(q): q.detach().requires_grad_(q.requires_grad) for q in self._params}
         ops.CTX.start_provider = inst.feeder.provide
+        # 16-bit weight copies (Point Transformer, fp16 mode): a caller's step-scoped cache holds tensors made outside this
+        # capture, for the parameters rather than their aliases -- the captured call keeps its OWN cache: every weight is cast
+        # once per call, inside the graph, from the live parameter storage
+        from .model import Ptran_transformer as _PT
+        keep_w16 = ops.CTX.w16_cache
+        ops.CTX.w16_cache = {} if (keep_w16 is not None or _PT.GEMM_DTYPE is not None) else None
         try:
             for m_, n_, q in self._slots:
                 m_._parameters[n_] = alias[id(q)]
@@ -330,6 +336,7 @@ class CallGraphs:
                         exported = e
         finally:
             ops.CTX.start_provider = None
+            ops.CTX.w16_cache = keep_w16
             for m_, n_, q in self._slots:
                 m_._parameters[n_] = q
         inst.single = isinstance(out, torch.Tensor)

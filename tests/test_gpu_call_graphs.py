@@ -108,6 +108,31 @@ def test_graphed_calls_equal_the_eager_caller_form_bit_for_bit(model, B, N):
     assert torch.equal(rng_a, rng_b), 'the CPU generator was advanced differently (FPS start draws)'
 
 
+def test_fp16_point_transformer_calls_are_graphed_with_and_without_a_step_cache():
+    """BASELINE config 5's arithmetic (fp16 linears, fp32 accumulation) through call graphs: bit-identical to the eager calls;
+    and a caller that keeps a step-scoped cache of 16-bit weight copies (ops.CTX.w16_cache, as SUGStep does) no longer
+    turns the captures away -- a captured call casts its weights inside its own graph."""
+    from sug_amd import ops
+    from sug_amd.model import Ptran_transformer as PT
+    keep = (PT.GEMM_DTYPE, PT.PROJ_16BIT)
+    PT.GEMM_DTYPE, PT.PROJ_16BIT = torch.float16, True
+    try:
+        a, rng_a, _, _ = _run('PTran', 2, 1024, 5, False)
+        b, rng_b, stats, (mgr, _) = _run('PTran', 2, 1024, 5, True)
+        assert stats['refused'] == 0 and stats['captured'] == 4 and stats['replayed'] == 4 * 4, (stats, [ks.why for ks in mgr.keys.values()])
+        assert a == b and torch.equal(rng_a, rng_b)
+        ops.CTX.w16_cache = {}
+        try:
+            c, rng_c, stats_c, _ = _run('PTran', 2, 1024, 5, True)
+        finally:
+            ops.CTX.w16_cache = None
+        assert stats_c['refused'] == 0 and stats_c['captured'] == 4, stats_c
+        assert [x[0] for x in c[2:]] == [x[0] for x in a[2:]] or all(
+            abs(u - v) <= 1e-6 * max(1.0, abs(v)) for x, y in zip(c, a) for u, v in zip(x[0], y[0]))
+    finally:
+        PT.GEMM_DTYPE, PT.PROJ_16BIT = keep
+
+
 def test_outputs_survive_the_next_replay_and_unused_parameters_keep_no_gradient():
     """What a caller may rely on: the tensors a call returns are its own (not overwritten by the instance's next replay);
     parameters the forward never uses (DGCNN.input_transform_net, adapt_layer_off.trans -- model/Model.py:61, model_utils.py:97)
