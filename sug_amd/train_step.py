@@ -390,6 +390,14 @@ class SUGStep:
         # scalar algebra with the constant factors multiplied on the host: every tensor-scalar op is a launch forward
         # and one backward (0.5*a + 0.5*b = 0.5*(a + b) exactly; the folded weights differ from the reference's
         # left-to-right products by an ulp at most)
+        if fused_ce is None and pair is None and self._combine_tail and model.training and pred_s1.is_cuda \
+                and isinstance(self.criterion, nn.CrossEntropyLoss) and self.criterion.weight is None \
+                and self.criterion.reduction == 'mean' and self.criterion.label_smoothing == 0.0 \
+                and M['ADV_WEIGHT'] <= 0 and M['TARGET_LOSS'] <= 0 and pred_s1.dim() == 2 \
+                and ops.ce_pair_supported(pred_s1, pred_s2, label):
+            # the separate-calls form (the four model(...) calls of an unchanged caller): CE of both heads in one launch each
+            # way as well (ops.ce_pair scores the first len(label) rows: here all of them)
+            fused_ce = ops.ce_pair(pred_s1, pred_s2, label, 0.5 * M['SRC_LOSS_WEIGHT'] * M['CLS_WEIGHT'], self.criterion.ignore_index)
         if fused_ce is not None:
             loss_cls = fused_ce
         elif M['ADV_WEIGHT'] > 0 or M['TARGET_LOSS'] > 0:
