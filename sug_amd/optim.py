@@ -262,6 +262,9 @@ class AdamChain:
         plans = [o._ensure_plan() for o in opts]
         gens = tuple(o.plan_generation for o in opts)
         J = self._joint if gens == self._joint_gens else None
+        if J is not None and not J['fallback'] and J['capturable'] and any(
+                b.step_dev.data_ptr() != J['steps'][i:i + 1].data_ptr() for i, b in enumerate(J['buckets'])):
+            J = None                    # another chain over the same optimizers has re-homed their device scalars since
         if J is None:
             J = self._build(plans)
             self._joint_gens = gens

@@ -141,5 +141,15 @@ def test_chain_falls_back_when_the_optimizers_do_not_fit():
             o.step()
     assert chain._joint['fallback']
     assert torch.equal(w, ref)
+    # two chains over the same (capturable) optimizers: each re-homes the optimizers' device scalars when it builds its
+    # table; the other one notices and rebuilds instead of advancing stale step counts
+    params, opts = _setup(Adam, graph_capturable=True)
+    c1, c2 = AdamChain(opts), AdamChain(opts)
+    for s, c in enumerate((c1, c2, c1, c2, c1)):
+        for p, g in zip(params, _grads(params, s)):
+            p.grad = g
+        c.step()
+    steps = {float(v['step']) for o in opts for v in o.state_dict()['state'].values()}
+    assert steps == {5.0}, steps
     with pytest.raises(RuntimeError, match='sug_amd.optim.Adam optimizers only'):
         AdamChain([torch.optim.Adam([w])])
